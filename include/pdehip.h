@@ -1,0 +1,221 @@
+/*
+ * pdehip.h — C ABI of libpdehip.so, the MI355X (gfx950) backend for py-pde's
+ * Cartesian finite-difference operators + explicit time steppers.
+ *
+ * This is the drop-in boundary: the entry points below are what a
+ * `pde.backends` plugin binds through ctypes.  Every function cites the reference
+ * interface it replaces (paths relative to the py-pde source tree).  There are no
+ * torch / numpy types in any signature: plain pointers, sizes and POD structs.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message of the
+ *     last failure (per thread) is returned by pdehip_last_error().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - all array pointers are DEVICE pointers unless the name says `host`.
+ *   - a "full" array is the ghost-padded C-contiguous array of py-pde
+ *     (pde/grids/base.py:329-337, pde/fields/base.py:116-160): shape
+ *     (ncomp, N0+2, N1+2, N2+2) (unused axes dropped), interior cell (i,j,k) lives
+ *     at [i+1, j+1, k+1].  A "valid" array is the C-contiguous interior
+ *     (ncomp, N0, N1, N2).
+ *   - ON THE DEVICE a full array keeps the ghost-padded index space of the reference but
+ *     every row of the fastest axis is shifted/padded so that its first interior cell is
+ *     16-byte aligned and the row pitch is a multiple of 16 bytes (all hot-kernel accesses
+ *     are aligned dwordx4).  pdehip_layout() reports pitches and the allocation size;
+ *     pdehip_valid_to_full / pdehip_hostfull_to_full convert from the host layouts.  Layers
+ *     along axis 0 stay contiguous (one block per slab face for the halo exchange).
+ *   - dtype PDEHIP_F32 stores fp32 but all arithmetic between a load and the store
+ *     of one kernel runs in fp64 registers (numba promotes float32 array elements
+ *     against float64 closure constants the same way, SURVEY.md §7 "fp32").
+ *   - the arithmetic of every kernel follows the reference expression order and is
+ *     compiled with -ffp-contract=off, so results are bit-identical to the CPU
+ *     oracle (oracle/pde_oracle.c) and to the reference's eager torch-CPU backend.
+ */
+#ifndef PDEHIP_H
+#define PDEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEHIP_MAX_DIM 3
+#define PDEHIP_ABI_VERSION 1
+
+enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
+/* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
+enum { PDEHIP_CENTRAL = 0, PDEHIP_FORWARD = 1, PDEHIP_BACKWARD = 2 };
+/* layout of an operator's output array */
+enum { PDEHIP_OUT_VALID = 0, PDEHIP_OUT_FULL = 1 };
+
+/* Geometry of a CartesianGrid / UnitGrid (pde/grids/cartesian.py:36-146, :473-507).
+ * `shape` and `dx` mirror grid.shape / grid.discretization. */
+typedef struct pdehip_grid {
+    int32_t ndim;                  /* 1, 2 or 3 */
+    int32_t dtype;                 /* PDEHIP_F64 | PDEHIP_F32 */
+    int64_t shape[PDEHIP_MAX_DIM]; /* valid cells per axis; unused axes must be 1 */
+    double dx[PDEHIP_MAX_DIM];     /* grid.discretization */
+} pdehip_grid_t;
+
+/* One side of one axis of a BoundariesList, already reduced to virtual-point data
+ * (pde/grids/boundaries/local.py:1611-1636 ConstBC1stOrderBase.set_ghost_cells,
+ *  :2022-2061 ConstBC2ndOrderBase.set_ghost_cells, data from get_virtual_point_data
+ *  :1728-1731 periodic, :1749-1753 Dirichlet, :1773-1778 Neumann, :1927-1938 Mixed,
+ *  :2081-2103 Curvature):
+ *      ghost = const + factor1 * full[index1 + 1]  (+ factor2 * full[index2 + 1])
+ * evaluated on the interior of the face only (corners/edges are never written).
+ */
+enum { PDEHIP_BC_SKIP = 0, PDEHIP_BC_ORDER1 = 1, PDEHIP_BC_ORDER2 = 2 };
+enum {
+    PDEHIP_BCF_ARRAYS = 1, /* const/factor given per (component, face cell) as fp64 device
+                              arrays of shape (ncomp, face cells in C order) */
+    PDEHIP_BCF_NORMAL = 2  /* `bc.normal`: only vector component == axis is written */
+};
+typedef struct pdehip_bc_face {
+    int32_t kind;  /* PDEHIP_BC_* */
+    int32_t flags; /* PDEHIP_BCF_* */
+    int64_t index1, index2; /* indices into the VALID array along the axis */
+    double const_v, factor1, factor2; /* used when !(flags & PDEHIP_BCF_ARRAYS) */
+    const double *const_arr, *factor1_arr, *factor2_arr; /* used when ARRAYS */
+} pdehip_bc_face_t;
+/* Faces are stored as faces[2*axis + upper] (lower = 0, upper = 1); they are applied in
+ * the reference order axis 0 (upper, lower), axis 1 (upper, lower), ...
+ * (pde/backends/numba/backend.py:335-340, pde/grids/boundaries/axis.py:236-238). */
+
+/* Right-hand side of the PDEs on the hot path, evaluated by the fused steppers. */
+enum {
+    PDEHIP_RHS_DIFFUSION = 0,    /* D * laplace(c)            pde/pdes/diffusion.py:119-121 */
+    PDEHIP_RHS_CAHN_HILLIARD = 1 /* laplace(c**3 - c - g*laplace(c)) pde/pdes/cahn_hilliard.py:115-122 */
+};
+typedef struct pdehip_rhs {
+    int32_t kind;
+    int32_t reserved;
+    double param;                   /* diffusivity D, or interface_width g */
+    pdehip_bc_face_t bc_c[2 * PDEHIP_MAX_DIM];  /* BCs of the state field */
+    pdehip_bc_face_t bc_mu[2 * PDEHIP_MAX_DIM]; /* BCs of mu (Cahn-Hilliard only) */
+    void *scratch_mu;               /* full array (Cahn-Hilliard only) */
+} pdehip_rhs_t;
+
+/* ---- runtime ------------------------------------------------------------------ */
+const char *pdehip_last_error(void);
+int pdehip_abi_version(void);
+int pdehip_device_count(int *count);
+int pdehip_set_device(int device);
+int pdehip_device_name(char *buf, size_t len);
+/* memory: replaces numpy allocation in NumbaBackend.make_operator
+ * (pde/backends/numba/backend.py:460-517) and TorchBackend.numpy_to_native
+ * (pde/backends/torch/backend.py:217-238); memory is zero-initialised */
+int pdehip_malloc(void **ptr, size_t bytes);
+int pdehip_free(void *ptr);
+int pdehip_memset(void *ptr, int value, size_t bytes, void *stream);
+int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
+int pdehip_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
+int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int pdehip_stream_create(void **stream);
+int pdehip_stream_destroy(void *stream);
+int pdehip_stream_synchronize(void *stream);
+int pdehip_stream_wait_event(void *stream, void *event);
+int pdehip_event_create(void **event);
+int pdehip_event_destroy(void *event);
+int pdehip_event_record(void *event, void *stream);
+int pdehip_event_synchronize(void *event);
+int pdehip_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* Device layout of a full array of this grid.  out8 = { pitch of normalised axis 0, pitch of
+ * normalised axis 1, elements per component, offset of interior cell (0,..,0), column of the
+ * first interior cell in a row, elements to allocate for ONE component incl. tail slack,
+ * tail slack, pitch (elements) of one layer along the grid's axis 0 }.  A device full array
+ * of `ncomp` components needs (ncomp * out8[2] + out8[6]) elements. */
+int pdehip_layout(const pdehip_grid_t *g, int64_t *out8);
+
+/* ---- data movement between the valid and the full layout ----------------------
+ * replaces NumpyBackend.make_valid_data_setter (pde/backends/numpy/backend.py:72-115) */
+int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, void *full,
+                         void *stream);
+int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *valid,
+                         void *stream);
+/* `hostfull` = a device copy of the reference's compact host full array (shape + 2 per axis,
+ * `field._data_full`, pde/fields/datafield_base.py:93-126), ghost cells included */
+int pdehip_hostfull_to_full(const pdehip_grid_t *g, int ncomp, const void *hostfull_dev,
+                            void *full, void *stream);
+int pdehip_full_to_hostfull(const pdehip_grid_t *g, int ncomp, const void *full,
+                            void *hostfull_dev, void *stream);
+
+/* ---- ghost cells ---------------------------------------------------------------
+ * replaces NumbaBackend.make_ghost_cell_setter (pde/backends/numba/backend.py:184-404) */
+int pdehip_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_face_t *faces,
+                           void *data_full, void *stream);
+
+/* ---- operators (no BCs: the caller guarantees ghost cells are set) ---------------
+ * replace the closures returned by make_laplace / make_gradient / make_divergence
+ * (pde/backends/numba/operators/cartesian.py:332-383, :553-587, :962-996), signature
+ * (arr_full, out_valid) of BackendBase.make_operator_no_bc (pde/backends/base.py:482-521).
+ * `out_layout` selects whether `out` is a valid or a full array (the interior of a full
+ * array is written, its ghost cells are left untouched). */
+int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout,
+                   void *stream);
+int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out,
+                    int out_layout, void *stream);
+int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, void *out,
+                      int out_layout, void *stream);
+/* sum_a (d_a f)^2, pde/backends/numba/operators/cartesian.py:590-809; central != 0 selects
+ * the central-difference form */
+int pdehip_gradient_squared(const pdehip_grid_t *g, int central, const void *in_full, void *out,
+                            int out_layout, void *stream);
+
+/* ---- fused stencil + pointwise kernels (all arrays full) --------------------------
+ * out = s2 * (s1 * laplace(in))                       [k = dt * (D * lap), RK stages] */
+int pdehip_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out_full, double s1,
+                          double s2, void *stream);
+/* out = y + s2 * (s1 * laplace(in)); y may alias in    [Euler: pde/solvers/euler.py:172-175] */
+int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void *y_full,
+                         void *out_full, double s1, double s2, void *stream);
+/* mu = c*c*c - c - gamma * laplace(c)                  [pde/pdes/cahn_hilliard.py:116-120] */
+int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full,
+                            double gamma, void *stream);
+
+/* ---- pointwise helpers over the interior of full arrays ----------------------------
+ * out = y + sum_j coef[j] * k[j], evaluated left to right (pde/solvers/runge_kutta.py:135-153);
+ * n <= 6; y == NULL drops the leading term (then out = coef[0]*k[0] + ...) */
+int pdehip_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int n,
+                   const double *coef_host, const void *const *k_full_host, void *stream);
+/* y += (k1 + 2*k2 + 2*k3 + k4) / 6                     [pde/solvers/runge_kutta.py:60] */
+int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const void *k1,
+                       const void *k2, const void *k3, const void *k4, void *stream);
+/* RKF45 tail (pde/solvers/runge_kutta.py:146-152):
+ *   err  = max | r1 k1 + r3 k3 + r4 k4 + r5 k5 + r6 k6 |   -> *err_dev (fp64 device scalar)
+ *   ynew = y + c1 k1 + c3 k3 + c4 k4 + c5 k5
+ * *err_dev is reset by the call; NaN propagates like numpy's max. */
+int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew,
+                         const void *const *k6_host, double *err_dev, void *stream);
+/* max |a - b| over the interior -> *out_dev (generic error estimate pde/solvers/base.py:416) */
+int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, const void *b_full,
+                        double *out_dev, void *stream);
+
+/* ---- fused time steppers ----------------------------------------------------------
+ * k_out = dt * rhs(y): sets ghost cells of y (and of mu) in place, then evaluates the RHS;
+ * replaces NumbaBackend.make_pde_rhs + the `dt * rhs(...)` temporaries
+ * (pde/backends/numba/backend.py:1158-1196, pde/solvers/runge_kutta.py:52-59) */
+int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
+                      void *k_out_full, double dt, void *stream);
+/* `nsteps` explicit Euler steps with fixed dt, ping-ponging between buf_a (initial state)
+ * and buf_b; *result receives the buffer holding the final state.  Replaces the jitted
+ * fixed-step loop (pde/backends/numba/_solvers.py:93-104) around
+ * EulerSolver._make_single_step_fixed_dt (pde/solvers/euler.py:149-179). */
+int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b,
+                     double dt, int64_t nsteps, void **result, void *stream);
+/* one classical RK4 step in place on y (pde/solvers/runge_kutta.py:29-66);
+ * work = 5 full arrays (k1..k4, tmp) */
+int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
+                    void *const *work5_host, double dt, void *stream);
+/* one RKF45 attempt (pde/solvers/runge_kutta.py:68-156): ynew and *err_dev are produced,
+ * y is unchanged apart from its ghost cells; work = 7 full arrays (k1..k6, tmp) */
+int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
+                         void *ynew_full, void *const *work7_host, double dt, double *err_dev,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEHIP_H */

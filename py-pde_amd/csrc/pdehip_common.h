@@ -1,0 +1,109 @@
+// pdehip_common.h — internal helpers shared by the translation units of libpdehip.so
+// (gfx950 only; no CUDA-compat paths).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/pdehip.h"
+
+namespace pdehip {
+
+// ---- error plumbing: int status + thread-local message (SURVEY.md §8b "error convention") --
+void set_error(const std::string &msg);
+#define PDEHIP_FAIL(code, ...)                         \
+    do {                                               \
+        char _buf[512];                                \
+        snprintf(_buf, sizeof(_buf), __VA_ARGS__);     \
+        ::pdehip::set_error(_buf);                     \
+        return (code);                                 \
+    } while (0)
+#define PDEHIP_HIP(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            PDEHIP_FAIL(100 + (int)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+#define PDEHIP_TRY(expr)          \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// error codes (mapped to Python exceptions by pde_hip/_lib.py)
+enum { E_OK = 0, E_VALUE = 1, E_NOTIMPL = 2, E_RUNTIME = 3 };
+
+// ---- device layout of a "full" array ---------------------------------------------------------
+// A grid is normalised to three axes (an n-D grid occupies the trailing n axes; padded axes
+// have n = 1 and no ghost layer).  The device layout differs from the reference's host layout
+// (shape + 2, compact) in ONE respect: every row of the fastest axis is shifted and padded so
+// that the first interior cell of each row is 16-byte aligned and the pitch is a multiple of
+// 16 bytes.  This makes every interior vector (double2 / float4) an aligned dwordx4 access.
+//   row:  [pad .. pad, ghost, interior(n2) ..., ghost, pad ..]     interior starts at `lpad`
+struct NGrid {
+    int ndim;
+    int dtype;
+    long n[3];         // valid cells
+    long gh[3];        // ghost width (1 on used axes, 0 on padded axes)
+    long p[3];         // pitches in elements (p[2] == 1)
+    long pc;           // elements of one component
+    long off;          // offset of interior cell (0,0,0)
+    long lpad;         // column of the first interior cell in a row
+    double dx[3];
+    double lap_scale[3];  // dx**-2, numpy semantics (pow(dx, -2))
+};
+
+inline long elem_size(int dtype) { return dtype == PDEHIP_F64 ? 8 : 4; }
+
+inline int norm_grid(const pdehip_grid_t *g, NGrid *n)
+{
+    if (!g) PDEHIP_FAIL(E_VALUE, "grid descriptor is NULL");
+    if (g->ndim < 1 || g->ndim > 3) PDEHIP_FAIL(E_NOTIMPL, "unsupported number of axes %d", g->ndim);
+    if (g->dtype != PDEHIP_F64 && g->dtype != PDEHIP_F32) PDEHIP_FAIL(E_NOTIMPL, "unsupported dtype code %d", g->dtype);
+    n->ndim = g->ndim;
+    n->dtype = g->dtype;
+    for (int ax = 0; ax < 3; ax++) { n->n[ax] = 1; n->gh[ax] = 0; n->dx[ax] = 1; n->lap_scale[ax] = 1; }
+    for (int a = 0; a < g->ndim; a++) {
+        int ax = 3 - g->ndim + a;
+        if (g->shape[a] < 1) PDEHIP_FAIL(E_VALUE, "grid shape must be positive (axis %d: %ld)", a, (long)g->shape[a]);
+        n->n[ax] = g->shape[a];
+        n->gh[ax] = 1;
+        n->dx[ax] = g->dx[a];
+        n->lap_scale[ax] = std::pow(g->dx[a], -2.0);
+    }
+    n->lpad = 16 / elem_size(g->dtype);
+    n->p[2] = 1;
+    n->p[1] = ((n->lpad + n->n[2] + 1 + n->lpad - 1) / n->lpad) * n->lpad;
+    n->p[0] = n->p[1] * (n->n[1] + 2 * n->gh[1]);
+    n->pc = n->p[0] * (n->n[0] + 2 * n->gh[0]);
+    n->off = n->gh[0] * n->p[0] + n->gh[1] * n->p[1] + n->lpad;
+    return 0;
+}
+
+// slack elements appended to every allocation so vector loads of clamped lanes stay in bounds
+constexpr long kAllocSlack = 64;
+
+struct OutStr { long off, s0, s1, sc; };
+inline OutStr out_strides(const NGrid &n, int layout)
+{
+    OutStr o;
+    if (layout == PDEHIP_OUT_FULL) { o.off = n.off; o.s0 = n.p[0]; o.s1 = n.p[1]; o.sc = n.pc; }
+    else { o.off = 0; o.s1 = n.n[2]; o.s0 = n.n[1] * n.n[2]; o.sc = n.n[0] * n.n[1] * n.n[2]; }
+    return o;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// kernel launchers implemented in pdehip_kernels.hip
+enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3 };
+int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
+                   double s2, double gamma, const void *y, hipStream_t st);
+int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
+
+}  // namespace pdehip

@@ -1,0 +1,433 @@
+// pdehip_kernels.hip — hand-written gfx950 (CDNA4) kernels for py-pde's Cartesian
+// finite-difference operators.  Bandwidth-bound stencil work: no MFMA.  The design goals are
+//   * every cell of the input is fetched from HBM once (register pipeline along the slowest axis,
+//     row re-use inside a wave, halo rows/columns served by L2),
+//   * every global access of the hot kernel is an aligned 16-byte (dwordx4) access,
+//   * neighbours along the fastest axis come from wavefront DPP shifts (64 lanes), not memory,
+//   * >> 256 workgroups per launch with an XCD-aware block -> tile map.
+// Arithmetic follows the reference expression order (pde/backends/numba/operators/
+// cartesian.py) and the file is compiled with -ffp-contract=off: results are bit-identical to
+// the CPU oracle.
+#include "pdehip_common.h"
+
+namespace pdehip {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC> struct VecT;
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecT<double, 1> { typedef double type; };
+template <> struct VecT<float, 1> { typedef float type; };
+
+// wavefront shift by one lane through DPP (gfx9 wave_shr:1 / wave_shl:1).  Lane 0 (resp. lane
+// 63) has no source lane and keeps `old`, which carries the halo value of the wave's tile.
+__device__ __forceinline__ double wave_shr1(double old, double src)
+{
+    // lane i receives src of lane i-1
+    unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
+    int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_shl1(double old, double src)
+{
+    // lane i receives src of lane i+1
+    unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
+    int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// XCD-aware block -> work-item map: hardware places block b on XCD b % 8 (speed only, never
+// correctness).  Give every XCD a contiguous chunk of the tile list so that tiles which share
+// halo rows / planes also share an L2.
+__device__ __forceinline__ long xcd_swizzle(long bid, long nblocks)
+{
+    const long nx = 8;
+    const long per = nblocks / nx;
+    if (bid >= per * nx) return bid;  // tail: identity
+    return (bid % nx) * per + bid / nx;
+}
+
+template <int MODE>
+__device__ __forceinline__ double epilogue(double lap, double c, double yv, double s1, double s2, double gamma)
+{
+    if (MODE == LAP_PLAIN) return lap;
+    if (MODE == LAP_SCALED) return s2 * (s1 * lap);        // dt * (D * lap)
+    if (MODE == LAP_EULER) return yv + s2 * (s1 * lap);    // pde/solvers/euler.py:174
+    return c * c * c - c - gamma * lap;                    // pde/pdes/cahn_hilliard.py:116-120
+}
+
+struct LapArgs {
+    const void *in;
+    void *out;
+    const void *y;
+    long n0, n1, n2;
+    long p0, p1, off;
+    long o_off, o_s0, o_s1;
+    double sx, sy, sz, s1, s2, gamma;
+    int ndim;
+    int lx;           // planes per x-chunk
+    long nxc, nty, ntz, nblocks;
+};
+
+// ---------------------------------------------------------------------------------------------
+// The hot kernel: register-pipelined Laplacian (+ fused epilogue).
+//
+// A workgroup is 4 wavefronts stacked along y; each wavefront owns a tile of RY rows x
+// (64*VEC) cells of the fastest axis and marches over `lx` planes of the slowest axis, keeping
+// three planes in registers:  prev (centre rows), cur (centre rows + one halo row above and
+// below), next (same, prefetched one plane ahead).  Per plane a lane issues RY+2 aligned
+// 16-byte loads plus RY broadcast loads for the two z-halo cells of the wave tile, and RY
+// aligned 16-byte stores.  z-neighbours inside the tile are exchanged with DPP wave shifts.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC, int RY, int MODE, bool HAS_X, bool Y_IS_IN>
+__global__ void __launch_bounds__(256) lap_march_kernel(LapArgs a)
+{
+    typedef typename VecT<T, VEC>::type V;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
+
+    long bid = xcd_swizzle(blockIdx.x, a.nblocks);
+    const long tz = bid % a.ntz;
+    bid /= a.ntz;
+    const long ty = bid % a.nty;
+    const long xc = bid / a.nty;
+
+    const long kw = tz * (64 * VEC);          // first cell of the wave tile (valid index)
+    long k0 = kw + (long)lane * VEC;          // first cell of this lane
+    const bool k_ok = k0 < a.n2;
+    if (k0 > a.n2) k0 = a.n2;                 // clamp idle lanes (keeps loads in bounds)
+    const long j0 = ty * (4 * RY) + (long)w * RY;
+    if (j0 >= a.n1) return;                   // whole wave outside (no barriers are used)
+    const long i0 = xc * a.lx;
+    const long i1 = (i0 + a.lx < a.n0) ? i0 + a.lx : a.n0;
+
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const T *yin = (const T *)a.y;
+
+    // row offsets (relative to plane base); rows beyond the grid are clamped to the ghost row
+    long roff[RY + 2];
+#pragma unroll
+    for (int r = 0; r < RY + 2; r++) {
+        long j = j0 + r - 1;
+        if (j > a.n1) j = a.n1;
+        roff[r] = a.off + j * a.p1;
+    }
+    // z-halo: lanes < 32 fetch the cell left of the tile, lanes >= 32 the cell right of it
+    long zh_k = (lane < 32) ? kw - 1 : kw + 64 * VEC;
+    if (zh_k > a.n2) zh_k = a.n2;
+
+    V cur[RY + 2], nxt[RY + 2];
+    V prev[RY];
+    T zh_cur[RY], zh_nxt[RY];
+
+    // prologue: plane i0-1 (prev, centre rows only), plane i0 (cur)
+    if (HAS_X) {
+        const T *pl = in + (i0 - 1) * a.p0;
+#pragma unroll
+        for (int r = 0; r < RY; r++) prev[r] = *(const V *)(pl + roff[r + 1] + k0);
+    }
+    {
+        const T *pl = in + i0 * a.p0;
+#pragma unroll
+        for (int r = 0; r < RY + 2; r++) cur[r] = *(const V *)(pl + roff[r] + k0);
+#pragma unroll
+        for (int r = 0; r < RY; r++) zh_cur[r] = pl[roff[r + 1] + zh_k];
+    }
+
+    for (long i = i0; i < i1; i++) {
+        if (HAS_X) {  // plane i+1 (the ghost plane when i+1 == n0)
+            const T *pl = in + (i + 1) * a.p0;
+#pragma unroll
+            for (int r = 0; r < RY + 2; r++) nxt[r] = *(const V *)(pl + roff[r] + k0);
+#pragma unroll
+            for (int r = 0; r < RY; r++) zh_nxt[r] = pl[roff[r + 1] + zh_k];
+        }
+        V yv[RY];
+        if (MODE == LAP_EULER && !Y_IS_IN) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) yv[r] = *(const V *)(yin + i * a.p0 + roff[r + 1] + k0);
+        }
+
+#pragma unroll
+        for (int r = 0; r < RY; r++) {
+            const V cc = cur[r + 1], up = cur[r], dn = cur[r + 2];
+            const double zl = wave_shr1((double)zh_cur[r], (double)cc[VEC - 1]);
+            const double zr = wave_shl1((double)zh_cur[r], (double)cc[0]);
+            V res;
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+                const double c = (double)cc[q];
+                const double left = (q == 0) ? zl : (double)cc[q > 0 ? q - 1 : 0];
+                const double right = (q == VEC - 1) ? zr : (double)cc[q < VEC - 1 ? q + 1 : q];
+                const double vm = 2 * c;
+                double lap;
+                if (HAS_X) {
+                    // cartesian.py:220-227
+                    const double lx = ((double)prev[r][q] - vm + (double)nxt[r + 1][q]) * a.sx;
+                    const double ly = ((double)up[q] - vm + (double)dn[q]) * a.sy;
+                    const double lz = (left - vm + right) * a.sz;
+                    lap = lx + ly + lz;
+                } else {
+                    // cartesian.py:147-151 (2-D; 1-D is handled by the generic kernel)
+                    const double ly = ((double)up[q] - vm + (double)dn[q]) * a.sy;
+                    const double lz = (left - vm + right) * a.sz;
+                    lap = ly + lz;
+                }
+                double yy = 0;
+                if (MODE == LAP_EULER) yy = Y_IS_IN ? c : (double)yv[r][q];
+                res[q] = (T)epilogue<MODE>(lap, c, yy, a.s1, a.s2, a.gamma);
+            }
+            if (k_ok && (j0 + r) < a.n1) {
+                T *po = out + a.o_off + i * a.o_s0 + (j0 + r) * a.o_s1 + k0;
+                *(V *)po = res;
+            }
+        }
+
+        if (HAS_X) {
+#pragma unroll
+            for (int r = 0; r < RY; r++) {
+                prev[r] = cur[r + 1];
+                zh_cur[r] = zh_nxt[r];
+            }
+#pragma unroll
+            for (int r = 0; r < RY + 2; r++) cur[r] = nxt[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic fallback: one cell per thread, direct loads (any shape / any alignment / 1-D).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) lap_generic_kernel(LapArgs a)
+{
+    const long total = a.n0 * a.n1 * a.n2;
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const T *yin = (const T *)a.y;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long k = t % a.n2;
+        const long j = (t / a.n2) % a.n1;
+        const long i = t / (a.n2 * a.n1);
+        const T *c = in + a.off + i * a.p0 + j * a.p1 + k;
+        const double mid = (double)c[0];
+        double lap;
+        if (a.ndim == 1) {
+            lap = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
+        } else if (a.ndim == 2) {
+            const double lx = ((double)c[-a.p1] - 2 * mid + (double)c[a.p1]) * a.sy;
+            const double ly = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
+            lap = lx + ly;
+        } else {
+            const double vm = 2 * mid;
+            const double lx = ((double)c[-a.p0] - vm + (double)c[a.p0]) * a.sx;
+            const double ly = ((double)c[-a.p1] - vm + (double)c[a.p1]) * a.sy;
+            const double lz = ((double)c[-1] - vm + (double)c[1]) * a.sz;
+            lap = lx + ly + lz;
+        }
+        double yy = 0;
+        if (MODE == LAP_EULER) yy = (double)yin[a.off + i * a.p0 + j * a.p1 + k];
+        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)epilogue<MODE>(lap, mid, yy, a.s1, a.s2, a.gamma);
+    }
+}
+
+static int g_force_generic = -1;
+static bool force_generic()
+{
+    if (g_force_generic < 0) {
+        const char *e = getenv("PDEHIP_FORCE_GENERIC");
+        g_force_generic = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_force_generic == 1;
+}
+
+template <typename T, int VEC, int RY, int MODE, bool HAS_X>
+static int launch_march(const LapArgs &a0, bool y_is_in, hipStream_t st)
+{
+    LapArgs a = a0;
+    a.ntz = (a.n2 + 64 * VEC - 1) / (64 * VEC);
+    a.nty = (a.n1 + 4 * RY - 1) / (4 * RY);
+    // choose the x-chunk length: enough workgroups to fill 256 CUs x ~8 waves, but chunks as
+    // long as possible (each chunk re-reads 2 halo planes)
+    long tiles = a.ntz * a.nty;
+    long lx = a.n0;
+    if (HAS_X) {
+        const long want_blocks = 2048;
+        long nxc = (want_blocks + tiles - 1) / tiles;
+        if (nxc < 1) nxc = 1;
+        if (nxc > a.n0) nxc = a.n0;
+        lx = (a.n0 + nxc - 1) / nxc;
+        if (lx < 8 && a.n0 >= 8) lx = 8;
+    }
+    a.lx = (int)lx;
+    a.nxc = (a.n0 + lx - 1) / lx;
+    a.nblocks = a.nxc * tiles;
+    if (y_is_in)
+        hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, MODE, HAS_X, true>), dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, MODE, HAS_X, false>), dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int MODE>
+static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, hipStream_t st)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec_ok = (n.n[2] % VEC == 0) && (o.s1 % VEC == 0) && (o.s0 % VEC == 0) && (o.off % VEC == 0) &&
+                        (((uintptr_t)a.out) % 16 == 0) && (((uintptr_t)a.in) % 16 == 0) &&
+                        (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0);
+    if (n.ndim >= 2 && vec_ok && !force_generic()) {
+        const bool y_is_in = (a.y == a.in) || a.y == nullptr;
+        if (n.ndim == 3) return launch_march<T, VEC, 4, MODE, true>(a, y_is_in, st);
+        return launch_march<T, VEC, 2, MODE, false>(a, y_is_in, st);
+    }
+    const long total = n.n[0] * n.n[1] * n.n[2];
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((lap_generic_kernel<T, MODE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
+                   double s2, double gamma, const void *y, hipStream_t st)
+{
+    if (!in || !out) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
+    if (mode == LAP_EULER && !y) PDEHIP_FAIL(E_VALUE, "laplace_euler: y is NULL");
+    LapArgs a;
+    a.in = in; a.out = out; a.y = (mode == LAP_EULER) ? y : nullptr;
+    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
+    a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
+    a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1;
+    a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
+    a.s1 = s1; a.s2 = s2; a.gamma = gamma;
+    a.ndim = n.ndim; a.lx = 1; a.nxc = a.nty = a.ntz = a.nblocks = 0;
+#define PDEHIP_MODE_SWITCH(T)                                                     \
+    switch (mode) {                                                               \
+    case LAP_PLAIN: return launch_laplace_t<T, LAP_PLAIN>(n, a, o, st);           \
+    case LAP_SCALED: return launch_laplace_t<T, LAP_SCALED>(n, a, o, st);         \
+    case LAP_EULER: return launch_laplace_t<T, LAP_EULER>(n, a, o, st);           \
+    case LAP_CH_MU: return launch_laplace_t<T, LAP_CH_MU>(n, a, o, st);           \
+    default: PDEHIP_FAIL(E_VALUE, "unknown laplace mode %d", mode);               \
+    }
+    if (n.dtype == PDEHIP_F64) { PDEHIP_MODE_SWITCH(double) }
+    PDEHIP_MODE_SWITCH(float)
+#undef PDEHIP_MODE_SWITCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// ghost cells: one launch for all faces.  Faces only read interior cells and write disjoint
+// ghost cells, so the reference's axis-by-axis order (numba/backend.py:335-340) cannot be
+// observed and all faces are processed concurrently.
+// ---------------------------------------------------------------------------------------------
+struct GhostFace {
+    int kind, flags, ax, side;
+    long index1, index2;
+    double c, f1, f2;
+    const double *ca, *f1a, *f2a;
+    long m1, m2;          // extent of the two other (normalised) axes
+    long q1, q2, g1, g2;  // their pitches and ghost widths
+    long pa;              // pitch along the BC axis
+    long ghost;           // full index of the ghost layer along the axis
+    long start;           // first work item of this face
+    int comp_axis;        // vector component addressed by a `normal` BC
+};
+struct GhostArgs {
+    GhostFace f[6];
+    int nfaces, ncomp;
+    long pc, lpad_off;    // component pitch, offset of column 0 of interior rows (lpad - gh2)
+    long total;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) ghost_kernel(GhostArgs a, T *data)
+{
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < a.total; t += (long)gridDim.x * blockDim.x) {
+        int fi = 0;
+#pragma unroll
+        for (int q = 1; q < 6; q++)
+            if (q < a.nfaces && t >= a.f[q].start) fi = q;
+        const GhostFace &f = a.f[fi];
+        long loc = t - f.start;
+        const long v = loc % f.m2;
+        loc /= f.m2;
+        const long u = loc % f.m1;
+        const int comp = (int)(loc / f.m1);
+        if ((f.flags & PDEHIP_BCF_NORMAL) && comp != f.comp_axis) continue;
+        T *d = data + (long)comp * a.pc + a.lpad_off;
+        const long base = (u + f.g1) * f.q1 + (v + f.g2) * f.q2;
+        double cst, f1, f2 = 0;
+        if (f.flags & PDEHIP_BCF_ARRAYS) {
+            const long fc = (long)((f.flags & PDEHIP_BCF_NORMAL) ? 0 : comp) * f.m1 * f.m2 + u * f.m2 + v;
+            cst = f.ca[fc];
+            f1 = f.f1a[fc];
+            if (f.kind == PDEHIP_BC_ORDER2) f2 = f.f2a[fc];
+        } else {
+            cst = f.c; f1 = f.f1; f2 = f.f2;
+        }
+        // local.py:1636  const + factor * data[index + 1]
+        double r = cst + f1 * (double)d[base + (f.index1 + 1) * f.pa];
+        if (f.kind == PDEHIP_BC_ORDER2) r = r + f2 * (double)d[base + (f.index2 + 1) * f.pa];  // local.py:2055-2059
+        d[base + f.ghost * f.pa] = (T)r;
+    }
+}
+
+int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st)
+{
+    if (!faces || !data) PDEHIP_FAIL(E_VALUE, "set_ghost_cells: NULL pointer");
+    if (ncomp < 1) PDEHIP_FAIL(E_VALUE, "set_ghost_cells: ncomp must be >= 1");
+    GhostArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ncomp = ncomp;
+    a.pc = n.pc;
+    a.lpad_off = n.lpad - n.gh[2];
+    long total = 0;
+    int nf = 0;
+    for (int ar = 0; ar < n.ndim; ar++) {
+        const int ax = 3 - n.ndim + ar;
+        for (int side = 1; side >= 0; side--) {
+            const pdehip_bc_face_t &s = faces[2 * ar + side];
+            if (s.kind == PDEHIP_BC_SKIP) continue;
+            if (s.kind != PDEHIP_BC_ORDER1 && s.kind != PDEHIP_BC_ORDER2)
+                PDEHIP_FAIL(E_VALUE, "unknown BC kind %d on axis %d", s.kind, ar);
+            if (s.index1 < 0 || s.index1 >= n.n[ax] || (s.kind == PDEHIP_BC_ORDER2 && (s.index2 < 0 || s.index2 >= n.n[ax])))
+                PDEHIP_FAIL(E_VALUE, "BC index out of range on axis %d", ar);
+            if ((s.flags & PDEHIP_BCF_ARRAYS) && (!s.const_arr || !s.factor1_arr || (s.kind == PDEHIP_BC_ORDER2 && !s.factor2_arr)))
+                PDEHIP_FAIL(E_VALUE, "BC arrays missing on axis %d", ar);
+            GhostFace &f = a.f[nf++];
+            const int o1 = (ax == 0) ? 1 : 0, o2 = (ax == 2) ? 1 : 2;
+            f.kind = s.kind; f.flags = s.flags; f.ax = ax; f.side = side;
+            f.index1 = s.index1; f.index2 = s.index2;
+            f.c = s.const_v; f.f1 = s.factor1; f.f2 = s.factor2;
+            f.ca = s.const_arr; f.f1a = s.factor1_arr; f.f2a = s.factor2_arr;
+            f.m1 = n.n[o1]; f.m2 = n.n[o2];
+            f.q1 = n.p[o1]; f.q2 = n.p[o2]; f.g1 = n.gh[o1]; f.g2 = n.gh[o2];
+            f.pa = n.p[ax];
+            f.ghost = side ? n.n[ax] + 1 : 0;
+            f.start = total;
+            f.comp_axis = ar;
+            total += (long)ncomp * f.m1 * f.m2;
+        }
+    }
+    if (nf == 0) return 0;
+    a.nfaces = nf;
+    a.total = total;
+    // pitches above are relative to column 0 of the *compact* row; the interior columns of the
+    // device layout start at lpad, the ghost column at lpad-1: shift via lpad_off = lpad - gh2
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (n.dtype == PDEHIP_F64)
+        hipLaunchKernelGGL((ghost_kernel<double>), dim3((unsigned)blocks), dim3(256), 0, st, a, (double *)data);
+    else
+        hipLaunchKernelGGL((ghost_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, a, (float *)data);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace pdehip

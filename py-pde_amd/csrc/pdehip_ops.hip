@@ -1,0 +1,494 @@
+// pdehip_ops.hip — gradient / divergence / gradient_squared, layout conversion and the
+// pointwise kernels of the Runge–Kutta steppers (all bandwidth-bound, 16-byte vector access
+// over the interior rows of the aligned device layout).
+#include "pdehip_common.h"
+
+namespace pdehip {
+
+struct DevGrid {
+    long n0, n1, n2;
+    long p0, p1, pc, off;
+    int ndim;
+};
+static DevGrid dev_grid(const NGrid &n)
+{
+    DevGrid d;
+    d.n0 = n.n[0]; d.n1 = n.n[1]; d.n2 = n.n[2];
+    d.p0 = n.p[0]; d.p1 = n.p[1]; d.pc = n.pc; d.off = n.off; d.ndim = n.ndim;
+    return d;
+}
+
+template <typename T, int VEC> struct VecOf;
+template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<double, 1> { typedef double type __attribute__((ext_vector_type(1))); };
+template <> struct VecOf<float, 1> { typedef float type __attribute__((ext_vector_type(1))); };
+
+// Iterate over all interior cells of `ncomp` components in chunks of VEC cells along the
+// fastest axis.  body(comp, i, j, k, e) with e = element offset inside the full array.
+template <int VEC, typename F>
+__device__ __forceinline__ void for_each_chunk(const DevGrid &g, int ncomp, F body)
+{
+    const long kc = g.n2 / VEC;
+    const long total = (long)ncomp * g.n0 * g.n1 * kc;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long r = t;
+        const long k = (r % kc) * VEC;
+        r /= kc;
+        const long j = r % g.n1;
+        r /= g.n1;
+        const long i = r % g.n0;
+        const int comp = (int)(r / g.n0);
+        body(comp, i, j, k, (long)comp * g.pc + g.off + i * g.p0 + j * g.p1 + k);
+    }
+}
+
+static inline unsigned grid_blocks(long items)
+{
+    long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 16384) b = 16384;
+    return (unsigned)b;
+}
+
+// ---- derivative operators (one cell per thread; neighbours through L1/L2) ------------------------
+struct DerivArgs {
+    DevGrid g;
+    const void *in;
+    void *out;
+    long o_off, o_s0, o_s1, o_sc;
+    double dx[3];
+    int method;   // gradient/divergence: PDEHIP_CENTRAL..; gradient_squared: central flag
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gradient_kernel(DerivArgs a)
+{
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const DevGrid &g = a.g;
+    for_each_chunk<1>(g, 1, [&](int, long i, long j, long k, long e) {
+        const double mid = (double)in[e];
+        for (int c = 0; c < g.ndim; c++) {
+            const int ax = 3 - g.ndim + c;
+            const long pa = (ax == 0) ? g.p0 : (ax == 1) ? g.p1 : 1;
+            const double dx = a.dx[ax];
+            const double hi = (double)in[e + pa], lo = (double)in[e - pa];
+            const double d = (a.method == PDEHIP_CENTRAL) ? hi - lo : (a.method == PDEHIP_FORWARD) ? hi - mid : mid - lo;
+            double r;
+            if (g.ndim == 1)  // cartesian.py:418-422 divides in 1-D
+                r = (a.method == PDEHIP_CENTRAL) ? d / (2 * dx) : d / dx;
+            else              // cartesian.py:464-474, :516-548 multiply by 0.5/dx or 1/dx
+                r = d * ((a.method == PDEHIP_CENTRAL) ? 0.5 / dx : 1 / dx);
+            out[(long)c * a.o_sc + a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)r;
+        }
+    });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) divergence_kernel(DerivArgs a)
+{
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const DevGrid &g = a.g;
+    for_each_chunk<1>(g, 1, [&](int, long i, long j, long k, long e) {
+        double acc = 0;
+        for (int c = 0; c < g.ndim; c++) {
+            const int ax = 3 - g.ndim + c;
+            const long pa = (ax == 0) ? g.p0 : (ax == 1) ? g.p1 : 1;
+            const double dx = a.dx[ax];
+            const T *ca = in + (long)c * g.pc;
+            const double hi = (double)ca[e + pa], lo = (double)ca[e - pa], mid = (double)ca[e];
+            const double d = (a.method == PDEHIP_CENTRAL) ? hi - lo : (a.method == PDEHIP_FORWARD) ? hi - mid : mid - lo;
+            double t;
+            if (g.ndim == 1)  // cartesian.py:843-848
+                t = (a.method == PDEHIP_CENTRAL) ? d / (2 * dx) : d / dx;
+            else              // cartesian.py:889-900, :942-957
+                t = d * ((a.method == PDEHIP_CENTRAL) ? 0.5 / dx : 1 / dx);
+            acc = (c == 0) ? t : acc + t;
+        }
+        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)acc;
+    });
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gradsq_kernel(DerivArgs a)
+{
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const DevGrid &g = a.g;
+    for_each_chunk<1>(g, 1, [&](int, long i, long j, long k, long e) {
+        const double mid = (double)in[e];
+        double acc = 0;
+        for (int c = 0; c < g.ndim; c++) {
+            const int ax = 3 - g.ndim + c;
+            const long pa = (ax == 0) ? g.p0 : (ax == 1) ? g.p1 : 1;
+            const double dx = a.dx[ax];
+            const double hi = (double)in[e + pa], lo = (double)in[e - pa];
+            double t;
+            if (a.method) {  // cartesian.py:665-668 central
+                const double d = hi - lo;
+                t = d * d * (0.25 / (dx * dx));
+            } else {         // cartesian.py:674-688 mean of forward/backward squares
+                const double dl = hi - mid, dr = mid - lo;
+                t = (dl * dl + dr * dr) * (0.5 / (dx * dx));
+            }
+            acc = (c == 0) ? t : acc + t;
+        }
+        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)acc;
+    });
+}
+
+static int launch_deriv(int which, const pdehip_grid_t *g, int method, const void *in, void *out,
+                        int layout, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in || !out) PDEHIP_FAIL(E_VALUE, "operator: NULL array pointer");
+    if (layout != PDEHIP_OUT_VALID && layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", layout);
+    if (which != 2 && (method < 0 || method > 2)) PDEHIP_FAIL(E_VALUE, "Unknown derivative type `%d`", method);
+    OutStr o = out_strides(n, layout);
+    DerivArgs a;
+    a.g = dev_grid(n);
+    a.in = in; a.out = out;
+    a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1; a.o_sc = o.sc;
+    for (int q = 0; q < 3; q++) a.dx[q] = n.dx[q];
+    a.method = method;
+    const unsigned blocks = grid_blocks(n.n[0] * n.n[1] * n.n[2]);
+    hipStream_t st = as_stream(stream);
+#define PDEHIP_LAUNCH(KERNEL)                                                                  \
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((KERNEL<double>), dim3(blocks), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((KERNEL<float>), dim3(blocks), dim3(256), 0, st, a);
+    if (which == 0) { PDEHIP_LAUNCH(gradient_kernel) }
+    else if (which == 1) { PDEHIP_LAUNCH(divergence_kernel) }
+    else { PDEHIP_LAUNCH(gradsq_kernel) }
+#undef PDEHIP_LAUNCH
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- layout conversion ---------------------------------------------------------------------------
+struct CopyArgs {
+    DevGrid g;
+    const void *src;
+    void *dst;
+    int ncomp;
+    int mode;  // 0 valid->full, 1 full->valid, 2 hostfull->full (all cells), 3 full->hostfull
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) layout_copy_kernel(CopyArgs a)
+{
+    const DevGrid &g = a.g;
+    if (a.mode < 2) {
+        const T *src = (const T *)a.src;
+        T *dst = (T *)a.dst;
+        for_each_chunk<1>(g, a.ncomp, [&](int comp, long i, long j, long k, long e) {
+            const long v = (((long)comp * g.n0 + i) * g.n1 + j) * g.n2 + k;
+            if (a.mode == 0) dst[e] = src[v];
+            else dst[v] = src[e];
+        });
+    } else {
+        // compact host-full layout: shape (ncomp, [n0+2], [n1+2], n2+2) for the used axes
+        const long g0 = (g.ndim >= 3) ? 1 : 0, g1 = (g.ndim >= 2) ? 1 : 0;
+        const long m0 = g.n0 + 2 * g0, m1 = g.n1 + 2 * g1, m2 = g.n2 + 2;
+        const long total = (long)a.ncomp * m0 * m1 * m2;
+        const T *src = (const T *)a.src;
+        T *dst = (T *)a.dst;
+        const long lpad = g.off - g0 * g.p0 - g1 * g.p1;  // column of the first interior cell
+        for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+            long r = t;
+            const long k = r % m2; r /= m2;
+            const long j = r % m1; r /= m1;
+            const long i = r % m0;
+            const long comp = r / m0;
+            const long e = comp * g.pc + i * g.p0 + j * g.p1 + (lpad - 1) + k;
+            if (a.mode == 2) dst[e] = src[t];
+            else dst[t] = src[e];
+        }
+    }
+}
+
+static int launch_copy(const pdehip_grid_t *g, int ncomp, const void *src, void *dst, int mode, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!src || !dst) PDEHIP_FAIL(E_VALUE, "layout copy: NULL array pointer");
+    if (ncomp < 1) PDEHIP_FAIL(E_VALUE, "ncomp must be >= 1");
+    CopyArgs a;
+    a.g = dev_grid(n); a.src = src; a.dst = dst; a.ncomp = ncomp; a.mode = mode;
+    const unsigned blocks = grid_blocks((long)ncomp * (n.n[0] + 2) * (n.n[1] + 2) * (n.n[2] + 2));
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((layout_copy_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((layout_copy_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- pointwise kernels of the RK steppers ----------------------------------------------------------
+struct LinArgs {
+    DevGrid g;
+    int ncomp, n;
+    void *out;
+    const void *y;
+    const void *k[6];
+    double coef[6];
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) lincomb_kernel(LinArgs a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        // evaluated left to right like `y + b1*k1 + b2*k2 + ...` (runge_kutta.py:135-145)
+        double acc[VEC];
+        int s = 0;
+        if (a.y) {
+            const V yv = *(const V *)((const T *)a.y + e);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) acc[q] = (double)yv[q];
+        } else {
+            const V k0 = *(const V *)((const T *)a.k[0] + e);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) acc[q] = a.coef[0] * (double)k0[q];
+            s = 1;
+        }
+        for (int m = s; m < a.n; m++) {
+            const V kv = *(const V *)((const T *)a.k[m] + e);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) acc[q] = acc[q] + a.coef[m] * (double)kv[q];
+        }
+        V o;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) o[q] = (T)acc[q];
+        *(V *)((T *)a.out + e) = o;
+    });
+}
+
+struct Rk4Args {
+    DevGrid g;
+    int ncomp;
+    void *y;
+    const void *k1, *k2, *k3, *k4;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) rk4_combine_kernel(Rk4Args a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        const V y = *(const V *)((const T *)a.y + e);
+        const V k1 = *(const V *)((const T *)a.k1 + e), k2 = *(const V *)((const T *)a.k2 + e);
+        const V k3 = *(const V *)((const T *)a.k3 + e), k4 = *(const V *)((const T *)a.k4 + e);
+        V o;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            // pde/solvers/runge_kutta.py:60
+            const double s = ((double)k1[q] + 2 * (double)k2[q] + 2 * (double)k3[q] + (double)k4[q]) / 6;
+            o[q] = (T)((double)y[q] + s);
+        }
+        *(V *)((T *)a.y + e) = o;
+    });
+}
+
+// block-wide max of non-negative doubles (NaN propagates: its bit pattern is the largest)
+__device__ __forceinline__ void block_max_to(double v, double *dst)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+#pragma unroll
+    for (int ofs = 32; ofs >= 1; ofs >>= 1) {
+        const unsigned long long o = __shfl_xor(b, ofs, 64);
+        b = (o > b) ? o : b;
+    }
+    __shared__ unsigned long long part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = part[0];
+        for (int q = 1; q < (int)(blockDim.x >> 6); q++) m = (part[q] > m) ? part[q] : m;
+        atomicMax((unsigned long long *)dst, m);
+    }
+}
+__device__ __forceinline__ double abs_nan_canon(double e)
+{
+    e = fabs(e);
+    return (e != e) ? __longlong_as_double(0x7ff8000000000000LL) : e;
+}
+__device__ __forceinline__ double max_nan(double a, double b)
+{
+    const unsigned long long x = (unsigned long long)__double_as_longlong(a), y = (unsigned long long)__double_as_longlong(b);
+    return __longlong_as_double((long long)((x > y) ? x : y));
+}
+
+struct Rkf45Args {
+    DevGrid g;
+    int ncomp;
+    const void *y;
+    void *ynew;
+    const void *k[6];
+    double *err;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) rkf45_combine_kernel(Rkf45Args a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    // pde/solvers/runge_kutta.py:117-125 (same quotients as the reference source)
+    const double r1 = 1.0 / 360, r3 = -128.0 / 4275, r4 = -2197.0 / 75240, r5 = 1.0 / 50, r6 = 2.0 / 55;
+    const double c1 = 25.0 / 216, c3 = 1408.0 / 2565, c4 = 2197.0 / 4104, c5 = -1.0 / 5;
+    double emax = 0;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        const V y = *(const V *)((const T *)a.y + e);
+        const V k1 = *(const V *)((const T *)a.k[0] + e), k3 = *(const V *)((const T *)a.k[2] + e);
+        const V k4 = *(const V *)((const T *)a.k[3] + e), k5 = *(const V *)((const T *)a.k[4] + e);
+        const V k6 = *(const V *)((const T *)a.k[5] + e);
+        V o;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            const double d1 = k1[q], d3 = k3[q], d4 = k4[q], d5 = k5[q], d6 = k6[q];
+            const double el = r1 * d1 + r3 * d3 + r4 * d4 + r5 * d5 + r6 * d6;   // :147
+            emax = max_nan(emax, abs_nan_canon(el));                              // :148
+            o[q] = (T)((double)y[q] + c1 * d1 + c3 * d3 + c4 * d4 + c5 * d5);    // :150
+        }
+        *(V *)((T *)a.ynew + e) = o;
+    });
+    block_max_to(emax, a.err);
+}
+
+struct DiffArgs {
+    DevGrid g;
+    int ncomp;
+    const void *a, *b;
+    double *err;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) max_abs_diff_kernel(DiffArgs a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    double emax = 0;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        const V x = *(const V *)((const T *)a.a + e), y = *(const V *)((const T *)a.b + e);
+#pragma unroll
+        for (int q = 0; q < VEC; q++) emax = max_nan(emax, abs_nan_canon((double)x[q] - (double)y[q]));
+    });
+    block_max_to(emax, a.err);
+}
+
+template <typename T> static constexpr int vec_of() { return 16 / sizeof(T); }
+
+#define PDEHIP_VEC_LAUNCH(KERNEL, ARGS, ITEMS)                                                         \
+    do {                                                                                               \
+        hipStream_t _st = as_stream(stream);                                                           \
+        if (n.dtype == PDEHIP_F64) {                                                                   \
+            if (n.n[2] % 2 == 0) hipLaunchKernelGGL((KERNEL<double, 2>), dim3(grid_blocks((ITEMS) / 2)), dim3(256), 0, _st, ARGS); \
+            else hipLaunchKernelGGL((KERNEL<double, 1>), dim3(grid_blocks(ITEMS)), dim3(256), 0, _st, ARGS); \
+        } else {                                                                                       \
+            if (n.n[2] % 4 == 0) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(grid_blocks((ITEMS) / 4)), dim3(256), 0, _st, ARGS); \
+            else hipLaunchKernelGGL((KERNEL<float, 1>), dim3(grid_blocks(ITEMS)), dim3(256), 0, _st, ARGS); \
+        }                                                                                              \
+        PDEHIP_HIP(hipGetLastError());                                                                 \
+    } while (0)
+
+}  // namespace pdehip
+
+using namespace pdehip;
+
+extern "C" {
+
+int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, void *full, void *stream)
+{ return launch_copy(g, ncomp, valid, full, 0, stream); }
+int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *valid, void *stream)
+{ return launch_copy(g, ncomp, full, valid, 1, stream); }
+int pdehip_hostfull_to_full(const pdehip_grid_t *g, int ncomp, const void *hostfull_dev, void *full, void *stream)
+{ return launch_copy(g, ncomp, hostfull_dev, full, 2, stream); }
+int pdehip_full_to_hostfull(const pdehip_grid_t *g, int ncomp, const void *full, void *hostfull_dev, void *stream)
+{ return launch_copy(g, ncomp, full, hostfull_dev, 3, stream); }
+
+int pdehip_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_face_t *faces, void *data_full, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    return launch_ghosts(n, ncomp, faces, data_full, as_stream(stream));
+}
+
+static int lap_entry(const pdehip_grid_t *g, const void *in, void *out, int layout, int mode, double s1,
+                     double s2, double gamma, const void *y, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (layout != PDEHIP_OUT_VALID && layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", layout);
+    return launch_laplace(n, in, out, out_strides(n, layout), mode, s1, s2, gamma, y, as_stream(stream));
+}
+
+int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream)
+{ return lap_entry(g, in_full, out, out_layout, LAP_PLAIN, 0, 0, 0, nullptr, stream); }
+int pdehip_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out_full, double s1, double s2, void *stream)
+{ return lap_entry(g, in_full, out_full, PDEHIP_OUT_FULL, LAP_SCALED, s1, s2, 0, nullptr, stream); }
+int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void *y_full, void *out_full, double s1, double s2, void *stream)
+{ return lap_entry(g, in_full, out_full, PDEHIP_OUT_FULL, LAP_EULER, s1, s2, 0, y_full, stream); }
+int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full, double gamma, void *stream)
+{ return lap_entry(g, c_full, mu_full, PDEHIP_OUT_FULL, LAP_CH_MU, 0, 0, gamma, nullptr, stream); }
+
+int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
+{ return launch_deriv(0, g, method, in_full, out, out_layout, stream); }
+int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
+{ return launch_deriv(1, g, method, in_full, out, out_layout, stream); }
+int pdehip_gradient_squared(const pdehip_grid_t *g, int central, const void *in_full, void *out, int out_layout, void *stream)
+{ return launch_deriv(2, g, central ? 1 : 0, in_full, out, out_layout, stream); }
+
+int pdehip_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int nk,
+                   const double *coef_host, const void *const *k_full_host, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (nk < 1 || nk > 6) PDEHIP_FAIL(E_VALUE, "lincomb supports 1..6 terms (got %d)", nk);
+    if (!out_full || !coef_host || !k_full_host) PDEHIP_FAIL(E_VALUE, "lincomb: NULL pointer");
+    LinArgs a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.n = nk; a.out = out_full; a.y = y_full;
+    for (int q = 0; q < 6; q++) { a.k[q] = q < nk ? k_full_host[q] : nullptr; a.coef[q] = q < nk ? coef_host[q] : 0; }
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(lincomb_kernel, a, items);
+    return 0;
+}
+
+int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const void *k1, const void *k2,
+                       const void *k3, const void *k4, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!y_full || !k1 || !k2 || !k3 || !k4) PDEHIP_FAIL(E_VALUE, "rk4_combine: NULL pointer");
+    Rk4Args a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.k4 = k4;
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(rk4_combine_kernel, a, items);
+    return 0;
+}
+
+int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew,
+                         const void *const *k6_host, double *err_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!y || !ynew || !k6_host || !err_dev) PDEHIP_FAIL(E_VALUE, "rkf45_combine: NULL pointer");
+    PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
+    Rkf45Args a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.y = y; a.ynew = ynew; a.err = err_dev;
+    for (int q = 0; q < 6; q++) a.k[q] = k6_host[q];
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(rkf45_combine_kernel, a, items);
+    return 0;
+}
+
+int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, const void *b_full,
+                        double *out_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!a_full || !b_full || !out_dev) PDEHIP_FAIL(E_VALUE, "max_abs_diff: NULL pointer");
+    PDEHIP_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), as_stream(stream)));
+    DiffArgs a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.a = a_full; a.b = b_full; a.err = out_dev;
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(max_abs_diff_kernel, a, items);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// pdehip_steppers.hip — fused right-hand sides and explicit time steppers (host-side launch
+// sequences on one stream; no host synchronisation inside a step loop).
+//
+// Kernel budget per step (algorithmic HBM traffic, values per cell):
+//   diffusion Euler        : ghosts + laplace_euler                     = 1 read + 1 write
+//   Cahn–Hilliard Euler    : ghosts + ch_mu (1r+1w) + ghosts + laplace_euler(mu; y=c) (2r+1w) = 5 values
+//   RK stage               : lincomb (1+j reads, 1 write) + rhs_scaled
+#include "pdehip_common.h"
+
+using namespace pdehip;
+
+namespace {
+
+// RKF45 tableau, pde/solvers/runge_kutta.py:92-112 (identical quotients)
+const double B2[] = {1.0 / 4};
+const double B3[] = {3.0 / 32, 9.0 / 32};
+const double B4[] = {1932.0 / 2197, -7200.0 / 2197, 7296.0 / 2197};
+const double B5[] = {439.0 / 216, -8.0, 3680.0 / 513, -845.0 / 4104};
+const double B6[] = {-8.0 / 27, 2.0, -3544.0 / 2565, 1859.0 / 4104, -11.0 / 40};
+
+int check_rhs(const pdehip_rhs_t *rhs)
+{
+    if (!rhs) PDEHIP_FAIL(E_VALUE, "rhs descriptor is NULL");
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION && rhs->kind != PDEHIP_RHS_CAHN_HILLIARD)
+        PDEHIP_FAIL(E_NOTIMPL, "unknown rhs kind %d", rhs->kind);
+    if (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD && !rhs->scratch_mu)
+        PDEHIP_FAIL(E_VALUE, "Cahn-Hilliard rhs needs a scratch array for mu");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full,
+                      double dt, void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    // numba/backend.py:501-517: set BCs on the full array, then apply the stencil
+    PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_c, y_full, stream));
+    if (rhs->kind == PDEHIP_RHS_DIFFUSION)
+        return pdehip_laplace_scaled(g, y_full, k_out_full, rhs->param, dt, stream);  // dt*(D*lap)
+    PDEHIP_TRY(pdehip_cahn_hilliard_mu(g, y_full, rhs->scratch_mu, rhs->param, stream));
+    PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_mu, rhs->scratch_mu, stream));
+    return pdehip_laplace_scaled(g, rhs->scratch_mu, k_out_full, 1.0, dt, stream);
+}
+
+int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b, double dt,
+                     int64_t nsteps, void **result, void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    if (!buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "euler_run: NULL pointer");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "euler_run: negative step count");
+    void *cur = buf_a, *nxt = buf_b;
+    for (int64_t s = 0; s < nsteps; s++) {
+        PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_c, cur, stream));
+        if (rhs->kind == PDEHIP_RHS_DIFFUSION) {
+            // state + dt * (D * laplace(state))   euler.py:174 with diffusion.py:121
+            PDEHIP_TRY(pdehip_laplace_euler(g, cur, cur, nxt, rhs->param, dt, stream));
+        } else {
+            PDEHIP_TRY(pdehip_cahn_hilliard_mu(g, cur, rhs->scratch_mu, rhs->param, stream));
+            PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_mu, rhs->scratch_mu, stream));
+            PDEHIP_TRY(pdehip_laplace_euler(g, rhs->scratch_mu, cur, nxt, 1.0, dt, stream));
+        }
+        void *t = cur; cur = nxt; nxt = t;
+    }
+    *result = cur;
+    return 0;
+}
+
+int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    if (!y || !w) PDEHIP_FAIL(E_VALUE, "rk4_step: NULL pointer");
+    void *k1 = w[0], *k2 = w[1], *k3 = w[2], *k4 = w[3], *tmp = w[4];
+    const double half = 0.5, one = 1.0;
+    const void *kk[1];
+    // runge_kutta.py:52-61
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, k1, dt, stream));
+    kk[0] = k1; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k2, dt, stream));
+    kk[0] = k2; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k3, dt, stream));
+    kk[0] = k3; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &one, kk, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k4, dt, stream));
+    return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, stream);
+}
+
+int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *ynew, void *const *w,
+                         double dt, double *err_dev, void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    if (!y || !ynew || !w || !err_dev) PDEHIP_FAIL(E_VALUE, "rkf45_attempt: NULL pointer");
+    void *tmp = w[6];
+    const void *k[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+    // runge_kutta.py:135-145
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, w[0], dt, stream));
+    PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, B2, k, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[1], dt, stream));
+    PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 2, B3, k, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[2], dt, stream));
+    PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 3, B4, k, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[3], dt, stream));
+    PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 4, B5, k, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[4], dt, stream));
+    PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 5, B6, k, stream));
+    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[5], dt, stream));
+    // runge_kutta.py:147-150
+    return pdehip_rkf45_combine(g, 1, y, ynew, k, err_dev, stream);
+}
+
+}  // extern "C"

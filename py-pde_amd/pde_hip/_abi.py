@@ -1,0 +1,152 @@
+"""ctypes mirror of ``include/pdehip.h`` (structs, enums and prototype table).
+
+The same table is used to bind ``libpdehip.so`` (the product) and — by ``oracle/pde_oracle.py``
+only, for tests — the CPU oracle, whose entry points have the same signatures without the
+trailing stream argument.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+MAX_DIM = 3
+ABI_VERSION = 1
+
+F64, F32 = 0, 1
+CENTRAL, FORWARD, BACKWARD = 0, 1, 2
+OUT_VALID, OUT_FULL = 0, 1
+BC_SKIP, BC_ORDER1, BC_ORDER2 = 0, 1, 2
+BCF_ARRAYS, BCF_NORMAL = 1, 2
+RHS_DIFFUSION, RHS_CAHN_HILLIARD = 0, 1
+
+METHODS = {"central": CENTRAL, "forward": FORWARD, "backward": BACKWARD}
+
+_DTYPES = {np.dtype(np.float64): F64, np.dtype(np.float32): F32}
+
+
+def dtype_code(dtype) -> int:
+    """Translate a numpy dtype to the PDEHIP_F* code; complex/ints are not supported."""
+    dt = np.dtype(dtype)
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        msg = f"hip backend supports float64 and float32 fields only (got {dt})"
+        raise NotImplementedError(msg) from None
+
+
+class Grid(C.Structure):
+    _fields_ = [
+        ("ndim", C.c_int32),
+        ("dtype", C.c_int32),
+        ("shape", C.c_int64 * MAX_DIM),
+        ("dx", C.c_double * MAX_DIM),
+    ]
+
+
+class BCFace(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("flags", C.c_int32),
+        ("index1", C.c_int64),
+        ("index2", C.c_int64),
+        ("const_v", C.c_double),
+        ("factor1", C.c_double),
+        ("factor2", C.c_double),
+        ("const_arr", C.c_void_p),
+        ("factor1_arr", C.c_void_p),
+        ("factor2_arr", C.c_void_p),
+    ]
+
+
+FaceArray = BCFace * (2 * MAX_DIM)
+
+
+class RHS(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("reserved", C.c_int32),
+        ("param", C.c_double),
+        ("bc_c", FaceArray),
+        ("bc_mu", FaceArray),
+        ("scratch_mu", C.c_void_p),
+    ]
+
+
+def make_grid(shape, dx, dtype) -> Grid:
+    """Build the POD grid descriptor from ``grid.shape`` / ``grid.discretization``."""
+    shape = tuple(int(s) for s in shape)
+    if not 1 <= len(shape) <= MAX_DIM:
+        msg = f"hip backend supports 1 to {MAX_DIM} dimensional Cartesian grids"
+        raise NotImplementedError(msg)
+    g = Grid()
+    g.ndim = len(shape)
+    g.dtype = dtype_code(dtype)
+    for a in range(MAX_DIM):
+        g.shape[a] = shape[a] if a < len(shape) else 1
+        g.dx[a] = float(dx[a]) if a < len(shape) else 1.0
+    return g
+
+
+_vp = C.c_void_p
+_pg = C.POINTER(Grid)
+_pf = C.POINTER(BCFace)
+_pr = C.POINTER(RHS)
+_pd = C.POINTER(C.c_double)
+_pvp = C.POINTER(C.c_void_p)
+_i, _i64, _d = C.c_int, C.c_int64, C.c_double
+
+# name -> argument types WITHOUT the trailing stream argument.  ``True`` in the second slot
+# marks functions that take a stream in libpdehip (the oracle twin drops it).
+COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
+    "valid_to_full": ([_pg, _i, _vp, _vp], True),
+    "full_to_valid": ([_pg, _i, _vp, _vp], True),
+    "hostfull_to_full": ([_pg, _i, _vp, _vp], True),
+    "full_to_hostfull": ([_pg, _i, _vp, _vp], True),
+    "set_ghost_cells": ([_pg, _i, _pf, _vp], True),
+    "laplace": ([_pg, _vp, _vp, _i], True),
+    "gradient": ([_pg, _i, _vp, _vp, _i], True),
+    "divergence": ([_pg, _i, _vp, _vp, _i], True),
+    "gradient_squared": ([_pg, _i, _vp, _vp, _i], True),
+    "laplace_scaled": ([_pg, _vp, _vp, _d, _d], True),
+    "laplace_euler": ([_pg, _vp, _vp, _vp, _d, _d], True),
+    "cahn_hilliard_mu": ([_pg, _vp, _vp, _d], True),
+    "lincomb": ([_pg, _i, _vp, _vp, _i, _pd, _pvp], True),
+    "rk4_combine": ([_pg, _i, _vp, _vp, _vp, _vp, _vp], True),
+    "rkf45_combine": ([_pg, _i, _vp, _vp, _pvp, _vp], True),
+    "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
+    "rhs_scaled": ([_pg, _pr, _vp, _vp, _d], True),
+    "euler_run": ([_pg, _pr, _vp, _vp, _d, _i64, _pvp], True),
+    "rk4_step": ([_pg, _pr, _vp, _pvp, _d], True),
+    "rkf45_attempt": ([_pg, _pr, _vp, _vp, _pvp, _d, _vp], True),
+}
+
+RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
+    "last_error": ([], C.c_char_p),
+    "abi_version": ([], _i),
+    "device_count": ([C.POINTER(_i)], _i),
+    "set_device": ([_i], _i),
+    "device_name": ([C.c_char_p, C.c_size_t], _i),
+    "layout": ([_pg, C.POINTER(C.c_int64)], _i),
+    "malloc": ([_pvp, C.c_size_t], _i),
+    "free": ([_vp], _i),
+    "memset": ([_vp, _i, C.c_size_t, _vp], _i),
+    "memcpy_h2d": ([_vp, _vp, C.c_size_t, _vp], _i),
+    "memcpy_d2h": ([_vp, _vp, C.c_size_t, _vp], _i),
+    "memcpy_d2d": ([_vp, _vp, C.c_size_t, _vp], _i),
+    "stream_create": ([_pvp], _i),
+    "stream_destroy": ([_vp], _i),
+    "stream_synchronize": ([_vp], _i),
+    "stream_wait_event": ([_vp, _vp], _i),
+    "event_create": ([_pvp], _i),
+    "event_destroy": ([_vp], _i),
+    "event_record": ([_vp, _vp], _i),
+    "event_synchronize": ([_vp], _i),
+    "event_elapsed_ms": ([_vp, _vp, C.POINTER(C.c_float)], _i),
+}
+
+
+def exported_symbols() -> list[str]:
+    """All symbols ``include/pdehip.h`` declares (checked by tests/test_cabi.py)."""
+    return ["pdehip_" + n for n in list(RUNTIME_PROTOTYPES) + list(COMPUTE_PROTOTYPES)]

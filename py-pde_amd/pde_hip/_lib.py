@@ -1,0 +1,111 @@
+"""ctypes binding of ``libpdehip.so`` (the C ABI declared in ``include/pdehip.h``).
+
+The library is built in-tree by ``py-pde_amd/Makefile`` (``__graft_entry__.build()``) into
+``py-pde_amd/lib/libpdehip.so``.  There is NO fallback: if the shared object is missing or no
+HIP device is visible, every compute entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+from . import _abi
+
+LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libpdehip.so"
+
+_E_VALUE, _E_NOTIMPL = 1, 2
+
+
+class HipRuntimeError(RuntimeError):
+    """An HIP runtime call inside libpdehip failed."""
+
+
+class _Lib:
+    """Thin wrapper turning the int status convention into Python exceptions.
+
+    Error mapping: 1 → ValueError, 2 → NotImplementedError,
+    anything else → RuntimeError, always with ``pdehip_last_error()`` as message.
+    """
+
+    def __init__(self, path: Path):
+        if not path.exists():
+            msg = (
+                f"{path} not found - build it with `make -C {path.parent.parent}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "The hip backend has no CPU fallback."
+            )
+            raise ImportError(msg)
+        self.path = path
+        self._h = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
+        for name, (args, res) in _abi.RUNTIME_PROTOTYPES.items():
+            fn = getattr(self._h, "pdehip_" + name)
+            fn.argtypes = args
+            fn.restype = res
+        for name, (args, has_stream) in _abi.COMPUTE_PROTOTYPES.items():
+            fn = getattr(self._h, "pdehip_" + name)
+            fn.argtypes = [*args, C.c_void_p] if has_stream else list(args)
+            fn.restype = C.c_int
+        if self._h.pdehip_abi_version() != _abi.ABI_VERSION:
+            msg = "libpdehip.so ABI version mismatch - rebuild the library"
+            raise ImportError(msg)
+
+    def last_error(self) -> str:
+        return self._h.pdehip_last_error().decode(errors="replace")
+
+    def check(self, rc: int) -> None:
+        if rc == 0:
+            return
+        msg = self.last_error()
+        if rc == _E_VALUE:
+            raise ValueError(msg)
+        if rc == _E_NOTIMPL:
+            raise NotImplementedError(msg)
+        raise HipRuntimeError(f"{msg} [code {rc}]")
+
+    def __getattr__(self, name: str):
+        fn = getattr(self._h, "pdehip_" + name)
+        if fn.restype is not C.c_int:
+            return fn
+
+        def call(*args):
+            self.check(fn(*args))
+
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
+
+
+_LIB: _Lib | None = None
+_DEVICE_READY = False
+
+
+def get_lib() -> _Lib:
+    """Load libpdehip.so (once)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib(LIB_PATH)
+    return _LIB
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    try:
+        get_lib().device_count(C.byref(n))
+    except HipRuntimeError:
+        return 0
+    return n.value
+
+
+def require_device(device: int | None = None) -> _Lib:
+    """Return the library after making sure a HIP device is usable; raise loudly otherwise."""
+    global _DEVICE_READY
+    lib = get_lib()
+    if not _DEVICE_READY or device is not None:
+        if device_count() < 1:
+            msg = "hip backend: no HIP device visible (MI355X required; there is no CPU fallback)"
+            raise RuntimeError(msg)
+        lib.set_device(0 if device is None else int(device))
+        _DEVICE_READY = True
+    return lib

@@ -1,0 +1,585 @@
+"""The ``hip`` backend: py-pde's backend plugin surface implemented on libpdehip.so.
+
+:class:`HipBackendMixin` implements the methods of ``pde.backends.base.BackendBase``
+(``pde/backends/base.py:65-755``) that the finite-difference / explicit-stepper hot path uses:
+``register_operator`` / ``get_operator_info`` (``:256-376``), ``make_operator_no_bc``
+(``:482-521``), ``make_operator`` (``:523-565``), ``make_ghost_cell_setter`` /
+``make_valid_data_setter`` / ``make_full_data_setter`` (``:378-429``), ``_apply_operator``
+(``:239-254``), ``numpy_to_native`` / ``native_to_numpy`` (``:186-205``), ``make_pde_rhs``
+(``:634-651``) and ``make_stepper`` (``:728-755``).
+
+The mixin only duck-types grids, boundary conditions, PDEs and solvers, so the same code
+serves (a) the stand-alone mirror classes of this package and (b) real py-pde objects when the
+backend is registered as a py-pde plugin (``pde_hip/pypde_plugin.py``).
+
+Native arrays are :class:`~pde_hip.device.DeviceArray` (ghost padded, device resident).
+There is no CPU path: everything below ends in a libpdehip call or raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import inspect
+import logging
+from collections import defaultdict
+from typing import Any, Callable, NamedTuple
+
+import numpy as np
+
+from . import _abi
+from ._lib import require_device
+from .device import DeviceArray, DeviceBuffer, DeviceScalar, GridInfo, ptr_array
+
+_logger = logging.getLogger("pde_hip.backend")
+
+
+class OperatorInfo(NamedTuple):
+    """Stores information about an operator (same fields as ``pde.grids.base.OperatorInfo``)."""
+
+    factory: Callable
+    rank_in: int
+    rank_out: int
+    name: str = ""
+
+
+# ---------------------------------------------------------------------------------------------
+# boundary conditions -> pdehip_bc_face_t[6]
+# ---------------------------------------------------------------------------------------------
+class FaceTable:
+    """ctypes face table + the device arrays it points to (kept alive with it)."""
+
+    def __init__(self):
+        self.c = _abi.FaceArray()
+        self.keepalive: list[DeviceBuffer] = []
+        for i in range(2 * _abi.MAX_DIM):
+            self.c[i].kind = _abi.BC_SKIP
+
+    def copy_into(self, dst) -> None:
+        for i in range(2 * _abi.MAX_DIM):
+            dst[i] = self.c[i]
+
+
+def _upload_f64(arr: np.ndarray) -> DeviceBuffer:
+    arr = np.ascontiguousarray(arr, dtype=np.float64)
+    buf = DeviceBuffer(arr.nbytes)
+    require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None)
+    return buf
+
+
+def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, bool]] | None = None, upload=None) -> FaceTable:
+    """Reduce a ``BoundariesList`` (mirror or real py-pde) to the C face table.
+
+    ``skip`` lists (axis, upper) faces that are filled by a halo exchange instead.  ``upload``
+    turns an fp64 host array into an object with a ``.ptr`` (default: copy to the device).
+    """
+    if upload is None:
+        upload = _upload_f64
+    if not hasattr(bcs, "__iter__"):
+        # BoundariesSetter & co: opaque python callables (pde/grids/boundaries/axes.py:504)
+        msg = "hip backend needs a BoundariesList of constant conditions"
+        raise NotImplementedError(msg)
+    grid = bcs.grid
+    table = FaceTable()
+    for ax, bc_axis in enumerate(bcs):
+        for upper, bc in ((False, bc_axis.low), (True, bc_axis.high)):
+            face = table.c[2 * ax + int(upper)]
+            if skip and (ax, upper) in skip:
+                continue
+            get = getattr(bc, "get_virtual_point_data", None)
+            if get is None or type(bc).__name__ in {"ExpressionBC", "ExpressionValueBC", "ExpressionDerivativeBC", "ExpressionMixedBC", "UserBC", "_MPIBC"}:
+                msg = f"hip backend does not support boundary condition {type(bc).__name__} (needs run-time code generation)"
+                raise NotImplementedError(msg)
+            data = get()
+            if len(data) == 3:
+                const, f1, i1 = data
+                f2, i2, kind = 0.0, 0, _abi.BC_ORDER1
+            elif len(data) == 5:
+                const, f1, i1, f2, i2 = data
+                kind = _abi.BC_ORDER2
+            else:
+                msg = f"unexpected virtual point data of {type(bc).__name__}"
+                raise NotImplementedError(msg)
+            face.kind = kind
+            face.index1, face.index2 = int(i1), int(i2)
+            normal = bool(getattr(bc, "normal", False))
+            face.flags = _abi.BCF_NORMAL if normal else 0
+            const, f1, f2 = np.asarray(const, dtype=np.float64), np.asarray(f1, dtype=np.float64), np.asarray(f2, dtype=np.float64)
+            if const.ndim == 0 and f1.ndim == 0 and f2.ndim == 0:
+                face.const_v, face.factor1, face.factor2 = float(const), float(f1), float(f2)
+                continue
+            # per (component, face cell) arrays.  Homogeneous tensor values have shape (dim,)*rank
+            # (local.py:1341-1352) and broadcast over the face; inhomogeneous ones carry the face.
+            face_shape = tuple(n for a, n in enumerate(grid.shape) if a != ax)
+            lead = () if normal else tuple(comp_shape)
+            target = lead + face_shape
+
+            def expand(v: np.ndarray) -> np.ndarray:
+                if bool(getattr(bc, "homogeneous", v.ndim <= len(lead))) and v.ndim <= len(lead):
+                    v = v.reshape(v.shape + (1,) * len(face_shape))
+                return np.broadcast_to(v, target)
+
+            face.flags |= _abi.BCF_ARRAYS
+            for name, v in (("const_arr", const), ("factor1_arr", f1), ("factor2_arr", f2)):
+                if name == "factor2_arr" and kind == _abi.BC_ORDER1:
+                    continue
+                buf = upload(np.ascontiguousarray(expand(v), dtype=np.float64))
+                table.keepalive.append(buf)
+                setattr(face, name, buf.ptr)
+    return table
+
+
+# ---------------------------------------------------------------------------------------------
+# right hand sides the fused steppers know
+# ---------------------------------------------------------------------------------------------
+class RhsSpec:
+    """``pdehip_rhs_t`` + everything that must stay alive with it."""
+
+    def __init__(self, kind: int, param: float, info: GridInfo, bc_c: FaceTable, bc_mu: FaceTable | None = None):
+        self.kind, self.param, self.info = kind, float(param), info
+        self.bc_c, self.bc_mu = bc_c, bc_mu
+        self.c = _abi.RHS()
+        self.c.kind = kind
+        self.c.param = float(param)
+        bc_c.copy_into(self.c.bc_c)
+        self.mu = None
+        if kind == _abi.RHS_CAHN_HILLIARD:
+            assert bc_mu is not None
+            bc_mu.copy_into(self.c.bc_mu)
+            self.mu = DeviceArray(info)
+            self.c.scratch_mu = self.mu.ptr
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _match_expression_rhs(expr_str: str, var: str, consts: dict[str, Any]) -> tuple[int, float] | None:
+    """Recognise ``D*laplace(c)`` and ``laplace(c**3 - c - g*laplace(c))`` (SURVEY.md cfg 5)."""
+    import sympy
+
+    expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
+    lap = sympy.Function("laplace")
+    c = sympy.Symbol(var)
+    local = {"laplace": lap, var: c}
+    for k, v in consts.items():
+        if np.isscalar(v):
+            local[k] = sympy.Float(float(v))
+    try:
+        expr = sympy.sympify(expr_str, locals=local)
+    except (sympy.SympifyError, SyntaxError, TypeError):
+        return None
+    D = sympy.Wild("D", exclude=[c, lap])
+    m = expr.match(D * lap(c))
+    if m is not None and m[D].is_number:
+        return _abi.RHS_DIFFUSION, float(m[D])
+    if isinstance(expr, lap) and len(expr.args) == 1:
+        inner = sympy.expand(expr.args[0])
+        g = sympy.Wild("g", exclude=[c, lap])
+        m = inner.match(c**3 - c - g * lap(c))
+        if m is not None and m[g].is_number:
+            return _abi.RHS_CAHN_HILLIARD, float(m[g])
+    return None
+
+
+class HipBackendMixin:
+    """Implementation shared by the stand-alone and the py-pde-plugin backend classes."""
+
+    implementation = "hip"
+    copy_data = True
+    supports_mpi = False
+
+    # set by concrete classes: _operators (per class), name, config
+    def _hip_init(self, device: int | None = None) -> None:
+        self._lib = require_device(device)
+        self.device = 0 if device is None else int(device)
+        self.stream = None  # HIP default stream; multi-GPU paths create their own
+        self._info_cache: dict[tuple, GridInfo] = {}
+        buf = C.create_string_buffer(256)
+        self._lib.device_name(buf, 256)
+        self.device_name = buf.value.decode()
+
+    @property
+    def info(self) -> dict[str, Any]:
+        return {"name": self.name, "implementation": self.implementation, "device": self.device_name}
+
+    # --- helpers -----------------------------------------------------------------------------
+    def grid_info(self, grid, dtype) -> GridInfo:
+        """Cached POD description of (grid, dtype)."""
+        if dtype is None:
+            dtype = np.float64
+        dt = np.dtype(dtype)
+        _abi.dtype_code(dt)  # raises NotImplementedError for complex (SURVEY.md §8b dtype)
+        key = (tuple(grid.shape), tuple(float(d) for d in grid.discretization), dt.str)
+        if key not in self._info_cache:
+            if not all(hasattr(grid, a) for a in ("shape", "discretization", "periodic")) or len(grid.shape) != getattr(grid, "dim", len(grid.shape)):
+                msg = f"hip backend only supports Cartesian grids (got {grid.__class__.__name__})"
+                raise NotImplementedError(msg)
+            self._info_cache[key] = GridInfo(grid.shape, grid.discretization, dt)
+        return self._info_cache[key]
+
+    def synchronize(self) -> None:
+        self._lib.stream_synchronize(self.stream)
+
+    # --- data movement -------------------------------------------------------------------------
+    def numpy_to_native(self, value, grid=None):
+        """Valid host data → :class:`DeviceArray` (needs ``grid`` to know the geometry)."""
+        if isinstance(value, DeviceArray) or not isinstance(value, np.ndarray):
+            return value
+        if grid is None:
+            msg = "hip backend: numpy_to_native needs the grid of the data"
+            raise TypeError(msg)
+        info = self.grid_info(grid, value.dtype)
+        comp_shape = value.shape[: value.ndim - len(info.shape)]
+        return DeviceArray(info, comp_shape).set_valid(value, self.stream)
+
+    def native_to_numpy(self, value):
+        if isinstance(value, DeviceArray):
+            return value.get_valid(stream=self.stream)
+        return value
+
+    def compile_function(self, func, **kwargs):
+        return func
+
+    # --- operator registry (pde/backends/base.py:256-376) ------------------------------------------
+    @classmethod
+    def register_operator(cls, grid_cls, name: str, factory_func=None, *, rank_in: int = 0, rank_out: int = 0):
+        def register(factory):
+            cls._operators[grid_cls][name] = OperatorInfo(factory=factory, rank_in=rank_in, rank_out=rank_out, name=name)
+            return factory
+
+        if factory_func is None:
+            return register
+        register(factory_func)
+        return None
+
+    def get_registered_operators(self, grid_id) -> set[str]:
+        grid_cls = grid_id if inspect.isclass(grid_id) else grid_id.__class__
+        ops: set[str] = set()
+        for backend_cls in inspect.getmro(self.__class__)[:-1]:
+            table = getattr(backend_cls, "_operators", {})
+            for gcls in inspect.getmro(grid_cls)[:-1]:
+                ops |= set(table.get(gcls, {}))
+        return ops
+
+    def get_operator_info(self, grid, operator):
+        if not isinstance(operator, str):
+            return operator
+        for backend_cls in inspect.getmro(self.__class__)[:-1]:
+            table = getattr(backend_cls, "_operators", {})
+            for gcls in inspect.getmro(grid.__class__)[:-1]:
+                if operator in table.get(gcls, {}):
+                    return table[gcls][operator]
+        msg = (
+            f"Backend `{self.name}` does not define operator '{operator}' for grid "
+            f"`{grid.__class__.__name__}`. Defined operators are: {sorted(self.get_registered_operators(grid))}."
+        )
+        raise NotImplementedError(msg)
+
+    # --- ghost cells (pde/backends/base.py:378-429) -------------------------------------------------
+    def make_ghost_cell_setter(self, bcs):
+        """``f(data_full: DeviceArray, args=None)`` — one fused kernel for all faces."""
+        tables: dict[tuple, FaceTable] = {}
+        lib = self._lib
+
+        def ghost_cell_setter(data_full: DeviceArray, args=None) -> None:
+            key = data_full.comp_shape
+            if key not in tables:
+                tables[key] = convert_bcs(bcs, key)
+            lib.set_ghost_cells(data_full.info.ref, data_full.ncomp, tables[key].c, data_full.ptr, self.stream)
+
+        return ghost_cell_setter
+
+    def make_valid_data_setter(self, grid, rank: int = 0):
+        def set_valid(data_full: DeviceArray, data_valid, args=None) -> None:
+            if isinstance(data_valid, DeviceArray):
+                # interior copy on the device: out = y + 0 is not bit-safe for -0.0, so copy bytes
+                self._lib.memcpy_d2d(data_full.ptr, data_valid.ptr, data_full.nbytes, self.stream)
+            else:
+                data_full.set_valid(np.asarray(data_valid), self.stream)
+
+        return set_valid
+
+    def make_full_data_setter(self, bcs):
+        set_valid = self.make_valid_data_setter(bcs.grid, 0)
+        set_bcs = self.make_ghost_cell_setter(bcs)
+
+        def set_valid_and_bcs(data_full: DeviceArray, data_valid, args=None) -> None:
+            set_valid(data_full, data_valid)
+            set_bcs(data_full, args=args)
+
+        return set_valid_and_bcs
+
+    # --- operators ------------------------------------------------------------------------------------
+    def make_operator_no_bc(self, grid, operator, *, dtype=None, **kwargs):
+        """``impl(arr_full: DeviceArray, out: DeviceArray)``; ghost cells are the caller's job."""
+        info = self.get_operator_info(grid, operator)
+        return info.factory(grid, backend=self, **kwargs)
+
+    def _apply_operator(self, func, *values: np.ndarray, out: np.ndarray, grid=None, **kwargs) -> None:
+        """Apply a native operator to host FULL arrays and write host ``out`` (base.py:239-254).
+
+        ``values`` are the reference's compact full arrays (``field._data_full``); ``out`` is
+        usually a strided interior view (fields/datafield_base.py:948).
+        """
+        if grid is None:
+            grid = getattr(func, "grid", None)
+        if grid is None:
+            msg = "hip backend: operator does not know its grid"
+            raise TypeError(msg)
+        nd = len(grid.shape)
+        natives = []
+        for v in values:
+            info = self.grid_info(grid, v.dtype)
+            natives.append(DeviceArray(info, v.shape[: v.ndim - nd]).set_hostfull(v, self.stream))
+        info = natives[0].info
+        res = DeviceArray(info, out.shape[: out.ndim - nd])
+        func(*natives, res, **kwargs)
+        out[...] = res.get_valid(stream=self.stream)
+
+    def make_operator(self, grid, operator, *, bcs, dtype=None, **kwargs):
+        """``op(arr, out=None, args=None) -> out`` with BCs (base.py:523-565, numpy/backend.py:178-255).
+
+        ``arr`` is a :class:`DeviceArray` (the ghost cells of ``arr`` itself are set in place —
+        the valid data is untouched) or, for convenience, host valid data, in which case host data
+        is returned.
+        """
+        info = self.get_operator_info(grid, operator)
+        op_no_bc = info.factory(grid, backend=self, **kwargs)
+        set_ghosts = self.make_ghost_cell_setter(bcs)
+        nd = len(grid.shape)
+        shape_in = (grid.dim,) * info.rank_in + tuple(grid.shape)
+        shape_out = (grid.dim,) * info.rank_out + tuple(grid.shape)
+
+        def apply_op(arr, out=None, args=None):
+            host = not isinstance(arr, DeviceArray)
+            if tuple(arr.shape) != shape_in:
+                msg = f"Incompatible shapes {tuple(arr.shape)} != {shape_in}"
+                raise ValueError(msg)
+            if out is not None and tuple(out.shape) != shape_out:
+                msg = f"Incompatible shapes {tuple(out.shape)} != {shape_out}"
+                raise ValueError(msg)
+            ginfo = self.grid_info(grid, arr.dtype if dtype is None or not host else dtype)
+            native = DeviceArray(ginfo, shape_in[: len(shape_in) - nd]).set_valid(np.asarray(arr), self.stream) if host else arr
+            set_ghosts(native, args=args)
+            res = out if isinstance(out, DeviceArray) else DeviceArray(native.info, shape_out[: len(shape_out) - nd])
+            op_no_bc(native, res)
+            if isinstance(out, DeviceArray):
+                return out
+            if host:
+                return res.get_valid(out=out, stream=self.stream)
+            return res
+
+        apply_op.grid = grid  # type: ignore[attr-defined]
+        return apply_op
+
+    # --- PDE right hand sides ---------------------------------------------------------------------------
+    def make_rhs_spec(self, eq, state) -> RhsSpec:
+        """Map a PDE object onto one of the fused device right-hand sides."""
+        name = eq.__class__.__name__
+        grid = state.grid
+        info = self.grid_info(grid, state.dtype)
+        if getattr(eq, "is_sde", False) or getattr(eq, "noise", 0):
+            msg = "hip backend does not support stochastic equations"
+            raise NotImplementedError(msg)
+        if state.__class__.__name__ != "ScalarField":
+            msg = "hip backend steppers support a single ScalarField state"
+            raise NotImplementedError(msg)
+        if name == "DiffusionPDE":
+            bcs = grid.get_boundary_conditions(eq.bc, rank=0)
+            return RhsSpec(_abi.RHS_DIFFUSION, eq.diffusivity, info, convert_bcs(bcs))
+        if name == "CahnHilliardPDE":
+            bc_c = grid.get_boundary_conditions(eq.bc_c, rank=0)
+            bc_mu = grid.get_boundary_conditions(eq.bc_mu, rank=0)
+            return RhsSpec(_abi.RHS_CAHN_HILLIARD, eq.interface_width, info, convert_bcs(bc_c), convert_bcs(bc_mu))
+        if name == "PDE":
+            rhs = dict(eq.rhs)
+            if len(rhs) != 1:
+                msg = "hip backend supports expression PDEs of a single scalar variable"
+                raise NotImplementedError(msg)
+            (var, expr), = rhs.items()
+            match = _match_expression_rhs(str(expr), var, dict(getattr(eq, "consts", {}) or {}))
+            if match is None:
+                msg = f"hip backend has no fused kernel for the expression `{expr}`"
+                raise NotImplementedError(msg)
+            bc_data = getattr(eq, "bc", "auto_periodic_neumann")
+            bc_ops = dict(getattr(eq, "bc_ops", {}) or {})
+            bc_data = bc_ops.get(f"{var}:laplace", bc_ops.get("*:laplace", bc_ops.get("*:*", bc_data)))
+            bcs = grid.get_boundary_conditions(bc_data, rank=0)
+            kind, param = match
+            table = convert_bcs(bcs)
+            return RhsSpec(kind, param, info, table, convert_bcs(bcs) if kind == _abi.RHS_CAHN_HILLIARD else None)
+        msg = f"hip backend has no fused right-hand side for {name}"
+        raise NotImplementedError(msg)
+
+    def make_pde_rhs(self, eq, state):
+        """``rhs(state_native, t) -> rate_native`` (base.py:634-651)."""
+        spec = self.make_rhs_spec(eq, state)
+        lib = self._lib
+
+        def pde_rhs(state_data: DeviceArray, t: float = 0) -> DeviceArray:
+            out = state_data.empty_like()
+            # 1.0 * (D * lap) == D * lap exactly
+            lib.rhs_scaled(spec.info.ref, spec.ref, state_data.ptr, out.ptr, 1.0, self.stream)
+            return out
+
+        pde_rhs.spec = spec  # type: ignore[attr-defined]
+        return pde_rhs
+
+    # --- steppers ----------------------------------------------------------------------------------------------
+    def make_inner_stepper(self, solver, state):
+        """Device-level stepper ``(state: DeviceArray, t_start, t_end) -> (DeviceArray, t_last)``.
+
+        Fixed steps follow ``pde/backends/numba/_solvers.py:93-118``; the adaptive loop follows
+        ``:240-281`` with ``_make_dt_adjuster`` (``pde/solvers/base.py:559-592``).
+        """
+        from .solvers import make_dt_adjuster
+
+        solver_name = solver.__class__.__name__
+        if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver"}:
+            msg = f"Backend `{self.name}` does not support solver {solver_name}"
+            raise NotImplementedError(msg)
+        spec = self.make_rhs_spec(solver.pde, state)
+        info, lib, stream = spec.info, self._lib, self.stream
+        is_rk = solver_name == "RungeKuttaSolver"
+        adaptive = bool(getattr(solver, "adaptive", False))
+        work = [DeviceArray(info) for _ in range((7 if adaptive else 5) if is_rk else (2 if adaptive else 1))]
+        work_ptrs = ptr_array(work)
+        if not adaptive:
+            dt = float(solver.info["dt"])
+
+            def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+                steps = max(1, round((t_end - t_start) / dt))
+                if is_rk:
+                    for _ in range(steps):
+                        lib.rk4_step(info.ref, spec.ref, state_data.ptr, work_ptrs, dt, stream)
+                    result = state_data
+                else:
+                    res = C.c_void_p()
+                    lib.euler_run(info.ref, spec.ref, state_data.ptr, work[0].ptr, dt, steps, C.byref(res), stream)
+                    if res.value != state_data.ptr:
+                        lib.memcpy_d2d(state_data.ptr, res.value, state_data.nbytes, stream)
+                    result = state_data
+                solver.info["steps"] += steps
+                return result, t_start + (steps - 1) * dt + dt  # `t + dt` of the last iteration
+
+            return fixed_stepper
+
+        # adaptive stepping --------------------------------------------------------------------
+        from .solvers import OnlineStatistics
+
+        solver.info["dt_adaptive"] = True
+        solver.info.setdefault("dt_statistics", OnlineStatistics())
+        adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
+        tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
+        err_dev = DeviceScalar()
+        ynew = DeviceArray(info)
+        sync_errors = getattr(solver, "_sync_errors", None) or (lambda e: e)
+
+        def attempt(state_data: DeviceArray, dt_step: float) -> float:
+            if is_rk:
+                lib.rkf45_attempt(info.ref, spec.ref, state_data.ptr, ynew.ptr, work_ptrs, dt_step, err_dev.ptr, stream)
+            else:
+                # generic estimate (solvers/base.py:409-423): one full step vs two half steps
+                res = C.c_void_p()
+                k1, k2a = work[0], work[1]
+                lib.euler_run(info.ref, spec.ref, state_data.ptr, k1.ptr, dt_step, 1, C.byref(res), stream)
+                lib.euler_run(info.ref, spec.ref, state_data.ptr, k2a.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
+                lib.euler_run(info.ref, spec.ref, k2a.ptr, ynew.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
+                lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
+            return err_dev.value(stream)
+
+        def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+            nonlocal ynew
+            dt_opt = float(solver.info["dt"])
+            t, steps = t_start, 0
+            stats = solver.info["dt_statistics"]
+            while True:
+                dt_step = max(min(dt_opt, t_end - t), dt_min)
+                error_rel = sync_errors(attempt(state_data, dt_step) / tolerance)
+                if error_rel <= 1:
+                    steps += 1
+                    t += dt_step
+                    lib.memcpy_d2d(state_data.ptr, ynew.ptr, state_data.nbytes, stream)
+                    stats.add(dt_step)
+                if t < t_end:
+                    dt_opt = adjust_dt(dt_step, error_rel)
+                else:
+                    break
+            solver.info["dt"] = dt_opt
+            solver.info["steps"] += steps
+            return state_data, t
+
+        return adaptive_stepper
+
+    def make_stepper(self, solver, state):
+        """``stepper(state_field, t_start, t_end) -> t_last`` mutating ``state.data`` (base.py:728-755).
+
+        Data crosses the PCIe bus once per call in each direction, i.e. once per tracker
+        interrupt, like the reference's torch backend (``pde/backends/torch/backend.py:654-662``).
+        """
+        inner = self.make_inner_stepper(solver, state)
+        info = self.grid_info(state.grid, state.dtype)
+        dev_state = DeviceArray(info)
+
+        def stepper(state_field, t_start: float, t_end: float) -> float:
+            dev_state.set_valid(state_field.data, self.stream)
+            result, t_last = inner(dev_state, t_start, t_end)
+            state_field.data[...] = result.get_valid(stream=self.stream)
+            return t_last
+
+        return stepper
+
+
+# ---------------------------------------------------------------------------------------------
+# stand-alone backend class + registry (mirrors pde/backends/registry.py:143-230 for one name)
+# ---------------------------------------------------------------------------------------------
+class BackendBase:
+    """Minimal stand-in for ``pde.backends.base.BackendBase`` used when py-pde is absent."""
+
+    _operators: dict = defaultdict(dict)
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        cls._operators = defaultdict(dict)
+        cls._logger = _logger.getChild(cls.__qualname__)
+
+    def __init__(self, config=None, *, name: str | None = None):
+        self.config = dict(config or {})
+        self.name = name or self.__class__.__name__
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(name={self.name!r})"
+
+
+class HipBackend(HipBackendMixin, BackendBase):
+    """MI355X backend (``backend="hip"`` or ``"hip:<device>"``)."""
+
+    def __init__(self, config=None, *, name: str = "hip", device: int | None = None):
+        super().__init__(config, name=name)
+        self._hip_init(device)
+
+    @classmethod
+    def from_args(cls, config, args: str = "", *, name: str | None = None):
+        """``get_backend("hip:2")`` → device 2 (pattern of torch/backend.py:82-96)."""
+        device = int(args) if args else None
+        return cls(config, name=name or (f"hip:{args}" if args else "hip"), device=device)
+
+
+_BACKENDS: dict[str, HipBackend] = {}
+
+
+def get_backend(backend="hip") -> HipBackend:
+    """Return the backend object for ``"hip"`` / ``"hip:<device>"`` or pass objects through."""
+    if isinstance(backend, HipBackendMixin):
+        return backend  # type: ignore[return-value]
+    if not isinstance(backend, str):
+        msg = f"Unknown backend {backend!r}"
+        raise TypeError(msg)
+    name, _, args = backend.partition(":")
+    if name not in {"hip", "default", "auto"}:
+        msg = f"pde_hip only provides the `hip` backend (got `{backend}`)"
+        raise KeyError(msg)
+    key = f"hip:{args}" if args else "hip"
+    if key not in _BACKENDS:
+        _BACKENDS[key] = HipBackend.from_args(None, args, name=key)
+    return _BACKENDS[key]

@@ -1,0 +1,105 @@
+"""Operator factories of the hip backend for Cartesian grids.
+
+Registered per ``(BackendClass, GridClass, name)`` exactly like the reference's numba operators
+(``pde/backends/numba/operators/cartesian.py:332``, ``:553``, ``:771``, ``:962``, ``:1026-1103``).
+Every factory returns ``impl(arr_full: DeviceArray, out: DeviceArray) -> None``; both arrays are in
+the device full layout and ``arr_full`` must have valid ghost cells.
+"""
+
+from __future__ import annotations
+
+from . import _abi
+from .device import DeviceArray
+
+
+def _check_method(method: str) -> int:
+    if method not in _abi.METHODS:
+        msg = f"Unknown derivative type `{method}`"
+        raise ValueError(msg)
+    return _abi.METHODS[method]
+
+
+def make_laplace(grid, *, backend, **kwargs):
+    """7/5/3-point Laplacian (cartesian.py:81-229, dispatch :332-383)."""
+    if kwargs.get("corner_weight"):
+        msg = "hip backend: 9-point 2-D stencil not implemented (SURVEY.md §8f)"
+        raise NotImplementedError(msg)
+    lib = backend._lib
+
+    def laplace(arr: DeviceArray, out: DeviceArray) -> None:
+        lib.laplace(arr.info.ref, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+    laplace.grid = grid
+    return laplace
+
+
+def make_gradient(grid, *, backend, method: str = "central", **kwargs):
+    """Gradient of a scalar field → vector field (cartesian.py:386-587)."""
+    code = _check_method(method)
+    lib = backend._lib
+
+    def gradient(arr: DeviceArray, out: DeviceArray) -> None:
+        lib.gradient(arr.info.ref, code, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+    gradient.grid = grid
+    return gradient
+
+
+def make_divergence(grid, *, backend, method: str = "central", **kwargs):
+    """Divergence of a vector field → scalar field (cartesian.py:812-996)."""
+    code = _check_method(method)
+    lib = backend._lib
+
+    def divergence(arr: DeviceArray, out: DeviceArray) -> None:
+        lib.divergence(arr.info.ref, code, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+    divergence.grid = grid
+    return divergence
+
+
+def make_gradient_squared(grid, *, backend, central: bool = True, **kwargs):
+    """Squared gradient magnitude (cartesian.py:590-809)."""
+    lib = backend._lib
+
+    def gradient_squared(arr: DeviceArray, out: DeviceArray) -> None:
+        lib.gradient_squared(arr.info.ref, int(bool(central)), arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+    gradient_squared.grid = grid
+    return gradient_squared
+
+
+def _vectorize_operator(make_operator, grid, **kwargs):
+    """Apply an operator to every component of the first tensor axis (cartesian.py:999-1023)."""
+    operator = make_operator(grid, **kwargs)
+    dim = grid.dim
+
+    def vectorized_operator(arr: DeviceArray, out: DeviceArray) -> None:
+        for i in range(dim):
+            operator(arr.component(i), out.component(i))
+
+    vectorized_operator.grid = grid
+    return vectorized_operator
+
+
+def make_vector_gradient(grid, *, backend, **kwargs):
+    return _vectorize_operator(make_gradient, grid, backend=backend, **kwargs)
+
+
+def make_vector_laplace(grid, *, backend, **kwargs):
+    return _vectorize_operator(make_laplace, grid, backend=backend, **kwargs)
+
+
+def make_tensor_divergence(grid, *, backend, **kwargs):
+    return _vectorize_operator(make_divergence, grid, backend=backend, **kwargs)
+
+
+def register_all(backend_cls, grid_cls) -> None:
+    """Register the Cartesian operators on ``backend_cls`` for ``grid_cls`` (and subclasses)."""
+    reg = backend_cls.register_operator
+    reg(grid_cls, "laplace", make_laplace, rank_in=0, rank_out=0)
+    reg(grid_cls, "gradient", make_gradient, rank_in=0, rank_out=1)
+    reg(grid_cls, "divergence", make_divergence, rank_in=1, rank_out=0)
+    reg(grid_cls, "gradient_squared", make_gradient_squared, rank_in=0, rank_out=0)
+    reg(grid_cls, "vector_gradient", make_vector_gradient, rank_in=1, rank_out=2)
+    reg(grid_cls, "vector_laplace", make_vector_laplace, rank_in=1, rank_out=1)
+    reg(grid_cls, "tensor_divergence", make_tensor_divergence, rank_in=2, rank_out=1)

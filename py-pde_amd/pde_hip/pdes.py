@@ -1,0 +1,109 @@
+"""PDE definitions on the hot path: Diffusion, Cahn–Hilliard and the expression class ``PDE``.
+
+Mirror of ``pde/pdes/base.py:355-565`` (``solve``, ``make_pde_rhs``), ``pde/pdes/diffusion.py:20-123``,
+``pde/pdes/cahn_hilliard.py:20-124`` and the subset of ``pde/pdes/pde.py`` whose right-hand sides
+map onto the fused device kernels.  ``evolution_rate`` is evaluated on the device.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+from .fields import ScalarField
+
+
+class PDEBase:
+    explicit_time_dependence = False
+    complex_valued = False
+    is_sde = False
+
+    def __init__(self):
+        self.diagnostics: dict[str, Any] = {}
+
+    def make_pde_rhs(self, state, backend="hip"):
+        """``rhs(state_native, t)`` from the backend (pdes/base.py:402-427)."""
+        from .backend import get_backend
+
+        return get_backend(backend).make_pde_rhs(self, state)
+
+    def evolution_rate(self, state: ScalarField, t: float = 0, *, backend="hip") -> ScalarField:
+        """Right-hand side for ``state`` as a new field (evaluated by the device kernels)."""
+        from .backend import get_backend
+
+        b = get_backend(backend)
+        rhs = b.make_pde_rhs(self, state)
+        native = b.numpy_to_native(state.data, grid=state.grid)
+        return ScalarField(state.grid, b.native_to_numpy(rhs(native, t)), label="evolution rate")
+
+    def solve(self, state, t_range, dt: float | None = None, tracker=None, *, solver="euler", ret_info: bool = False,
+              backend="hip", interval: float | None = None, **kwargs):
+        """Solve the PDE (pdes/base.py:451-565).  ``adaptive`` defaults to ``dt is None``."""
+        from .solvers import Controller, SolverBase
+
+        if isinstance(solver, str):
+            kwargs.setdefault("adaptive", dt is None)
+            solver_obj = SolverBase.from_name(solver, pde=self, backend=backend, **kwargs)
+        else:
+            solver_obj = solver
+        controller = Controller(solver_obj, t_range=t_range, tracker=tracker, interval=interval)
+        final = controller.run(state, dt)
+        self.diagnostics = controller.diagnostics
+        if ret_info:
+            return final, self.diagnostics
+        return final
+
+
+class DiffusionPDE(PDEBase):
+    r""":math:`\partial_t c = D \nabla^2 c` (pdes/diffusion.py)."""
+
+    default_bc = "auto_periodic_neumann"
+
+    def __init__(self, diffusivity: float = 1, *, bc=None, noise: float = 0):
+        super().__init__()
+        if noise:
+            msg = "hip backend does not support stochastic equations"
+            raise NotImplementedError(msg)
+        self.diffusivity = diffusivity
+        self.noise = 0
+        self.bc = self.default_bc if bc is None else bc
+
+    @property
+    def expression(self) -> str:
+        return f"{self.diffusivity} * laplace(c)"
+
+
+class CahnHilliardPDE(PDEBase):
+    r""":math:`\partial_t c = \nabla^2(c^3 - c - \gamma \nabla^2 c)` (pdes/cahn_hilliard.py)."""
+
+    default_bc_c = "auto_periodic_neumann"
+    default_bc_mu = "auto_periodic_neumann"
+
+    def __init__(self, interface_width: float = 1, *, bc_c=None, bc_mu=None):
+        super().__init__()
+        self.interface_width = interface_width
+        self.bc_c = self.default_bc_c if bc_c is None else bc_c
+        self.bc_mu = self.default_bc_mu if bc_mu is None else bc_mu
+
+    @property
+    def expression(self) -> str:
+        return f"laplace(c**3 - c - {self.interface_width} * laplace(c))"
+
+
+class PDE(PDEBase):
+    """PDE given by an expression string per variable (pdes/pde.py).
+
+    The hip backend recognises ``D*laplace(c)`` and ``laplace(c**3 - c - g*laplace(c))`` and runs
+    them on the fused kernels; any other expression raises ``NotImplementedError`` (a run-time
+    expression compiler is the next component).
+    """
+
+    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None):
+        super().__init__()
+        self.rhs = dict(rhs)
+        self.bc = bc
+        self.bc_ops = dict(bc_ops or {})
+        self.consts = dict(consts or {})
+
+    @property
+    def expression(self) -> str:
+        return next(iter(self.rhs.values()))

@@ -1,0 +1,117 @@
+"""Slab decomposition of a Cartesian grid along axis 0 (one slab per GPU / process).
+
+Partitioning arithmetic of the reference's ``GridMesh`` (``pde/grids/_mesh.py:96-111`` cell
+ranges, ``:401-444`` neighbours incl. periodic wrap, ``:535-569`` inter-node faces replaced by an
+exchange) restricted to the ``[n, 1, 1]`` decomposition: with axis-0 slabs in C order every halo
+face is one contiguous block, and every rank has exactly two neighbours (2 of its 7 xGMI links).
+The reference's "auto" choice would be 2x2x2 for 512^3 on 8 ranks — slabs are a deliberate
+deviation.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .grids import CartesianGrid
+
+
+def subdivide(num: int, chunks: int) -> np.ndarray:
+    """Cells per chunk, identical to ``_subdivide`` in pde/grids/_mesh.py:96-111."""
+    if chunks > num:
+        msg = f"Cannot divide {num} cells into {chunks} slabs"
+        raise RuntimeError(msg)
+    return np.diff(np.linspace(0, num, chunks + 1).astype(int))
+
+
+class SlabMesh:
+    """The part of a grid owned by ``rank`` out of ``size`` ranks."""
+
+    def __init__(self, grid: CartesianGrid, size: int, rank: int):
+        if not 0 <= rank < size:
+            msg = f"rank {rank} outside of world size {size}"
+            raise ValueError(msg)
+        self.grid, self.size, self.rank = grid, int(size), int(rank)
+        counts = subdivide(grid.shape[0], size)
+        offsets = np.concatenate([[0], np.cumsum(counts)])
+        self.counts = counts
+        self.lo, self.hi = int(offsets[rank]), int(offsets[rank + 1])
+        self.n_local = self.hi - self.lo
+        periodic0 = bool(grid.periodic[0])
+        # neighbours along axis 0 (None = physical boundary)
+        if size == 1:
+            self.lower = self.upper = None
+        else:
+            self.lower = rank - 1 if rank > 0 else (size - 1 if periodic0 else None)
+            self.upper = rank + 1 if rank < size - 1 else (0 if periodic0 else None)
+        (lo_b, _), dx0 = grid.axes_bounds[0], grid.discretization[0]
+        bounds = [(lo_b + self.lo * dx0, lo_b + self.hi * dx0), *grid.axes_bounds[1:]]
+        periodic = [periodic0 and size == 1, *grid.periodic[1:]]
+        self.subgrid = CartesianGrid(bounds, (self.n_local, *grid.shape[1:]), periodic)
+        # keep the discretization bit-identical to the parent grid (bounds arithmetic may round)
+        self.subgrid._discretization = grid.discretization.copy()
+
+    @property
+    def exchanged_faces(self) -> set[tuple[int, bool]]:
+        """(axis, upper) faces whose ghost layer comes from a neighbour instead of a BC."""
+        faces = set()
+        if self.lower is not None:
+            faces.add((0, False))
+        if self.upper is not None:
+            faces.add((0, True))
+        return faces
+
+    def extract(self, data: np.ndarray) -> np.ndarray:
+        """Local block of global valid data (``GridMesh.extract_field_data``, _mesh.py:446-479)."""
+        nd = self.grid.num_axes
+        idx = (...,) + (slice(self.lo, self.hi),) + (slice(None),) * (nd - 1)
+        return data[idx]
+
+    def sub_boundaries(self, bcs):
+        """BCs of the slab: physical BCs stay on outer faces; inter-slab faces get a placeholder
+        (they are listed in :attr:`exchanged_faces` and never evaluated).  Per-face arrays of the
+        other axes are sliced along axis 0; the reference refuses those
+        (``Cannot transfer complicated BC to subgrid``, local.py:1515-1540)."""
+        from .boundaries import BCBase, BoundariesList, BoundaryPair, BoundaryPeriodic, _PeriodicBC
+
+        out = []
+        for ax, pair in enumerate(bcs):
+            if ax == 0:
+                if isinstance(pair, BoundaryPeriodic) and self.size > 1:
+                    low = _PeriodicBC(self.subgrid, 0, False, rank=pair.low.rank, flip_sign=pair.flip_sign)
+                    high = _PeriodicBC(self.subgrid, 0, True, rank=pair.low.rank, flip_sign=pair.flip_sign)
+                    if pair.flip_sign:
+                        msg = "anti-periodic axis 0 cannot be slab decomposed"
+                        raise NotImplementedError(msg)
+                    out.append(BoundaryPair(low, high))
+                    continue
+                out.append(self._rebind_pair(pair, slice_axis0=False))
+            else:
+                out.append(self._rebind_pair(pair, slice_axis0=True))
+        return BoundariesList(out)
+
+    def _rebind_pair(self, pair, *, slice_axis0: bool):
+        from .boundaries import BoundaryPair, BoundaryPeriodic
+
+        if isinstance(pair, BoundaryPeriodic):
+            return BoundaryPeriodic(self.subgrid, pair.axis, rank=pair.low.rank, flip_sign=pair.flip_sign)
+        return BoundaryPair(self._rebind(pair.low, slice_axis0), self._rebind(pair.high, slice_axis0))
+
+    def _rebind(self, bc, slice_axis0: bool):
+        import copy
+
+        new = copy.copy(bc)
+        new.grid = self.subgrid
+        if slice_axis0 and not bc.homogeneous:
+            # face arrays of axes >= 1 have axis 0 as their first face axis
+            lead = len(bc._shape_tensor)
+            idx = (slice(None),) * lead + (slice(self.lo, self.hi),)
+            new._value = np.ascontiguousarray(bc.value[idx])
+            if hasattr(bc, "const") and np.ndim(bc.const) > lead:
+                new.const = np.ascontiguousarray(bc.const[idx])
+        return new
+
+
+def combine(blocks: list[np.ndarray], num_axes: int) -> np.ndarray:
+    """Concatenate per-rank valid blocks along axis 0 (``combine_field_data``, _mesh.py:657-696)."""
+    axis = blocks[0].ndim - num_axes
+    return np.concatenate(blocks, axis=axis)

@@ -1,0 +1,262 @@
+"""World-size-2 (and 3) CPU tests of the slab decomposition + halo-exchange orchestration.
+
+Like the reference's MPI tests (``tests/grids/test_grid_mesh.py:163-204`` exchanged ghosts ==
+ghosts of the unsplit field, ``tests/solvers/test_explicit_mpi_solvers.py:22-53`` distributed ==
+serial with equal step counts) but over ``torch.distributed``/gloo.  The numerical kernels are
+provided by an engine built on the CPU ORACLE (test infrastructure, injected here only); the
+orchestration — partitioning, BC hand-over, P2P ordering, overlap bookkeeping, MAX all-reduce — is
+the product code in ``pde_hip/distributed.py`` and ``pde_hip/mesh.py``.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from helpers import ROOT, host_faces, interior, oracle_grid, to_full
+
+import pde_hip
+from oracle import pde_oracle as O
+from pde_hip import _abi
+from pde_hip.mesh import SlabMesh, combine, subdivide
+
+
+class OracleEngine:
+    """CPU engine with the HipEngine interface; kernels = oracle functions, memory = torch CPU."""
+
+    device_type = "cpu"
+    torch = torch
+    comp = None
+    halo = None
+
+    def layout(self, g):
+        shape = [g.shape[a] for a in range(g.ndim)]
+        full = [s + 2 for s in shape]
+        return {"comp_elems": int(np.prod(full)), "slack": 0, "layer_pitch": int(np.prod(full[1:])) if len(full) > 1 else 1}
+
+    def alloc(self, nelems, dtype):
+        return torch.zeros(nelems, dtype=torch.float64 if np.dtype(dtype) == np.float64 else torch.float32)
+
+    def upload_f64(self, arr):
+        class Host:
+            pass
+
+        h = Host()
+        h.arr = np.ascontiguousarray(arr, dtype=np.float64)
+        h.ptr = h.arr.ctypes.data
+        return h
+
+    def _view(self, g, buf):
+        shape = tuple(g.shape[a] + 2 for a in range(g.ndim))
+        return buf.numpy().reshape(shape)
+
+    def set_valid(self, g, buf, host_valid):
+        nd = g.ndim
+        self._view(g, buf)[(slice(1, -1),) * nd] = host_valid
+
+    def get_valid(self, g, buf, shape, dtype):
+        return self._view(g, buf)[(slice(1, -1),) * g.ndim].copy()
+
+    def call(self, name, stream, *args):
+        rc = getattr(O.lib(), "oracle_" + name)(*args)
+        assert rc == 0, f"oracle_{name} -> {rc}"
+
+    def use(self, stream):
+        return contextlib.nullcontext()
+
+    def record(self, stream):
+        return None
+
+    def wait(self, stream, event):
+        return None
+
+    def synchronize(self):
+        return None
+
+    def scalar(self):
+        return torch.zeros(1, dtype=torch.float64)
+
+
+# ---- pure partitioning logic (single process) -------------------------------------------------------
+def test_subdivide_matches_reference_rule():
+    np.testing.assert_array_equal(subdivide(512, 8), [64] * 8)
+    np.testing.assert_array_equal(subdivide(10, 3), [3, 3, 4])  # np.diff(np.linspace(0,10,4).astype(int))
+    with pytest.raises(RuntimeError):
+        subdivide(2, 3)
+
+
+def test_mesh_split_combine_and_neighbours():
+    grid = pde_hip.CartesianGrid([[0, 5], [0, 2]], [10, 4], periodic=[True, False])
+    data = np.random.default_rng(0).random(grid.shape)
+    meshes = [SlabMesh(grid, 3, r) for r in range(3)]
+    np.testing.assert_array_equal(combine([m.extract(data) for m in meshes], 2), data)
+    assert [(m.lower, m.upper) for m in meshes] == [(2, 1), (0, 2), (1, 0)]
+    assert all(m.exchanged_faces == {(0, False), (0, True)} for m in meshes)
+    np.testing.assert_array_equal(meshes[1].subgrid.discretization, grid.discretization)
+    assert meshes[2].subgrid.shape == (4, 4) and meshes[2].subgrid.periodic == [False, False]
+    g2 = pde_hip.UnitGrid([8, 4], periodic=False)
+    m0, m1 = SlabMesh(g2, 2, 0), SlabMesh(g2, 2, 1)
+    assert (m0.lower, m0.upper, m1.lower, m1.upper) == (None, 1, 0, None)
+    assert m0.exchanged_faces == {(0, True)} and m1.exchanged_faces == {(0, False)}
+    one = SlabMesh(grid, 1, 0)
+    assert one.lower is None and one.subgrid.periodic == [True, False] and one.exchanged_faces == set()
+
+
+def test_sub_boundaries_slice_inhomogeneous_values():
+    grid = pde_hip.UnitGrid([8, 4], periodic=False)
+    vals = np.arange(8.0)
+    bcs = grid.get_boundary_conditions({"x-": {"value": 1.0}, "x+": {"derivative": 2.0}, "y-": {"value": vals}, "y+": "derivative"})
+    m1 = SlabMesh(grid, 2, 1)
+    sub = m1.sub_boundaries(bcs)
+    np.testing.assert_array_equal(sub[1].low.value, vals[4:])
+    assert sub[0].high.get_virtual_point_data()[2] == 3  # index relative to the slab
+    t = host_faces(sub, skip=m1.exchanged_faces)
+    assert t.c[0].kind == _abi.BC_SKIP and t.c[1].kind == _abi.BC_ORDER1
+
+
+# ---- multi-process runs ----------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, size, port, fn_name, queue):
+    try:
+        for p in (str(ROOT), str(ROOT / "py-pde_amd"), str(ROOT / "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+        result = globals()[fn_name](rank, size)
+        queue.put((rank, "ok", result))
+    except Exception:  # noqa: BLE001
+        queue.put((rank, "error", traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def run_distributed(fn_name: str, size: int):
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, size, port, fn_name, queue)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        rank, status, payload = queue.get(timeout=120)
+        assert status == "ok", f"rank {rank} failed:\n{payload}"
+        results[rank] = payload
+    for p in procs:
+        p.join(timeout=30)
+    return results
+
+
+def _serial_reference(eq, grid, data, t_range, dt, solver):
+    """Unsplit solve with the oracle driven by the same controller logic (see test_oracle_golden)."""
+    from test_oracle_golden import oracle_solve
+
+    case = {"bc": eq.bc if hasattr(eq, "bc") else eq.bc_c, "t_range": t_range, "dt": dt, "solver": solver}
+    if eq.__class__.__name__ == "DiffusionPDE":
+        case.update(pde="diffusion", D=eq.diffusivity)
+    else:
+        case.update(pde="cahn_hilliard", gamma=eq.interface_width)
+    return oracle_solve(case, grid, np.float64, data)
+
+
+CASES = {
+    "diff3d_periodic": (lambda: pde_hip.DiffusionPDE(0.8), lambda: pde_hip.UnitGrid([12, 6, 8], periodic=True), 2.0, 0.1, "euler"),
+    "diff2d_dirichlet": (lambda: pde_hip.DiffusionPDE(1.0, bc={"x-": {"value": 1.0}, "x+": {"derivative": 0.5}, "y": "periodic"}),
+                         lambda: pde_hip.CartesianGrid([[0, 5], [0, 3]], [10, 6], periodic=[False, True]), 1.0, 0.02, "euler"),
+    "ch2d_euler": (lambda: pde_hip.CahnHilliardPDE(0.7), lambda: pde_hip.UnitGrid([8, 8], periodic=[True, False]), 0.05, 1e-3, "euler"),
+    "ch2d_rk4": (lambda: pde_hip.CahnHilliardPDE(1.0), lambda: pde_hip.UnitGrid([9, 8], periodic=[False, True]), 0.02, 1e-3, "runge-kutta"),
+    "ch3d_rkf45": (lambda: pde_hip.CahnHilliardPDE(1.0), lambda: pde_hip.UnitGrid([8, 6, 6], periodic=True), 0.2, None, "runge-kutta"),
+    "diff1d_thin": (lambda: pde_hip.DiffusionPDE(1.0), lambda: pde_hip.UnitGrid([4], periodic=True), 1.0, 0.1, "euler"),
+}
+
+
+def solve_all_cases(rank, size):
+    from pde_hip.distributed import SlabStepper
+
+    out = {}
+    for name, (mk_eq, mk_grid, t_range, dt, solver) in CASES.items():
+        eq, grid = mk_eq(), mk_grid()
+        data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)  # replicated initial state
+        stepper = SlabStepper(eq, grid, engine=OracleEngine())
+        final, info = stepper.solve(data, t_range, dt, solver)
+        out[name] = (final, info["steps"], info["dt"])
+    return out
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_distributed_equals_serial(size):
+    """Slab-parallel solve == serial solve, BIT-EXACT, same step count (reference: rtol 1e-7)."""
+    results = run_distributed("solve_all_cases", size)
+    for name, (mk_eq, mk_grid, t_range, dt, solver) in CASES.items():
+        eq, grid = mk_eq(), mk_grid()
+        if grid.shape[0] < size:
+            continue
+        data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)
+        expect, steps, dt_last = _serial_reference(eq, grid, data, t_range, dt, solver)
+        for rank in range(size):
+            final, nsteps, dt_r = results[rank][name]
+            np.testing.assert_array_equal(final, expect, err_msg=f"{name} rank {rank}")
+            assert nsteps == steps
+            assert dt_r == pytest.approx(dt_last, rel=1e-12)
+
+
+def exchanged_ghosts(rank, size):
+    """After one exchange the ghost layers equal the neighbour's boundary layers."""
+    from pde_hip.distributed import SlabStepper
+
+    grid = pde_hip.UnitGrid([8, 5], periodic=[True, False])
+    data = np.arange(40.0).reshape(8, 5)
+    st = SlabStepper(pde_hip.DiffusionPDE(), grid, engine=OracleEngine())
+    buf = st.scatter(data)
+    st.start_exchange(buf, None)
+    st._ghosts(st.faces_c, buf, None)
+    return st.engine._view(st.g, buf).copy()
+
+
+def test_exchanged_ghost_cells_equal_unsplit_field():
+    """tests/grids/test_grid_mesh.py:163-204 — `assert_equal` on exchanged ghosts."""
+    size = 2
+    results = run_distributed("exchanged_ghosts", size)
+    grid = pde_hip.UnitGrid([8, 5], periodic=[True, False])
+    full = to_full(grid, np.arange(40.0).reshape(8, 5))
+    O.set_ghost_cells(oracle_grid(grid), 1, host_faces(grid.get_boundary_conditions("auto_periodic_neumann")).c, full)
+    for rank in range(size):
+        local = results[rank]
+        lo = rank * 4
+        np.testing.assert_array_equal(local[1:-1, :], full[lo + 1 : lo + 5, :])          # interior + y ghosts
+        np.testing.assert_array_equal(local[0, 1:-1], full[lo, 1:-1] if rank else full[8, 1:-1])   # lower ghost layer
+        np.testing.assert_array_equal(local[-1, 1:-1], full[lo + 5, 1:-1] if rank == 0 else full[1, 1:-1])
+
+
+def nan_error_sync(rank, size):
+    from pde_hip.distributed import SlabStepper
+
+    st = SlabStepper(pde_hip.DiffusionPDE(), pde_hip.UnitGrid([4, 4], periodic=True), engine=OracleEngine())
+    st.err[0] = float("nan") if rank == 1 else 0.5
+    a = st.sync_max(st.err)
+    st.err[0] = 0.25 * (rank + 1)
+    b = st.sync_max(st.err)
+    return (a, b)
+
+
+def test_error_max_allreduce_propagates_nan():
+    results = run_distributed("nan_error_sync", 2)
+    for rank in range(2):
+        a, b = results[rank]
+        assert np.isnan(a) and b == 0.5

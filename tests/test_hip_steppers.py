@@ -1,0 +1,194 @@
+"""GPU parity tests for the fused right-hand sides and explicit steppers.
+
+`eq.solve(..., backend="hip")` through the mirror API is compared with the reference's own
+solutions (tests/golden/steppers.npz) and, step by step, with the CPU oracle through the C ABI.
+Tolerances: fp64 bit-exact vs oracle and vs the reference torch-CPU Euler runs; 1e-10 relative
+(BASELINE.json north_star) vs the reference numpy+scipy RK4/RKF45/adaptive-Euler runs with equal
+step counts; fp32 1e-5 relative vs the reference's pure-fp32 torch run.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+from helpers import case_ids, get_case, host_faces, interior, make_grid, max_rel, oracle_grid, to_full
+
+import pde_hip
+from oracle import pde_oracle as O
+from pde_hip import _abi
+from pde_hip.device import DeviceArray, DeviceScalar, ptr_array
+
+pytestmark = pytest.mark.gpu
+
+STEPS = case_ids("steppers.npz")
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return pde_hip.get_backend("hip")
+
+
+def _make_eq(case):
+    if case["pde"] == "diffusion":
+        return pde_hip.DiffusionPDE(case["D"], bc=case["bc"])
+    return pde_hip.CahnHilliardPDE(case["gamma"], bc_c=case["bc"], bc_mu=case["bc"])
+
+
+@pytest.mark.parametrize("cid", STEPS)
+def test_solve_vs_reference(golden_steppers, cid):
+    case = get_case(golden_steppers, cid)
+    grid = make_grid(case)
+    dtype = np.dtype(case.get("dtype", "float64"))
+    state = pde_hip.ScalarField(grid, golden_steppers[f"{cid}/input"], dtype=dtype)
+    eq = _make_eq(case)
+    res, info = eq.solve(state, t_range=case["t_range"], dt=case["dt"], solver=case["solver"], backend="hip", ret_info=True)
+    ref = golden_steppers[f"{cid}/final"]
+    assert info["solver"]["steps"] == int(golden_steppers[f"{cid}/steps"])
+    np.testing.assert_allclose(info["controller"]["t_final"], float(golden_steppers[f"{cid}/t_final"]), rtol=1e-12)
+    assert res.data.dtype == dtype
+    if dtype == np.float32:
+        assert max_rel(res.data.astype(np.float64), ref.astype(np.float64)) < 1e-5
+    elif case["backend"] == "torch":
+        np.testing.assert_array_equal(res.data, ref)
+    else:
+        assert max_rel(res.data, ref) < 1e-10
+        np.testing.assert_allclose(info["solver"]["dt"], float(golden_steppers[f"{cid}/dt_last"]), rtol=1e-6)
+    if case["dt"] is None:
+        stats = info["solver"]["dt_statistics"]
+        assert stats["count"] == info["solver"]["steps"] and stats["min"] > 0
+    # the input state is not modified (Controller copies, controller.py:434)
+    np.testing.assert_array_equal(state.data, golden_steppers[f"{cid}/input"].astype(dtype))
+
+
+def test_expression_pde_equals_class(golden_steppers):
+    """PDE({'c': 'laplace(c**3 - c - laplace(c))'}) == CahnHilliardPDE (tests/pdes/test_generic_pdes.py:27-63)."""
+    cid = "ch2d_rkf45_numpy"
+    case = get_case(golden_steppers, cid)
+    grid = make_grid(case)
+    state = pde_hip.ScalarField(grid, golden_steppers[f"{cid}/input"])
+    eq = pde_hip.PDE({"c": "laplace(c**3 - c - laplace(c))"}, bc=case["bc"])
+    res = eq.solve(state, t_range=case["t_range"], dt=None, solver="runge-kutta", backend="hip")
+    assert max_rel(res.data, golden_steppers[f"{cid}/final"]) < 1e-10
+    eq_d = pde_hip.PDE({"u": "D * laplace(u)"}, bc=case["bc"], consts={"D": 0.5})
+    r1 = eq_d.evolution_rate(state).data
+    r2 = pde_hip.DiffusionPDE(0.5, bc=case["bc"]).evolution_rate(state).data
+    np.testing.assert_array_equal(r1, r2)
+    with pytest.raises(NotImplementedError, match="no fused kernel"):
+        pde_hip.PDE({"c": "laplace(c) + c**2"}).evolution_rate(state)
+
+
+def test_pde_rhs_vs_oracle(backend, rng):
+    """make_pde_rhs == numpy-semantics evolution_rate (tests/pdes/test_generic_pdes.py:27-63)."""
+    grid = pde_hip.CartesianGrid([[0, 4], [0, 6], [0, 5]], [8, 12, 10], periodic=[True, False, False])
+    bc = {"x": "periodic", "y": {"value": 0.2}, "z": {"derivative": 0.1}}
+    data = rng.uniform(-1, 1, grid.shape)
+    state = pde_hip.ScalarField(grid, data)
+    g = oracle_grid(grid)
+    faces = host_faces(grid.get_boundary_conditions(bc))
+    for eq, rhs in [
+        (pde_hip.DiffusionPDE(0.3, bc=bc), O.make_rhs(_abi.RHS_DIFFUSION, 0.3, faces.c)),
+        (pde_hip.CahnHilliardPDE(0.8, bc_c=bc, bc_mu=bc), O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, faces.c, faces.c, np.zeros(grid._shape_full))),
+    ]:
+        scratch = np.zeros(grid._shape_full)
+        rhs.scratch_mu = scratch.ctypes.data
+        expect = interior(grid, O.rhs_scaled(g, rhs, to_full(grid, data), 1.0))
+        np.testing.assert_array_equal(eq.evolution_rate(state).data, expect)
+
+
+@pytest.mark.parametrize("shape,dtype", [((32, 64), np.float64), ((8, 12, 128), np.float64), ((16, 16, 64), np.float32), ((50,), np.float64)])
+@pytest.mark.parametrize("kind", ["diffusion", "cahn_hilliard"])
+def test_cabi_steppers_vs_oracle(backend, rng, shape, dtype, kind):
+    """pdehip_euler_run / rk4_step / rkf45_attempt through the C ABI, bit-exact against the oracle."""
+    grid = pde_hip.CartesianGrid([[0, n * 0.9] for n in shape], shape, periodic=[True] + [False] * (len(shape) - 1))
+    bc = "auto_periodic_neumann"
+    bcs = grid.get_boundary_conditions(bc)
+    data = rng.uniform(-0.5, 0.5, shape).astype(dtype)
+    g = oracle_grid(grid, dtype)
+    hf = host_faces(bcs)
+    scratch = np.zeros(grid._shape_full, dtype)
+    if kind == "diffusion":
+        orhs = O.make_rhs(_abi.RHS_DIFFUSION, 0.6, hf.c)
+        eq = pde_hip.DiffusionPDE(0.6, bc=bc)
+    else:
+        orhs = O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.9, hf.c, hf.c, scratch)
+        eq = pde_hip.CahnHilliardPDE(0.9, bc_c=bc, bc_mu=bc)
+    dt = 0.002
+    state = pde_hip.ScalarField(grid, data, dtype=dtype)
+    spec = backend.make_rhs_spec(eq, state)
+    info, lib = spec.info, backend._lib
+
+    # Euler, 7 steps (odd -> result lands in the second buffer)
+    a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
+    res = C.c_void_p()
+    lib.euler_run(info.ref, spec.ref, a.ptr, b.ptr, dt, 7, C.byref(res), None)
+    assert res.value == b.ptr
+    np.testing.assert_array_equal(b.get_valid(), interior(grid, O.euler_run(g, orhs, to_full(grid, data), dt, 7)))
+
+    # RK4
+    y = DeviceArray(info).set_valid(data)
+    work = [DeviceArray(info) for _ in range(7)]
+    lib.rk4_step(info.ref, spec.ref, y.ptr, ptr_array(work[:5]), dt, None)
+    yo = to_full(grid, data)
+    O.rk4_step(g, orhs, yo, dt)
+    np.testing.assert_array_equal(y.get_valid(), interior(grid, yo))
+
+    # RKF45 attempt
+    y.set_valid(data)
+    ynew, err = DeviceArray(info), DeviceScalar()
+    lib.rkf45_attempt(info.ref, spec.ref, y.ptr, ynew.ptr, ptr_array(work), dt, err.ptr, None)
+    yo_new, err_o = O.rkf45_attempt(g, orhs, to_full(grid, data), dt)
+    np.testing.assert_array_equal(ynew.get_valid(), interior(grid, yo_new))
+    assert err.value() == err_o
+    np.testing.assert_array_equal(y.get_valid(), data)  # y itself is unchanged
+
+
+def test_nan_propagates_to_error_norm(backend):
+    """A NaN in the state must surface as error=NaN (adaptive loop shrinks dt, solvers/base.py:577-590)."""
+    grid = pde_hip.UnitGrid([16, 16], periodic=True)
+    data = np.zeros(grid.shape)
+    data[3, 4] = np.nan
+    eq = pde_hip.DiffusionPDE()
+    state = pde_hip.ScalarField(grid, data)
+    spec = backend.make_rhs_spec(eq, state)
+    y, ynew, err = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info), DeviceScalar()
+    work = [DeviceArray(spec.info) for _ in range(7)]
+    backend._lib.rkf45_attempt(spec.info.ref, spec.ref, y.ptr, ynew.ptr, ptr_array(work), 1e-3, err.ptr, None)
+    assert np.isnan(err.value())
+    with pytest.raises(RuntimeError, match="Encountered NaN"):
+        eq.solve(state, t_range=1.0, dt=None, solver="runge-kutta", backend="hip")
+
+
+def test_unsupported_solver_and_pde(backend):
+    grid = pde_hip.UnitGrid([8, 8])
+    state = pde_hip.ScalarField(grid, 1.0)
+
+    class ImplicitSolver(pde_hip.solvers.SolverBase):
+        name = "implicit-test"
+
+    with pytest.raises(NotImplementedError, match="does not support solver"):
+        pde_hip.DiffusionPDE().solve(state, 1.0, dt=0.1, solver=ImplicitSolver(pde_hip.DiffusionPDE()))
+    with pytest.raises(ValueError, match="Unknown solver"):
+        pde_hip.DiffusionPDE().solve(state, 1.0, dt=0.1, solver="no-such-solver")
+    with pytest.raises(NotImplementedError, match="stochastic"):
+        pde_hip.DiffusionPDE(noise=0.1)
+
+
+def test_diffusion_steady_state_and_erf(backend):
+    """Known answers of the reference's solver tests.
+
+    * heaviside initial state -> 0.5 + 0.5 erf(x/2) at t=1 within 1e-2 (tests/solvers/test_generic_solvers.py:123-148)
+    * Dirichlet steady state is linear (tests/pdes/test_diffusion_pdes.py:45-70)
+    """
+    from scipy.special import erf
+
+    grid = pde_hip.CartesianGrid([[-10, 10]], 100)
+    x = grid.axes_coords[0]
+    state = pde_hip.ScalarField(grid, (x > 0).astype(float))
+    for solver, dt in [("euler", 0.005), ("runge-kutta", 0.01), ("runge-kutta", None), ("euler", None)]:
+        res = pde_hip.DiffusionPDE().solve(state, t_range=1.0, dt=dt, solver=solver, backend="hip")
+        np.testing.assert_allclose(res.data, 0.5 + 0.5 * erf(x / 2), atol=1e-2, rtol=1e-2)
+    g2 = pde_hip.UnitGrid([16])
+    res = pde_hip.DiffusionPDE(bc={"x-": {"value": 0}, "x+": {"value": 1}}).solve(pde_hip.ScalarField(g2, 0.5), t_range=400, dt=0.2, backend="hip")
+    np.testing.assert_allclose(res.data, (g2.axes_coords[0]) / 16, atol=1e-3)

@@ -1,0 +1,242 @@
+"""Benchmark of the hot path: 3-D DiffusionPDE 512^3 fp64, explicit Euler, on N MI355X GPUs.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches one rank per GPU through torch.distributed.run.  One "step" = one explicit Euler
+step of the whole 512^3 grid = ghost-cell kernel + fused (Laplacian + D*, dt*, += ) kernel, state
+resident in HBM (ping-pong buffers), i.e. 16 algorithmic bytes per cell-step.
+N > 1 slab-decomposes the SAME grid along axis 0 (strong scaling) with RCCL halo exchange
+overlapped with the interior kernel (pde_hip/distributed.py).
+
+Rank 0 prints ONE JSON line with the whole-job throughput in Mcells/s (cell-steps per second),
+plus `roofline` for the dominant kernel (HIP-event timing on the launch stream) and, at N = 1,
+`cpu_baseline` = the CPU oracle (plain-C restatement of the reference formulas, OpenMP) timed on
+this box's host cores on a bounded sample of the same workload.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for _p in (ROOT, ROOT / "py-pde_amd"):
+    if str(_p) not in sys.path:
+        sys.path.insert(0, str(_p))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+BYTES_PER_CELL_STEP = 16  # fp64: 1 read + 1 write per cell
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=512, help="cells per axis (BASELINE config: 512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, seconds: float) -> dict:
+    """Time the oracle's Euler loop (reference formulas in C, OpenMP over axis 0 like numba's prange)."""
+    from oracle import pde_oracle as O
+    from pde_hip import _abi
+
+    n_cpu = min(n, 512)
+    cores = os.cpu_count() or 1
+    g = _abi.make_grid((n_cpu,) * 3, (1.0,) * 3, np.float64)
+    faces = _abi.FaceArray()
+    for ax in range(3):
+        for side, idx in ((0, n_cpu - 1), (1, 0)):  # periodic: lower reads N-1, upper reads 0
+            f = faces[2 * ax + side]
+            f.kind, f.flags, f.index1, f.const_v, f.factor1 = _abi.BC_ORDER1, 0, idx, 0.0, 1.0
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, 1.0, faces)
+    rng = np.random.default_rng(0)
+    a = O.valid_to_full((n_cpu,) * 3, rng.random((n_cpu,) * 3))
+    b = np.zeros_like(a)
+    res = C.c_void_p()
+    lib = O.lib()
+    lib.oracle_euler_run(C.byref(g), C.byref(rhs), a.ctypes.data, b.ctypes.data, 0.1, 1, C.byref(res))  # warm-up (page faults)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        lib.oracle_euler_run(C.byref(g), C.byref(rhs), a.ctypes.data, b.ctypes.data, 0.1, 2, C.byref(res))
+        steps += 2
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 40:
+            break
+    return {
+        "value": round(n_cpu**3 * steps / el / 1e6, 2),
+        "unit": "Mcells/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} Euler steps of DiffusionPDE {n_cpu}^3 fp64 periodic (oracle/pde_oracle.c, OpenMP {cores} threads, {el:.1f} s)",
+    }
+
+
+def bench_single(args) -> dict:
+    import pde_hip
+    from pde_hip.device import DeviceArray
+
+    backend = pde_hip.get_backend("hip")
+    lib = backend._lib
+    n = args.size
+    grid = pde_hip.UnitGrid([n, n, n], periodic=True)
+    eq = pde_hip.DiffusionPDE(1.0)
+    rng = np.random.default_rng(0)
+    state = pde_hip.ScalarField.random_uniform(grid, rng=rng)
+    spec = backend.make_rhs_spec(eq, state)
+    info = spec.info
+    a, b = DeviceArray(info).set_valid(state.data), DeviceArray(info)
+    stream = C.c_void_p()
+    lib.stream_create(C.byref(stream))
+    ev = [C.c_void_p() for _ in range(4)]
+    for e in ev:
+        lib.event_create(C.byref(e))
+    res = C.c_void_p()
+    dt = 0.1
+    lib.euler_run(info.ref, spec.ref, a.ptr, b.ptr, dt, args.warmup, C.byref(res), stream)
+    lib.stream_synchronize(stream)
+    cur = res.value
+    nxt = b.ptr if cur == a.ptr else a.ptr
+    # timed region: exactly K steps, bracketed by synchronisation
+    t0 = time.perf_counter()
+    lib.event_record(ev[0], stream)
+    lib.euler_run(info.ref, spec.ref, cur, nxt, dt, args.steps, C.byref(res), stream)
+    lib.event_record(ev[1], stream)
+    lib.stream_synchronize(stream)
+    wall = time.perf_counter() - t0
+    ms_events = C.c_float()
+    lib.event_elapsed_ms(ev[0], ev[1], C.byref(ms_events))
+    # dominant kernel alone (fused laplace+Euler), HIP events on its launch stream
+    reps = max(20, min(args.steps, 200))
+    lib.event_record(ev[2], stream)
+    for _ in range(reps):
+        lib.laplace_euler(info.ref, cur, cur, nxt, 1.0, dt, stream)
+    lib.event_record(ev[3], stream)
+    lib.stream_synchronize(stream)
+    ms_kernel = C.c_float()
+    lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms_kernel))
+    t_kernel = ms_kernel.value / reps * 1e-3
+    cells = n**3
+    achieved = cells * BYTES_PER_CELL_STEP / t_kernel / 1e9
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        try:
+            traffic = json.loads(tfile.read_text()).get(f"lap_march_euler_{n}")
+        except (ValueError, OSError):
+            traffic = None
+    out = {
+        "wall": wall,
+        "ms_events": ms_events.value,
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "lap_march_kernel<double,2,RY,EULER> (fused laplace + D*, dt*, +=)",
+            "kernel_ms": round(t_kernel * 1e3, 4), "algorithmic_bytes_per_launch": cells * BYTES_PER_CELL_STEP,
+        },
+        "device": backend.device_name,
+    }
+    return out
+
+
+def bench_distributed(args) -> dict:
+    import torch
+    import torch.distributed as dist
+
+    import pde_hip
+    from pde_hip.distributed import HipEngine, SlabStepper
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n = args.size
+    grid = pde_hip.UnitGrid([n, n, n], periodic=True)
+    eq = pde_hip.DiffusionPDE(1.0)
+    stepper = SlabStepper(eq, grid, engine=HipEngine(local_rank))
+    # synthetic data: every rank fills its own slab (no global array is ever materialised)
+    rng = np.random.default_rng(1000 + rank)
+    cur = stepper.buf("state_a")
+    stepper.engine.set_valid(stepper.g, cur, rng.random(stepper.mesh.subgrid.shape))
+    nxt = stepper.buf("state_b")
+    dt = 0.1
+    cur = stepper.euler_steps(cur, nxt, dt, args.warmup)
+    nxt = stepper.buf("state_b") if cur is stepper.buf("state_a") else stepper.buf("state_a")
+    stepper.engine.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cur = stepper.euler_steps(cur, nxt, dt, args.steps)
+    stepper.engine.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    wall = float(el.item())
+    # sanity: the field stays finite and its mean is conserved by periodic diffusion
+    local = stepper.gather_local(cur)
+    ok = bool(np.isfinite(local).all())
+    dist.destroy_process_group()
+    return {"wall": wall, "rank": rank, "finite": ok, "device": stepper.engine.lib and "MI355X"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = args.size
+    cells = n**3
+    if args.gpus > 1 or world > 1:
+        r = bench_distributed(args)
+        if r["rank"] != 0:
+            return
+        ngpu = max(args.gpus, world)
+        wall = r["wall"]
+        line = {"roofline": None, "cpu_baseline": None}
+        parallelism = f"slab{ngpu} (axis-0 slabs, RCCL send/recv halo exchange overlapped with interior kernel)"
+    else:
+        r = bench_single(args)
+        ngpu = 1
+        wall = r["wall"]
+        line = {"roofline": r["roofline"]}
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, args.cpu_seconds)
+        parallelism = "single GPU"
+    value = cells * args.steps / wall / 1e6
+    out = {
+        "metric": "Mcells/s (and % HBM roofline) for 3D DiffusionPDE 512^3 fp64; 1/2/4/8-GPU scaling",
+        "value": round(value, 1),
+        "unit": "Mcells/s",
+        "n_gpus": ngpu,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"DiffusionPDE(D=1) on UnitGrid([{n}]*3, periodic=True) fp64, explicit Euler dt=0.1, "
+                        "state resident in HBM, ghost cells + fused laplace/update per step",
+            "cells": cells,
+            "parallelism": parallelism,
+            "hbm_roofline_frac_whole_step": round(value * 1e6 * BYTES_PER_CELL_STEP / 1e9 / (HBM_PEAK_GBS * ngpu), 4),
+        },
+        **line,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

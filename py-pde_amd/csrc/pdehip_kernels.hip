@@ -71,6 +71,7 @@ struct LapArgs {
     int ndim;
     int lx;           // planes per x-chunk
     long nxc, nty, ntz, nblocks;
+    int no_swizzle;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,14 +84,14 @@ struct LapArgs {
 // 16-byte loads plus RY broadcast loads for the two z-halo cells of the wave tile, and RY
 // aligned 16-byte stores.  z-neighbours inside the tile are exchanged with DPP wave shifts.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int RY, int MODE, bool HAS_X, bool Y_IS_IN>
+template <typename T, int VEC, int RY, int MODE, bool HAS_X, bool Y_IS_IN, bool NT = false>
 __global__ void __launch_bounds__(256) lap_march_kernel(LapArgs a)
 {
     typedef typename VecT<T, VEC>::type V;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
 
-    long bid = xcd_swizzle(blockIdx.x, a.nblocks);
+    long bid = a.no_swizzle ? (long)blockIdx.x : xcd_swizzle(blockIdx.x, a.nblocks);
     const long tz = bid % a.ntz;
     bid /= a.ntz;
     const long ty = bid % a.nty;
@@ -184,7 +185,8 @@ __global__ void __launch_bounds__(256) lap_march_kernel(LapArgs a)
             }
             if (k_ok && (j0 + r) < a.n1) {
                 T *po = out + a.o_off + i * a.o_s0 + (j0 + r) * a.o_s1 + k0;
-                *(V *)po = res;
+                if (NT) __builtin_nontemporal_store(res, (V *)po);
+                else *(V *)po = res;
             }
         }
 
@@ -307,7 +309,7 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
     a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1;
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2; a.gamma = gamma;
-    a.ndim = n.ndim; a.lx = 1; a.nxc = a.nty = a.ntz = a.nblocks = 0;
+    a.ndim = n.ndim; a.lx = 1; a.nxc = a.nty = a.ntz = a.nblocks = 0; a.no_swizzle = 0;
 #define PDEHIP_MODE_SWITCH(T)                                                     \
     switch (mode) {                                                               \
     case LAP_PLAIN: return launch_laplace_t<T, LAP_PLAIN>(n, a, o, st);           \

@@ -87,7 +87,7 @@ inline int norm_grid(const pdehip_grid_t *g, NGrid *n)
 }
 
 // slack elements appended to every allocation so vector loads of clamped lanes stay in bounds
-constexpr long kAllocSlack = 64;
+constexpr long kAllocSlack = 2048;
 
 struct OutStr { long off, s0, s1, sc; };
 inline OutStr out_strides(const NGrid &n, int layout)
@@ -102,8 +102,19 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 // kernel launchers implemented in pdehip_kernels.hip
 enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3 };
+// input-side BCs the stencil kernel evaluates on the fly (scalar first-order conditions)
+struct InputBCs {
+    int on[3][2];      // [normalised axis][lower, upper]
+    long idx[3][2];
+    double c[3][2], f[3][2];
+};
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
-                   double s2, double gamma, const void *y, hipStream_t st);
+                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr);
+bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
+// BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`
+// (see pdehip_ops.hip)
+int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void *out, int mode, double s1,
+                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream);
 
 }  // namespace pdehip

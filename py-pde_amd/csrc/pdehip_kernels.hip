@@ -1,10 +1,18 @@
 // pdehip_kernels.hip — hand-written gfx950 (CDNA4) kernels for py-pde's Cartesian
-// finite-difference operators.  Bandwidth-bound stencil work: no MFMA.  The design goals are
-//   * every cell of the input is fetched from HBM once (register pipeline along the slowest axis,
-//     row re-use inside a wave, halo rows/columns served by L2),
-//   * every global access of the hot kernel is an aligned 16-byte (dwordx4) access,
-//   * neighbours along the fastest axis come from wavefront DPP shifts (64 lanes), not memory,
-//   * >> 256 workgroups per launch with an XCD-aware block -> tile map.
+// finite-difference operators.  Bandwidth-bound stencil work: no MFMA.  Design:
+//   * every cell of the input is fetched from HBM once: a wavefront marches along the slowest
+//     axis keeping three planes of its tile in registers (prev / cur / next),
+//   * a wave tile is RY rows x (CZ chunks of 64 lanes x 16 bytes): with CZ covering the whole
+//     fastest axis a wave streams RY*row_pitch CONTIGUOUS bytes per plane, which is what the
+//     HBM write path wants (measured: scattered 1 KiB pieces 4.0-4.4 TB/s, contiguous 5.6+),
+//   * every global access is an aligned 16-byte dwordx4; neighbours along the fastest axis come
+//     from wavefront DPP shifts / readlane, never from memory; the two halo cells of a wave
+//     tile are one broadcast load,
+//   * no LDS, no barriers: halo rows between neighbouring tiles are served by the XCD's L2,
+//     which is why the block -> tile map hands each XCD a contiguous range of tiles,
+//   * first-order BCs with scalar coefficients are evaluated on the fly on the input side (halo
+//     rows/planes/cells are loaded from the source layer and transformed), so that an Euler step
+//     is a single kernel and ghost cells are never materialised inside a time loop.
 // Arithmetic follows the reference expression order (pde/backends/numba/operators/
 // cartesian.py) and the file is compiled with -ffp-contract=off: results are bit-identical to
 // the CPU oracle.
@@ -18,14 +26,11 @@ namespace pdehip {
 template <typename T, int VEC> struct VecT;
 template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
 template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct VecT<double, 1> { typedef double type; };
-template <> struct VecT<float, 1> { typedef float type; };
 
 // wavefront shift by one lane through DPP (gfx9 wave_shr:1 / wave_shl:1).  Lane 0 (resp. lane
-// 63) has no source lane and keeps `old`, which carries the halo value of the wave's tile.
+// 63) has no source lane and keeps `old`, which carries the value from outside the chunk.
 __device__ __forceinline__ double wave_shr1(double old, double src)
 {
-    // lane i receives src of lane i-1
     unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
     int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x138, 0xf, 0xf, false);
     int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x138, 0xf, 0xf, false);
@@ -33,22 +38,27 @@ __device__ __forceinline__ double wave_shr1(double old, double src)
 }
 __device__ __forceinline__ double wave_shl1(double old, double src)
 {
-    // lane i receives src of lane i+1
     unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
     int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x130, 0xf, 0xf, false);
     int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x130, 0xf, 0xf, false);
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    unsigned long long s = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(s & 0xffffffffu), lane);
+    int hi = __builtin_amdgcn_readlane((int)(s >> 32), lane);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 
 // XCD-aware block -> work-item map: hardware places block b on XCD b % 8 (speed only, never
-// correctness).  Give every XCD a contiguous chunk of the tile list so that tiles which share
-// halo rows / planes also share an L2.
+// correctness).  Every XCD gets a contiguous range of the tile list so that tiles sharing halo
+// rows also share an L2.
 __device__ __forceinline__ long xcd_swizzle(long bid, long nblocks)
 {
-    const long nx = 8;
-    const long per = nblocks / nx;
-    if (bid >= per * nx) return bid;  // tail: identity
-    return (bid % nx) * per + bid / nx;
+    const long per = nblocks / 8;
+    if (bid >= per * 8) return bid;  // tail: identity
+    return (bid % 8) * per + bid / 8;
 }
 
 template <int MODE>
@@ -59,6 +69,13 @@ __device__ __forceinline__ double epilogue(double lap, double c, double yv, doub
     if (MODE == LAP_EULER) return yv + s2 * (s1 * lap);    // pde/solvers/euler.py:174
     return c * c * c - c - gamma * lap;                    // pde/pdes/cahn_hilliard.py:116-120
 }
+
+// boundary condition evaluated on the fly on the input side:  virtual = c + f * in[idx]
+struct InBC {
+    int on;
+    long idx;      // valid index along the axis the virtual value is computed from
+    double c, f;
+};
 
 struct LapArgs {
     const void *in;
@@ -72,135 +89,11 @@ struct LapArgs {
     int lx;           // planes per x-chunk
     long nxc, nty, ntz, nblocks;
     int no_swizzle;
+    int any_ibc;
+    InBC ibc[3][2];   // [normalised axis][lower, upper]
 };
 
-// ---------------------------------------------------------------------------------------------
-// The hot kernel: register-pipelined Laplacian (+ fused epilogue).
-//
-// A workgroup is 4 wavefronts stacked along y; each wavefront owns a tile of RY rows x
-// (64*VEC) cells of the fastest axis and marches over `lx` planes of the slowest axis, keeping
-// three planes in registers:  prev (centre rows), cur (centre rows + one halo row above and
-// below), next (same, prefetched one plane ahead).  Per plane a lane issues RY+2 aligned
-// 16-byte loads plus RY broadcast loads for the two z-halo cells of the wave tile, and RY
-// aligned 16-byte stores.  z-neighbours inside the tile are exchanged with DPP wave shifts.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int RY, int MODE, bool HAS_X, bool Y_IS_IN, bool NT = false>
-__global__ void __launch_bounds__(256) lap_march_kernel(LapArgs a)
-{
-    typedef typename VecT<T, VEC>::type V;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
-
-    long bid = a.no_swizzle ? (long)blockIdx.x : xcd_swizzle(blockIdx.x, a.nblocks);
-    const long tz = bid % a.ntz;
-    bid /= a.ntz;
-    const long ty = bid % a.nty;
-    const long xc = bid / a.nty;
-
-    const long kw = tz * (64 * VEC);          // first cell of the wave tile (valid index)
-    long k0 = kw + (long)lane * VEC;          // first cell of this lane
-    const bool k_ok = k0 < a.n2;
-    if (k0 > a.n2) k0 = a.n2;                 // clamp idle lanes (keeps loads in bounds)
-    const long j0 = ty * (4 * RY) + (long)w * RY;
-    if (j0 >= a.n1) return;                   // whole wave outside (no barriers are used)
-    const long i0 = xc * a.lx;
-    const long i1 = (i0 + a.lx < a.n0) ? i0 + a.lx : a.n0;
-
-    const T *in = (const T *)a.in;
-    T *out = (T *)a.out;
-    const T *yin = (const T *)a.y;
-
-    // row offsets (relative to plane base); rows beyond the grid are clamped to the ghost row
-    long roff[RY + 2];
-#pragma unroll
-    for (int r = 0; r < RY + 2; r++) {
-        long j = j0 + r - 1;
-        if (j > a.n1) j = a.n1;
-        roff[r] = a.off + j * a.p1;
-    }
-    // z-halo: lanes < 32 fetch the cell left of the tile, lanes >= 32 the cell right of it
-    long zh_k = (lane < 32) ? kw - 1 : kw + 64 * VEC;
-    if (zh_k > a.n2) zh_k = a.n2;
-
-    V cur[RY + 2], nxt[RY + 2];
-    V prev[RY];
-    T zh_cur[RY], zh_nxt[RY];
-
-    // prologue: plane i0-1 (prev, centre rows only), plane i0 (cur)
-    if (HAS_X) {
-        const T *pl = in + (i0 - 1) * a.p0;
-#pragma unroll
-        for (int r = 0; r < RY; r++) prev[r] = *(const V *)(pl + roff[r + 1] + k0);
-    }
-    {
-        const T *pl = in + i0 * a.p0;
-#pragma unroll
-        for (int r = 0; r < RY + 2; r++) cur[r] = *(const V *)(pl + roff[r] + k0);
-#pragma unroll
-        for (int r = 0; r < RY; r++) zh_cur[r] = pl[roff[r + 1] + zh_k];
-    }
-
-    for (long i = i0; i < i1; i++) {
-        if (HAS_X) {  // plane i+1 (the ghost plane when i+1 == n0)
-            const T *pl = in + (i + 1) * a.p0;
-#pragma unroll
-            for (int r = 0; r < RY + 2; r++) nxt[r] = *(const V *)(pl + roff[r] + k0);
-#pragma unroll
-            for (int r = 0; r < RY; r++) zh_nxt[r] = pl[roff[r + 1] + zh_k];
-        }
-        V yv[RY];
-        if (MODE == LAP_EULER && !Y_IS_IN) {
-#pragma unroll
-            for (int r = 0; r < RY; r++) yv[r] = *(const V *)(yin + i * a.p0 + roff[r + 1] + k0);
-        }
-
-#pragma unroll
-        for (int r = 0; r < RY; r++) {
-            const V cc = cur[r + 1], up = cur[r], dn = cur[r + 2];
-            const double zl = wave_shr1((double)zh_cur[r], (double)cc[VEC - 1]);
-            const double zr = wave_shl1((double)zh_cur[r], (double)cc[0]);
-            V res;
-#pragma unroll
-            for (int q = 0; q < VEC; q++) {
-                const double c = (double)cc[q];
-                const double left = (q == 0) ? zl : (double)cc[q > 0 ? q - 1 : 0];
-                const double right = (q == VEC - 1) ? zr : (double)cc[q < VEC - 1 ? q + 1 : q];
-                const double vm = 2 * c;
-                double lap;
-                if (HAS_X) {
-                    // cartesian.py:220-227
-                    const double lx = ((double)prev[r][q] - vm + (double)nxt[r + 1][q]) * a.sx;
-                    const double ly = ((double)up[q] - vm + (double)dn[q]) * a.sy;
-                    const double lz = (left - vm + right) * a.sz;
-                    lap = lx + ly + lz;
-                } else {
-                    // cartesian.py:147-151 (2-D; 1-D is handled by the generic kernel)
-                    const double ly = ((double)up[q] - vm + (double)dn[q]) * a.sy;
-                    const double lz = (left - vm + right) * a.sz;
-                    lap = ly + lz;
-                }
-                double yy = 0;
-                if (MODE == LAP_EULER) yy = Y_IS_IN ? c : (double)yv[r][q];
-                res[q] = (T)epilogue<MODE>(lap, c, yy, a.s1, a.s2, a.gamma);
-            }
-            if (k_ok && (j0 + r) < a.n1) {
-                T *po = out + a.o_off + i * a.o_s0 + (j0 + r) * a.o_s1 + k0;
-                if (NT) __builtin_nontemporal_store(res, (V *)po);
-                else *(V *)po = res;
-            }
-        }
-
-        if (HAS_X) {
-#pragma unroll
-            for (int r = 0; r < RY; r++) {
-                prev[r] = cur[r + 1];
-                zh_cur[r] = zh_nxt[r];
-            }
-#pragma unroll
-            for (int r = 0; r < RY + 2; r++) cur[r] = nxt[r];
-        }
-    }
-}
+#include "pdehip_march.inc"
 
 // ---------------------------------------------------------------------------------------------
 // generic fallback: one cell per thread, direct loads (any shape / any alignment / 1-D).
@@ -238,41 +131,55 @@ __global__ void __launch_bounds__(256) lap_generic_kernel(LapArgs a)
     }
 }
 
-static int g_force_generic = -1;
-static bool force_generic()
+// ---------------------------------------------------------------------------------------------
+// launch configuration
+// ---------------------------------------------------------------------------------------------
+struct Tune {
+    int ry, cz, wy, pf;
+    long blocks;
+    bool force_generic, set;
+};
+static Tune g_tune = {0, 0, 0, 0, 0, false, false};
+static const Tune &tune()
 {
-    if (g_force_generic < 0) {
+    if (!g_tune.set) {
+        g_tune.set = true;
         const char *e = getenv("PDEHIP_FORCE_GENERIC");
-        g_force_generic = (e && e[0] == '1') ? 1 : 0;
+        g_tune.force_generic = (e && e[0] == '1');
+        // PDEHIP_TUNE="ry,cz,wy,pf,blocks" selects one of the instantiated tile shapes (tuning aid)
+        if ((e = getenv("PDEHIP_TUNE")) != nullptr) sscanf(e, "%d,%d,%d,%d,%ld", &g_tune.ry, &g_tune.cz, &g_tune.wy, &g_tune.pf, &g_tune.blocks);
     }
-    return g_force_generic == 1;
+    return g_tune;
 }
 
-template <typename T, int VEC, int RY, int MODE, bool HAS_X>
-static int launch_march(const LapArgs &a0, bool y_is_in, hipStream_t st)
+template <typename T, int VEC, int RY, int CZ, int WY, int PF, int MODE, bool HAS_X>
+static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipStream_t st)
 {
     LapArgs a = a0;
-    a.ntz = (a.n2 + 64 * VEC - 1) / (64 * VEC);
-    a.nty = (a.n1 + 4 * RY - 1) / (4 * RY);
-    // choose the x-chunk length: enough workgroups to fill 256 CUs x ~8 waves, but chunks as
-    // long as possible (each chunk re-reads 2 halo planes)
-    long tiles = a.ntz * a.nty;
+    a.ntz = (a.n2 + 64 * VEC * CZ - 1) / (64 * VEC * CZ);
+    a.nty = (a.n1 + WY * RY - 1) / (WY * RY);
+    // x-chunk length: enough workgroups to keep 256 CUs streaming, chunks as long as possible
+    // (each chunk re-reads two halo planes)
+    const long tiles = a.ntz * a.nty;
     long lx = a.n0;
     if (HAS_X) {
-        const long want_blocks = 2048;
         long nxc = (want_blocks + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;
         if (nxc > a.n0) nxc = a.n0;
         lx = (a.n0 + nxc - 1) / nxc;
-        if (lx < 8 && a.n0 >= 8) lx = 8;
     }
     a.lx = (int)lx;
     a.nxc = (a.n0 + lx - 1) / lx;
     a.nblocks = a.nxc * tiles;
-    if (y_is_in)
-        hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, MODE, HAS_X, true>), dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, MODE, HAS_X, false>), dim3((unsigned)a.nblocks), dim3(256), 0, st, a);
+    constexpr bool kCanFuse = true;
+    const dim3 grid((unsigned)a.nblocks), block(64 * WY);
+    if (a.any_ibc) {
+        if (y_is_in) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, kCanFuse>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, false, kCanFuse>), grid, block, 0, st, a);
+    } else {
+        if (y_is_in) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, false, false>), grid, block, 0, st, a);
+    }
     PDEHIP_HIP(hipGetLastError());
     return 0;
 }
@@ -281,14 +188,33 @@ template <typename T, int MODE>
 static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, hipStream_t st)
 {
     constexpr int VEC = 16 / sizeof(T);
+    const Tune &tn = tune();
     const bool vec_ok = (n.n[2] % VEC == 0) && (o.s1 % VEC == 0) && (o.s0 % VEC == 0) && (o.off % VEC == 0) &&
                         (((uintptr_t)a.out) % 16 == 0) && (((uintptr_t)a.in) % 16 == 0) &&
                         (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0);
-    if (n.ndim >= 2 && vec_ok && !force_generic()) {
+    if (n.ndim >= 2 && vec_ok && !tn.force_generic) {
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
-        if (n.ndim == 3) return launch_march<T, VEC, 4, MODE, true>(a, y_is_in, st);
-        return launch_march<T, VEC, 2, MODE, false>(a, y_is_in, st);
+        // chunks per row: cover the whole fastest axis with one wave where possible
+        const long chunks = (n.n[2] + 64 * VEC - 1) / (64 * VEC);
+        int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+        // measured on MI355X at 512^3 fp64 (profiles/r01_sweep_tiles.log): 2 rows x whole-row chunks, ~1024
+        // single-wave workgroups (4 per CU) gives 0.41 ms per pass = 65 % of the 8 TB/s HBM peak
+        int ry = 2, wy = 1, pf = 1;
+        long blocks = 1024;
+        if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
+#define PDEHIP_CFG(RY_, CZ_, WY_, PF_)                                                                   \
+    if (ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) {                                              \
+        if (n.ndim == 3) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st); \
+        return launch_march<T, VEC, 8, CZ_, 1, 1, MODE, false>(a, y_is_in, blocks, st); /* 2-D: taller tiles */ \
     }
+        PDEHIP_CFG(4, 4, 1, 1)
+        PDEHIP_CFG(2, 2, 1, 1)
+        PDEHIP_CFG(2, 1, 1, 1)
+        PDEHIP_CFG(2, 4, 1, 1)
+#undef PDEHIP_CFG
+        PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
+    }
+    if (a.any_ibc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");
     const long total = n.n[0] * n.n[1] * n.n[2];
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -297,19 +223,38 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
     return 0;
 }
 
+// true when launch_laplace would take the vectorised kernel (the only one with fused ghosts)
+bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y)
+{
+    const long vec = 16 / elem_size(n.dtype);
+    return n.ndim >= 2 && (n.n[2] % vec == 0) && !tune().force_generic && ((uintptr_t)in % 16 == 0) &&
+           ((uintptr_t)out % 16 == 0) && (y == nullptr || (uintptr_t)y % 16 == 0);
+}
+
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
-                   double s2, double gamma, const void *y, hipStream_t st)
+                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg)
 {
     if (!in || !out) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
     if (mode == LAP_EULER && !y) PDEHIP_FAIL(E_VALUE, "laplace_euler: y is NULL");
     LapArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = in; a.out = out; a.y = (mode == LAP_EULER) ? y : nullptr;
     a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
     a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
     a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1;
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2; a.gamma = gamma;
-    a.ndim = n.ndim; a.lx = 1; a.nxc = a.nty = a.ntz = a.nblocks = 0; a.no_swizzle = 0;
+    a.ndim = n.ndim; a.lx = 1;
+    if (fg) {
+        for (int ax = 0; ax < 3; ax++)
+            for (int side = 0; side < 2; side++) {
+                a.ibc[ax][side].on = fg->on[ax][side];
+                a.ibc[ax][side].idx = fg->idx[ax][side];
+                a.ibc[ax][side].c = fg->c[ax][side];
+                a.ibc[ax][side].f = fg->f[ax][side];
+                a.any_ibc |= fg->on[ax][side];
+            }
+    }
 #define PDEHIP_MODE_SWITCH(T)                                                     \
     switch (mode) {                                                               \
     case LAP_PLAIN: return launch_laplace_t<T, LAP_PLAIN>(n, a, o, st);           \

@@ -391,6 +391,44 @@ template <typename T> static constexpr int vec_of() { return 16 / sizeof(T); }
 
 using namespace pdehip;
 
+namespace pdehip {
+// Apply the BCs `in_faces` to `in` and evaluate the stencil (mode LAP_*) into the FULL array `out`.
+// Scalar first-order faces are evaluated on the fly inside the stencil kernel (the ghost cells of
+// `in` are neither written nor read for them); array-valued / second-order faces are written into
+// the ghost cells of `in` by the ghost kernel first (numba/backend.py:501-517 order: BCs, then stencil).
+int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void *out, int mode, double s1,
+                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in_faces) PDEHIP_FAIL(E_VALUE, "input faces are NULL");
+    InputBCs fg;
+    memset(&fg, 0, sizeof(fg));
+    pdehip_bc_face_t rest[2 * PDEHIP_MAX_DIM];
+    int n_rest = 0, n_fused = 0;
+    static int fuse_axes = -1;   // PDEHIP_FUSE_AXES: bit per normalised axis (tuning / testing aid)
+    if (fuse_axes < 0) { const char *e = getenv("PDEHIP_FUSE_AXES"); fuse_axes = e ? atoi(e) : 7; }
+    const bool can_fuse = laplace_can_fuse_bcs(n, in, out, mode == LAP_EULER ? y : nullptr);
+    for (int a = 0; a < PDEHIP_MAX_DIM; a++)
+        for (int side = 0; side < 2; side++) {
+            pdehip_bc_face_t &r = rest[2 * a + side];
+            if (a >= n.ndim) { memset(&r, 0, sizeof(r)); continue; }
+            r = in_faces[2 * a + side];
+            if (r.kind == PDEHIP_BC_SKIP) continue;
+            const int ax = 3 - n.ndim + a;
+            if (can_fuse && ((fuse_axes >> ax) & 1) && r.kind == PDEHIP_BC_ORDER1 && r.flags == 0 && r.index1 >= 0 && r.index1 < n.n[ax]) {
+                fg.on[ax][side] = 1; fg.idx[ax][side] = r.index1; fg.c[ax][side] = r.const_v; fg.f[ax][side] = r.factor1;
+                r.kind = PDEHIP_BC_SKIP;
+                n_fused++;
+            } else {
+                n_rest++;
+            }
+        }
+    if (n_rest) PDEHIP_TRY(launch_ghosts(n, 1, rest, in, as_stream(stream)));
+    return launch_laplace(n, in, out, out_strides(n, PDEHIP_OUT_FULL), mode, s1, s2, gamma, y, as_stream(stream), n_fused ? &fg : nullptr);
+}
+}  // namespace pdehip
+
 extern "C" {
 
 int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, void *full, void *stream)
@@ -417,6 +455,7 @@ static int lap_entry(const pdehip_grid_t *g, const void *in, void *out, int layo
     if (layout != PDEHIP_OUT_VALID && layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", layout);
     return launch_laplace(n, in, out, out_strides(n, layout), mode, s1, s2, gamma, y, as_stream(stream));
 }
+
 
 int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream)
 { return lap_entry(g, in_full, out, out_layout, LAP_PLAIN, 0, 0, 0, nullptr, stream); }

@@ -36,13 +36,12 @@ int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_f
                       double dt, void *stream)
 {
     PDEHIP_TRY(check_rhs(rhs));
-    // numba/backend.py:501-517: set BCs on the full array, then apply the stencil
-    PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_c, y_full, stream));
-    if (rhs->kind == PDEHIP_RHS_DIFFUSION)
-        return pdehip_laplace_scaled(g, y_full, k_out_full, rhs->param, dt, stream);  // dt*(D*lap)
-    PDEHIP_TRY(pdehip_cahn_hilliard_mu(g, y_full, rhs->scratch_mu, rhs->param, stream));
-    PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_mu, rhs->scratch_mu, stream));
-    return pdehip_laplace_scaled(g, rhs->scratch_mu, k_out_full, 1.0, dt, stream);
+    // numba/backend.py:501-517: BCs, then the stencil — here one kernel (BCs evaluated on the fly)
+    if (rhs->kind == PDEHIP_RHS_DIFFUSION)   // dt * (D * lap)
+        return laplace_with_input_bcs(g, y_full, nullptr, k_out_full, LAP_SCALED, rhs->param, dt, 0, rhs->bc_c, stream);
+    // mu = c^3 - c - g*lap(c) with bc_c;  k = dt * lap(mu) with bc_mu
+    PDEHIP_TRY(laplace_with_input_bcs(g, y_full, nullptr, rhs->scratch_mu, LAP_CH_MU, 0, 0, rhs->param, rhs->bc_c, stream));
+    return laplace_with_input_bcs(g, rhs->scratch_mu, nullptr, k_out_full, LAP_SCALED, 1.0, dt, 0, rhs->bc_mu, stream);
 }
 
 int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b, double dt,
@@ -53,14 +52,12 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "euler_run: negative step count");
     void *cur = buf_a, *nxt = buf_b;
     for (int64_t s = 0; s < nsteps; s++) {
-        PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_c, cur, stream));
         if (rhs->kind == PDEHIP_RHS_DIFFUSION) {
-            // state + dt * (D * laplace(state))   euler.py:174 with diffusion.py:121
-            PDEHIP_TRY(pdehip_laplace_euler(g, cur, cur, nxt, rhs->param, dt, stream));
+            // state + dt * (D * laplace(state))   euler.py:174 with diffusion.py:121 — ONE kernel per step
+            PDEHIP_TRY(laplace_with_input_bcs(g, cur, cur, nxt, LAP_EULER, rhs->param, dt, 0, rhs->bc_c, stream));
         } else {
-            PDEHIP_TRY(pdehip_cahn_hilliard_mu(g, cur, rhs->scratch_mu, rhs->param, stream));
-            PDEHIP_TRY(pdehip_set_ghost_cells(g, 1, rhs->bc_mu, rhs->scratch_mu, stream));
-            PDEHIP_TRY(pdehip_laplace_euler(g, rhs->scratch_mu, cur, nxt, 1.0, dt, stream));
+            PDEHIP_TRY(laplace_with_input_bcs(g, cur, nullptr, rhs->scratch_mu, LAP_CH_MU, 0, 0, rhs->param, rhs->bc_c, stream));
+            PDEHIP_TRY(laplace_with_input_bcs(g, rhs->scratch_mu, cur, nxt, LAP_EULER, 1.0, dt, 0, rhs->bc_mu, stream));
         }
         void *t = cur; cur = nxt; nxt = t;
     }

@@ -51,6 +51,9 @@ class FaceTable:
     def __init__(self):
         self.c = _abi.FaceArray()
         self.keepalive: list[DeviceBuffer] = []
+        # the ctypes array itself also references the buffers, so `convert_bcs(...).c` is safe to
+        # pass on after the FaceTable object went out of scope
+        self.c._keepalive = self.keepalive
         for i in range(2 * _abi.MAX_DIM):
             self.c[i].kind = _abi.BC_SKIP
 

@@ -238,7 +238,13 @@ def main():
         },
         **line,
     }
-    print(json.dumps(out))
+    # RCCL writes its version banner through C stdio; drain that buffer first so the JSON line is last
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

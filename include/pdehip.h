@@ -215,6 +215,29 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
                          void *ynew_full, void *const *work7_host, double dt, double *err_dev,
                          void *stream);
 
+/* ---- slab-parallel layer: one process per GPU, axis-0 slabs, RCCL over xGMI -----------------------
+ * Replaces the reference's MPI path: face exchange inside every right-hand side
+ * (pde/backends/numba_mpi/backend.py:30-194, pde/grids/boundaries/local.py:561-662), the MAX
+ * all-reduce of the adaptive error (pde/backends/base.py:678-712) and the MPI stepper wrapper
+ * (pde/solvers/explicit_mpi.py:133-226).  `librccl_path` names the librccl.so already loaded in the
+ * process (RCCL is resolved with dlsym, not linked).  Rank 0 creates a 128-byte unique id, the host
+ * distributes it, every rank calls pdehip_comm_create.  `lower` / `upper` are the neighbour ranks
+ * along axis 0 (-1 = physical boundary). */
+int pdehip_comm_unique_id(const char *librccl_path, void *id128);
+int pdehip_comm_create(const char *librccl_path, const void *id128, int rank, int size, void **comm);
+int pdehip_comm_destroy(void *comm);
+/* send valid layers 1 / n of the local slab to the neighbours, receive their layers into the ghost
+ * layers n+1 / 0 (ncclSend/ncclRecv in one group, enqueued on `stream`) */
+int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper,
+                         void *stream);
+/* in-place MAX over all ranks of one fp64 device scalar; NaN wins like numpy.max */
+int pdehip_allreduce_max(void *comm, double *dev_scalar, void *stream);
+/* `nsteps` Euler steps of the diffusion right-hand side on the local slab: the exchange of the new
+ * boundary layers overlaps the interior kernel (second HIP stream); no host synchronisation */
+int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
+                          int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

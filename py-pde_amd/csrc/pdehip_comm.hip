@@ -1,0 +1,255 @@
+// pdehip_comm.hip — slab-parallel halo exchange and the slab Euler loop, straight on RCCL.
+//
+// Replaces the reference's MPI face exchange inside every right-hand side
+// (pde/backends/numba_mpi/backend.py:30-194, pde/grids/boundaries/local.py:561-662) and the
+// MAX all-reduce of the adaptive error (pde/backends/base.py:678-712).  One process per GPU; the
+// communicator is created from an ncclUniqueId that the host distributes (torch.distributed).
+//
+// librccl is NOT linked: the host passes the path of the librccl.so that is already loaded in the
+// process (torch ships its own copy) and the entry points are resolved with dlsym, so there is
+// exactly one RCCL in the address space.
+//
+// Measured motivation (profiles/r01_probe_slab.log): driving send/recv through
+// torch.distributed.batch_isend_irecv costs ~260 us of host time per step, 5x the 53 us a
+// 64x512x512 slab needs on the GPU; the loop below enqueues a step in a few tens of us and never
+// synchronises with the host.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "pdehip_common.h"
+
+using namespace pdehip;
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl(const char *path)
+{
+    if (g_rccl.handle) return 0;
+    void *h = dlopen((path && path[0]) ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) PDEHIP_FAIL(E_RUNTIME, "cannot load RCCL (%s): %s", path ? path : "librccl.so", dlerror());
+#define PDEHIP_SYM(field, name)                                                          \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));             \
+    if (!g_rccl.field) PDEHIP_FAIL(E_RUNTIME, "RCCL symbol %s not found", name)
+    PDEHIP_SYM(GetUniqueId, "ncclGetUniqueId");
+    PDEHIP_SYM(CommInitRank, "ncclCommInitRank");
+    PDEHIP_SYM(CommDestroy, "ncclCommDestroy");
+    PDEHIP_SYM(GetErrorString, "ncclGetErrorString");
+    PDEHIP_SYM(GroupStart, "ncclGroupStart");
+    PDEHIP_SYM(GroupEnd, "ncclGroupEnd");
+    PDEHIP_SYM(Send, "ncclSend");
+    PDEHIP_SYM(Recv, "ncclRecv");
+    PDEHIP_SYM(AllReduce, "ncclAllReduce");
+#undef PDEHIP_SYM
+    g_rccl.handle = h;
+    return 0;
+}
+
+#define PDEHIP_NCCL(expr)                                                                                  \
+    do {                                                                                                   \
+        ncclResult_t _r = (expr);                                                                          \
+        if (_r != ncclSuccess) PDEHIP_FAIL(E_RUNTIME, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+struct Comm {
+    ncclComm_t comm;
+    int rank, size;
+    hipStream_t halo;            // stream of the exchange + boundary-layer kernels
+    hipEvent_t ev_comp, ev_halo, ev_bnd;
+    double *scratch2;            // device: {value, nan flag} for the MAX all-reduce
+};
+
+// pointer to full layer `layer` (0 = lower ghost layer) of a slab
+inline char *layer_ptr(const NGrid &n, void *buf, long layer)
+{
+    return static_cast<char *>(buf) + layer * n.p[3 - n.ndim] * elem_size(n.dtype);
+}
+
+// Post the halo exchange of `buf` on `st`.  Order per peer: the "downward" pair first, then the
+// "upward" pair — RCCL matches sends and receives to one peer in issue order, so the 2-rank periodic
+// ring and the 1-rank self exchange pair up correctly (same order as pde_hip/distributed.py, which is
+// tested on CPU with gloo at world sizes 2 and 3).
+int exchange(Comm *c, const NGrid &n, void *buf, int lower, int upper, hipStream_t st)
+{
+    if (lower < 0 && upper < 0) return 0;
+    const long nloc = n.n[3 - n.ndim];
+    const size_t bytes = (size_t)n.p[3 - n.ndim] * elem_size(n.dtype);
+    PDEHIP_NCCL(g_rccl.GroupStart());
+    if (lower >= 0) PDEHIP_NCCL(g_rccl.Send(layer_ptr(n, buf, 1), bytes, ncclInt8, lower, c->comm, st));
+    if (upper >= 0) {
+        PDEHIP_NCCL(g_rccl.Recv(layer_ptr(n, buf, nloc + 1), bytes, ncclInt8, upper, c->comm, st));
+        PDEHIP_NCCL(g_rccl.Send(layer_ptr(n, buf, nloc), bytes, ncclInt8, upper, c->comm, st));
+    }
+    if (lower >= 0) PDEHIP_NCCL(g_rccl.Recv(layer_ptr(n, buf, 0), bytes, ncclInt8, lower, c->comm, st));
+    PDEHIP_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+// faces of a sub-slab of layers [first, first+count) (1-based valid layers of the slab): the
+// inter-layer faces inside the slab are real data (SKIP); physical / exchanged faces keep the slab's
+// descriptor with the index translated into the sub-slab
+void sub_faces(const pdehip_bc_face_t *faces, long nloc, long first, long count, pdehip_bc_face_t *out)
+{
+    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) out[i] = faces[i];
+    if (first > 1) out[0].kind = PDEHIP_BC_SKIP;
+    else out[0].index1 -= (first - 1), out[0].index2 -= (first - 1);
+    if (first + count - 1 < nloc) out[1].kind = PDEHIP_BC_SKIP;
+    else out[1].index1 -= (first - 1), out[1].index2 -= (first - 1);
+}
+
+__global__ void pack_nan_kernel(const double *in, double *out2)
+{
+    const double v = in[0];
+    const bool isn = (v != v);
+    out2[0] = isn ? 0.0 : v;
+    out2[1] = isn ? 1.0 : 0.0;
+}
+__global__ void unpack_nan_kernel(const double *in2, double *out)
+{
+    out[0] = (in2[1] > 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : in2[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdehip_comm_unique_id(const char *librccl_path, void *id128)
+{
+    PDEHIP_TRY(load_rccl(librccl_path));
+    if (!id128) PDEHIP_FAIL(E_VALUE, "id buffer is NULL");
+    ncclUniqueId id;
+    PDEHIP_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int pdehip_comm_create(const char *librccl_path, const void *id128, int rank, int size, void **comm)
+{
+    PDEHIP_TRY(load_rccl(librccl_path));
+    if (!id128 || !comm) PDEHIP_FAIL(E_VALUE, "comm_create: NULL pointer");
+    if (rank < 0 || rank >= size) PDEHIP_FAIL(E_VALUE, "comm_create: rank %d outside of world size %d", rank, size);
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    Comm *c = new Comm();
+    c->rank = rank; c->size = size;
+    PDEHIP_NCCL(g_rccl.CommInitRank(&c->comm, size, id, rank));
+    PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_comp, hipEventDisableTiming));
+    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
+    PDEHIP_HIP(hipMalloc(&c->scratch2, 2 * sizeof(double)));
+    *comm = c;
+    return 0;
+}
+
+int pdehip_comm_destroy(void *comm)
+{
+    if (!comm) return 0;
+    Comm *c = static_cast<Comm *>(comm);
+    hipStreamSynchronize(c->halo);
+    g_rccl.CommDestroy(c->comm);
+    hipStreamDestroy(c->halo);
+    hipEventDestroy(c->ev_comp); hipEventDestroy(c->ev_halo); hipEventDestroy(c->ev_bnd);
+    hipFree(c->scratch2);
+    delete c;
+    return 0;
+}
+
+int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper, void *stream)
+{
+    if (!comm || !buf_full) PDEHIP_FAIL(E_VALUE, "halo_exchange: NULL pointer");
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g_local, &n));
+    return exchange(static_cast<Comm *>(comm), n, buf_full, lower, upper, as_stream(stream));
+}
+
+int pdehip_allreduce_max(void *comm, double *dev_scalar, void *stream)
+{
+    if (!comm || !dev_scalar) PDEHIP_FAIL(E_VALUE, "allreduce_max: NULL pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    if (c->size == 1) return 0;
+    hipStream_t st = as_stream(stream);
+    // NaN must win like numpy's max: reduce {value with NaN -> 0, NaN flag}
+    hipLaunchKernelGGL(pack_nan_kernel, dim3(1), dim3(1), 0, st, dev_scalar, c->scratch2);
+    PDEHIP_NCCL(g_rccl.AllReduce(c->scratch2, c->scratch2, 2, ncclFloat64, ncclMax, c->comm, st));
+    hipLaunchKernelGGL(unpack_nan_kernel, dim3(1), dim3(1), 0, st, c->scratch2, dev_scalar);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+// nsteps explicit Euler steps of the diffusion equation on one slab; all work is enqueued without
+// host synchronisation:
+//   comp stream : interior kernel (layers 2..n-1)   ............................ | next step
+//   halo stream : boundary kernels (layers 1, n) - send/recv of the new layers 1, n
+// The exchange of step s+1's input overlaps the interior kernel of step s.  BCs of the faces this
+// rank owns are evaluated on the fly inside the kernels; exchanged faces read the received layers.
+int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
+                          void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler_run: NULL pointer");
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION) PDEHIP_FAIL(E_NOTIMPL, "slab_euler_run implements the diffusion right-hand side");
+    Comm *c = static_cast<Comm *>(comm);
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g_local, &n));
+    const long nloc = g_local->shape[0];
+    hipStream_t comp = as_stream(stream), halo = c->halo;
+    // faces: exchanged ones are read from the ghost layers
+    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
+    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) faces[i] = rhs->bc_c[i];
+    if (lower >= 0) faces[0].kind = PDEHIP_BC_SKIP;
+    if (upper >= 0) faces[1].kind = PDEHIP_BC_SKIP;
+    const size_t esz = elem_size(n.dtype);
+    const size_t lp = (size_t)n.p[3 - n.ndim] * esz;   // bytes per layer
+
+    auto sub_step = [&](hipStream_t st, void *cur, void *nxt, long first, long count) -> int {
+        if (count <= 0) return 0;
+        pdehip_grid_t gs = *g_local;
+        gs.shape[0] = count;
+        pdehip_bc_face_t sf[2 * PDEHIP_MAX_DIM];
+        sub_faces(faces, nloc, first, count, sf);
+        char *pc = static_cast<char *>(cur) + (first - 1) * lp, *pn = static_cast<char *>(nxt) + (first - 1) * lp;
+        return laplace_with_input_bcs(&gs, pc, pc, pn, LAP_EULER, rhs->param, dt, 0, sf, st);
+    };
+
+    void *cur = buf_a, *nxt = buf_b;
+    // ghost layers of the initial state
+    PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
+    PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
+    PDEHIP_TRY(exchange(c, n, cur, lower, upper, halo));
+    for (int64_t s = 0; s < nsteps; s++) {
+        // interior layers need no exchanged data; they must wait for the boundary layers of `cur`
+        // (written on the halo stream in the previous step)
+        if (s > 0) PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_bnd, 0));
+        PDEHIP_TRY(sub_step(comp, cur, nxt, 2, nloc - 2));
+        PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
+        // boundary layers: the received ghost layers are ordered by the halo stream itself
+        PDEHIP_TRY(sub_step(halo, cur, nxt, 1, 1));
+        if (nloc > 1) PDEHIP_TRY(sub_step(halo, cur, nxt, nloc, 1));
+        PDEHIP_HIP(hipEventRecord(c->ev_bnd, halo));
+        PDEHIP_TRY(exchange(c, n, nxt, lower, upper, halo));   // overlaps the interior kernel
+        // the next step overwrites `cur`: its interior kernel (comp) and boundary kernels (halo, in
+        // order) must be done; the halo stream additionally waits for this step's interior kernel
+        PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
+        void *t = cur; cur = nxt; nxt = t;
+    }
+    // make the compute stream see everything
+    PDEHIP_HIP(hipEventRecord(c->ev_halo, halo));
+    PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_halo, 0));
+    *result = cur;
+    return 0;
+}
+
+}  // extern "C"

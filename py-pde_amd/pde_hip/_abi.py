@@ -147,6 +147,17 @@ RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
 }
 
 
+# slab-parallel layer (pdehip_comm.hip): name -> full argument list
+COMM_PROTOTYPES: dict[str, list] = {
+    "comm_unique_id": [C.c_char_p, _vp],
+    "comm_create": [C.c_char_p, _vp, _i, _i, _pvp],
+    "comm_destroy": [_vp],
+    "halo_exchange": [_vp, _pg, _vp, _i, _i, _vp],
+    "allreduce_max": [_vp, _vp, _vp],
+    "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+}
+
+
 def exported_symbols() -> list[str]:
     """All symbols ``include/pdehip.h`` declares (checked by tests/test_cabi.py)."""
-    return ["pdehip_" + n for n in list(RUNTIME_PROTOTYPES) + list(COMPUTE_PROTOTYPES)]
+    return ["pdehip_" + n for n in list(RUNTIME_PROTOTYPES) + list(COMPUTE_PROTOTYPES) + list(COMM_PROTOTYPES)]

@@ -47,6 +47,10 @@ class _Lib:
             fn = getattr(self._h, "pdehip_" + name)
             fn.argtypes = [*args, C.c_void_p] if has_stream else list(args)
             fn.restype = C.c_int
+        for name, args in _abi.COMM_PROTOTYPES.items():
+            fn = getattr(self._h, "pdehip_" + name)
+            fn.argtypes = list(args)
+            fn.restype = C.c_int
         if self._h.pdehip_abi_version() != _abi.ABI_VERSION:
             msg = "libpdehip.so ABI version mismatch - rebuild the library"
             raise ImportError(msg)

@@ -50,6 +50,31 @@ class HipEngine:
         self.comp = torch.cuda.Stream(device=self.device)
         self.halo = torch.cuda.Stream(device=self.device)
 
+    # native RCCL communicator -----------------------------------------------------------------
+    def make_comm(self, dist, group, size: int, rank: int):
+        """Create libpdehip's own RCCL communicator (ncclUniqueId distributed through ``dist``).
+
+        libpdehip resolves RCCL from the librccl.so torch already loaded, so there is one RCCL in
+        the process.  Returns ``None`` when ``PDEHIP_COMM=torch`` asks for the torch P2P path.
+        """
+        import os
+
+        if os.environ.get("PDEHIP_COMM", "native") == "torch":
+            return None
+        path = os.path.join(os.path.dirname(self.torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            path = "librccl.so"
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            self.lib.comm_unique_id(path.encode(), uid)
+        if size > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        self.lib.comm_create(path.encode(), uid, rank, size, C.byref(comm))
+        return comm
+
     # layout / memory -------------------------------------------------------------------------
     def layout(self, g: _abi.Grid) -> dict[str, int]:
         lay = (C.c_int64 * 8)()
@@ -152,6 +177,21 @@ class SlabStepper:
         self._bufs: dict[str, Any] = {}
         self.err = self.engine.scalar()
         self.steps_done = 0
+        # libpdehip's own RCCL communicator (product path); engines without one (the CPU test
+        # engine, or PDEHIP_COMM=torch) use torch.distributed point-to-point ops instead
+        self.comm = None
+        if self.exchanging or self.size > 1:
+            make = getattr(self.engine, "make_comm", None)
+            if make is not None:
+                self.comm = make(dist, group, self.size, self.rank)
+        # the C ABI wants the full face table (physical faces on, exchanged ones are skipped there)
+        self._rhs_c = None
+        if self.comm is not None and self.kind == _abi.RHS_DIFFUSION:
+            self._faces_all = convert_bcs(self.mesh.sub_boundaries(bc_c), skip=skip, upload=self.engine.upload_f64)
+            self._rhs_c = _abi.RHS()
+            self._rhs_c.kind = _abi.RHS_DIFFUSION
+            self._rhs_c.param = self.param
+            self._faces_all.copy_into(self._rhs_c.bc_c)
 
     # --- buffers ---------------------------------------------------------------------------------
     def buf(self, name: str):
@@ -181,6 +221,11 @@ class SlabStepper:
         periodic ring and the 1-rank self exchange pair up correctly.
         """
         if not self.exchanging:
+            return
+        if self.comm is not None:   # native path: ncclSend/ncclRecv group issued by libpdehip
+            lower = -1 if self.lower is None else self.lower
+            upper = -1 if self.upper is None else self.upper
+            self.engine.lib.halo_exchange(self.comm, C.byref(self.g), self.ptr(buf), lower, upper, self.engine.stream_ptr(stream))
             return
         dist = self.dist
         n = self.n
@@ -248,7 +293,15 @@ class SlabStepper:
                     self._stencil_pass("euler", self.faces_mu, mu, nxt, y=cur, s1=1.0, s2=dt)
                 cur, nxt = nxt, cur
             return cur
-        # overlapped diffusion path -------------------------------------------------------------
+        if self._rhs_c is not None:
+            # native overlapped loop: the whole step sequence is enqueued by ONE C call
+            lower = -1 if self.lower is None else self.lower
+            upper = -1 if self.upper is None else self.upper
+            res = C.c_void_p()
+            eng.lib.slab_euler_run(self.comm, C.byref(self.g), C.byref(self._rhs_c), lower, upper, self.ptr(cur), self.ptr(nxt),
+                                   dt, nsteps, C.byref(res), eng.stream_ptr(comp))
+            return cur if res.value == self.ptr(cur) else nxt
+        # overlapped diffusion path (torch P2P / CPU test engine) ------------------------------------
         eng.wait(halo, eng.record(comp))
         self.start_exchange(cur, halo)            # ghost layers of the initial state
         ev_boundary = None
@@ -300,6 +353,10 @@ class SlabStepper:
 
     def sync_max(self, err_tensor) -> float:
         """MAX all-reduce of the error scalar (``make_mpi_synchronizer``, backends/base.py:678-712)."""
+        if self.size > 1 and self.comm is not None:
+            self.engine.lib.allreduce_max(self.comm, err_tensor.data_ptr(), self.engine.stream_ptr(self.engine.comp))
+            self.engine.synchronize()
+            return float(err_tensor.cpu()[0])
         if self.size > 1:
             with self.engine.use(self.engine.comp):
                 # NaN must win the reduction like np.max: reduce a NaN flag alongside

@@ -53,23 +53,31 @@ def _expect(eq_kind, param, grid, bc, data, dt, steps, solver="euler"):
     return interior(grid, y)
 
 
+@pytest.mark.parametrize("comm_mode", ["native", "torch"])
 @pytest.mark.parametrize("force", [True, False])
-@pytest.mark.parametrize("shape", [(16, 12, 128), (3, 8, 64), (12, 256)])
-def test_diffusion_euler_overlapped_self_exchange(process_group, force, shape):
+@pytest.mark.parametrize("shape", [(16, 12, 128), (3, 8, 64), (2, 4, 64), (1, 4, 64), (12, 256)])
+def test_diffusion_euler_overlapped_self_exchange(process_group, monkeypatch, comm_mode, force, shape):
+    """native = libpdehip's own RCCL communicator + C step loop; torch = torch.distributed P2P ops."""
     from pde_hip.distributed import HipEngine, SlabStepper
+
+    monkeypatch.setenv("PDEHIP_COMM", comm_mode)
 
     grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
     data = np.random.default_rng(2).uniform(-1, 1, shape)
     eq = pde_hip.DiffusionPDE(0.8)
     st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=force)
     assert st.exchanging == force
+    assert (st.comm is not None) == (force and comm_mode == "native")
     final, info = st.solve(data, t_range=1.1, dt=0.1, solver="euler")
     assert info["steps"] == 11
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.8, grid, eq.bc, data, 0.1, 11))
 
 
-def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group):
+@pytest.mark.parametrize("comm_mode", ["native", "torch"])
+def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group, monkeypatch, comm_mode):
     from pde_hip.distributed import HipEngine, SlabStepper
+
+    monkeypatch.setenv("PDEHIP_COMM", comm_mode)
 
     grid = pde_hip.UnitGrid([8, 8, 64], periodic=True)
     data = np.random.default_rng(3).uniform(-0.1, 0.1, grid.shape)

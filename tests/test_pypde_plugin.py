@@ -1,0 +1,94 @@
+"""The hip backend as a plugin of the REAL py-pde (CPU checks; skipped where py-pde is absent).
+
+In the build container py-pde lives at /root/reference (read-only); on the GPU box it does not
+exist, so these tests only cover what can be verified without a device: registration, config
+linking, class attributes, operator registry, conversion of real py-pde BoundariesList objects into
+the C face table (checked against py-pde's own numpy ghost cells through the oracle), RHS
+recognition, and the loud failure without a GPU.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REF = Path("/root/reference")
+if not (REF / "pde").exists():
+    pytest.skip("py-pde (reference) not available", allow_module_level=True)
+if str(REF) not in sys.path:
+    sys.path.append(str(REF))
+
+import pde  # noqa: E402
+from helpers import HostBuf, face_mask  # noqa: E402
+
+import pde_hip.pypde_plugin as plugin  # noqa: E402
+from oracle import pde_oracle as O  # noqa: E402
+from pde_hip import _abi, _lib  # noqa: E402
+from pde_hip.backend import _match_expression_rhs, convert_bcs  # noqa: E402
+
+
+def test_registration_and_class_attributes():
+    from pde.backends import backend_registry
+
+    assert "hip" in backend_registry._packages and backend_registry._classes["hip"] is plugin.HipBackend
+    cls = plugin.HipBackend
+    assert issubclass(cls, pde.backends.base.BackendBase)
+    assert cls.implementation == "hip" and cls.copy_data is True and cls.supports_mpi is False
+    assert pde.config["backend"]["hip"]["device"] == 0
+    ops = cls._operators[pde.CartesianGrid]
+    assert {"laplace", "gradient", "divergence", "gradient_squared", "vector_laplace"} <= set(ops)
+    plugin.register()  # idempotent
+
+
+def test_get_backend_fails_loudly_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pde.backends.backend_registry.get_backend("hip")
+    # ... and py-pde's other backends are unaffected
+    assert pde.backends.backend_registry.get_backend("numpy").name == "numpy"
+
+
+@pytest.mark.parametrize("bc", [
+    "auto_periodic_neumann",
+    {"x-": {"value": 1.5}, "x+": {"derivative": 0.3}, "y": "periodic"},
+    {"x-": {"value": "sin(y)"}, "x+": {"type": "mixed", "value": 2.0, "const": 0.5}, "y": "periodic"},
+    {"x": "extrapolate", "y": "periodic"},
+])
+def test_real_boundaries_to_face_table(bc):
+    """convert_bcs on py-pde's own BoundariesList + oracle ghost setter == py-pde's numpy set_ghost_cells."""
+    grid = pde.CartesianGrid([[0, 3], [1, 4.5]], [6, 5], periodic=[False, True])
+    field = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(0))
+    bcs = grid.get_boundary_conditions(bc, rank=0)
+    table = convert_bcs(bcs, upload=HostBuf)
+    full = field._data_full.copy()
+    full[0, :] = full[-1, :] = full[:, 0] = full[:, -1] = 0
+    O.set_ghost_cells(_abi.make_grid(grid.shape, grid.discretization, np.float64), 1, table.c, full)
+    field.set_ghost_cells(bc)
+    mask = face_mask(grid)
+    np.testing.assert_array_equal(full[mask], field._data_full[mask])
+
+
+def test_unsupported_boundaries_raise_not_implemented():
+    grid = pde.UnitGrid([4, 4])
+    bcs = grid.get_boundary_conditions({"value_expression": "t"}, rank=0)
+    with pytest.raises(NotImplementedError, match="does not support boundary condition"):
+        convert_bcs(bcs, upload=HostBuf)
+
+
+def test_rhs_recognition_on_real_pde_objects():
+    """The attributes make_rhs_spec reads exist on the real classes; expression PDE is matched."""
+    eq = pde.DiffusionPDE(0.7, bc="auto_periodic_neumann")
+    assert (eq.__class__.__name__, eq.diffusivity, eq.bc) == ("DiffusionPDE", 0.7, "auto_periodic_neumann")
+    ch = pde.CahnHilliardPDE(interface_width=0.5)
+    assert ch.__class__.__name__ == "CahnHilliardPDE" and ch.interface_width == 0.5 and hasattr(ch, "bc_c") and hasattr(ch, "bc_mu")
+    gen = pde.PDE({"c": "laplace(c**3 - c - laplace(c))"})
+    (var, expr), = gen.rhs.items()
+    assert _match_expression_rhs(str(expr), var, dict(gen.consts)) == (_abi.RHS_CAHN_HILLIARD, 1.0)
+    solver = pde.solvers.EulerSolver(eq, backend="numpy")
+    assert solver.__class__.__name__ == "EulerSolver" and hasattr(solver, "adaptive") and hasattr(solver, "tolerance")
+    rk = pde.solvers.RungeKuttaSolver(eq, backend="numpy", adaptive=True)
+    assert (rk.dt_min, rk.dt_max, rk.tolerance) == (1e-10, 1e10, 1e-4)

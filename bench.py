@@ -72,7 +72,7 @@ def cpu_baseline(n: int, seconds: float) -> dict:
         lib.oracle_euler_run(C.byref(g), C.byref(rhs), a.ctypes.data, b.ctypes.data, 0.1, 2, C.byref(res))
         steps += 2
         el = time.perf_counter() - t0
-        if el >= seconds or steps >= 40:
+        if el >= seconds or steps >= 2000:
             break
     return {
         "value": round(n_cpu**3 * steps / el / 1e6, 2),

@@ -194,24 +194,42 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
                         (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0);
     if (n.ndim >= 2 && vec_ok && !tn.force_generic) {
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
-        // chunks per row: cover the whole fastest axis with one wave where possible
+        // chunks per row: cover the whole fastest axis with one wave where possible (contiguous
+        // RY x row bytes per wave and plane is what the HBM write path likes) ...
         const long chunks = (n.n[2] + 64 * VEC - 1) / (64 * VEC);
         int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         // measured on MI355X at 512^3 fp64 (profiles/r01_sweep_tiles.log): 2 rows x whole-row chunks, ~1024
         // single-wave workgroups (4 per CU) gives 0.41 ms per pass = 65 % of the 8 TB/s HBM peak
-        int ry = 2, wy = 1, pf = 1;
+        // fp32 (fp64 registers, 4 cells per lane) is VALU-heavier: 4-row tiles measured 585 vs 454 Gcells/s at 512^3
+        int ry = (n.ndim == 3) ? ((sizeof(T) == 4 && cz >= 2) ? 4 : 2) : 8, wy = 1, pf = 1;
         long blocks = 1024;
+        // ... but never starve the chip: small grids get smaller tiles until there are >= 512 wave
+        // tiles (a 512^2 grid as 8-row x 512-cell tiles would be 64 waves on 256 CUs)
+        auto n_tiles = [&](int ry_, int cz_) {
+            const long per_plane = ((n.n[1] + ry_ - 1) / ry_) * ((n.n[2] + 64L * VEC * cz_ - 1) / (64L * VEC * cz_));
+            return n.ndim == 3 ? per_plane * n.n[0] : per_plane;   // 3-D can also split along x
+        };
+        if (n.ndim == 2 && n_tiles(ry, cz) < 512) ry = 2;
+        while (cz > 1 && n_tiles(ry, cz) < 512) cz /= 2;
+        if (n.ndim == 3 && ry == 4 && cz < 2) ry = 2;   // only (4,4) and (4,2) are instantiated
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
-#define PDEHIP_CFG(RY_, CZ_, WY_, PF_)                                                                   \
-    if (ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) {                                              \
-        if (n.ndim == 3) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st); \
-        return launch_march<T, VEC, 8, CZ_, 1, 1, MODE, false>(a, y_is_in, blocks, st); /* 2-D: taller tiles */ \
-    }
-        PDEHIP_CFG(4, 4, 1, 1)
-        PDEHIP_CFG(2, 2, 1, 1)
-        PDEHIP_CFG(2, 1, 1, 1)
-        PDEHIP_CFG(2, 4, 1, 1)
-#undef PDEHIP_CFG
+#define PDEHIP_CFG3(RY_, CZ_, WY_, PF_) \
+    if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st);
+#define PDEHIP_CFG2(RY_, CZ_) \
+    if (n.ndim == 2 && ry == RY_ && cz == CZ_) return launch_march<T, VEC, RY_, CZ_, 1, 1, MODE, false>(a, y_is_in, blocks, st);
+        PDEHIP_CFG3(2, 4, 1, 1)
+        PDEHIP_CFG3(2, 2, 1, 1)
+        PDEHIP_CFG3(2, 1, 1, 1)
+        PDEHIP_CFG3(4, 4, 1, 1)
+        PDEHIP_CFG3(4, 2, 1, 1)
+        PDEHIP_CFG2(8, 4)
+        PDEHIP_CFG2(8, 2)
+        PDEHIP_CFG2(8, 1)
+        PDEHIP_CFG2(2, 4)
+        PDEHIP_CFG2(2, 2)
+        PDEHIP_CFG2(2, 1)
+#undef PDEHIP_CFG3
+#undef PDEHIP_CFG2
         PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
     }
     if (a.any_ibc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");

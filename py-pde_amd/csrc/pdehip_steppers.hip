@@ -28,6 +28,24 @@ int check_rhs(const pdehip_rhs_t *rhs)
     return 0;
 }
 
+// cache of captured Euler-step graphs (see pdehip_euler_run)
+constexpr int64_t kGraphSteps = 32;   // even: the ping-pong buffers are back in place after a block
+constexpr int kGraphCache = 8;
+struct GraphKey {
+    pdehip_grid_t g;
+    pdehip_rhs_t rhs;
+    void *a, *b;
+    double dt;
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    hipEvent_t ev = nullptr;
+};
+GraphEntry g_graphs[kGraphCache];
+unsigned g_graph_next = 0;
+
 }  // namespace
 
 extern "C" {
@@ -51,14 +69,64 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     if (!buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "euler_run: NULL pointer");
     if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "euler_run: negative step count");
     void *cur = buf_a, *nxt = buf_b;
-    for (int64_t s = 0; s < nsteps; s++) {
-        if (rhs->kind == PDEHIP_RHS_DIFFUSION) {
+    auto one_step = [&](void *c, void *n, void *st) -> int {
+        if (rhs->kind == PDEHIP_RHS_DIFFUSION)
             // state + dt * (D * laplace(state))   euler.py:174 with diffusion.py:121 — ONE kernel per step
-            PDEHIP_TRY(laplace_with_input_bcs(g, cur, cur, nxt, LAP_EULER, rhs->param, dt, 0, rhs->bc_c, stream));
-        } else {
-            PDEHIP_TRY(laplace_with_input_bcs(g, cur, nullptr, rhs->scratch_mu, LAP_CH_MU, 0, 0, rhs->param, rhs->bc_c, stream));
-            PDEHIP_TRY(laplace_with_input_bcs(g, rhs->scratch_mu, cur, nxt, LAP_EULER, 1.0, dt, 0, rhs->bc_mu, stream));
+            return laplace_with_input_bcs(g, c, c, n, LAP_EULER, rhs->param, dt, 0, rhs->bc_c, st);
+        PDEHIP_TRY(laplace_with_input_bcs(g, c, nullptr, rhs->scratch_mu, LAP_CH_MU, 0, 0, rhs->param, rhs->bc_c, st));
+        return laplace_with_input_bcs(g, rhs->scratch_mu, c, n, LAP_EULER, 1.0, dt, 0, rhs->bc_mu, st);
+    };
+    // Launch-bound regime (small grids: a 512^2 step is ~3 us of GPU work, the host needs ~3.5 us per
+    // launch): capture a block of steps into a hipGraph and replay it, so the inner loop costs one graph
+    // launch per kGraphSteps steps instead of 1-2 kernel launches per step.  Building a graph costs
+    // milliseconds, so graphs are cached (same grid, rhs, buffers and dt -> same graph) and only built
+    // for long runs; a stepper that is called once per tracker interrupt re-uses its graph.
+    int64_t s = 0;
+    long cells = 1;
+    for (int a = 0; a < g->ndim; a++) cells *= g->shape[a];
+    static int use_graph = -1;
+    if (use_graph < 0) { const char *e = getenv("PDEHIP_GRAPH"); use_graph = e ? atoi(e) : 1; }
+    if (use_graph && cells <= (1L << 22) && nsteps >= kGraphSteps) {
+        GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.g = *g; key.rhs = *rhs; key.a = buf_a; key.b = buf_b; key.dt = dt;
+        GraphEntry *entry = nullptr;
+        for (auto &e : g_graphs)
+            if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) { entry = &e; break; }
+        if (!entry && nsteps >= 2048) {
+            GraphEntry &e = g_graphs[g_graph_next++ % kGraphCache];
+            if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
+            if (!e.cap) PDEHIP_HIP(hipStreamCreateWithFlags(&e.cap, hipStreamNonBlocking));
+            if (!e.ev) PDEHIP_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+            hipGraph_t graph = nullptr;
+            int rc = 0;
+            PDEHIP_HIP(hipStreamBeginCapture(e.cap, hipStreamCaptureModeThreadLocal));
+            for (int64_t q = 0; q < kGraphSteps && rc == 0; q++) {
+                rc = one_step(cur, nxt, e.cap);
+                void *t = cur; cur = nxt; nxt = t;   // even number of swaps: back in place
+            }
+            const hipError_t ce = hipStreamEndCapture(e.cap, &graph);
+            if (rc == 0 && ce == hipSuccess && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                e.key = key;
+                entry = &e;
+            } else {
+                e.exec = nullptr;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
         }
+        if (entry) {
+            hipStream_t user = as_stream(stream);
+            // order the replays after the user's stream and hand the result back to it (no host sync)
+            PDEHIP_HIP(hipEventRecord(entry->ev, user));
+            PDEHIP_HIP(hipStreamWaitEvent(entry->cap, entry->ev, 0));
+            for (; s + kGraphSteps <= nsteps; s += kGraphSteps) PDEHIP_HIP(hipGraphLaunch(entry->exec, entry->cap));
+            PDEHIP_HIP(hipEventRecord(entry->ev, entry->cap));
+            PDEHIP_HIP(hipStreamWaitEvent(user, entry->ev, 0));
+        }
+    }
+    for (; s < nsteps; s++) {
+        PDEHIP_TRY(one_step(cur, nxt, stream));
         void *t = cur; cur = nxt; nxt = t;
     }
     *result = cur;

@@ -23,7 +23,8 @@ def worker(n: int) -> None:
     b = pde_hip.get_backend("hip")
     lib = b._lib
     grid = pde_hip.UnitGrid([n, n, n], periodic=True)
-    state = pde_hip.ScalarField(grid, np.random.default_rng(0).random((n, n, n)))
+    dtype = np.dtype(os.environ.get("SWEEP_DTYPE", "float64"))
+    state = pde_hip.ScalarField(grid, np.random.default_rng(0).random((n, n, n)), dtype=dtype)
     spec = b.make_rhs_spec(pde_hip.DiffusionPDE(), state)
     info = spec.info
     a, bb = DeviceArray(info).set_valid(state.data), DeviceArray(info)
@@ -56,8 +57,8 @@ def worker(n: int) -> None:
 
     tk, tp, ts = timed(kern, 50), timed(plain, 50), timed(step, 100)
     cells = n**3
-    print(f"{os.environ.get('PDEHIP_TUNE', 'default'):>16}: euler kernel {tk:.4f} ms ({cells*16/tk/1e6/8000*100:.1f}%)  "
-          f"laplace {tp:.4f} ms ({cells*16/tp/1e6/8000*100:.1f}%)  euler step {ts:.4f} ms ({cells/ts/1e6:.1f} Gcells/s, {cells*16/ts/1e6/8000*100:.1f}%)", flush=True)
+    print(f"{os.environ.get('PDEHIP_TUNE', 'default'):>16}: euler kernel {tk:.4f} ms ({cells*2*dtype.itemsize/tk/1e6/8000*100:.1f}%)  "
+          f"laplace {tp:.4f} ms ({cells*2*dtype.itemsize/tp/1e6/8000*100:.1f}%)  euler step {ts:.4f} ms ({cells/ts/1e6:.1f} Gcells/s, {cells*2*dtype.itemsize/ts/1e6/8000*100:.1f}%)", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,61 @@
+"""Kernel timings (HIP events) of the operator family for several grids / dtypes (tuning aid)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "py-pde_amd")]
+import numpy as np
+
+import pde_hip
+from pde_hip import _abi
+from pde_hip.device import DeviceArray
+
+b = pde_hip.get_backend("hip")
+lib = b._lib
+ev = [C.c_void_p() for _ in range(2)]
+for e in ev:
+    lib.event_create(C.byref(e))
+ms = C.c_float()
+
+
+def timed(fn, reps=50):
+    for _ in range(3):
+        fn()
+    lib.stream_synchronize(None)
+    lib.event_record(ev[0], None)
+    for _ in range(reps):
+        fn()
+    lib.event_record(ev[1], None)
+    lib.stream_synchronize(None)
+    lib.event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+    return ms.value / reps
+
+
+print("| grid | dtype | op | ms | Gcells/s | algorithmic GB/s | % of 8 TB/s |")
+print("|---|---|---|---:|---:|---:|---:|")
+for shape, dtype in [((1024, 1024), np.float64), ((4096, 4096), np.float64), ((8192, 8192), np.float64), ((512, 512), np.float64),
+                     ((256, 256, 256), np.float32), ((512, 512, 512), np.float32), ((512, 512, 512), np.float64), ((256, 256, 256), np.float64),
+                     ((1024, 512, 512), np.float64)]:
+    grid = pde_hip.UnitGrid(shape, periodic=True)
+    info = b.grid_info(grid, dtype)
+    it = np.dtype(dtype).itemsize
+    cells = int(np.prod(shape))
+    a = DeviceArray(info).set_valid(np.random.default_rng(0).random(shape).astype(dtype))
+    o = DeviceArray(info)
+    dim = len(shape)
+    v = DeviceArray(info, (dim,))
+    b.make_ghost_cell_setter(grid.get_boundary_conditions("periodic"))(a)
+    spec = b.make_rhs_spec(pde_hip.DiffusionPDE(), pde_hip.ScalarField(grid, 0.0, dtype=dtype))
+    res = C.c_void_p()
+    rows = [
+        ("laplace", lambda: lib.laplace(info.ref, a.ptr, o.ptr, _abi.OUT_FULL, None), 2 * it),
+        ("euler step (1 kernel, BCs on the fly)", lambda: lib.euler_run(info.ref, spec.ref, a.ptr, o.ptr, 0.1, 1, C.byref(res), None), 2 * it),
+        ("gradient", lambda: lib.gradient(info.ref, 0, a.ptr, v.ptr, _abi.OUT_FULL, None), (1 + dim) * it),
+        ("divergence", lambda: lib.divergence(info.ref, 0, v.ptr, o.ptr, _abi.OUT_FULL, None), (1 + dim) * it),
+        ("ghost cells (all faces)", lambda: b.make_ghost_cell_setter(grid.get_boundary_conditions("periodic"))(a), 0),
+    ]
+    for name, fn, bpc in rows:
+        t = timed(fn)
+        print(f"| {'x'.join(map(str, shape))} | {np.dtype(dtype).name} | {name} | {t:.4f} | {cells/t/1e6:.1f} | {cells*bpc/t/1e6:.0f} | {cells*bpc/t/1e6/80:.1f} |", flush=True)
+    del a, o, v

@@ -101,7 +101,8 @@ inline OutStr out_strides(const NGrid &n, int layout)
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // kernel launchers implemented in pdehip_kernels.hip
-enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3 };
+enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
+       LAP_GRAD_C = 4, LAP_GRAD_F = 5, LAP_GRAD_B = 6, LAP_GRADSQ_C = 7, LAP_GRADSQ_N = 8 };
 // input-side BCs the stencil kernel evaluates on the fly (scalar first-order conditions)
 struct InputBCs {
     int on[3][2];      // [normalised axis][lower, upper]
@@ -110,6 +111,8 @@ struct InputBCs {
 };
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
                    double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr);
+int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, const double *gs, hipStream_t st, bool *done);
+int launch_div_march(const NGrid &n, int method, const void *in, void *out, const OutStr &o, hipStream_t st, bool *done);
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
 // BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`

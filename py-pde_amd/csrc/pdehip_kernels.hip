@@ -89,11 +89,14 @@ struct LapArgs {
     int lx;           // planes per x-chunk
     long nxc, nty, ntz, nblocks;
     int no_swizzle;
+    long o_sc;        // component stride of the output (gradient modes)
+    double gs[3];     // per-axis scale of the derivative modes
     int any_ibc;
     InBC ibc[3][2];   // [normalised axis][lower, upper]
 };
 
 #include "pdehip_march.inc"
+#include "pdehip_div.inc"
 
 // ---------------------------------------------------------------------------------------------
 // generic fallback: one cell per thread, direct loads (any shape / any alignment / 1-D).
@@ -171,14 +174,17 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     a.lx = (int)lx;
     a.nxc = (a.n0 + lx - 1) / lx;
     a.nblocks = a.nxc * tiles;
-    constexpr bool kCanFuse = true;
+    // only the Euler epilogue reads a second array; on-the-fly BCs exist for the four laplace epilogues
+    constexpr bool kHasY = (MODE == LAP_EULER);
+    constexpr bool kIbc = (MODE <= LAP_CH_MU);
     const dim3 grid((unsigned)a.nblocks), block(64 * WY);
+    if (a.any_ibc && !kIbc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs are not built for the derivative epilogues");
     if (a.any_ibc) {
-        if (y_is_in) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, kCanFuse>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, false, kCanFuse>), grid, block, 0, st, a);
+        if (y_is_in || !kHasY) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, kIbc>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, !kHasY, kIbc>), grid, block, 0, st, a);
     } else {
-        if (y_is_in) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, false, false>), grid, block, 0, st, a);
+        if (y_is_in || !kHasY) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, !kHasY, false>), grid, block, 0, st, a);
     }
     PDEHIP_HIP(hipGetLastError());
     return 0;
@@ -233,6 +239,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
     }
     if (a.any_ibc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");
+    if (MODE > LAP_CH_MU) PDEHIP_FAIL(E_RUNTIME, "internal: derivative epilogues need the vectorised kernel");
     const long total = n.n[0] * n.n[1] * n.n[2];
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -247,6 +254,99 @@ bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const
     const long vec = 16 / elem_size(n.dtype);
     return n.ndim >= 2 && (n.n[2] % vec == 0) && !tune().force_generic && ((uintptr_t)in % 16 == 0) &&
            ((uintptr_t)out % 16 == 0) && (y == nullptr || (uintptr_t)y % 16 == 0);
+}
+
+// divergence through its own register-pipelined kernel (three input components, pdehip_div.inc)
+template <typename T, int METHOD>
+static int launch_div_t(const NGrid &n, DivArgs a, hipStream_t st)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    const long chunks = (n.n[2] + 64 * VEC - 1) / (64 * VEC);
+    int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+    auto tiles_for = [&](int cz_) { return ((n.n[1] + 1) / 2) * ((n.n[2] + 64L * VEC * cz_ - 1) / (64L * VEC * cz_)); };
+    while (cz > 1 && tiles_for(cz) * (n.ndim == 3 ? n.n[0] : 1) < 512) cz /= 2;
+    const long tiles = tiles_for(cz);
+    a.ntz = (n.n[2] + 64L * VEC * cz - 1) / (64L * VEC * cz);
+    a.nty = (n.n[1] + 1) / 2;
+    long lx = n.n[0];
+    if (n.ndim == 3) {
+        long nxc = (1024 + tiles - 1) / tiles;
+        if (nxc < 1) nxc = 1;
+        if (nxc > n.n[0]) nxc = n.n[0];
+        lx = (n.n[0] + nxc - 1) / nxc;
+    }
+    a.lx = (int)lx;
+    a.nxc = (n.n[0] + lx - 1) / lx;
+    a.nblocks = a.nxc * tiles;
+    const dim3 grid((unsigned)a.nblocks), block(64);
+#define PDEHIP_DIV(CZ_)                                                                                             \
+    if (cz == CZ_) {                                                                                                \
+        if (n.ndim == 3) hipLaunchKernelGGL((div_march_kernel<T, VEC, 2, CZ_, METHOD, true>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((div_march_kernel<T, VEC, 2, CZ_, METHOD, false>), grid, block, 0, st, a);            \
+    }
+    PDEHIP_DIV(4) PDEHIP_DIV(2) PDEHIP_DIV(1)
+#undef PDEHIP_DIV
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_div_march(const NGrid &n, int method, const void *in, void *out, const OutStr &o, hipStream_t st, bool *done)
+{
+    *done = false;
+    const long vec = 16 / elem_size(n.dtype);
+    const bool vec_ok = n.ndim >= 2 && (n.n[2] % vec == 0) && (o.s1 % vec == 0) && (o.s0 % vec == 0) && (o.off % vec == 0) &&
+                        (n.pc % vec == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)in % 16 == 0) && !tune().force_generic;
+    if (!vec_ok) return 0;
+    DivArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out;
+    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
+    a.p0 = n.p[0]; a.p1 = n.p[1]; a.pc = n.pc; a.off = n.off;
+    a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1;
+    for (int q = 0; q < 3; q++) a.gs[q] = (method == PDEHIP_CENTRAL) ? 0.5 / n.dx[q] : 1 / n.dx[q];   // cartesian.py:876-879, :928-931
+    *done = true;
+#define PDEHIP_DM(T)                                                                   \
+    switch (method) {                                                                  \
+    case PDEHIP_CENTRAL: return launch_div_t<T, PDEHIP_CENTRAL>(n, a, st);             \
+    case PDEHIP_FORWARD: return launch_div_t<T, PDEHIP_FORWARD>(n, a, st);             \
+    case PDEHIP_BACKWARD: return launch_div_t<T, PDEHIP_BACKWARD>(n, a, st);           \
+    default: PDEHIP_FAIL(E_VALUE, "Unknown derivative type `%d`", method);             \
+    }
+    if (n.dtype == PDEHIP_F64) { PDEHIP_DM(double) }
+    PDEHIP_DM(float)
+#undef PDEHIP_DM
+}
+
+// gradient / gradient_squared through the register-pipelined kernel (same loads as the Laplacian,
+// different epilogue).  Returns 1 without launching when the shape needs the generic derivative kernels.
+int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, const double *gs, hipStream_t st, bool *done)
+{
+    *done = false;
+    const long vec = 16 / elem_size(n.dtype);
+    const bool vec_ok = n.ndim >= 2 && (n.n[2] % vec == 0) && (o.s1 % vec == 0) && (o.s0 % vec == 0) && (o.off % vec == 0) &&
+                        (o.sc % vec == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)in % 16 == 0) && !tune().force_generic;
+    if (!vec_ok) return 0;
+    LapArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.y = nullptr;
+    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
+    a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
+    a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1; a.o_sc = o.sc;
+    for (int q = 0; q < 3; q++) a.gs[q] = gs[q];
+    a.ndim = n.ndim; a.lx = 1;
+    *done = true;
+#define PDEHIP_DMODE(T)                                                            \
+    switch (mode) {                                                                \
+    case LAP_GRAD_C: return launch_laplace_t<T, LAP_GRAD_C>(n, a, o, st);          \
+    case LAP_GRAD_F: return launch_laplace_t<T, LAP_GRAD_F>(n, a, o, st);          \
+    case LAP_GRAD_B: return launch_laplace_t<T, LAP_GRAD_B>(n, a, o, st);          \
+    case LAP_GRADSQ_C: return launch_laplace_t<T, LAP_GRADSQ_C>(n, a, o, st);      \
+    case LAP_GRADSQ_N: return launch_laplace_t<T, LAP_GRADSQ_N>(n, a, o, st);      \
+    default: PDEHIP_FAIL(E_VALUE, "unknown derivative mode %d", mode);             \
+    }
+    if (n.dtype == PDEHIP_F64) { PDEHIP_DMODE(double) }
+    PDEHIP_DMODE(float)
+#undef PDEHIP_DMODE
 }
 
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,

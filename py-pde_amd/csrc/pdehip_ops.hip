@@ -148,6 +148,24 @@ static int launch_deriv(int which, const pdehip_grid_t *g, int method, const voi
     if (layout != PDEHIP_OUT_VALID && layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", layout);
     if (which != 2 && (method < 0 || method > 2)) PDEHIP_FAIL(E_VALUE, "Unknown derivative type `%d`", method);
     OutStr o = out_strides(n, layout);
+    if (which != 1) {
+        // gradient / gradient_squared: same loads as the Laplacian -> register-pipelined kernel
+        double gs[3];
+        for (int q = 0; q < 3; q++) {
+            const double dx = n.dx[q];
+            if (which == 0) gs[q] = (method == PDEHIP_CENTRAL) ? 0.5 / dx : 1 / dx;       // cartesian.py:451-454, :503-506
+            else gs[q] = method ? 0.25 / (dx * dx) : 0.5 / (dx * dx);                      // cartesian.py:661, :672
+        }
+        const int mode = (which == 0) ? (method == PDEHIP_CENTRAL ? LAP_GRAD_C : method == PDEHIP_FORWARD ? LAP_GRAD_F : LAP_GRAD_B)
+                                      : (method ? LAP_GRADSQ_C : LAP_GRADSQ_N);
+        bool done = false;
+        PDEHIP_TRY(launch_deriv_march(n, in, out, o, mode, gs, as_stream(stream), &done));
+        if (done) return 0;
+    } else {
+        bool done = false;
+        PDEHIP_TRY(launch_div_march(n, method, in, out, o, as_stream(stream), &done));
+        if (done) return 0;
+    }
     DerivArgs a;
     a.g = dev_grid(n);
     a.in = in; a.out = out;

@@ -164,6 +164,14 @@ int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, v
 int pdehip_gradient_squared(const pdehip_grid_t *g, int central, const void *in_full, void *out,
                             int out_layout, void *stream);
 
+/* first (order = 1, `method` as above) or second (order = 2, central) derivative along ONE axis:
+ * the `d_dx`, `d_dy_forward`, `d2_dx2`, ... pattern operators of NumbaBackend.get_operator_info
+ * (pde/backends/numba/backend.py:119-182), formulas of make_derivative / make_derivative2
+ * (pde/backends/numba/operators/common.py:19-193): (r - l) / (2 dx), (r - c) / dx, (c - l) / dx,
+ * (r - 2 c + l) * (1 / dx**2) */
+int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int method, const void *in_full,
+                           void *out, int out_layout, void *stream);
+
 /* ---- fused stencil + pointwise kernels (all arrays full) --------------------------
  * out = s2 * (s1 * laplace(in))                       [k = dt * (D * lap), RK stages] */
 int pdehip_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out_full, double s1,

@@ -116,6 +116,12 @@ def gradient_squared(g, arr_full, central=True, layout=_abi.OUT_VALID):
     return out
 
 
+def axis_derivative(g, arr_full, axis, order=1, method="central", layout=_abi.OUT_VALID):
+    out = _out_array(g, (), layout, arr_full.dtype)
+    _check(lib().oracle_axis_derivative(C.byref(g), axis, order, _abi.METHODS[method], _p(arr_full), _p(out), layout), "axis_derivative")
+    return out
+
+
 def laplace_scaled(g, arr_full, s1, s2):
     out = np.zeros_like(arr_full)
     _check(lib().oracle_laplace_scaled(C.byref(g), _p(arr_full), _p(out), s1, s2), "laplace_scaled")

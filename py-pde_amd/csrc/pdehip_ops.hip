@@ -139,6 +139,32 @@ __global__ void __launch_bounds__(256) gradsq_kernel(DerivArgs a)
     });
 }
 
+struct AxisArgs {
+    DevGrid g;
+    const void *in;
+    void *out;
+    long o_off, o_s0, o_s1;
+    long pa;        // pitch along the axis
+    double dx;
+    int order, method;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) axis_derivative_kernel(AxisArgs a)
+{
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    for_each_chunk<1>(a.g, 1, [&](int, long i, long j, long k, long e) {
+        const double c = (double)in[e], l = (double)in[e - a.pa], r = (double)in[e + a.pa];
+        double v;
+        if (a.order == 2) v = (r - 2 * c + l) * (1 / (a.dx * a.dx));              // common.py:150-190
+        else if (a.method == PDEHIP_CENTRAL) v = (r - l) / (2 * a.dx);            // common.py:60-110
+        else if (a.method == PDEHIP_FORWARD) v = (r - c) / a.dx;
+        else v = (c - l) / a.dx;
+        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)v;
+    });
+}
+
 static int launch_deriv(int which, const pdehip_grid_t *g, int method, const void *in, void *out,
                         int layout, void *stream)
 {
@@ -483,6 +509,29 @@ int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void
 { return lap_entry(g, in_full, out_full, PDEHIP_OUT_FULL, LAP_EULER, s1, s2, 0, y_full, stream); }
 int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full, double gamma, void *stream)
 { return lap_entry(g, c_full, mu_full, PDEHIP_OUT_FULL, LAP_CH_MU, 0, 0, gamma, nullptr, stream); }
+
+int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int method, const void *in_full, void *out,
+                           int out_layout, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in_full || !out) PDEHIP_FAIL(E_VALUE, "axis_derivative: NULL array pointer");
+    if (axis < 0 || axis >= n.ndim) PDEHIP_FAIL(E_VALUE, "axis %d out of range for a %d-dimensional grid", axis, n.ndim);
+    if (order != 1 && order != 2) PDEHIP_FAIL(E_VALUE, "derivative order must be 1 or 2 (got %d)", order);
+    if (method < 0 || method > 2) PDEHIP_FAIL(E_VALUE, "Unknown derivative type `%d`", method);
+    if (out_layout != PDEHIP_OUT_VALID && out_layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", out_layout);
+    const OutStr o = out_strides(n, out_layout);
+    const int ax = 3 - n.ndim + axis;
+    AxisArgs a;
+    a.g = dev_grid(n); a.in = in_full; a.out = out;
+    a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1;
+    a.pa = n.p[ax]; a.dx = n.dx[ax]; a.order = order; a.method = method;
+    const unsigned blocks = grid_blocks(n.n[0] * n.n[1] * n.n[2]);
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((axis_derivative_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((axis_derivative_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
 
 int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
 { return launch_deriv(0, g, method, in_full, out, out_layout, stream); }

@@ -109,6 +109,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "gradient": ([_pg, _i, _vp, _vp, _i], True),
     "divergence": ([_pg, _i, _vp, _vp, _i], True),
     "gradient_squared": ([_pg, _i, _vp, _vp, _i], True),
+    "axis_derivative": ([_pg, _i, _i, _i, _vp, _vp, _i], True),
     "laplace_scaled": ([_pg, _vp, _vp, _d, _d], True),
     "laplace_euler": ([_pg, _vp, _vp, _vp, _d, _d], True),
     "cahn_hilliard_mu": ([_pg, _vp, _vp, _d], True),

@@ -22,6 +22,33 @@ class HipRuntimeError(RuntimeError):
     """An HIP runtime call inside libpdehip failed."""
 
 
+def _preload_torch_hip_runtime() -> None:
+    """Make sure ONE HIP runtime serves the process when PyTorch-ROCm is installed.
+
+    torch wheels bundle their own ``libamdhip64.so`` (same SONAME as the system ROCm one).  The
+    multi-GPU layer uses torch for process groups, so both libpdehip and torch live in one process;
+    whichever HIP runtime is loaded first is shared by both.  torch only works with its own copy
+    (its bundled HSA runtime must match), so that copy is loaded first — without importing torch.
+    Set ``PDEHIP_PRELOAD_TORCH_HIP=0`` to use the system runtime (then never import torch afterwards).
+    """
+    if os.environ.get("PDEHIP_PRELOAD_TORCH_HIP", "1") == "0":
+        return
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=getattr(os, "RTLD_NOW", 2) | getattr(os, "RTLD_GLOBAL", 0x100))
+        except OSError:
+            pass
+
+
 class _Lib:
     """Thin wrapper turning the int status convention into Python exceptions.
 
@@ -38,6 +65,7 @@ class _Lib:
             )
             raise ImportError(msg)
         self.path = path
+        _preload_torch_hip_runtime()
         self._h = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
         for name, (args, res) in _abi.RUNTIME_PROTOTYPES.items():
             fn = getattr(self._h, "pdehip_" + name)

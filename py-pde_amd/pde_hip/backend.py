@@ -272,6 +272,25 @@ class HipBackendMixin:
             for gcls in inspect.getmro(grid.__class__)[:-1]:
                 if operator in table.get(gcls, {}):
                     return table[gcls][operator]
+        # pattern operators `d_d<axis>[_central|_forward|_backward]` and `d2_d<axis>2`
+        # (pde/backends/numba/backend.py:143-173)
+        import functools
+
+        from .operators import make_axis_derivative
+
+        axes = list(getattr(grid, "axes", []))
+        if operator.startswith("d_d"):
+            axis_name, method = operator[len("d_d"):], "central"
+            for direction in ("central", "forward", "backward"):
+                if axis_name.endswith("_" + direction):
+                    method, axis_name = direction, axis_name[: -len("_" + direction)]
+                    break
+            if axis_name in axes:
+                factory = functools.partial(make_axis_derivative, axis=axes.index(axis_name), order=1, method=method)
+                return OperatorInfo(factory, rank_in=0, rank_out=0, name=operator)
+        if operator.startswith("d2_d") and operator.endswith("2") and operator[len("d2_d"):-1] in axes:
+            factory = functools.partial(make_axis_derivative, axis=axes.index(operator[len("d2_d"):-1]), order=2)
+            return OperatorInfo(factory, rank_in=0, rank_out=0, name=operator)
         msg = (
             f"Backend `{self.name}` does not define operator '{operator}' for grid "
             f"`{grid.__class__.__name__}`. Defined operators are: {sorted(self.get_registered_operators(grid))}."

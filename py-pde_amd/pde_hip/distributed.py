@@ -183,7 +183,21 @@ class SlabStepper:
         if self.exchanging or self.size > 1:
             make = getattr(self.engine, "make_comm", None)
             if make is not None:
-                self.comm = make(dist, group, self.size, self.rank)
+                try:
+                    self.comm = make(dist, group, self.size, self.rank)
+                    ok = self.comm is not None
+                except (RuntimeError, OSError) as err:  # e.g. RCCL library not resolvable
+                    import logging
+
+                    logging.getLogger("pde_hip.distributed").warning("native RCCL communicator unavailable (%s); using torch P2P ops", err)
+                    self.comm, ok = None, False
+                if self.size > 1:
+                    # all ranks must agree on the transport, otherwise their collectives would not match
+                    flag = self.engine.torch.tensor([1 if ok else 0], device=self.engine.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                    if int(flag.item()) == 0 and self.comm is not None:
+                        self.engine.lib.comm_destroy(self.comm)
+                        self.comm = None
         # the C ABI wants the full face table (physical faces on, exchanged ones are skipped there)
         self._rhs_c = None
         if self.comm is not None and self.kind == _abi.RHS_DIFFUSION:

@@ -68,6 +68,18 @@ def make_gradient_squared(grid, *, backend, central: bool = True, **kwargs):
     return gradient_squared
 
 
+def make_axis_derivative(grid, *, backend, axis: int, order: int = 1, method: str = "central", **kwargs):
+    """`d_dx`, `d_dy_forward`, `d2_dx2`, ... (numba/backend.py:143-173, operators/common.py:19-193)."""
+    code = _check_method(method)
+    lib = backend._lib
+
+    def derivative(arr: DeviceArray, out: DeviceArray) -> None:
+        lib.axis_derivative(arr.info.ref, axis, order, code, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+    derivative.grid = grid
+    return derivative
+
+
 def _vectorize_operator(make_operator, grid, **kwargs):
     """Apply an operator to every component of the first tensor axis (cartesian.py:999-1023)."""
     operator = make_operator(grid, **kwargs)

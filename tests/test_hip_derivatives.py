@@ -83,3 +83,30 @@ def test_div_grad_equals_wide_laplacian(backend):
     const = pde_hip.ScalarField(grid, 2.5)
     np.testing.assert_array_equal(const.gradient("periodic").data, 0)
     np.testing.assert_array_equal(const.gradient_squared("periodic").data, 0)
+
+
+@pytest.mark.parametrize("shape", [(7, 9, 12), (33, 130), (40,)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_axis_derivative_pattern_operators(backend, shape, dtype):
+    """`d_dx`, `d_dy_forward`, `d2_dz2`, ... (numba/backend.py:143-173) vs the oracle (bit-exact) and, in 1-D,
+    vs the reference's own gradient (whose 1-D formula is the same `/ (2 dx)` expression)."""
+    nd = len(shape)
+    grid = pde_hip.CartesianGrid([[0, n * 0.6] for n in shape], shape)
+    data = np.random.default_rng(4).uniform(-1, 1, shape).astype(dtype)
+    field = pde_hip.ScalarField(grid, data, dtype=dtype)
+    bc = {"value": 0.2}
+    g = oracle_grid(grid, dtype)
+    full = to_full(grid, data)
+    O.set_ghost_cells(g, 1, host_faces(grid.get_boundary_conditions(bc)).c, full)
+    for ax, name in enumerate(grid.axes):
+        np.testing.assert_array_equal(field.apply_operator(f"d_d{name}", bc).data, O.axis_derivative(g, full, ax, 1, "central"))
+        np.testing.assert_array_equal(field.apply_operator(f"d_d{name}_forward", bc).data, O.axis_derivative(g, full, ax, 1, "forward"))
+        np.testing.assert_array_equal(field.apply_operator(f"d_d{name}_backward", bc).data, O.axis_derivative(g, full, ax, 1, "backward"))
+        np.testing.assert_array_equal(field.apply_operator(f"d2_d{name}2", bc).data, O.axis_derivative(g, full, ax, 2))
+    if nd == 1:
+        np.testing.assert_array_equal(field.apply_operator("d_dx", bc).data, field.gradient(bc).data[0])
+    # the sum of the second derivatives is the Laplacian up to rounding (tests/grids/test_cartesian_grids.py:276-294)
+    total = sum(field.apply_operator(f"d2_d{name}2", bc).data.astype(np.float64) for name in grid.axes)
+    np.testing.assert_allclose(total, field.laplace(bc).data, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-4 if dtype == np.float32 else 1e-10)
+    with pytest.raises(NotImplementedError, match="does not define operator"):
+        field.apply_operator("d_dq", bc)

@@ -310,6 +310,7 @@ int main(int argc, char **argv)
         printf("write_only : %.3f ms %.0f GB/s\n", t * 1e3, nv * 16.0 / t / 1e9);
     }
     for (long wb : {256L, 512L, 1024L, 2048L}) {
+        if (argc > 2) break;
         run<2, 1, 4, 1, false>(a, wb, 1);
         run<1, 1, 4, 1, false>(a, wb, 1);
         run<2, 2, 4, 1, false>(a, wb, 1);
@@ -327,5 +328,22 @@ int main(int argc, char **argv)
     run<2, 1, 4, 1, true>(a, 512, 1);
     run<2, 4, 4, 1, true>(a, 512, 1);
     run<2, 4, 4, 1, false>(a, 512, 0);
+    // does the relative placement of the input and the output array matter (HBM channel / bank overlap)?
+    {
+        double *big;
+        const size_t extra = 64u << 20;
+        CK(hipMalloc(&big, g_elems * 8 + extra));
+        for (size_t off_bytes : {(size_t)0, (size_t)256, (size_t)4096, (size_t)(64 << 10), (size_t)(1 << 20), (size_t)(2 << 20) + 4096, (size_t)(8 << 20) + 12288, (size_t)(32 << 20) + 65536}) {
+            A b = a;
+            b.out = (double *)((char *)big + off_bytes);
+            b.swz = 1;
+            b.ntz = 1; b.nty = (b.n1 + 1) / 2;
+            long tiles = b.nty, nxc = (1024 + tiles - 1) / tiles;
+            long lx = (b.n0 + nxc - 1) / nxc;
+            b.lx = (int)lx; b.nxc = (b.n0 + lx - 1) / lx; b.nblocks = b.nxc * tiles;
+            double t = time_it([&] { hipLaunchKernelGGL((march<2, 4, 1, 1, false>), dim3((unsigned)b.nblocks), dim3(64), 0, 0, b); });
+            printf("out offset %10zu B (out-in = %ld B): %.4f ms  %.1f GB/s\n", off_bytes, (long)((char *)b.out - (char *)b.in), t * 1e3, 16.0 * b.n0 * b.n1 * b.n2 / t / 1e9);
+        }
+    }
     return 0;
 }

@@ -246,6 +246,23 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
                           int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                           void *stream);
 
+/* ---- run-time specialised right-hand sides (generic `PDE({...})` expressions) ----------------------
+ * Replaces the sympy -> numba code generation of pde/pdes/pde.py:401-499 / pde/tools/expressions.py:
+ * 361-388.  `epilogue_body` is the body of
+ *     double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)
+ * (C statements ending in `return ...;`).  pdehip_jit_apply evaluates, for every interior cell,
+ *     out = pde_epilogue(in, laplace(in), gradient_squared(in), extra[0], extra[1], extra[2], params)
+ * in ONE pass of the register-pipelined stencil kernel compiled around the epilogue with hiprtc
+ * (cached per tile shape); `in_faces` are evaluated on the fly / by the ghost kernel first (NULL: ghost
+ * cells of `in_full` are already set).  All arrays are FULL arrays of the same grid. */
+int pdehip_jit_create(const char *epilogue_body, void **handle);
+int pdehip_jit_destroy(void *handle);
+/* compile (not load) the kernels of this expression for a dtype / dimension: works without a GPU */
+int pdehip_jit_check(void *handle, int dtype, int ndim);
+int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host,
+                     void *out_full, const double *params_host, int nparams, const pdehip_bc_face_t *in_faces,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,11 +159,11 @@ int pdehip_comm_destroy(void *comm)
 {
     if (!comm) return 0;
     Comm *c = static_cast<Comm *>(comm);
-    hipStreamSynchronize(c->halo);
+    (void)hipStreamSynchronize(c->halo);
     g_rccl.CommDestroy(c->comm);
-    hipStreamDestroy(c->halo);
-    hipEventDestroy(c->ev_comp); hipEventDestroy(c->ev_halo); hipEventDestroy(c->ev_bnd);
-    hipFree(c->scratch2);
+    (void)hipStreamDestroy(c->halo);
+    (void)hipEventDestroy(c->ev_comp); (void)hipEventDestroy(c->ev_halo); (void)hipEventDestroy(c->ev_bnd);
+    (void)hipFree(c->scratch2);
     delete c;
     return 0;
 }

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "../../include/pdehip.h"
+#include "pdehip_device.h"
 
 namespace pdehip {
 
@@ -101,8 +102,6 @@ inline OutStr out_strides(const NGrid &n, int layout)
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 // kernel launchers implemented in pdehip_kernels.hip
-enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
-       LAP_GRAD_C = 4, LAP_GRAD_F = 5, LAP_GRAD_B = 6, LAP_GRADSQ_C = 7, LAP_GRADSQ_N = 8 };
 // input-side BCs the stencil kernel evaluates on the fly (scalar first-order conditions)
 struct InputBCs {
     int on[3][2];      // [normalised axis][lower, upper]

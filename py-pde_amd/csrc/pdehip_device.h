@@ -1,0 +1,97 @@
+// pdehip_device.h — device-side definitions shared by the offline build (hipcc) and the run-time
+// build (hiprtc, pdehip_jit.hip) of the register-pipelined stencil kernel.  No host headers.
+#pragma once
+
+namespace pdehip {
+
+// epilogue selector of lap_march_kernel
+enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
+       LAP_GRAD_C = 4, LAP_GRAD_F = 5, LAP_GRAD_B = 6, LAP_GRADSQ_C = 7, LAP_GRADSQ_N = 8,
+       LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */ };
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC> struct VecT;
+template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// wavefront shift by one lane through DPP (gfx9 wave_shr:1 / wave_shl:1).  Lane 0 (resp. lane
+// 63) has no source lane and keeps `old`, which carries the value from outside the chunk.
+__device__ __forceinline__ double wave_shr1(double old, double src)
+{
+    unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
+    int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_shl1(double old, double src)
+{
+    unsigned long long o = __double_as_longlong(old), s = __double_as_longlong(src);
+    int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffu), (int)(s & 0xffffffffu), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(s >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    unsigned long long s = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(s & 0xffffffffu), lane);
+    int hi = __builtin_amdgcn_readlane((int)(s >> 32), lane);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// XCD-aware block -> work-item map: hardware places block b on XCD b % 8 (speed only, never
+// correctness).  Every XCD gets a contiguous range of the tile list so that tiles sharing halo
+// rows also share an L2.
+__device__ __forceinline__ long xcd_swizzle(long bid, long nblocks)
+{
+    const long per = nblocks / 8;
+    if (bid >= per * 8) return bid;  // tail: identity
+    return (bid % 8) * per + bid / 8;
+}
+
+template <int MODE>
+__device__ __forceinline__ double epilogue(double lap, double c, double yv, double s1, double s2, double gamma)
+{
+    if (MODE == LAP_PLAIN) return lap;
+    if (MODE == LAP_SCALED) return s2 * (s1 * lap);        // dt * (D * lap)
+    if (MODE == LAP_EULER) return yv + s2 * (s1 * lap);    // pde/solvers/euler.py:174
+    return c * c * c - c - gamma * lap;                    // pde/pdes/cahn_hilliard.py:116-120
+}
+
+// boundary condition evaluated on the fly on the input side:  virtual = c + f * in[idx]
+struct InBC {
+    int on;
+    long idx;      // valid index along the axis the virtual value is computed from
+    double c, f;
+};
+
+struct LapArgs {
+    const void *in;
+    void *out;
+    const void *y;
+    long n0, n1, n2;
+    long p0, p1, off;
+    long o_off, o_s0, o_s1;
+    double sx, sy, sz, s1, s2, gamma;
+    int ndim;
+    int lx;           // planes per x-chunk
+    long nxc, nty, ntz, nblocks;
+    int no_swizzle;
+    long o_sc;        // component stride of the output (gradient modes)
+    double gs[3];     // per-axis scale of the derivative modes
+    int any_ibc;
+    const void *ex[3];   // LAP_CUSTOM: up to three extra input arrays (centre values only)
+    double par[12];      // LAP_CUSTOM: run-time scalars of the generated epilogue (dt, constants, t, ...)
+    InBC ibc[3][2];   // [normalised axis][lower, upper]
+};
+
+// LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the
+// offline build never instantiates that mode and only needs the declaration to parse.
+#ifdef PDEHIP_JIT
+__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p);
+#else
+__device__ __forceinline__ double pde_epilogue(double, double, double, double, double, double, const double *) { return 0.0; }
+#endif
+
+}  // namespace pdehip

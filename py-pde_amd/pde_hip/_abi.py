@@ -156,6 +156,11 @@ COMM_PROTOTYPES: dict[str, list] = {
     "halo_exchange": [_vp, _pg, _vp, _i, _i, _vp],
     "allreduce_max": [_vp, _vp, _vp],
     "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    # run-time specialised expression kernels (pdehip_jit.hip)
+    "jit_create": [C.c_char_p, _pvp],
+    "jit_destroy": [_vp],
+    "jit_check": [_vp, _i, _i],
+    "jit_apply": [_vp, _pg, _vp, _pvp, _vp, _pd, _i, _pf, _vp],
 }
 
 

@@ -435,7 +435,18 @@ class HipBackendMixin:
 
     def make_pde_rhs(self, eq, state):
         """``rhs(state_native, t) -> rate_native`` (base.py:634-651)."""
-        spec = self.make_rhs_spec(eq, state)
+        try:
+            spec = self.make_rhs_spec(eq, state)
+        except NotImplementedError:
+            erhs = self.make_expression_rhs(eq, state)   # raises NotImplementedError itself if unsupported
+
+            def expr_rhs(state_data: DeviceArray, t: float = 0) -> DeviceArray:
+                out = state_data.empty_like()
+                erhs.apply(state_data, out, "rate", 0.0, float(t))
+                return out
+
+            expr_rhs.expression = erhs  # type: ignore[attr-defined]
+            return expr_rhs
         lib = self._lib
 
         def pde_rhs(state_data: DeviceArray, t: float = 0) -> DeviceArray:
@@ -446,6 +457,129 @@ class HipBackendMixin:
 
         pde_rhs.spec = spec  # type: ignore[attr-defined]
         return pde_rhs
+
+    def make_expression_rhs(self, eq, state):
+        """Generic expression PDE (pde/pdes/pde.py) -> run-time specialised kernels (pde_hip/expr.py)."""
+        from .expr import ExpressionPlan, ExpressionRhs
+
+        if eq.__class__.__name__ != "PDE":
+            msg = f"hip backend has no right-hand side for {eq.__class__.__name__}"
+            raise NotImplementedError(msg)
+        if getattr(eq, "is_sde", False) or getattr(eq, "noise", 0):
+            msg = "hip backend does not support stochastic equations"
+            raise NotImplementedError(msg)
+        if state.__class__.__name__ != "ScalarField":
+            msg = "hip backend expression kernels support a single ScalarField state"
+            raise NotImplementedError(msg)
+        rhs = dict(eq.rhs)
+        if len(rhs) != 1:
+            msg = "hip backend supports expression PDEs of a single scalar variable"
+            raise NotImplementedError(msg)
+        (var, expr), = rhs.items()
+        plan = ExpressionPlan(str(expr), var, dict(getattr(eq, "consts", {}) or {}))
+        grid = state.grid
+        info = self.grid_info(grid, state.dtype)
+        bc_default = getattr(eq, "bc", "auto_periodic_neumann")
+        bc_ops = dict(getattr(eq, "bc_ops", {}) or {})
+        bc_state = bc_ops.get(f"{var}:laplace", bc_ops.get(f"{var}:*", bc_ops.get("*:laplace", bc_ops.get("*:*", bc_default))))
+        faces_state = convert_bcs(grid.get_boundary_conditions(bc_state, rank=0))
+        faces_tmp = convert_bcs(grid.get_boundary_conditions(bc_ops.get("*:*", bc_default), rank=0))
+        return ExpressionRhs(self, plan, info, faces_state, faces_tmp)
+
+    def _make_expression_stepper(self, solver, state):
+        """Python-level twin of the C steppers for expression right-hand sides: the same update rules
+        (pde/solvers/euler.py:172-175, runge_kutta.py:52-61, :135-153) with the RHS evaluated by the
+        run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass."""
+        from .solvers import OnlineStatistics, make_dt_adjuster
+
+        erhs = self.make_expression_rhs(solver.pde, state)
+        info, lib, stream = erhs.info, self._lib, self.stream
+        is_rk = solver.__class__.__name__ == "RungeKuttaSolver"
+        adaptive = bool(getattr(solver, "adaptive", False))
+        nwork = (7 if adaptive else 5) if is_rk else (2 if adaptive else 1)
+        work = [DeviceArray(info) for _ in range(nwork)]
+        B = [[1 / 4], [3 / 32, 9 / 32], [1932 / 2197, -7200 / 2197, 7296 / 2197], [439 / 216, -8.0, 3680 / 513, -845 / 4104],
+             [-8 / 27, 2.0, -3544 / 2565, 1859 / 4104, -11 / 40]]
+        A = [0.0, 1 / 4, 3 / 8, 12 / 13, 1.0, 1 / 2]
+
+        def lincomb(out, y, coefs, ks):
+            cf = (C.c_double * len(coefs))(*coefs)
+            lib.lincomb(info.ref, 1, out.ptr, y.ptr, len(ks), cf, ptr_array(ks), stream)
+
+        def rk4_step(y, t, dt):
+            k1, k2, k3, k4, tmp = work[:5]
+            erhs.apply(y, k1, "scaled", dt, t)
+            lincomb(tmp, y, [0.5], [k1])
+            erhs.apply(tmp, k2, "scaled", dt, t + 0.5 * dt)
+            lincomb(tmp, y, [0.5], [k2])
+            erhs.apply(tmp, k3, "scaled", dt, t + 0.5 * dt)
+            lincomb(tmp, y, [1.0], [k3])
+            erhs.apply(tmp, k4, "scaled", dt, t + dt)
+            lib.rk4_combine(info.ref, 1, y.ptr, k1.ptr, k2.ptr, k3.ptr, k4.ptr, stream)
+
+        if not adaptive:
+            dt = float(solver.info["dt"])
+
+            def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+                steps = max(1, round((t_end - t_start) / dt))
+                cur, nxt = state_data, work[0]
+                for i in range(steps):
+                    t = t_start + i * dt
+                    if is_rk:
+                        rk4_step(cur, t, dt)
+                    else:
+                        erhs.apply(cur, nxt, "euler", dt, t)
+                        cur, nxt = nxt, cur
+                if cur is not state_data:
+                    lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
+                solver.info["steps"] += steps
+                return state_data, t_start + (steps - 1) * dt + dt
+
+            return fixed_stepper
+
+        solver.info["dt_adaptive"] = True
+        solver.info.setdefault("dt_statistics", OnlineStatistics())
+        adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
+        tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
+        err_dev, ynew = DeviceScalar(), DeviceArray(info)
+
+        def attempt(y, t, dt_step) -> float:
+            if is_rk:
+                ks, tmp = work[:6], work[6]
+                erhs.apply(y, ks[0], "scaled", dt_step, t)
+                for s_, b in enumerate(B):
+                    lincomb(tmp, y, b, ks[: s_ + 1])
+                    erhs.apply(tmp, ks[s_ + 1], "scaled", dt_step, t + A[s_ + 1] * dt_step)
+                lib.rkf45_combine(info.ref, 1, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
+            else:
+                k1, k2a = work[0], work[1]
+                erhs.apply(y, k1, "euler", dt_step, t)
+                erhs.apply(y, k2a, "euler", 0.5 * dt_step, t)
+                erhs.apply(k2a, ynew, "euler", 0.5 * dt_step, t + 0.5 * dt_step)
+                lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
+            return err_dev.value(stream)
+
+        def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+            dt_opt = float(solver.info["dt"])
+            t, steps = t_start, 0
+            stats = solver.info["dt_statistics"]
+            while True:
+                dt_step = max(min(dt_opt, t_end - t), dt_min)
+                error_rel = attempt(state_data, t, dt_step) / tolerance
+                if error_rel <= 1:
+                    steps += 1
+                    t += dt_step
+                    lib.memcpy_d2d(state_data.ptr, ynew.ptr, state_data.nbytes, stream)
+                    stats.add(dt_step)
+                if t < t_end:
+                    dt_opt = adjust_dt(dt_step, error_rel)
+                else:
+                    break
+            solver.info["dt"] = dt_opt
+            solver.info["steps"] += steps
+            return state_data, t
+
+        return adaptive_stepper
 
     # --- steppers ----------------------------------------------------------------------------------------------
     def make_inner_stepper(self, solver, state):
@@ -460,7 +594,10 @@ class HipBackendMixin:
         if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver"}:
             msg = f"Backend `{self.name}` does not support solver {solver_name}"
             raise NotImplementedError(msg)
-        spec = self.make_rhs_spec(solver.pde, state)
+        try:
+            spec = self.make_rhs_spec(solver.pde, state)
+        except NotImplementedError:
+            return self._make_expression_stepper(solver, state)   # generic expression PDE
         info, lib, stream = spec.info, self._lib, self.stream
         is_rk = solver_name == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))

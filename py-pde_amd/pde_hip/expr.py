@@ -1,0 +1,259 @@
+"""Expression right-hand sides: sympy expression -> passes of run-time specialised stencil kernels.
+
+Covers the generic ``PDE({"c": "<expression>"})`` class of the reference for a single scalar field
+(``pde/pdes/pde.py:299-499``: the reference substitutes operator calls into the expression and lets
+numba compile it; temporaries are materialised for every arithmetic operation).  Here the expression
+is split into the minimal number of *passes*; each pass is ONE launch of the register-pipelined stencil
+kernel compiled (hiprtc, ``csrc/pdehip_jit.hip``) around a generated pointwise epilogue:
+
+    out = f(a, laplace(a), gradient_squared(a), b1, b2, b3; dt, t)        a = the pass' stencil array
+
+so e.g. ``c - c**3 + laplace(c)`` (Allen–Cahn) or ``nu*laplace(h) + lam*gradient_squared(h)`` (KPZ) are a
+single pass with 1 read + 1 write per cell, ``laplace(c**3 - c - laplace(c))`` is two passes, and the
+Euler update / RK stage scaling is folded into the last pass.  Supported: ``laplace`` and
+``gradient_squared`` (central) of the field or of any pointwise sub-expression, elementary functions,
+constants, explicit time ``t``.  Anything else raises ``NotImplementedError`` like the reference does
+for unknown backends (``pde/pdes/pde.py:469-496``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from . import _abi
+
+MAX_EXTRA = 3
+OPERATORS = ("laplace", "gradient_squared")
+P_DT, P_T = 0, 1  # slots of the run-time parameter vector
+
+
+class _Pass:
+    """One kernel launch: stencil array `src`, centre-only arrays `extras`, result array `out`."""
+
+    def __init__(self, src: str, extras: list[str], out: str, expr):
+        self.src, self.extras, self.out, self.expr = src, extras, out, expr
+
+
+def _sympy():
+    import sympy
+
+    return sympy
+
+
+class ExpressionPlan:
+    """Lower ``expr`` (string, variable ``var``) into passes.  Array names: ``"state"``, ``"tmp<k>"``."""
+
+    def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None):
+        sp = _sympy()
+        self.var = var
+        expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
+        self._ops = {name: sp.Function(name) for name in OPERATORS}
+        local: dict[str, Any] = dict(self._ops)
+        self._state = sp.Symbol("__state", real=True)  # internal name: must not clash with the code symbols
+        self._t = sp.Symbol("__t", real=True)
+        local[var] = self._state
+        local["t"] = self._t
+        for k, v in (consts or {}).items():
+            if not np.isscalar(v):
+                msg = "hip backend: array-valued constants in expressions are not supported"
+                raise NotImplementedError(msg)
+            local[k] = sp.Float(float(v))
+        try:
+            expr = sp.sympify(expr_str, locals=local)
+        except (sp.SympifyError, SyntaxError, TypeError) as err:
+            msg = f"cannot parse expression `{expr_str}`: {err}"
+            raise ValueError(msg) from err
+        unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(OPERATORS)
+        if unknown:
+            msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
+            raise NotImplementedError(msg)
+        free = {str(s) for s in expr.free_symbols} - {"__state", "__t"}
+        if free:
+            msg = f"unknown symbol(s) {sorted(free)} in `{expr_str}` (pass them in `consts`)"
+            raise ValueError(msg)
+        self.uses_time = self._t in expr.free_symbols
+        self.passes: list[_Pass] = []
+        self._ntmp = 0
+        self._memo: dict[Any, str] = {}
+        self._arrays = {"state": self._state}  # array name -> sympy symbol standing for its centre value
+        self._lower_top(expr)
+
+    # --- lowering --------------------------------------------------------------------------------
+    def _new_tmp(self) -> str:
+        sp = _sympy()
+        name = f"tmp{self._ntmp}"
+        self._ntmp += 1
+        self._arrays[name] = sp.Symbol(f"__{name}", real=True)
+        return name
+
+    def _materialise(self, expr) -> str:
+        """Name of the temporary holding the (operator-lowered) pointwise expression ``expr``;
+        identical sub-expressions share one temporary."""
+        if expr not in self._memo:
+            tmp = self._new_tmp()
+            self._emit(expr, tmp)
+            self._memo[expr] = tmp
+        return self._memo[expr]
+
+    def _array_of(self, sym) -> str | None:
+        for name, s in self._arrays.items():
+            if s == sym:
+                return name
+        return None
+
+    def _lower_ops(self, expr):
+        """Replace every operator application by an atom ``op(array_symbol)``; operator arguments that
+        are not plain arrays are materialised into temporaries first (innermost first)."""
+        sp = _sympy()
+        if isinstance(expr, sp.core.function.AppliedUndef):
+            (arg,) = expr.args
+            arg = self._lower_ops(arg)
+            if self._array_of(arg) is None:
+                arg = self._arrays[self._materialise(arg)]
+            return expr.func(arg)
+        if expr.args:
+            return expr.func(*[self._lower_ops(a) for a in expr.args])
+        return expr
+
+    def _emit(self, expr, out: str) -> None:
+        """Emit the passes that evaluate the (operator-lowered) pointwise expression into ``out``."""
+        sp = _sympy()
+        atoms = list(expr.atoms(sp.core.function.AppliedUndef))
+        by_array: dict[str, list] = {}
+        for a in atoms:
+            by_array.setdefault(self._array_of(a.args[0]), []).append(a)
+        # the stencil array of this pass: the one that leaves the fewest operator atoms (on other arrays,
+        # not yet materialised) to be computed by passes of their own; ties prefer the latest temporary
+        if by_array:
+            names = list(by_array)
+
+            def cost(name):
+                return sum(1 for other, lst in by_array.items() if other != name for a in lst if a not in self._memo)
+
+            src = min(reversed(names), key=cost)
+        else:
+            used = [n for n, s in self._arrays.items() if s in expr.free_symbols]
+            src = used[0] if used else "state"
+        # operator atoms on OTHER arrays become (or re-use) temporaries
+        for name, lst in by_array.items():
+            if name == src:
+                continue
+            for a in lst:
+                expr = expr.subs(a, self._arrays[self._materialise(a)])
+        extras = [n for n, s in self._arrays.items() if n != src and s in expr.free_symbols]
+        if len(extras) > MAX_EXTRA:
+            msg = "hip backend: expression needs more than 3 auxiliary fields in one pass"
+            raise NotImplementedError(msg)
+        self.passes.append(_Pass(src, extras, out, expr))
+
+    def _lower_top(self, expr) -> None:
+        self._emit(self._lower_ops(expr), "out")
+
+    # --- code generation ---------------------------------------------------------------------------
+    def epilogue(self, p: _Pass, wrap: str) -> tuple[str, list[str]]:
+        """C body of ``pde_epilogue`` for pass ``p`` and the arrays bound to e0..e2.
+
+        ``wrap`` in {"rate", "scaled", "euler"} selects what the LAST pass returns: F, dt*F, state + dt*F.
+        """
+        sp = _sympy()
+        from sympy.printing.c import C99CodePrinter
+
+        class Printer(C99CodePrinter):
+            def _print_Pow(self, e):  # small integer powers as repeated multiplication (numba does the same)
+                b, ex = e.as_base_exp()
+                if ex.is_Integer and 1 <= abs(int(ex)) <= 8:
+                    prod = "*".join([f"({self._print(b)})"] * abs(int(ex)))
+                    return f"({prod})" if ex > 0 else f"(1.0/({prod}))"
+                return super()._print_Pow(e)
+
+        c, lap, gsq = sp.symbols("c lap gsq", real=True)
+        e_syms = sp.symbols("e0 e1 e2", real=True)
+        sub: dict[Any, Any] = {}
+        src_sym = self._arrays[p.src]
+        for a in p.expr.atoms(sp.core.function.AppliedUndef):
+            sub[a] = lap if a.func.__name__ == "laplace" else gsq
+        sub2 = dict(sub)
+        sub2[src_sym] = c
+        sub2[self._t] = sp.Symbol("t", real=True)
+        for i, name in enumerate(p.extras):
+            sub2[self._arrays[name]] = e_syms[i]
+        expr = p.expr.subs(sub2, simultaneous=True)
+        extras = list(p.extras)
+        code = Printer({"precision": 17}).doprint(expr)
+        lines = [f"const double t = p[{P_T}]; (void)t;", f"const double F = {code};"]
+        if p.out != "out" or wrap == "rate":
+            lines.append("return F;")
+        elif wrap == "scaled":
+            lines.append(f"return p[{P_DT}] * F;")
+        elif wrap == "euler":
+            if p.src == "state":
+                y = "c"
+            else:
+                if "state" not in extras:
+                    if len(extras) >= MAX_EXTRA:
+                        msg = "hip backend: no slot left for the state in the Euler update"
+                        raise NotImplementedError(msg)
+                    extras.append("state")
+                y = f"e{extras.index('state')}"
+            lines.append(f"return {y} + p[{P_DT}] * F;")
+        else:
+            raise ValueError(wrap)
+        return "\n".join(lines), extras
+
+    def describe(self) -> list[str]:
+        return [f"{p.out} <- f({p.src}; ops={sorted({a.func.__name__ for a in p.expr.atoms(_sympy().core.function.AppliedUndef)})}; extras={p.extras})" for p in self.passes]
+
+
+class ExpressionRhs:
+    """Device evaluation of an :class:`ExpressionPlan` (kernels compiled lazily, cached per wrap mode)."""
+
+    def __init__(self, backend, plan: ExpressionPlan, info, faces_state, faces_tmp):
+        from .device import DeviceArray
+
+        self.backend, self.plan, self.info = backend, plan, info
+        self.lib = backend._lib
+        self.faces = {"state": faces_state}
+        self.tmps = {}
+        for p in plan.passes:
+            if p.out != "out":
+                self.tmps[p.out] = DeviceArray(info)
+                self.faces[p.out] = faces_tmp
+        self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
+
+    def _kernel(self, index: int, wrap: str):
+        key = (index, wrap if self.plan.passes[index].out == "out" else "rate")
+        if key not in self._kernels:
+            p = self.plan.passes[index]
+            body, extras = self.plan.epilogue(p, key[1])
+            h = C.c_void_p()
+            self.lib.jit_create(body.encode(), C.byref(h))
+            self._kernels[key] = (h, extras)
+        return self._kernels[key]
+
+    def check(self, dtype, ndim: int) -> None:
+        """Compile every kernel (no device needed) — surfaces code-generation errors early."""
+        for i in range(len(self.plan.passes)):
+            for wrap in ("rate", "scaled", "euler"):
+                h, _ = self._kernel(i, wrap)
+                self.lib.jit_check(h, _abi.dtype_code(dtype), ndim)
+
+    def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
+        """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler)."""
+        arrays = {"state": state, "out": out, **self.tmps}
+        params = (C.c_double * 2)(dt, t)
+        for i, p in enumerate(self.plan.passes):
+            h, extras = self._kernel(i, wrap)
+            ex = (C.c_void_p * 3)()
+            for m, name in enumerate(extras):
+                ex[m] = arrays[name].ptr
+            self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+
+    def __del__(self):
+        for h, _ in getattr(self, "_kernels", {}).values():
+            try:
+                self.lib.jit_destroy(h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass

@@ -256,12 +256,14 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
     if (fast) {
         const long chunks = (n.n[2] + 64L * vec - 1) / (64L * vec);
         int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
-        int ry = (n.ndim == 3) ? 2 : 8;
+        int ry = 2;   // measured: 2-row tiles win in 2-D as well (4096^2 Allen-Cahn 80 % vs 40 % of the HBM peak with 8 rows)
+        static int ry_env = -1;   // PDEHIP_JIT_RY: rows per wave tile (tuning aid; any value works, kernels are built on demand)
+        if (ry_env < 0) { const char *e = getenv("PDEHIP_JIT_RY"); ry_env = e ? atoi(e) : 0; }
+        if (ry_env > 0) ry = ry_env;
         auto n_tiles = [&](int ry_, int cz_) {
             const long per_plane = ((n.n[1] + ry_ - 1) / ry_) * ((n.n[2] + 64L * vec * cz_ - 1) / (64L * vec * cz_));
             return n.ndim == 3 ? per_plane * n.n[0] : per_plane;
         };
-        if (n.ndim == 2 && n_tiles(ry, cz) < 512) ry = 2;
         while (cz > 1 && n_tiles(ry, cz) < 512) cz /= 2;
         const bool hasx = n.ndim == 3, ibc = n_fused > 0;
         const std::string key = std::string(tname) + "," + std::to_string(ry) + "," + std::to_string(cz) + "," + (hasx ? "x" : "-") + (ibc ? "b" : "-");

@@ -133,7 +133,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // measured on MI355X at 512^3 fp64 (profiles/r01_sweep_tiles.log): 2 rows x whole-row chunks, ~1024
         // single-wave workgroups (4 per CU) gives 0.41 ms per pass = 65 % of the 8 TB/s HBM peak
         // fp32 (fp64 registers, 4 cells per lane) is VALU-heavier: 4-row tiles measured 585 vs 454 Gcells/s at 512^3
-        int ry = (n.ndim == 3) ? ((sizeof(T) == 4 && cz >= 2) ? 4 : 2) : 8, wy = 1, pf = 1;
+        int ry = (n.ndim == 3 && sizeof(T) == 4 && cz >= 2) ? 4 : 2, wy = 1, pf = 1;   // 2-D: 2-row tiles too (4096^2: 79 % vs 57 % with 8 rows)
         long blocks = 1024;
         // ... but never starve the chip: small grids get smaller tiles until there are >= 512 wave
         // tiles (a 512^2 grid as 8-row x 512-cell tiles would be 64 waves on 256 CUs)
@@ -141,7 +141,6 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
             const long per_plane = ((n.n[1] + ry_ - 1) / ry_) * ((n.n[2] + 64L * VEC * cz_ - 1) / (64L * VEC * cz_));
             return n.ndim == 3 ? per_plane * n.n[0] : per_plane;   // 3-D can also split along x
         };
-        if (n.ndim == 2 && n_tiles(ry, cz) < 512) ry = 2;
         while (cz > 1 && n_tiles(ry, cz) < 512) cz /= 2;
         if (n.ndim == 3 && ry == 4 && cz < 2) ry = 2;   // only (4,4) and (4,2) are instantiated
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
@@ -154,9 +153,6 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         PDEHIP_CFG3(2, 1, 1, 1)
         PDEHIP_CFG3(4, 4, 1, 1)
         PDEHIP_CFG3(4, 2, 1, 1)
-        PDEHIP_CFG2(8, 4)
-        PDEHIP_CFG2(8, 2)
-        PDEHIP_CFG2(8, 1)
         PDEHIP_CFG2(2, 4)
         PDEHIP_CFG2(2, 2)
         PDEHIP_CFG2(2, 1)

@@ -170,6 +170,8 @@ def _serial_reference(eq, grid, data, t_range, dt, solver):
     case = {"bc": eq.bc if hasattr(eq, "bc") else eq.bc_c, "t_range": t_range, "dt": dt, "solver": solver}
     if eq.__class__.__name__ == "DiffusionPDE":
         case.update(pde="diffusion", D=eq.diffusivity)
+    elif eq.__class__.__name__ == "PDE":      # expression form of Cahn-Hilliard (BASELINE config 5)
+        case.update(pde="cahn_hilliard", gamma=eq.consts["g"])
     else:
         case.update(pde="cahn_hilliard", gamma=eq.interface_width)
     return oracle_solve(case, grid, np.float64, data)
@@ -182,6 +184,8 @@ CASES = {
     "ch2d_euler": (lambda: pde_hip.CahnHilliardPDE(0.7), lambda: pde_hip.UnitGrid([8, 8], periodic=[True, False]), 0.05, 1e-3, "euler"),
     "ch2d_rk4": (lambda: pde_hip.CahnHilliardPDE(1.0), lambda: pde_hip.UnitGrid([9, 8], periodic=[False, True]), 0.02, 1e-3, "runge-kutta"),
     "ch3d_rkf45": (lambda: pde_hip.CahnHilliardPDE(1.0), lambda: pde_hip.UnitGrid([8, 6, 6], periodic=True), 0.2, None, "runge-kutta"),
+    "expr_ch3d_rkf45": (lambda: pde_hip.PDE({"c": "laplace(c**3 - c - g*laplace(c))"}, consts={"g": 0.9}),
+                        lambda: pde_hip.UnitGrid([6, 6, 8], periodic=True), 0.1, None, "runge-kutta"),
     "diff1d_thin": (lambda: pde_hip.DiffusionPDE(1.0), lambda: pde_hip.UnitGrid([4], periodic=True), 1.0, 0.1, "euler"),
 }
 

@@ -179,6 +179,17 @@ int pdehip_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out
 /* out = y + s2 * (s1 * laplace(in)); y may alias in    [Euler: pde/solvers/euler.py:172-175] */
 int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void *y_full,
                          void *out_full, double s1, double s2, void *stream);
+/* TWO explicit Euler steps of the diffusion equation in one sweep (temporal blocking):
+ *     out = E(E(in)),  E(u) = u + dt * (D * laplace(u)) with the BCs `faces` applied to u
+ * i.e. two iterations of the loop body of pde/backends/numba/_solvers.py:98-108 with
+ * pde/solvers/euler.py:172-175 and pde/pdes/diffusion.py:119-121, bit-identical to two single steps;
+ * the intermediate level lives in registers only, ghost cells of `in` are neither read nor written.
+ * Covers 3-D grids whose fastest axis is a multiple of 64 x 16 bytes, an even number of rows, >= 4 cells
+ * per axis, and faces that are periodic or scalar first-order (Dirichlet / Neumann / mixed) per axis pair.
+ * *done = 0 and nothing is written when the case is not covered (pdehip_euler_run then falls back to
+ * single steps by itself). */
+int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full,
+                            void *out_full, double diffusivity, double dt, int *done, void *stream);
 /* mu = c*c*c - c - gamma * laplace(c)                  [pde/pdes/cahn_hilliard.py:116-120] */
 int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full,
                             double gamma, void *stream);

@@ -84,6 +84,7 @@ struct LapArgs {
     const void *ex[3];   // LAP_CUSTOM: up to three extra input arrays (centre values only)
     double par[12];      // LAP_CUSTOM: run-time scalars of the generated epilogue (dt, constants, t, ...)
     InBC ibc[3][2];   // [normalised axis][lower, upper]
+    int per[3];       // euler2_kernel: axis is periodic (else both faces are local first-order BCs)
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

@@ -22,6 +22,7 @@ namespace pdehip {
 
 
 #include "pdehip_march.inc"
+#include "pdehip_march2.inc"
 #include "pdehip_div.inc"
 
 // ---------------------------------------------------------------------------------------------
@@ -306,6 +307,94 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
     if (n.dtype == PDEHIP_F64) { PDEHIP_MODE_SWITCH(double) }
     PDEHIP_MODE_SWITCH(float)
 #undef PDEHIP_MODE_SWITCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// two Euler steps per sweep (pdehip_march2.inc).  *done = false when the grid / BCs are outside
+// what the kernel covers; the caller then takes two single steps.
+// ---------------------------------------------------------------------------------------------
+struct Tune2 { int ry; long blocks; int off; bool set; };
+static const Tune2 &tune2()
+{
+    static Tune2 t = {0, 0, 0, false};
+    if (!t.set) {
+        t.set = true;
+        // PDEHIP_EULER2="ry,blocks" tile rows / workgroup count (tuning aid), PDEHIP_EULER2=off disables the kernel
+        const char *e = getenv("PDEHIP_EULER2");
+        if (e && !strcmp(e, "off")) t.off = 1;
+        else if (e) sscanf(e, "%d,%ld", &t.ry, &t.blocks);
+    }
+    return t;
+}
+
+template <typename T>
+static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done)
+{
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int CW = 64 * VEC;
+    const Tune2 &t2 = tune2();
+    int ry = t2.ry ? t2.ry : 4;
+    if (n.n[1] % ry) ry = 2;
+    if (n.n[2] % CW || n.n[1] % ry || (ry != 2 && ry != 4)) return 0;
+    a.ntz = n.n[2] / CW;
+    a.nty = n.n[1] / ry;
+    const long tiles = a.ntz * a.nty;
+    // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
+    long nxc = ((t2.blocks ? t2.blocks : 4096) + tiles - 1) / tiles;
+    if (nxc < 1) nxc = 1;
+    if (nxc > n.n[0] / 8) nxc = n.n[0] / 8 > 0 ? n.n[0] / 8 : 1;
+    const long lx = (n.n[0] + nxc - 1) / nxc;
+    a.lx = (int)lx;
+    a.nxc = (n.n[0] + lx - 1) / lx;
+    a.nblocks = a.nxc * tiles;
+    const dim3 grid((unsigned)a.nblocks), block(64);
+#define PDEHIP_E2(RY_)                                                                                   \
+    if (ry == RY_) {                                                                                     \
+        if (xplain) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, true>), grid, block, 0, st, a);       \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, false>), grid, block, 0, st, a);             \
+    }
+    PDEHIP_E2(2) PDEHIP_E2(4)
+#undef PDEHIP_E2
+    PDEHIP_HIP(hipGetLastError());
+    *done = true;
+    return 0;
+}
+
+int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
+                  bool xplain, hipStream_t st, bool *done)
+{
+    *done = false;
+    const long vec = 16 / elem_size(n.dtype);
+    if (tune2().off || tune().force_generic || n.ndim != 3 || in == out) return 0;
+    if (n.n[0] < 4 || n.n[1] < 4 || n.n[2] < 4 || n.p[0] >= (1L << 31)) return 0;
+    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[0] % vec || n.p[1] % vec) return 0;
+    LapArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int ax = 0; ax < 3; ax++) {
+        if (ax == 0 && xplain) continue;
+        // both faces periodic, or both local (virtual point from the adjacent cell)
+        const bool on = fg.on[ax][0] && fg.on[ax][1];
+        const bool per = on && fg.idx[ax][0] == n.n[ax] - 1 && fg.idx[ax][1] == 0 && fg.c[ax][0] == 0 && fg.c[ax][1] == 0 &&
+                         fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
+        const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n.n[ax] - 1;
+        if (!per && !loc) return 0;
+        a.per[ax] = per ? 1 : 0;
+        for (int side = 0; side < 2; side++) {
+            a.ibc[ax][side].on = 1;
+            a.ibc[ax][side].idx = fg.idx[ax][side];
+            a.ibc[ax][side].c = fg.c[ax][side];
+            a.ibc[ax][side].f = fg.f[ax][side];
+        }
+    }
+    a.in = in; a.out = out; a.y = in;
+    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
+    a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
+    a.o_off = n.off; a.o_s0 = n.p[0]; a.o_s1 = n.p[1];
+    a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
+    a.s1 = s1; a.s2 = s2;
+    a.ndim = 3; a.any_ibc = 1;
+    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done);
+    return launch_euler2_t<float>(n, a, xplain, st, done);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -471,9 +471,39 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
     if (n_rest) PDEHIP_TRY(launch_ghosts(n, 1, rest, in, as_stream(stream)));
     return launch_laplace(n, in, out, out_strides(n, PDEHIP_OUT_FULL), mode, s1, s2, gamma, y, as_stream(stream), n_fused ? &fg : nullptr);
 }
+
+int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
+                          const pdehip_bc_face_t *faces, void *stream, bool *done)
+{
+    *done = false;
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in || !out || !faces) PDEHIP_FAIL(E_VALUE, "euler2: NULL pointer");
+    if (n.ndim != 3) return 0;
+    InputBCs fg;
+    memset(&fg, 0, sizeof(fg));
+    for (int a = 0; a < 3; a++)
+        for (int side = 0; side < 2; side++) {
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[a]) return 0;
+            fg.on[a][side] = 1; fg.idx[a][side] = r.index1; fg.c[a][side] = r.const_v; fg.f[a][side] = r.factor1;
+        }
+    return launch_euler2(n, in, out, s1, s2, fg, false, as_stream(stream), done);
+}
 }  // namespace pdehip
 
 extern "C" {
+
+int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full, void *out_full,
+                            double diffusivity, double dt, int *done, void *stream)
+{
+    if (!done) PDEHIP_FAIL(E_VALUE, "diffusion_euler2: NULL pointer");
+    bool d = false;
+    *done = 0;
+    PDEHIP_TRY(euler2_with_input_bcs(g, in_full, out_full, diffusivity, dt, faces, stream, &d));
+    *done = d ? 1 : 0;
+    return 0;
+}
 
 int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, void *full, void *stream)
 { return launch_copy(g, ncomp, valid, full, 0, stream); }

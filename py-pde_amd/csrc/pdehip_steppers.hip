@@ -76,6 +76,19 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
         PDEHIP_TRY(laplace_with_input_bcs(g, c, nullptr, rhs->scratch_mu, LAP_CH_MU, 0, 0, rhs->param, rhs->bc_c, st));
         return laplace_with_input_bcs(g, rhs->scratch_mu, c, n, LAP_EULER, 1.0, dt, 0, rhs->bc_mu, st);
     };
+    // Two steps per sweep where the temporal-blocking kernel covers the grid and its BCs (the intermediate
+    // level never touches HBM: 16 B per cell for two steps), else one step per sweep.
+    bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION;
+    auto advance = [&](void *c, void *n, void *st, int64_t left, int *took) -> int {
+        if (two_ok && left >= 2) {
+            bool done = false;
+            PDEHIP_TRY(euler2_with_input_bcs(g, c, n, rhs->param, dt, rhs->bc_c, st, &done));
+            if (done) { *took = 2; return 0; }
+            two_ok = false;
+        }
+        *took = 1;
+        return one_step(c, n, st);
+    };
     // Launch-bound regime (small grids: a 512^2 step is ~3 us of GPU work, the host needs ~3.5 us per
     // launch): capture a block of steps into a hipGraph and replay it, so the inner loop costs one graph
     // launch per kGraphSteps steps instead of 1-2 kernel launches per step.  Building a graph costs
@@ -101,9 +114,11 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
             hipGraph_t graph = nullptr;
             int rc = 0;
             PDEHIP_HIP(hipStreamBeginCapture(e.cap, hipStreamCaptureModeThreadLocal));
-            for (int64_t q = 0; q < kGraphSteps && rc == 0; q++) {
-                rc = one_step(cur, nxt, e.cap);
-                void *t = cur; cur = nxt; nxt = t;   // even number of swaps: back in place
+            for (int64_t q = 0; q < kGraphSteps && rc == 0;) {
+                int took = 0;
+                rc = advance(cur, nxt, e.cap, kGraphSteps - q, &took);
+                q += took;
+                void *t = cur; cur = nxt; nxt = t;   // even number of swaps (16 double steps or 32 single steps): back in place
             }
             const hipError_t ce = hipStreamEndCapture(e.cap, &graph);
             if (rc == 0 && ce == hipSuccess && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -125,8 +140,10 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
             PDEHIP_HIP(hipStreamWaitEvent(user, entry->ev, 0));
         }
     }
-    for (; s < nsteps; s++) {
-        PDEHIP_TRY(one_step(cur, nxt, stream));
+    while (s < nsteps) {
+        int took = 0;
+        PDEHIP_TRY(advance(cur, nxt, stream, nsteps - s, &took));
+        s += took;
         void *t = cur; cur = nxt; nxt = t;
     }
     *result = cur;

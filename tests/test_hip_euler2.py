@@ -1,0 +1,120 @@
+"""Temporal-blocking kernel (two Euler steps per sweep, pdehip_march2.inc) == two single steps of the oracle.
+
+Bit-exact for fp64 and fp32: the intermediate level is rounded to the storage type and the BCs are applied
+to it exactly like the reference does between two steps (pde/backends/numba/_solvers.py:98-108 loop body
+with pde/solvers/euler.py:172-175).  Geometry cases cover one / several tiles along every axis, several
+x-chunks (recomputed halo planes) and every combination of periodic / local faces per axis.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+
+import numpy as np
+import pytest
+from helpers import host_faces, interior, oracle_grid, to_full
+
+import pde_hip
+from oracle import pde_oracle as O
+from pde_hip import _abi
+from pde_hip.backend import convert_bcs
+from pde_hip.device import DeviceArray, GridInfo
+
+pytestmark = pytest.mark.gpu
+
+LOCAL = [
+    ({"value": 0.5}, {"derivative": 0.25}),
+    ({"type": "mixed", "value": 1.5, "const": 0.2}, {"value": -0.3}),
+    ({"derivative": -1.0}, {"type": "mixed", "value": -0.5, "const": 1.0}),
+]
+
+
+def _setup(shape, periodic, dtype, seed=3):
+    grid = pde_hip.CartesianGrid([[0, n * (0.7 + 0.1 * i)] for i, n in enumerate(shape)], shape, periodic=periodic)
+    bc = {}
+    for i, a in enumerate(grid.axes):
+        if periodic[i]:
+            bc[a] = "periodic"
+        else:
+            bc[a + "-"], bc[a + "+"] = LOCAL[i]
+    bcs = grid.get_boundary_conditions(bc)
+    data = np.random.default_rng(seed).uniform(-0.5, 0.5, shape).astype(dtype)
+    return grid, bc, bcs, data
+
+
+def _oracle_steps(grid, bcs, data, D, dt, steps):
+    g = oracle_grid(grid, data.dtype)
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, D, host_faces(bcs).c)
+    return interior(grid, O.euler_run(g, rhs, to_full(grid, data), dt, steps))
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return pde_hip.get_backend("hip")
+
+
+def _euler2(backend, grid, bcs, data, D, dt):
+    info = GridInfo(grid.shape, grid.discretization, data.dtype)
+    faces = convert_bcs(bcs)
+    a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
+    done = C.c_int(0)
+    backend._lib.diffusion_euler2(info.ref, faces.c, a.ptr, b.ptr, D, dt, C.byref(done), None)
+    return done.value, b.get_valid()
+
+
+PERIODIC = list(itertools.product([True, False], repeat=3))
+
+
+@pytest.mark.parametrize("periodic", PERIODIC, ids=["".join("P" if p else "L" for p in per) for per in PERIODIC])
+@pytest.mark.parametrize("dtype,shape", [
+    (np.float64, (8, 8, 128)),      # one tile per plane, one x-chunk
+    (np.float64, (40, 12, 256)),    # 2 chunks along z, 3 tiles along y, several x-chunks
+    (np.float64, (5, 6, 128)),      # 2-row tiles (6 % 4 != 0), odd plane count
+    (np.float32, (9, 8, 256)),
+    (np.float32, (33, 16, 512)),
+])
+def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
+    grid, bc, bcs, data = _setup(shape, list(periodic), dtype)
+    done, got = _euler2(backend, grid, bcs, data, 0.6, 2e-3)
+    assert done == 1
+    np.testing.assert_array_equal(got, _oracle_steps(grid, bcs, data, 0.6, 2e-3, 2))
+
+
+@pytest.mark.parametrize("steps", [1, 2, 5, 8])
+@pytest.mark.parametrize("periodic", [(True, True, True), (False, True, False)])
+def test_euler_run_uses_pairs_and_stays_bit_exact(backend, steps, periodic):
+    grid, bc, bcs, data = _setup((12, 8, 128), list(periodic), np.float64, seed=5)
+    eq = pde_hip.DiffusionPDE(0.8, bc=bc)
+    state = pde_hip.ScalarField(grid, data)
+    spec = backend.make_rhs_spec(eq, state)
+    a, b = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info)
+    res = C.c_void_p()
+    backend._lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, 1e-3, steps, C.byref(res), None)
+    got = (b if res.value == b.ptr else a).get_valid()
+    np.testing.assert_array_equal(got, _oracle_steps(grid, bcs, data, 0.8, 1e-3, steps))
+    # an odd number of sweeps leaves the result in the second buffer: 1 step -> b, 2 -> b, 5 -> a (3 sweeps ... b), ...
+    sweeps = steps // 2 + steps % 2
+    assert (res.value == b.ptr) == (sweeps % 2 == 1)
+
+
+def test_cases_outside_the_kernel_report_not_done(backend):
+    for shape, periodic, bc_override in [
+        ((8, 8, 64), [True] * 3, None),                       # fastest axis is not a multiple of 128 cells
+        ((8, 7, 128), [True] * 3, None),                      # odd number of rows
+        ((8, 8, 128), [False] * 3, {"curvature": 0.3}),       # second-order faces
+        ((8, 8, 128), [True] * 3, "anti-periodic"),           # wraps with a factor -1
+    ]:
+        grid, bc, bcs, data = _setup(shape, periodic, np.float64)
+        if bc_override is not None:
+            bcs = grid.get_boundary_conditions(bc_override)
+        done, _ = _euler2(backend, grid, bcs, data, 0.6, 2e-3)
+        assert done == 0
+    # ... and the time loop silently takes single steps there (same results as before)
+    grid, bc, bcs, data = _setup((6, 7, 128), [True, False, True], np.float64)
+    eq = pde_hip.DiffusionPDE(0.8, bc=bc)
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data))
+    a, b = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info)
+    res = C.c_void_p()
+    backend._lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, 1e-3, 4, C.byref(res), None)
+    np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _oracle_steps(grid, bcs, data, 0.8, 1e-3, 4))

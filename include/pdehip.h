@@ -256,6 +256,17 @@ int pdehip_allreduce_max(void *comm, double *dev_scalar, void *stream);
 int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
                           int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                           void *stream);
+/* Same contract, two steps per sweep (see pdehip_diffusion_euler2): TWO layers per side are exchanged once
+ * per two steps, so both the HBM traffic per step and the number of exchanges are halved.  The slab is worked
+ * on in a private copy with two halo layers per side; the result is written back to `buf_a` (*result).
+ * Preconditions the CALLER checks globally (all ranks must take the same path): both neighbours exist on every
+ * rank (periodic slowest axis; replaces the _MPIBC exchange of pde/grids/boundaries/local.py:561-662 for both
+ * levels), >= 4 local layers on every rank, and *ok != 0 from pdehip_slab_euler2_supported (grid shape, dtype
+ * and the faces of the two other axes are covered by the kernel).  E_NOTIMPL otherwise. */
+int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok);
+int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
+                           int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
+                           void *stream);
 
 /* ---- run-time specialised right-hand sides (generic `PDE({...})` expressions) ----------------------
  * Replaces the sympy -> numba code generation of pde/pdes/pde.py:401-499 / pde/tools/expressions.py:

@@ -70,6 +70,8 @@ struct Comm {
     hipStream_t halo;            // stream of the exchange + boundary-layer kernels
     hipEvent_t ev_comp, ev_halo, ev_bnd;
     double *scratch2;            // device: {value, nan flag} for the MAX all-reduce
+    void *ext[2] = {nullptr, nullptr};   // slab copies with TWO halo layers per side (two-steps-per-sweep loop)
+    size_t ext_bytes = 0;
 };
 
 // pointer to full layer `layer` (0 = lower ghost layer) of a slab
@@ -164,6 +166,7 @@ int pdehip_comm_destroy(void *comm)
     (void)hipStreamDestroy(c->halo);
     (void)hipEventDestroy(c->ev_comp); (void)hipEventDestroy(c->ev_halo); (void)hipEventDestroy(c->ev_bnd);
     (void)hipFree(c->scratch2);
+    (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
     delete c;
     return 0;
 }
@@ -249,6 +252,127 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     PDEHIP_HIP(hipEventRecord(c->ev_halo, halo));
     PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_halo, 0));
     *result = cur;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Two Euler steps per sweep on a slab (temporal blocking, pdehip_march2.inc) — halves both the HBM traffic per
+// step and the NUMBER of halo exchanges: two layers per side are exchanged once per two steps.
+//
+// The slab is copied into a private array with two halo layers per side (layers 0,1 | own 2..n+1 | n+2,n+3):
+//   comp stream : interior sweep (own layers 4..n-1; reads own layers only)        ............ | next pair
+//   halo stream : boundary sweeps (layers 2,3 and n,n+1; read the received halos) - send/recv of the new
+//                 boundary layers, overlapping the interior sweep
+// Requires: both neighbours present on EVERY rank (periodic slowest axis), >= 4 local layers on every rank and a
+// grid / faces the kernel covers (pdehip_slab_euler2_supported) — the caller decides globally, all ranks alike.
+// ---------------------------------------------------------------------------------------------------------
+static int exchange2(Comm *c, size_t lp, long nloc, void *ext, int lower, int upper, hipStream_t st)
+{
+    char *b = static_cast<char *>(ext);
+    PDEHIP_NCCL(g_rccl.GroupStart());
+    PDEHIP_NCCL(g_rccl.Send(b + 2 * lp, 2 * lp, ncclInt8, lower, c->comm, st));            // own first two layers -> lower
+    PDEHIP_NCCL(g_rccl.Recv(b + (nloc + 2) * lp, 2 * lp, ncclInt8, upper, c->comm, st));   // upper halo <- upper
+    PDEHIP_NCCL(g_rccl.Send(b + nloc * lp, 2 * lp, ncclInt8, upper, c->comm, st));         // own last two layers -> upper
+    PDEHIP_NCCL(g_rccl.Recv(b, 2 * lp, ncclInt8, lower, c->comm, st));                     // lower halo <- lower
+    PDEHIP_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    if (!g_local || !rhs || !ok) PDEHIP_FAIL(E_VALUE, "slab_euler2_supported: NULL pointer");
+    *ok = 0;
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION || g_local->ndim != 3 || g_local->shape[0] < 4) return 0;
+    bool done = false;
+    pdehip_grid_t gs = *g_local;
+    gs.shape[0] = 2;   // the smallest launch of the loop
+    PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, true, true));
+    *ok = done ? 1 : 0;
+    return 0;
+}
+
+int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
+                           void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler2_run: NULL pointer");
+    int ok = 0;
+    PDEHIP_TRY(pdehip_slab_euler2_supported(g_local, rhs, &ok));
+    if (!ok || lower < 0 || upper < 0) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: grid, faces or neighbours are not covered by the two-step kernel");
+    Comm *c = static_cast<Comm *>(comm);
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g_local, &n));
+    const long nloc = g_local->shape[0];
+    hipStream_t comp = as_stream(stream), halo = c->halo;
+    const size_t esz = elem_size(n.dtype);
+    const size_t lp = (size_t)n.p[0] * esz;   // bytes per layer
+    // private arrays with two halo layers per side: the layout of a slab of nloc+2 layers
+    pdehip_grid_t ge = *g_local;
+    ge.shape[0] = nloc + 2;
+    NGrid ne;
+    PDEHIP_TRY(norm_grid(&ge, &ne));
+    const size_t need = (size_t)(ne.pc + kAllocSlack) * esz;
+    if (c->ext_bytes < need) {
+        PDEHIP_HIP(hipStreamSynchronize(halo));
+        (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
+        c->ext[0] = c->ext[1] = nullptr; c->ext_bytes = 0;
+        PDEHIP_HIP(hipMalloc(&c->ext[0], need));
+        PDEHIP_HIP(hipMalloc(&c->ext[1], need));
+        c->ext_bytes = need;
+        PDEHIP_HIP(hipMemsetAsync(c->ext[0], 0, need, comp));
+        PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
+    }
+    char *cur = static_cast<char *>(c->ext[0]), *nxt = static_cast<char *>(c->ext[1]);
+    // own layers: slab layers 1..nloc -> private layers 2..nloc+1 (same row layout, one layer further in)
+    PDEHIP_HIP(hipMemcpyAsync(cur + 2 * lp, static_cast<char *>(buf_a) + lp, (size_t)nloc * lp, hipMemcpyDeviceToDevice, comp));
+
+    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
+    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) faces[i] = rhs->bc_c[i];
+    faces[0].kind = faces[1].kind = PDEHIP_BC_SKIP;   // slowest axis: real layers on both sides
+
+    // two steps on private layers [first, first+count)
+    // (ends > 0: the first and the last `ends` layers of the range in one launch)
+    auto sweep2 = [&](hipStream_t st, long first, long count, int ends) -> int {
+        if (count <= 0) return 0;
+        pdehip_grid_t gs = *g_local;
+        gs.shape[0] = count;
+        bool done = false;
+        PDEHIP_TRY(euler2_with_input_bcs(&gs, cur + (first - 1) * lp, nxt + (first - 1) * lp, rhs->param, dt, faces, st, &done, true, false, ends));
+        if (!done) PDEHIP_FAIL(E_RUNTIME, "internal: two-step kernel refused a sub-slab");
+        return 0;
+    };
+
+    // comp stream : interior sweep (reads own layers only)                          | interior sweep ...
+    // halo stream : [wait interior s-1] boundary sweep - send/recv new boundary layers | [wait] boundary sweep ...
+    // Measured alternatives (profiles/r01_probe_slab_euler2.md): boundary sweep first on the compute stream, then the
+    // interior sweep — the RCCL kernel then crawls behind the full-occupancy interior sweep and ends with it (worse at
+    // every slab thickness); capping the interior sweep at 75 % of the wave slots helps only thin slabs.
+    PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
+    PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
+    PDEHIP_TRY(exchange2(c, lp, nloc, cur, lower, upper, halo));
+    int64_t s = 0;
+    bool first_pair = true;
+    for (; s + 2 <= nsteps; s += 2) {
+        if (!first_pair) PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_bnd, 0));   // boundary layers of `cur` (halo stream)
+        first_pair = false;
+        PDEHIP_TRY(sweep2(comp, 4, nloc - 4, 0));
+        PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
+        PDEHIP_TRY(sweep2(halo, 2, nloc, 2));   // own layers 2,3 and nloc,nloc+1 (needs the received halo layers)
+        PDEHIP_HIP(hipEventRecord(c->ev_bnd, halo));
+        if (s + 2 < nsteps) PDEHIP_TRY(exchange2(c, lp, nloc, nxt, lower, upper, halo));   // overlaps the interior sweep
+        // the next pair overwrites `cur` and its boundary sweep reads the interior layers written now
+        PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    PDEHIP_HIP(hipEventRecord(c->ev_halo, halo));
+    PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_halo, 0));
+    if (s < nsteps) {
+        // odd step count: one single step; layers 1 and nloc+2 act as its ghost layers (already exchanged)
+        pdehip_grid_t gs = *g_local;
+        PDEHIP_TRY(laplace_with_input_bcs(&gs, cur + lp, cur + lp, nxt + lp, LAP_EULER, rhs->param, dt, 0, faces, comp));
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    PDEHIP_HIP(hipMemcpyAsync(static_cast<char *>(buf_a) + lp, cur + 2 * lp, (size_t)nloc * lp, hipMemcpyDeviceToDevice, comp));
+    *result = buf_a;
     return 0;
 }
 

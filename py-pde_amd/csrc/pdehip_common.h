@@ -115,11 +115,13 @@ int launch_div_march(const NGrid &n, int method, const void *in, void *out, cons
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, bool xplain,
-                  hipStream_t st, bool *done);
+                  hipStream_t st, bool *done, bool dry_run = false, int ends = 0);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done);
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, bool xplain = false, bool dry_run = false, int ends = 0);
+// xplain: the slowest axis has two real halo layers on either side (slab decomposition) instead of BCs; `in` / `out` then
+// point one layer before the first layer to update, like every sub-slab launch (pdehip_comm.hip)
 // BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`
 // (see pdehip_ops.hip)
 int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void *out, int mode, double s1,

@@ -85,6 +85,7 @@ struct LapArgs {
     double par[12];      // LAP_CUSTOM: run-time scalars of the generated epilogue (dt, constants, t, ...)
     InBC ibc[3][2];   // [normalised axis][lower, upper]
     int per[3];       // euler2_kernel: axis is periodic (else both faces are local first-order BCs)
+    long xstride;     // euler2_kernel: first plane of x-chunk xc is xc * xstride (== lx, or n0 - lx for the two-ended boundary sweep)
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

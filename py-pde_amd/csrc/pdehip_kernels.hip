@@ -328,32 +328,48 @@ static const Tune2 &tune2()
 }
 
 template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done)
+static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends)
 {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int CW = 64 * VEC;
     const Tune2 &t2 = tune2();
+    // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32 computes in fp64 registers, 4 cells per lane: only the
+    // 2-row tile fits the register file without spilling
     int ry = t2.ry ? t2.ry : 4;
-    if (n.n[1] % ry) ry = 2;
+    if (n.n[1] % ry || sizeof(T) == 4) ry = 2;
     if (n.n[2] % CW || n.n[1] % ry || (ry != 2 && ry != 4)) return 0;
     a.ntz = n.n[2] / CW;
     a.nty = n.n[1] / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
-    long nxc = ((t2.blocks ? t2.blocks : 4096) + tiles - 1) / tiles;
-    if (nxc < 1) nxc = 1;
-    if (nxc > n.n[0] / 8) nxc = n.n[0] / 8 > 0 ? n.n[0] / 8 : 1;
-    const long lx = (n.n[0] + nxc - 1) / nxc;
-    a.lx = (int)lx;
-    a.nxc = (n.n[0] + lx - 1) / lx;
+    if (ends > 0) {
+        // boundary sweep of a slab: the first and the last `ends` planes in ONE launch
+        a.lx = ends; a.nxc = 2; a.xstride = n.n[0] - ends;
+    } else {
+        // whole grid: ~4096 single-wave workgroups (two rounds over the 256 CUs x 8 wave slots).  Interior sweep of a
+        // THIN slab (exchange-bound): at most 1536, so that the RCCL kernel of the halo stream finds free wave slots
+        // at once — workgroups march for the whole sweep, a kernel launched behind a full sweep waits for its first
+        // round to end (measured: 90 us for 13 us of work).  Thick slabs are compute-bound: full occupancy.
+        const bool thin = xplain && n.n[0] < 96;
+        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 4096);
+        long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
+        if (nxc < 1) nxc = 1;
+        if (nxc > n.n[0] / 16) nxc = n.n[0] / 16 > 0 ? n.n[0] / 16 : 1;
+        const long lx = (n.n[0] + nxc - 1) / nxc;
+        a.lx = (int)lx;
+        a.nxc = (n.n[0] + lx - 1) / lx;
+        a.xstride = lx;
+    }
     a.nblocks = a.nxc * tiles;
     const dim3 grid((unsigned)a.nblocks), block(64);
+    if (dry_run) { *done = true; return 0; }
 #define PDEHIP_E2(RY_)                                                                                   \
     if (ry == RY_) {                                                                                     \
         if (xplain) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, true>), grid, block, 0, st, a);       \
         else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, false>), grid, block, 0, st, a);             \
     }
-    PDEHIP_E2(2) PDEHIP_E2(4)
+    PDEHIP_E2(2)
+    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4) }
 #undef PDEHIP_E2
     PDEHIP_HIP(hipGetLastError());
     *done = true;
@@ -361,12 +377,12 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
 }
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
-                  bool xplain, hipStream_t st, bool *done)
+                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends)
 {
     *done = false;
     const long vec = 16 / elem_size(n.dtype);
     if (tune2().off || tune().force_generic || n.ndim != 3 || in == out) return 0;
-    if (n.n[0] < 4 || n.n[1] < 4 || n.n[2] < 4 || n.p[0] >= (1L << 31)) return 0;
+    if (n.n[0] < (xplain ? 1 : 4) || n.n[1] < 4 || n.n[2] < 4 || n.p[0] >= (1L << 31)) return 0;
     if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[0] % vec || n.p[1] % vec) return 0;
     LapArgs a;
     memset(&a, 0, sizeof(a));
@@ -393,8 +409,8 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2;
     a.ndim = 3; a.any_ibc = 1;
-    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done);
-    return launch_euler2_t<float>(n, a, xplain, st, done);
+    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends);
+    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -473,7 +473,7 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
 }
 
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done)
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, bool xplain, bool dry_run, int ends)
 {
     *done = false;
     NGrid n;
@@ -482,13 +482,13 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     if (n.ndim != 3) return 0;
     InputBCs fg;
     memset(&fg, 0, sizeof(fg));
-    for (int a = 0; a < 3; a++)
+    for (int a = xplain ? 1 : 0; a < 3; a++)
         for (int side = 0; side < 2; side++) {
             const pdehip_bc_face_t &r = faces[2 * a + side];
             if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[a]) return 0;
             fg.on[a][side] = 1; fg.idx[a][side] = r.index1; fg.c[a][side] = r.const_v; fg.f[a][side] = r.factor1;
         }
-    return launch_euler2(n, in, out, s1, s2, fg, false, as_stream(stream), done);
+    return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
 }  // namespace pdehip
 

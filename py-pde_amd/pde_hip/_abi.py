@@ -156,6 +156,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     "halo_exchange": [_vp, _pg, _vp, _i, _i, _vp],
     "allreduce_max": [_vp, _vp, _vp],
     "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    "slab_euler2_supported": [_pg, _pr, C.POINTER(_i)],
+    "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)
     "diffusion_euler2": [_pg, _pf, _vp, _vp, _d, _d, C.POINTER(_i), _vp],
     # run-time specialised expression kernels (pdehip_jit.hip)

@@ -220,6 +220,13 @@ class SlabStepper:
             self._rhs_c.kind = _abi.RHS_DIFFUSION
             self._rhs_c.param = self.param
             self._faces_all.copy_into(self._rhs_c.bc_c)
+        # two steps per sweep (temporal blocking, two halo layers exchanged every other step): decided from GLOBAL
+        # information only, so that all ranks take the same path
+        self._euler2 = False
+        if self._rhs_c is not None and self.exchanging and grid.periodic[0] and min(self.mesh.counts) >= 4 and grid.num_axes == 3:
+            ok = C.c_int(0)
+            self.engine.lib.slab_euler2_supported(C.byref(self.g), C.byref(self._rhs_c), C.byref(ok))
+            self._euler2 = bool(ok.value)
 
     # --- buffers ---------------------------------------------------------------------------------
     def buf(self, name: str):
@@ -326,8 +333,9 @@ class SlabStepper:
             lower = -1 if self.lower is None else self.lower
             upper = -1 if self.upper is None else self.upper
             res = C.c_void_p()
-            eng.lib.slab_euler_run(self.comm, C.byref(self.g), C.byref(self._rhs_c), lower, upper, self.ptr(cur), self.ptr(nxt),
-                                   dt, nsteps, C.byref(res), eng.stream_ptr(comp))
+            run = eng.lib.slab_euler2_run if self._euler2 and nsteps >= 2 else eng.lib.slab_euler_run
+            run(self.comm, C.byref(self.g), C.byref(self._rhs_c), lower, upper, self.ptr(cur), self.ptr(nxt),
+                dt, nsteps, C.byref(res), eng.stream_ptr(comp))
             return cur if res.value == self.ptr(cur) else nxt
         # overlapped diffusion path (torch P2P / CPU test engine) ------------------------------------
         eng.wait(halo, eng.record(comp))

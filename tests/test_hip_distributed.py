@@ -73,6 +73,30 @@ def test_diffusion_euler_overlapped_self_exchange(process_group, monkeypatch, co
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.8, grid, eq.bc, data, 0.1, 11))
 
 
+@pytest.mark.parametrize("shape,periodic,steps", [
+    ((16, 12, 128), [True, False, False], 11),   # 5 double sweeps + 1 single step, local faces on y and z
+    ((4, 8, 256), [True, True, True], 6),        # interior sweep empty (4 layers = 2 + 2 boundary layers)
+    ((9, 6, 128), [True, True, False], 2),       # 2-row tiles, one double sweep
+    ((40, 8, 128), [True, False, True], 7),
+])
+def test_diffusion_euler_two_steps_per_sweep_slab_loop(process_group, monkeypatch, shape, periodic, steps):
+    """The slab loop with two halo layers (exchange every other step) == serial oracle, bit-exact."""
+    from pde_hip.distributed import HipEngine, SlabStepper
+
+    monkeypatch.setenv("PDEHIP_COMM", "native")
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    data = np.random.default_rng(4).uniform(-1, 1, shape)
+    eq = pde_hip.DiffusionPDE(0.7)
+    st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
+    assert st.comm is not None and st._euler2
+    final, info = st.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
+    assert info["steps"] == steps
+    np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps))
+    # grids the kernel does not cover keep the one-step loop
+    st1 = SlabStepper(eq, pde_hip.UnitGrid((8, 8, 64), periodic=True), engine=HipEngine(0), force_exchange=True)
+    assert not st1._euler2
+
+
 @pytest.mark.parametrize("comm_mode", ["native", "torch"])
 def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group, monkeypatch, comm_mode):
     from pde_hip.distributed import HipEngine, SlabStepper

@@ -213,13 +213,16 @@ int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, c
                         double *out_dev, void *stream);
 
 /* ---- fused time steppers ----------------------------------------------------------
- * k_out = dt * rhs(y): sets ghost cells of y (and of mu) in place, then evaluates the RHS;
+ * k_out = dt * rhs(y): applies the BCs of y (and of mu) — on the fly inside the stencil kernel where the
+ * faces allow it, else by setting the ghost cells in place — then evaluates the RHS;
  * replaces NumbaBackend.make_pde_rhs + the `dt * rhs(...)` temporaries
  * (pde/backends/numba/backend.py:1158-1196, pde/solvers/runge_kutta.py:52-59) */
 int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
                       void *k_out_full, double dt, void *stream);
 /* `nsteps` explicit Euler steps with fixed dt, ping-ponging between buf_a (initial state)
- * and buf_b; *result receives the buffer holding the final state.  Replaces the jitted
+ * and buf_b; *result receives the buffer holding the final state (which of the two depends on the number
+ * of sweeps: the diffusion RHS advances two steps per sweep where pdehip_diffusion_euler2 covers the grid).
+ * Replaces the jitted
  * fixed-step loop (pde/backends/numba/_solvers.py:93-104) around
  * EulerSolver._make_single_step_fixed_dt (pde/solvers/euler.py:149-179). */
 int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b,

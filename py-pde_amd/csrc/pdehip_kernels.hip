@@ -313,16 +313,17 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
 // two Euler steps per sweep (pdehip_march2.inc).  *done = false when the grid / BCs are outside
 // what the kernel covers; the caller then takes two single steps.
 // ---------------------------------------------------------------------------------------------
-struct Tune2 { int ry; long blocks; int off; bool set; };
+struct Tune2 { int ry; long blocks; int off; bool set; int order; };
 static const Tune2 &tune2()
 {
-    static Tune2 t = {0, 0, 0, false};
+    static Tune2 t = {0, 0, 0, false, -1};
     if (!t.set) {
         t.set = true;
-        // PDEHIP_EULER2="ry,blocks" tile rows / workgroup count (tuning aid), PDEHIP_EULER2=off disables the kernel
+        // PDEHIP_EULER2="ry,blocks,waves" tile rows / wave tiles per sweep / waves per workgroup (tuning aid),
+        // PDEHIP_EULER2=off disables the kernel
         const char *e = getenv("PDEHIP_EULER2");
         if (e && !strcmp(e, "off")) t.off = 1;
-        else if (e) sscanf(e, "%d,%ld", &t.ry, &t.blocks);
+        else if (e) sscanf(e, "%d,%ld,%d", &t.ry, &t.blocks, &t.order);
     }
     return t;
 }
@@ -360,14 +361,16 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
         a.nxc = (n.n[0] + lx - 1) / lx;
         a.xstride = lx;
     }
-    a.nblocks = a.nxc * tiles;
-    const dim3 grid((unsigned)a.nblocks), block(64);
+    // waves per workgroup = neighbouring chunks of the same rows (1, 2 or 4; PDEHIP_EULER2 third field overrides)
+    int nwz = (a.ntz % 4 == 0) ? 4 : (a.ntz % 2 == 0 ? 2 : 1);
+    if (t2.order > 0 && a.ntz % t2.order == 0 && (t2.order == 1 || t2.order == 2 || t2.order == 4)) nwz = t2.order;
+    a.nblocks = a.nxc * tiles / nwz;
+    a.no_swizzle = 0;
+    const dim3 grid((unsigned)a.nblocks), block(64 * nwz);
     if (dry_run) { *done = true; return 0; }
-#define PDEHIP_E2(RY_)                                                                                   \
-    if (ry == RY_) {                                                                                     \
-        if (xplain) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, true>), grid, block, 0, st, a);       \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, false>), grid, block, 0, st, a);             \
-    }
+    if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
+#define PDEHIP_E2(RY_) \
+    if (ry == RY_) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_>), grid, block, 0, st, a);
     PDEHIP_E2(2)
     if constexpr (sizeof(T) == 8) { PDEHIP_E2(4) }
 #undef PDEHIP_E2

@@ -93,7 +93,7 @@ def test_euler_run_uses_pairs_and_stays_bit_exact(backend, steps, periodic):
     backend._lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, 1e-3, steps, C.byref(res), None)
     got = (b if res.value == b.ptr else a).get_valid()
     np.testing.assert_array_equal(got, _oracle_steps(grid, bcs, data, 0.8, 1e-3, steps))
-    # an odd number of sweeps leaves the result in the second buffer: 1 step -> b, 2 -> b, 5 -> a (3 sweeps ... b), ...
+    # an odd number of sweeps leaves the result in the second buffer (1 step: 1 sweep, 2: 1, 5: 3, 8: 4 sweeps)
     sweeps = steps // 2 + steps % 2
     assert (res.value == b.ptr) == (sweeps % 2 == 1)
 

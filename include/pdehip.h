@@ -190,6 +190,15 @@ int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void
  * single steps by itself). */
 int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full,
                             void *out_full, double diffusivity, double dt, int *done, void *stream);
+/* ONE sweep for the Cahn-Hilliard right-hand side (pde/pdes/cahn_hilliard.py:115-122): mu = c^3 - c - gamma*laplace(c)
+ * with the faces of c, then laplace(mu) with the faces of mu; mu lives in registers only (same two-level kernel as
+ * pdehip_diffusion_euler2, bit-identical to pdehip_cahn_hilliard_mu + pdehip_laplace_euler / _scaled):
+ *     euler != 0: out = c + dt * laplace(mu)   (one explicit Euler step)      euler == 0: out = dt * laplace(mu)
+ * *done = 0 and nothing written when grid / faces are not covered (same rules as pdehip_diffusion_euler2, and the
+ * faces of c and mu must be periodic on the same axes); pdehip_rhs_scaled / pdehip_euler_run use it by themselves. */
+int pdehip_cahn_hilliard_fused(const pdehip_grid_t *g, const pdehip_bc_face_t *faces_c,
+                               const pdehip_bc_face_t *faces_mu, const void *c_full, void *out_full, double gamma,
+                               double dt, int euler, int *done, void *stream);
 /* mu = c*c*c - c - gamma * laplace(c)                  [pde/pdes/cahn_hilliard.py:116-120] */
 int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full,
                             double gamma, void *stream);

@@ -9,6 +9,9 @@ enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
        LAP_GRAD_C = 4, LAP_GRAD_F = 5, LAP_GRAD_B = 6, LAP_GRADSQ_C = 7, LAP_GRADSQ_N = 8,
        LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */ };
 
+// the two fused levels of euler2_kernel (pdehip_march2.inc)
+enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2 };
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
@@ -86,6 +89,7 @@ struct LapArgs {
     InBC ibc[3][2];   // [normalised axis][lower, upper]
     int per[3];       // euler2_kernel: axis is periodic (else both faces are local first-order BCs)
     long xstride;     // euler2_kernel: first plane of x-chunk xc is xc * xstride (== lx, or n0 - lx for the two-ended boundary sweep)
+    InBC ibc1[3][2];  // euler2_kernel: faces of the intermediate level when it is another field (Cahn-Hilliard: mu)
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

@@ -329,7 +329,7 @@ static const Tune2 &tune2()
 }
 
 template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends)
+static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2)
 {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int CW = 64 * VEC;
@@ -369,8 +369,12 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     const dim3 grid((unsigned)a.nblocks), block(64 * nwz);
     if (dry_run) { *done = true; return 0; }
     if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
-#define PDEHIP_E2(RY_) \
-    if (ry == RY_) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_>), grid, block, 0, st, a);
+#define PDEHIP_E2(RY_)                                                                                               \
+    if (ry == RY_) {                                                                                                 \
+        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION>), grid, block, 0, st, a); \
+        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED>), grid, block, 0, st, a);                  \
+    }
     PDEHIP_E2(2)
     if constexpr (sizeof(T) == 8) { PDEHIP_E2(4) }
 #undef PDEHIP_E2
@@ -379,11 +383,22 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     return 0;
 }
 
+// periodic (1) / local (0) / not covered (-1) classification of the two faces of one axis
+static int classify_axis(const InputBCs &fg, int ax, long n)
+{
+    const bool on = fg.on[ax][0] && fg.on[ax][1];
+    const bool per = on && fg.idx[ax][0] == n - 1 && fg.idx[ax][1] == 0 && fg.c[ax][0] == 0 && fg.c[ax][1] == 0 &&
+                     fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
+    const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n - 1;
+    return per ? 1 : (loc ? 0 : -1);
+}
+
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
-                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends)
+                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma)
 {
     *done = false;
     const long vec = 16 / elem_size(n.dtype);
+    if (m2 != E2_DIFFUSION && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
     if (tune2().off || tune().force_generic || n.ndim != 3 || in == out) return 0;
     if (n.n[0] < (xplain ? 1 : 4) || n.n[1] < 4 || n.n[2] < 4 || n.p[0] >= (1L << 31)) return 0;
     if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[0] % vec || n.p[1] % vec) return 0;
@@ -391,20 +406,23 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     memset(&a, 0, sizeof(a));
     for (int ax = 0; ax < 3; ax++) {
         if (ax == 0 && xplain) continue;
-        // both faces periodic, or both local (virtual point from the adjacent cell)
-        const bool on = fg.on[ax][0] && fg.on[ax][1];
-        const bool per = on && fg.idx[ax][0] == n.n[ax] - 1 && fg.idx[ax][1] == 0 && fg.c[ax][0] == 0 && fg.c[ax][1] == 0 &&
-                         fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
-        const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n.n[ax] - 1;
-        if (!per && !loc) return 0;
-        a.per[ax] = per ? 1 : 0;
+        // both faces periodic, or both local (virtual point from the adjacent cell); the same for both levels
+        const int cls = classify_axis(fg, ax, n.n[ax]);
+        if (cls < 0 || (fg1 && classify_axis(*fg1, ax, n.n[ax]) != cls)) return 0;
+        a.per[ax] = cls;
         for (int side = 0; side < 2; side++) {
             a.ibc[ax][side].on = 1;
             a.ibc[ax][side].idx = fg.idx[ax][side];
             a.ibc[ax][side].c = fg.c[ax][side];
             a.ibc[ax][side].f = fg.f[ax][side];
+            const InputBCs &f1 = fg1 ? *fg1 : fg;
+            a.ibc1[ax][side].on = 1;
+            a.ibc1[ax][side].idx = f1.idx[ax][side];
+            a.ibc1[ax][side].c = f1.c[ax][side];
+            a.ibc1[ax][side].f = f1.f[ax][side];
         }
     }
+    a.gamma = gamma;
     a.in = in; a.out = out; a.y = in;
     a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
     a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
@@ -412,8 +430,8 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2;
     a.ndim = 3; a.any_ibc = 1;
-    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends);
-    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends);
+    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2);
+    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2);
 }
 
 // ---------------------------------------------------------------------------------------------

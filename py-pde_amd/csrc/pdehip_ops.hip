@@ -490,6 +490,33 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
         }
     return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
+
+static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, InputBCs *fg)
+{
+    memset(fg, 0, sizeof(*fg));
+    for (int a = 0; a < 3; a++)
+        for (int side = 0; side < 2; side++) {
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[a]) return false;
+            fg->on[a][side] = 1; fg->idx[a][side] = r.index1; fg->c[a][side] = r.const_v; fg->f[a][side] = r.factor1;
+        }
+    return true;
+}
+
+int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
+                        const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done)
+{
+    *done = false;
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in || !out || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    if (n.ndim != 3) return 0;
+    InputBCs fc, fm;
+    if (!faces_to_input_bcs(n, faces_c, &fc) || !faces_to_input_bcs(n, faces_mu, &fm)) return 0;
+    // level 2 is `y + s2 * (s1 * lap(mu))` resp. `s2 * (s1 * lap(mu))` with s1 = 1 like the two-kernel path (pdehip_steppers.hip)
+    return launch_euler2(n, in, out, 1.0, dt, fc, false, as_stream(stream), done, false, 0,
+                         euler ? E2_CH_EULER : E2_CH_SCALED, &fm, gamma);
+}
 }  // namespace pdehip
 
 extern "C" {
@@ -501,6 +528,17 @@ int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *face
     bool d = false;
     *done = 0;
     PDEHIP_TRY(euler2_with_input_bcs(g, in_full, out_full, diffusivity, dt, faces, stream, &d));
+    *done = d ? 1 : 0;
+    return 0;
+}
+
+int pdehip_cahn_hilliard_fused(const pdehip_grid_t *g, const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu,
+                               const void *c_full, void *out_full, double gamma, double dt, int euler, int *done, void *stream)
+{
+    if (!done) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    bool d = false;
+    *done = 0;
+    PDEHIP_TRY(cahn_hilliard_fused(g, c_full, out_full, gamma, dt, euler != 0, faces_c, faces_mu, stream, &d));
     *done = d ? 1 : 0;
     return 0;
 }

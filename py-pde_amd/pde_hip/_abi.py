@@ -160,6 +160,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)
     "diffusion_euler2": [_pg, _pf, _vp, _vp, _d, _d, C.POINTER(_i), _vp],
+    "cahn_hilliard_fused": [_pg, _pf, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],
     # run-time specialised expression kernels (pdehip_jit.hip)
     "jit_create": [C.c_char_p, _pvp],
     "jit_destroy": [_vp],

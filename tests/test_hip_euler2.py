@@ -118,3 +118,67 @@ def test_cases_outside_the_kernel_report_not_done(backend):
     res = C.c_void_p()
     backend._lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, 1e-3, 4, C.byref(res), None)
     np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _oracle_steps(grid, bcs, data, 0.8, 1e-3, 4))
+
+
+LOCAL_MU = [
+    ({"derivative": 0.3}, {"value": 0.1}),
+    ({"value": -0.2}, {"type": "mixed", "value": 0.7, "const": -0.4}),
+    ({"type": "mixed", "value": -1.5, "const": 0.3}, {"derivative": 0.6}),
+]
+
+
+@pytest.mark.parametrize("periodic", PERIODIC, ids=["".join("P" if p else "L" for p in per) for per in PERIODIC])
+@pytest.mark.parametrize("dtype,shape", [
+    (np.float64, (8, 8, 128)),
+    (np.float64, (37, 12, 256)),
+    (np.float64, (5, 6, 128)),
+    (np.float32, (9, 8, 256)),
+])
+def test_cahn_hilliard_in_one_sweep_equals_two_kernels(backend, periodic, dtype, shape):
+    """mu = c^3 - c - g lap(c) (faces of c) and lap(mu) (DIFFERENT faces of mu) fused with mu in registers ==
+    oracle Euler step / oracle dt*rhs, bit-exact."""
+    grid, bc_c, bcs_c, data = _setup(shape, list(periodic), dtype, seed=9)
+    bc_mu = {}
+    for i, a in enumerate(grid.axes):
+        if periodic[i]:
+            bc_mu[a] = "periodic"
+        else:
+            bc_mu[a + "-"], bc_mu[a + "+"] = LOCAL_MU[i]
+    bcs_mu = grid.get_boundary_conditions(bc_mu)
+    info = GridInfo(grid.shape, grid.discretization, data.dtype)
+    fc, fm = convert_bcs(bcs_c), convert_bcs(bcs_mu)
+    g = oracle_grid(grid, dtype)
+    scratch = np.zeros(grid._shape_full, dtype)
+    orhs = O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, host_faces(bcs_c).c, host_faces(bcs_mu).c, scratch)
+    a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
+    done = C.c_int(0)
+    backend._lib.cahn_hilliard_fused(info.ref, fc.c, fm.c, a.ptr, b.ptr, 0.8, 1e-3, 1, C.byref(done), None)
+    assert done.value == 1
+    np.testing.assert_array_equal(b.get_valid(), interior(grid, O.euler_run(g, orhs, to_full(grid, data), 1e-3, 1)))
+    backend._lib.cahn_hilliard_fused(info.ref, fc.c, fm.c, a.ptr, b.ptr, 0.8, 0.02, 0, C.byref(done), None)
+    assert done.value == 1
+    np.testing.assert_array_equal(b.get_valid(), interior(grid, O.rhs_scaled(g, orhs, to_full(grid, data), 0.02)))
+
+
+def test_cahn_hilliard_solvers_use_the_fused_sweep(backend):
+    """Euler / RK4 / RKF45 through the stepper entry points on a covered grid (the fused sweep is taken inside)."""
+    grid, bc, bcs, data = _setup((10, 8, 128), [True, False, False], np.float64, seed=12)
+    eq = pde_hip.CahnHilliardPDE(0.9, bc_c=bc, bc_mu=bc)
+    state = pde_hip.ScalarField(grid, data)
+    from test_oracle_golden import oracle_solve
+
+    for solver, dt in [("euler", 1e-3), ("runge-kutta", 1e-3), ("runge-kutta", None)]:
+        res, info = eq.solve(state, t_range=0.01, dt=dt, solver=solver, backend="hip", ret_info=True)
+        case = {"bc": bc, "t_range": 0.01, "dt": dt, "solver": solver, "pde": "cahn_hilliard", "gamma": 0.9}
+        expect, steps, _ = oracle_solve(case, grid, np.float64, data)
+        assert info["solver"]["steps"] == steps
+        np.testing.assert_array_equal(res.data, expect)
+    # faces of c and mu periodic on different axes cannot be fused: two kernels, same numbers as the oracle
+    grid2 = pde_hip.UnitGrid([8, 8, 128], periodic=[True, True, False])
+    info2 = GridInfo(grid2.shape, grid2.discretization, np.float64)
+    f1 = convert_bcs(grid2.get_boundary_conditions("auto_periodic_neumann"))
+    f2 = convert_bcs(grid2.get_boundary_conditions({"x": "periodic", "y": "anti-periodic", "z": {"value": 0}}))
+    a, b = DeviceArray(info2).set_valid(np.zeros(grid2.shape)), DeviceArray(info2)
+    done = C.c_int(1)
+    backend._lib.cahn_hilliard_fused(info2.ref, f1.c, f2.c, a.ptr, b.ptr, 1.0, 1e-3, 1, C.byref(done), None)
+    assert done.value == 0

@@ -338,8 +338,8 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     // 2-row tile fits the register file without spilling
     int ry = t2.ry ? t2.ry : 4;
     if (n.n[1] % ry || sizeof(T) == 4) ry = 2;
-    if (n.n[2] % CW || n.n[1] % ry || (ry != 2 && ry != 4)) return 0;
-    a.ntz = n.n[2] / CW;
+    if (n.n[2] % VEC || n.n[1] % ry || (ry != 2 && ry != 4)) return 0;
+    a.ntz = (n.n[2] + CW - 1) / CW;   // the row may end inside the last chunk
     a.nty = n.n[1] / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes

@@ -93,7 +93,7 @@ def test_diffusion_euler_two_steps_per_sweep_slab_loop(process_group, monkeypatc
     assert info["steps"] == steps
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps))
     # grids the kernel does not cover keep the one-step loop
-    st1 = SlabStepper(eq, pde_hip.UnitGrid((8, 8, 64), periodic=True), engine=HipEngine(0), force_exchange=True)
+    st1 = SlabStepper(eq, pde_hip.UnitGrid((8, 7, 64), periodic=True), engine=HipEngine(0), force_exchange=True)
     assert not st1._euler2
 
 

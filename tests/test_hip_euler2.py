@@ -73,6 +73,10 @@ PERIODIC = list(itertools.product([True, False], repeat=3))
     (np.float64, (5, 6, 128)),      # 2-row tiles (6 % 4 != 0), odd plane count
     (np.float32, (9, 8, 256)),
     (np.float32, (33, 16, 512)),
+    (np.float64, (6, 8, 64)),       # row shorter than a chunk
+    (np.float64, (7, 4, 200)),      # row ends inside the second chunk (36 of 64 lanes own cells)
+    (np.float64, (5, 4, 130)),      # ... one lane of the last chunk owns cells
+    (np.float32, (6, 8, 100)),
 ])
 def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
     grid, bc, bcs, data = _setup(shape, list(periodic), dtype)
@@ -100,7 +104,7 @@ def test_euler_run_uses_pairs_and_stays_bit_exact(backend, steps, periodic):
 
 def test_cases_outside_the_kernel_report_not_done(backend):
     for shape, periodic, bc_override in [
-        ((8, 8, 64), [True] * 3, None),                       # fastest axis is not a multiple of 128 cells
+        ((8, 8, 63), [True] * 3, None),                       # odd row length: no 16-byte vectors
         ((8, 7, 128), [True] * 3, None),                      # odd number of rows
         ((8, 8, 128), [False] * 3, {"curvature": 0.3}),       # second-order faces
         ((8, 8, 128), [True] * 3, "anti-periodic"),           # wraps with a factor -1
@@ -133,6 +137,8 @@ LOCAL_MU = [
     (np.float64, (37, 12, 256)),
     (np.float64, (5, 6, 128)),
     (np.float32, (9, 8, 256)),
+    (np.float64, (6, 4, 72)),
+    (np.float32, (5, 4, 264)),
 ])
 def test_cahn_hilliard_in_one_sweep_equals_two_kernels(backend, periodic, dtype, shape):
     """mu = c^3 - c - g lap(c) (faces of c) and lap(mu) (DIFFERENT faces of mu) fused with mu in registers ==

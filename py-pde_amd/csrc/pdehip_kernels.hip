@@ -336,29 +336,43 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     const Tune2 &t2 = tune2();
     // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32 computes in fp64 registers, 4 cells per lane: only the
     // 2-row tile fits the register file without spilling
+    const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
     int ry = t2.ry ? t2.ry : 4;
-    if (n.n[1] % ry || sizeof(T) == 4) ry = 2;
-    if (n.n[2] % VEC || n.n[1] % ry || (ry != 2 && ry != 4)) return 0;
-    a.ntz = (n.n[2] + CW - 1) / CW;   // the row may end inside the last chunk
-    a.nty = n.n[1] / ry;
+    if (a.n1 % ry || sizeof(T) == 4) ry = 2;
+    if (!has_y) ry = 1;
+    if (a.n2 % VEC || a.n1 % ry || (ry != 1 && ry != 2 && ry != 4)) return 0;
+    a.ntz = (a.n2 + CW - 1) / CW;   // the row may end inside the last chunk
+    a.nty = a.n1 / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
     if (ends > 0) {
         // boundary sweep of a slab: the first and the last `ends` planes in ONE launch
-        a.lx = ends; a.nxc = 2; a.xstride = n.n[0] - ends;
+        a.lx = ends; a.nxc = 2; a.xstride = a.n0 - ends;
+    } else if (!has_y) {
+        // 2-D: a wave's march is a chain of dependent row loads (~1 us each out of the Infinity Cache for grids of a few
+        // MB), so short chunks win until the chip is full: up to ~4096 waves, chunks of at least `minlx` rows (the
+        // 4 overlap rows per chunk cost no HBM traffic for cache-resident grids)
+        const long minlx = t2.order > 0 ? t2.order : 2;
+        long nxc = (t2.blocks ? t2.blocks : 4096) / tiles;
+        if (nxc > a.n0 / minlx) nxc = a.n0 / minlx;
+        if (nxc < 1) nxc = 1;
+        const long lx = (a.n0 + nxc - 1) / nxc;
+        a.lx = (int)lx;
+        a.nxc = (a.n0 + lx - 1) / lx;
+        a.xstride = lx;
     } else {
         // whole grid: ~4096 single-wave workgroups (two rounds over the 256 CUs x 8 wave slots).  Interior sweep of a
         // THIN slab (exchange-bound): at most 1536, so that the RCCL kernel of the halo stream finds free wave slots
         // at once — workgroups march for the whole sweep, a kernel launched behind a full sweep waits for its first
         // round to end (measured: 90 us for 13 us of work).  Thick slabs are compute-bound: full occupancy.
-        const bool thin = xplain && n.n[0] < 96;
+        const bool thin = xplain && a.n0 < 96;
         const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 4096);
         long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;
-        if (nxc > n.n[0] / 16) nxc = n.n[0] / 16 > 0 ? n.n[0] / 16 : 1;
-        const long lx = (n.n[0] + nxc - 1) / nxc;
+        if (nxc > a.n0 / 16) nxc = a.n0 / 16 > 0 ? a.n0 / 16 : 1;
+        const long lx = (a.n0 + nxc - 1) / nxc;
         a.lx = (int)lx;
-        a.nxc = (n.n[0] + lx - 1) / lx;
+        a.nxc = (a.n0 + lx - 1) / lx;
         a.xstride = lx;
     }
     // waves per workgroup = neighbouring chunks of the same rows (1, 2 or 4; PDEHIP_EULER2 third field overrides)
@@ -369,14 +383,15 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     const dim3 grid((unsigned)a.nblocks), block(64 * nwz);
     if (dry_run) { *done = true; return 0; }
     if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
-#define PDEHIP_E2(RY_)                                                                                               \
-    if (ry == RY_) {                                                                                                 \
-        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION>), grid, block, 0, st, a); \
-        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED>), grid, block, 0, st, a);                  \
+#define PDEHIP_E2(RY_, HY_)                                                                                               \
+    if (ry == RY_ && has_y == HY_) {                                                                                      \
+        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_>), grid, block, 0, st, a); \
+        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_>), grid, block, 0, st, a);                  \
     }
-    PDEHIP_E2(2)
-    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4) }
+    PDEHIP_E2(1, false)
+    PDEHIP_E2(2, true)
+    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true) }
 #undef PDEHIP_E2
     PDEHIP_HIP(hipGetLastError());
     *done = true;
@@ -399,37 +414,43 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     *done = false;
     const long vec = 16 / elem_size(n.dtype);
     if (m2 != E2_DIFFUSION && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
-    if (tune2().off || tune().force_generic || n.ndim != 3 || in == out) return 0;
-    if (n.n[0] < (xplain ? 1 : 4) || n.n[1] < 4 || n.n[2] < 4 || n.p[0] >= (1L << 31)) return 0;
-    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[0] % vec || n.p[1] % vec) return 0;
+    if (tune2().off || tune().force_generic || (n.ndim != 3 && n.ndim != 2) || in == out) return 0;
+    // kernel axes (march, rows, lanes) <- normalised grid axes: 3-D (0, 1, 2); 2-D (1, -, 2): the march axis is the first
+    // grid axis and there are no rows
+    const int am = n.ndim == 3 ? 0 : 1;
+    if (n.ndim == 2 && xplain) return 0;
+    if (n.n[am] < (xplain ? 1 : 4) || (n.ndim == 3 && n.n[1] < 4) || n.n[2] < 4 || n.p[am] >= (1L << 31)) return 0;
+    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[am] % vec || n.p[1] % vec) return 0;
     LapArgs a;
     memset(&a, 0, sizeof(a));
-    for (int ax = 0; ax < 3; ax++) {
-        if (ax == 0 && xplain) continue;
+    for (int k = 0; k < 3; k++) {   // k = kernel axis
+        if (k == 0 && xplain) continue;
+        if (k == 1 && n.ndim == 2) { a.per[1] = 1; continue; }
+        const int ax = (k == 0) ? am : k;
         // both faces periodic, or both local (virtual point from the adjacent cell); the same for both levels
         const int cls = classify_axis(fg, ax, n.n[ax]);
         if (cls < 0 || (fg1 && classify_axis(*fg1, ax, n.n[ax]) != cls)) return 0;
-        a.per[ax] = cls;
+        a.per[k] = cls;
         for (int side = 0; side < 2; side++) {
-            a.ibc[ax][side].on = 1;
-            a.ibc[ax][side].idx = fg.idx[ax][side];
-            a.ibc[ax][side].c = fg.c[ax][side];
-            a.ibc[ax][side].f = fg.f[ax][side];
+            a.ibc[k][side].on = 1;
+            a.ibc[k][side].idx = fg.idx[ax][side];
+            a.ibc[k][side].c = fg.c[ax][side];
+            a.ibc[k][side].f = fg.f[ax][side];
             const InputBCs &f1 = fg1 ? *fg1 : fg;
-            a.ibc1[ax][side].on = 1;
-            a.ibc1[ax][side].idx = f1.idx[ax][side];
-            a.ibc1[ax][side].c = f1.c[ax][side];
-            a.ibc1[ax][side].f = f1.f[ax][side];
+            a.ibc1[k][side].on = 1;
+            a.ibc1[k][side].idx = f1.idx[ax][side];
+            a.ibc1[k][side].c = f1.c[ax][side];
+            a.ibc1[k][side].f = f1.f[ax][side];
         }
     }
     a.gamma = gamma;
     a.in = in; a.out = out; a.y = in;
-    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
-    a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
-    a.o_off = n.off; a.o_s0 = n.p[0]; a.o_s1 = n.p[1];
-    a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
+    a.n0 = n.n[am]; a.n1 = n.ndim == 3 ? n.n[1] : 1; a.n2 = n.n[2];
+    a.p0 = n.p[am]; a.p1 = n.ndim == 3 ? n.p[1] : 0; a.off = n.off;
+    a.o_off = n.off; a.o_s0 = a.p0; a.o_s1 = a.p1;
+    a.sx = n.lap_scale[am]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2;
-    a.ndim = 3; a.any_ibc = 1;
+    a.ndim = n.ndim; a.any_ibc = 1;
     if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2);
     return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2);
 }

@@ -472,6 +472,20 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
     return launch_laplace(n, in, out, out_strides(n, PDEHIP_OUT_FULL), mode, s1, s2, gamma, y, as_stream(stream), n_fused ? &fg : nullptr);
 }
 
+// faces (grid axes) -> on-the-fly BC table (normalised axes); false when a face is not a scalar first-order condition
+static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, InputBCs *fg, int first_axis = 0)
+{
+    memset(fg, 0, sizeof(*fg));
+    for (int a = first_axis; a < n.ndim; a++)
+        for (int side = 0; side < 2; side++) {
+            const int ax = 3 - n.ndim + a;
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) return false;
+            fg->on[ax][side] = 1; fg->idx[ax][side] = r.index1; fg->c[ax][side] = r.const_v; fg->f[ax][side] = r.factor1;
+        }
+    return true;
+}
+
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
                           const pdehip_bc_face_t *faces, void *stream, bool *done, bool xplain, bool dry_run, int ends)
 {
@@ -479,28 +493,10 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
     if (!in || !out || !faces) PDEHIP_FAIL(E_VALUE, "euler2: NULL pointer");
-    if (n.ndim != 3) return 0;
+    if (n.ndim < 2) return 0;
     InputBCs fg;
-    memset(&fg, 0, sizeof(fg));
-    for (int a = xplain ? 1 : 0; a < 3; a++)
-        for (int side = 0; side < 2; side++) {
-            const pdehip_bc_face_t &r = faces[2 * a + side];
-            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[a]) return 0;
-            fg.on[a][side] = 1; fg.idx[a][side] = r.index1; fg.c[a][side] = r.const_v; fg.f[a][side] = r.factor1;
-        }
+    if (!faces_to_input_bcs(n, faces, &fg, xplain ? 1 : 0)) return 0;
     return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
-}
-
-static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, InputBCs *fg)
-{
-    memset(fg, 0, sizeof(*fg));
-    for (int a = 0; a < 3; a++)
-        for (int side = 0; side < 2; side++) {
-            const pdehip_bc_face_t &r = faces[2 * a + side];
-            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[a]) return false;
-            fg->on[a][side] = 1; fg->idx[a][side] = r.index1; fg->c[a][side] = r.const_v; fg->f[a][side] = r.factor1;
-        }
-    return true;
 }
 
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
@@ -510,7 +506,7 @@ int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, doubl
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
     if (!in || !out || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
-    if (n.ndim != 3) return 0;
+    if (n.ndim < 2) return 0;
     InputBCs fc, fm;
     if (!faces_to_input_bcs(n, faces_c, &fc) || !faces_to_input_bcs(n, faces_mu, &fm)) return 0;
     // level 2 is `y + s2 * (s1 * lap(mu))` resp. `s2 * (s1 * lap(mu))` with s1 = 1 like the two-kernel path (pdehip_steppers.hip)

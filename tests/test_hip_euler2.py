@@ -188,3 +188,51 @@ def test_cahn_hilliard_solvers_use_the_fused_sweep(backend):
     done = C.c_int(1)
     backend._lib.cahn_hilliard_fused(info2.ref, f1.c, f2.c, a.ptr, b.ptr, 1.0, 1e-3, 1, C.byref(done), None)
     assert done.value == 0
+
+
+PERIODIC2 = list(itertools.product([True, False], repeat=2))
+
+
+@pytest.mark.parametrize("periodic", PERIODIC2, ids=["".join("P" if p else "L" for p in per) for per in PERIODIC2])
+@pytest.mark.parametrize("dtype,shape", [
+    (np.float64, (16, 128)),
+    (np.float64, (41, 256)),     # several chunks along the march axis (chunks of >= 4 rows), odd row count
+    (np.float64, (9, 200)),      # row ends inside the second chunk
+    (np.float64, (64, 64)),      # BASELINE config 1 shape
+    (np.float32, (12, 256)),
+    (np.float32, (7, 100)),
+])
+def test_two_dimensional_grids(backend, periodic, dtype, shape):
+    """2-D: the same two-level kernel marching along the first axis (no rows): two diffusion steps per sweep and the
+    Cahn-Hilliard right-hand side in one sweep, bit-exact against the oracle."""
+    grid, bc, bcs, data = _setup(shape, list(periodic), dtype, seed=21)
+    done, got = _euler2(backend, grid, bcs, data, 0.6, 2e-3)
+    assert done == 1
+    np.testing.assert_array_equal(got, _oracle_steps(grid, bcs, data, 0.6, 2e-3, 2))
+    bc_mu = {}
+    for i, a in enumerate(grid.axes):
+        if periodic[i]:
+            bc_mu[a] = "periodic"
+        else:
+            bc_mu[a + "-"], bc_mu[a + "+"] = LOCAL_MU[i]
+    bcs_mu = grid.get_boundary_conditions(bc_mu)
+    info = GridInfo(grid.shape, grid.discretization, data.dtype)
+    fc, fm = convert_bcs(bcs), convert_bcs(bcs_mu)
+    g = oracle_grid(grid, dtype)
+    scratch = np.zeros(grid._shape_full, dtype)
+    orhs = O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, host_faces(bcs).c, host_faces(bcs_mu).c, scratch)
+    a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
+    d = C.c_int(0)
+    backend._lib.cahn_hilliard_fused(info.ref, fc.c, fm.c, a.ptr, b.ptr, 0.8, 1e-3, 1, C.byref(d), None)
+    assert d.value == 1
+    np.testing.assert_array_equal(b.get_valid(), interior(grid, O.euler_run(g, orhs, to_full(grid, data), 1e-3, 1)))
+    backend._lib.cahn_hilliard_fused(info.ref, fc.c, fm.c, a.ptr, b.ptr, 0.8, 0.02, 0, C.byref(d), None)
+    assert d.value == 1
+    np.testing.assert_array_equal(b.get_valid(), interior(grid, O.rhs_scaled(g, orhs, to_full(grid, data), 0.02)))
+    # the stepper entry point: 9 steps = 4 double sweeps + 1 single step
+    eq = pde_hip.DiffusionPDE(0.8, bc=bc)
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data, dtype=dtype))
+    a, b = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info)
+    res = C.c_void_p()
+    backend._lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, 1e-3, 9, C.byref(res), None)
+    np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _oracle_steps(grid, bcs, data, 0.8, 1e-3, 9))

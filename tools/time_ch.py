@@ -12,12 +12,15 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import pde_hip  # noqa: E402
 from pde_hip.device import DeviceArray, DeviceScalar, ptr_array  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+shape = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "256").split(",")]
+if len(shape) == 1:
+    shape = shape * 3
+n = "x".join(map(str, shape))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dtype = np.dtype(sys.argv[3]) if len(sys.argv) > 3 else np.dtype("float64")
 backend = pde_hip.get_backend("hip")
 lib = backend._lib
-grid = pde_hip.UnitGrid([n, n, n], periodic=True)
+grid = pde_hip.UnitGrid(shape, periodic=True)
 state = pde_hip.ScalarField.random_uniform(grid, -0.1, 0.1, rng=np.random.default_rng(0), dtype=dtype)
 spec = backend.make_rhs_spec(pde_hip.CahnHilliardPDE(1.0), state)
 a, b = DeviceArray(spec.info).set_valid(state.data), DeviceArray(spec.info)
@@ -37,7 +40,7 @@ for _ in range(3):
     lib.stream_synchronize(stream)
     lib.event_elapsed_ms(e0, e1, C.byref(ms))
     best = min(best, ms.value / steps)
-cells = n ** 3
+cells = int(np.prod(shape))
 tag = f"EULER2={os.environ.get('PDEHIP_EULER2', 'default'):>8s} CH n={n} {dtype}"
 print(f"{tag}: Euler {best:.4f} ms/step  {cells / best / 1e6:.1f} Gcells/s")
 work = [DeviceArray(spec.info) for _ in range(7)]

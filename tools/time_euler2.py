@@ -12,13 +12,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import pde_hip  # noqa: E402
 from pde_hip.device import DeviceArray  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+shape = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512").split(",")]
+if len(shape) == 1:
+    shape = shape * 3
+n = "x".join(map(str, shape))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 dtype = np.dtype(sys.argv[3]) if len(sys.argv) > 3 else np.dtype("float64")
 per = os.environ.get("TIME_PERIODIC", "1") == "1"
 backend = pde_hip.get_backend("hip")
 lib = backend._lib
-grid = pde_hip.UnitGrid([n, n, n], periodic=per)
+grid = pde_hip.UnitGrid(shape, periodic=per)
 state = pde_hip.ScalarField.random_uniform(grid, rng=np.random.default_rng(0), dtype=dtype)
 spec = backend.make_rhs_spec(pde_hip.DiffusionPDE(1.0), state)
 a, b = DeviceArray(spec.info).set_valid(state.data), DeviceArray(spec.info)
@@ -38,6 +41,6 @@ for _ in range(3):
     ms = C.c_float()
     lib.event_elapsed_ms(e0, e1, C.byref(ms))
     best = min(best, ms.value / steps)
-cells = n ** 3
+cells = int(np.prod(shape))
 print(f"EULER2={os.environ.get('PDEHIP_EULER2', 'default'):>10s} n={n} {dtype} periodic={per}: {best:.4f} ms/step  {cells / best / 1e6:.1f} Gcells/s  "
       f"{cells * 2 * dtype.itemsize / best / 1e9 / 8:.1%} of 8 TB/s (16 B/cell-step)")

@@ -276,6 +276,14 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
  * levels), >= 4 local layers on every rank, and *ok != 0 from pdehip_slab_euler2_supported (grid shape, dtype
  * and the faces of the two other axes are covered by the kernel).  E_NOTIMPL otherwise. */
 int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok);
+/* Cahn-Hilliard right-hand side on a slab in ONE sweep (pdehip_cahn_hilliard_fused with real halo layers on the slowest
+ * axis): two layers of c per side are exchanged, mu needs no exchange of its own (the reference exchanges c and mu,
+ * one layer each, per evaluation).  `c_ext` / `out_ext` are slab arrays with TWO halo layers per side (the layout of a
+ * slab of n+2 layers; own layers 2..n+1).  euler != 0: out = c + dt*laplace(mu); euler == 0: out = dt*laplace(mu).
+ * Same global preconditions as pdehip_slab_euler2_run, with >= 2 own layers per rank and pdehip_slab_ch_supported. */
+int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok);
+int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
+                         void *c_ext, void *out_ext, double dt, int euler, void *stream);
 int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
                            int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                            void *stream);

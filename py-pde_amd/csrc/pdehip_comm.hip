@@ -376,4 +376,47 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Cahn-Hilliard right-hand side on a slab in ONE sweep (fused two-level kernel, mu in registers): two layers of c per
+// side are exchanged, mu needs no exchange of its own (the reference exchanges c AND mu, one layer each:
+// pde/grids/boundaries/local.py:561-662 per operator application).  `c_ext` / `out_ext` are slab arrays with TWO halo
+// layers per side (layers 0,1 | own 2..n+1 | n+2,n+3), i.e. the layout of a slab of n+2 layers.
+//   euler != 0: out = c + dt * laplace(mu)        euler == 0: out = dt * laplace(mu)
+// Preconditions as for pdehip_slab_euler2_run (periodic slowest axis, >= 2 own layers on every rank, *ok from
+// pdehip_slab_ch_supported), checked globally by the caller.
+// ---------------------------------------------------------------------------------------------------------
+int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    if (!g_local || !rhs || !ok) PDEHIP_FAIL(E_VALUE, "slab_ch_supported: NULL pointer");
+    *ok = 0;
+    if (rhs->kind != PDEHIP_RHS_CAHN_HILLIARD || g_local->ndim != 3 || g_local->shape[0] < 2) return 0;
+    bool done = false;
+    PDEHIP_TRY(cahn_hilliard_fused(g_local, (const void *)16, (void *)32, rhs->param, 0.0, false, rhs->bc_c, rhs->bc_mu, nullptr,
+                                   &done, true, true));
+    *ok = done ? 1 : 0;
+    return 0;
+}
+
+int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
+                         void *c_ext, void *out_ext, double dt, int euler, void *stream)
+{
+    if (!comm || !rhs || !c_ext || !out_ext) PDEHIP_FAIL(E_VALUE, "slab_ch_sweep: NULL pointer");
+    if (lower < 0 || upper < 0) PDEHIP_FAIL(E_NOTIMPL, "slab_ch_sweep needs both neighbours (periodic slowest axis)");
+    Comm *c = static_cast<Comm *>(comm);
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g_local, &n));
+    const long nloc = g_local->shape[0];
+    const size_t lp = (size_t)n.p[0] * elem_size(n.dtype);
+    hipStream_t st = as_stream(stream);
+    PDEHIP_TRY(exchange2(c, lp, nloc, c_ext, lower, upper, st));
+    pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
+    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) { fc[i] = rhs->bc_c[i]; fm[i] = rhs->bc_mu[i]; }
+    fc[0].kind = fc[1].kind = fm[0].kind = fm[1].kind = PDEHIP_BC_SKIP;
+    bool done = false;
+    PDEHIP_TRY(cahn_hilliard_fused(g_local, static_cast<char *>(c_ext) + lp, static_cast<char *>(out_ext) + lp, rhs->param, dt,
+                                   euler != 0, fc, fm, stream, &done, true));
+    if (!done) PDEHIP_FAIL(E_NOTIMPL, "slab_ch_sweep: grid or faces are not covered by the two-level kernel");
+    return 0;
+}
+
 }  // extern "C"

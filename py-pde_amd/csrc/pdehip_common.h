@@ -124,7 +124,8 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
 // one Cahn-Hilliard sweep: mu = c^3 - c - gamma*lap(c) with the faces of c, then (euler) out = c + dt*lap(mu) or
 // (!euler) out = dt*lap(mu) with the faces of mu — mu never leaves the registers; *done as above
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
-                        const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done);
+                        const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
+                        bool xplain = false, bool dry_run = false);
 // xplain: the slowest axis has two real halo layers on either side (slab decomposition) instead of BCs; `in` / `out` then
 // point one layer before the first layer to update, like every sub-slab launch (pdehip_comm.hip)
 // BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`

@@ -500,7 +500,8 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
 }
 
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
-                        const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done)
+                        const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
+                        bool xplain, bool dry_run)
 {
     *done = false;
     NGrid n;
@@ -508,9 +509,9 @@ int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, doubl
     if (!in || !out || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
     if (n.ndim < 2) return 0;
     InputBCs fc, fm;
-    if (!faces_to_input_bcs(n, faces_c, &fc) || !faces_to_input_bcs(n, faces_mu, &fm)) return 0;
+    if (!faces_to_input_bcs(n, faces_c, &fc, xplain ? 1 : 0) || !faces_to_input_bcs(n, faces_mu, &fm, xplain ? 1 : 0)) return 0;
     // level 2 is `y + s2 * (s1 * lap(mu))` resp. `s2 * (s1 * lap(mu))` with s1 = 1 like the two-kernel path (pdehip_steppers.hip)
-    return launch_euler2(n, in, out, 1.0, dt, fc, false, as_stream(stream), done, false, 0,
+    return launch_euler2(n, in, out, 1.0, dt, fc, xplain, as_stream(stream), done, dry_run, 0,
                          euler ? E2_CH_EULER : E2_CH_SCALED, &fm, gamma);
 }
 }  // namespace pdehip

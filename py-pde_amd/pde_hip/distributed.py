@@ -227,12 +227,31 @@ class SlabStepper:
             ok = C.c_int(0)
             self.engine.lib.slab_euler2_supported(C.byref(self.g), C.byref(self._rhs_c), C.byref(ok))
             self._euler2 = bool(ok.value)
+        # Cahn-Hilliard: the right-hand side in ONE sweep (mu in registers) after ONE exchange of two layers of c
+        self._ch_rhs = None
+        if (self.comm is not None and self.kind == _abi.RHS_CAHN_HILLIARD and self.exchanging and grid.periodic[0]
+                and min(self.mesh.counts) >= 2 and grid.num_axes == 3):
+            rhs = _abi.RHS()
+            rhs.kind, rhs.param = _abi.RHS_CAHN_HILLIARD, self.param
+            self.faces_c.copy_into(rhs.bc_c)
+            self.faces_mu.copy_into(rhs.bc_mu)
+            ok = C.c_int(0)
+            self.engine.lib.slab_ch_supported(C.byref(self.g), C.byref(rhs), C.byref(ok))
+            if ok.value:
+                self._ch_rhs = rhs
 
     # --- buffers ---------------------------------------------------------------------------------
     def buf(self, name: str):
+        """Slab array (n + 2 layers) as a flat tensor; the allocation holds ONE MORE layer on either side, so the same
+        memory is also a slab array with two halo layers per side (``ext_ptr``) for the two-level kernels."""
         if name not in self._bufs:
-            self._bufs[name] = self.engine.alloc(self.nelems, self.dtype)
+            full = self.engine.alloc(self.nelems + 2 * self.layer_pitch, self.dtype)
+            self._bufs[name] = full[self.layer_pitch : self.layer_pitch + self.nelems]
         return self._bufs[name]
+
+    def ext_ptr(self, buf) -> int:
+        """Pointer to the array with two halo layers per side that contains ``buf`` (own layers 2..n+1)."""
+        return buf.data_ptr() - self.layer_pitch * self.itemsize
 
     def layer(self, buf, index: int):
         """Full layer ``index`` (0 = lower ghost layer) as a flat tensor view (contiguous)."""
@@ -303,10 +322,19 @@ class SlabStepper:
         """k_out = dt * rhs(y)  (same sequence as pdehip_rhs_scaled, plus the halo exchange)."""
         if self.kind == _abi.RHS_DIFFUSION:
             self._stencil_pass("scaled", self.faces_c, y, k_out, s1=self.param, s2=dt)
+        elif self._ch_rhs is not None:
+            self._ch_sweep(y, k_out, dt, euler=False)
         else:
             mu = self.buf("mu")
             self._stencil_pass("mu", self.faces_c, y, mu, s1=self.param)
             self._stencil_pass("scaled", self.faces_mu, mu, k_out, s1=1.0, s2=dt)
+
+    def _ch_sweep(self, c, out, dt: float, *, euler: bool) -> None:
+        """Exchange two layers of c per side, then the fused Cahn-Hilliard sweep (mu in registers) on the comp stream."""
+        lower = -1 if self.lower is None else self.lower
+        upper = -1 if self.upper is None else self.upper
+        self.engine.lib.slab_ch_sweep(self.comm, C.byref(self.g), C.byref(self._ch_rhs), lower, upper, self.ext_ptr(c),
+                                      self.ext_ptr(out), dt, 1 if euler else 0, self.engine.stream_ptr(self.engine.comp))
 
     def lincomb(self, out, y, coefs, ks) -> None:
         cf = (C.c_double * len(coefs))(*coefs)
@@ -320,6 +348,10 @@ class SlabStepper:
         comp, halo = eng.comp, eng.halo
         if self.kind != _abi.RHS_DIFFUSION or not self.exchanging:
             for _ in range(nsteps):
+                if self._ch_rhs is not None:
+                    self._ch_sweep(cur, nxt, dt, euler=True)
+                    cur, nxt = nxt, cur
+                    continue
                 if self.kind == _abi.RHS_DIFFUSION:
                     self._stencil_pass("euler", self.faces_c, cur, nxt, y=cur, s1=self.param, s2=dt)
                 else:

@@ -97,6 +97,24 @@ def test_diffusion_euler_two_steps_per_sweep_slab_loop(process_group, monkeypatc
     assert not st1._euler2
 
 
+@pytest.mark.parametrize("shape,periodic", [((8, 8, 64), [True, True, True]), ((6, 12, 128), [True, False, False]), ((2, 4, 72), [True, False, True])])
+def test_cahn_hilliard_slab_one_sweep_per_rhs(process_group, monkeypatch, shape, periodic):
+    """Slab Cahn-Hilliard with the fused sweep: ONE exchange (two layers of c) per right-hand side, mu never exchanged;
+    Euler and RK4 equal the serial oracle bit for bit."""
+    from pde_hip.distributed import HipEngine, SlabStepper
+
+    monkeypatch.setenv("PDEHIP_COMM", "native")
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    data = np.random.default_rng(6).uniform(-0.2, 0.2, shape)
+    eq = pde_hip.CahnHilliardPDE(0.9)
+    for solver, steps in [("euler", 5), ("runge-kutta", 3)]:
+        st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
+        assert st._ch_rhs is not None
+        final, info = st.solve(data, t_range=steps * 1e-3, dt=1e-3, solver=solver)
+        assert info["steps"] == steps
+        np.testing.assert_array_equal(final, _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, eq.bc_c, data, 1e-3, steps, solver))
+
+
 @pytest.mark.parametrize("comm_mode", ["native", "torch"])
 def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group, monkeypatch, comm_mode):
     from pde_hip.distributed import HipEngine, SlabStepper

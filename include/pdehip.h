@@ -211,6 +211,10 @@ int pdehip_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void
 /* y += (k1 + 2*k2 + 2*k3 + k4) / 6                     [pde/solvers/runge_kutta.py:60] */
 int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const void *k1,
                        const void *k2, const void *k3, const void *k4, void *stream);
+/* y += dt * (1.5 * rate_cur - 0.5 * rate_prev)        [Adams-Bashforth: pde/solvers/adams_bashforth.py:41-44,
+ * pde/backends/numba/_solvers.py:160-167; the rates are unscaled right-hand sides = pdehip_rhs_scaled with dt = 1] */
+int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const void *rate_cur,
+                       const void *rate_prev, double dt, void *stream);
 /* RKF45 tail (pde/solvers/runge_kutta.py:146-152):
  *   err  = max | r1 k1 + r3 k3 + r4 k4 + r5 k5 + r6 k6 |   -> *err_dev (fp64 device scalar)
  *   ynew = y + c1 k1 + c3 k3 + c4 k4 + c5 k5

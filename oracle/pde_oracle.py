@@ -159,6 +159,24 @@ def rk4_combine(g, ncomp, y_full, k1, k2, k3, k4):
     return y_full
 
 
+def ab2_combine(g, ncomp, y_full, rate_cur, rate_prev, dt):
+    _check(lib().oracle_ab2_combine(C.byref(g), ncomp, _p(y_full), _p(rate_cur), _p(rate_prev), dt), "ab2_combine")
+    return y_full
+
+
+def adams_bashforth_run(g, rhs, y_full, dt, steps):
+    """pde/solvers/adams_bashforth.py:31-70: prev = y - dt*rhs(y); then `steps` AB2 steps (rates are unscaled: dt = 1)."""
+    y = y_full
+    rate_cur = rhs_scaled(g, rhs, y, 1.0)
+    lincomb_out = lincomb(g, 1, y, [-dt], [rate_cur])          # y - dt * rhs(y)
+    rate_prev = rhs_scaled(g, rhs, lincomb_out, 1.0)
+    for _ in range(steps):
+        rate_cur = rhs_scaled(g, rhs, y, 1.0)
+        ab2_combine(g, 1, y, rate_cur, rate_prev, dt)
+        rate_prev = rate_cur                                   # = rhs(previous state): recomputed by the reference
+    return y
+
+
 def rkf45_combine(g, ncomp, y_full, ks):
     ynew = np.zeros_like(y_full)
     err = C.c_double(0)

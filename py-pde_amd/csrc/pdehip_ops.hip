@@ -333,6 +333,31 @@ __global__ void __launch_bounds__(256) rk4_combine_kernel(Rk4Args a)
     });
 }
 
+struct Ab2Args {
+    DevGrid g;
+    int ncomp;
+    void *y;
+    const void *rc, *rp;
+    double dt;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) ab2_combine_kernel(Ab2Args a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        const V y = *(const V *)((const T *)a.y + e);
+        const V rc = *(const V *)((const T *)a.rc + e), rp = *(const V *)((const T *)a.rp + e);
+        V o;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            // pde/solvers/adams_bashforth.py:44
+            const double s = a.dt * (1.5 * (double)rc[q] - 0.5 * (double)rp[q]);
+            o[q] = (T)((double)y[q] + s);
+        }
+        *(V *)((T *)a.y + e) = o;
+    });
+}
+
 // block-wide max of non-negative doubles (NaN propagates: its bit pattern is the largest)
 __device__ __forceinline__ void block_max_to(double v, double *dst)
 {
@@ -630,6 +655,19 @@ int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const vo
     a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.k4 = k4;
     const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
     PDEHIP_VEC_LAUNCH(rk4_combine_kernel, a, items);
+    return 0;
+}
+
+int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const void *rate_cur, const void *rate_prev,
+                       double dt, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!y_full || !rate_cur || !rate_prev) PDEHIP_FAIL(E_VALUE, "ab2_combine: NULL pointer");
+    Ab2Args a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.rc = rate_cur; a.rp = rate_prev; a.dt = dt;
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(ab2_combine_kernel, a, items);
     return 0;
 }
 

@@ -116,6 +116,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "lincomb": ([_pg, _i, _vp, _vp, _i, _pd, _pvp], True),
     "rk4_combine": ([_pg, _i, _vp, _vp, _vp, _vp, _vp], True),
     "rkf45_combine": ([_pg, _i, _vp, _vp, _pvp, _vp], True),
+    "ab2_combine": ([_pg, _i, _vp, _vp, _vp, _d], True),
     "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
     "rhs_scaled": ([_pg, _pr, _vp, _vp, _d], True),
     "euler_run": ([_pg, _pr, _vp, _vp, _d, _i64, _pvp], True),

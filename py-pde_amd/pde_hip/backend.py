@@ -582,6 +582,36 @@ class HipBackendMixin:
         return adaptive_stepper
 
     # --- steppers ----------------------------------------------------------------------------------------------
+    def _make_adams_bashforth_stepper(self, solver, spec):
+        """Two-step Adams-Bashforth (pde/solvers/adams_bashforth.py:31-70, pde/backends/numba/_solvers.py:121-196).
+
+        The reference re-evaluates ``rhs(state_prev)`` in every step; it equals the ``rhs_cur`` of the step before
+        bit for bit, so it is kept instead: one right-hand side per step.  Rates are ``pdehip_rhs_scaled`` with dt = 1.
+        """
+        info, lib, stream = spec.info, self._lib, self.stream
+        dt = float(solver.info["dt"])
+        rates = [DeviceArray(info), DeviceArray(info)]   # [current, previous], roles swap every step
+        tmp = DeviceArray(info)
+        minus_dt = (C.c_double * 1)(-dt)
+        first = [True]
+
+        def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+            steps = max(1, round((t_end - t_start) / dt))
+            if first[0]:
+                # state_prev = state - dt * rhs(state)  ->  rate_prev = rhs(state_prev)
+                lib.rhs_scaled(info.ref, spec.ref, state_data.ptr, rates[0].ptr, 1.0, stream)
+                lib.lincomb(info.ref, 1, tmp.ptr, state_data.ptr, 1, minus_dt, ptr_array([rates[0]]), stream)
+                lib.rhs_scaled(info.ref, spec.ref, tmp.ptr, rates[1].ptr, 1.0, stream)
+                first[0] = False
+            for _ in range(steps):
+                lib.rhs_scaled(info.ref, spec.ref, state_data.ptr, rates[0].ptr, 1.0, stream)
+                lib.ab2_combine(info.ref, 1, state_data.ptr, rates[0].ptr, rates[1].ptr, dt, stream)
+                rates.reverse()
+            solver.info["steps"] += steps
+            return state_data, t_start + (steps - 1) * dt + dt
+
+        return fixed_stepper
+
     def make_inner_stepper(self, solver, state):
         """Device-level stepper ``(state: DeviceArray, t_start, t_end) -> (DeviceArray, t_last)``.
 
@@ -591,13 +621,17 @@ class HipBackendMixin:
         from .solvers import make_dt_adjuster
 
         solver_name = solver.__class__.__name__
-        if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver"}:
+        if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver", "AdamsBashforthSolver"}:
             msg = f"Backend `{self.name}` does not support solver {solver_name}"
             raise NotImplementedError(msg)
         try:
             spec = self.make_rhs_spec(solver.pde, state)
         except NotImplementedError:
+            if solver_name == "AdamsBashforthSolver":
+                raise
             return self._make_expression_stepper(solver, state)   # generic expression PDE
+        if solver_name == "AdamsBashforthSolver":
+            return self._make_adams_bashforth_stepper(solver, spec)
         info, lib, stream = spec.info, self._lib, self.stream
         is_rk = solver_name == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))

@@ -41,7 +41,8 @@ class PDEBase:
         from .solvers import Controller, SolverBase
 
         if isinstance(solver, str):
-            kwargs.setdefault("adaptive", dt is None)
+            if solver in {"euler", "explicit", "runge-kutta"}:   # pdes/base.py:532-535
+                kwargs.setdefault("adaptive", dt is None)
             solver_obj = SolverBase.from_name(solver, pde=self, backend=backend, **kwargs)
         else:
             solver_obj = solver

@@ -138,6 +138,12 @@ class RungeKuttaSolver(AdaptiveSolverBase):
     name = "runge-kutta"
 
 
+class AdamsBashforthSolver(SolverBase):
+    """Explicit two-step Adams-Bashforth: ``y += dt * (1.5 f(y_n) - 0.5 f(y_{n-1}))`` (solvers/adams_bashforth.py:17-75)."""
+
+    name = "adams-bashforth"
+
+
 class Controller:
     """Advance a state over ``t_range``, interrupting for trackers (solvers/controller.py:146-298).
 

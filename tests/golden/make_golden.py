@@ -142,6 +142,13 @@ STEP_CASES = [
          bc="auto_periodic_neumann", solver="euler", dt=None, t_range=1.0, backend="numpy"),
     dict(id="ch2d_f32_euler_torch", pde="cahn_hilliard", gamma=1.0, bounds=[[0, 8], [0, 8]], shape=[8, 8], periodic=[True, True],
          bc="auto_periodic_neumann", solver="euler", dt=1e-3, t_range=0.1, backend="torch", dtype="float32"),
+    # Adams-Bashforth (pde/solvers/adams_bashforth.py; only the numpy and numba backends implement it)
+    dict(id="diff2d_ab_numpy", pde="diffusion", D=0.5, bounds=[[0, 8], [0, 8]], shape=[8, 8], periodic=[False, True],
+         bc="auto_periodic_neumann", solver="adams-bashforth", dt=0.05, t_range=1.0, backend="numpy"),
+    dict(id="diff3d_ab_numpy", pde="diffusion", D=1.0, bounds=[[0, 4], [0, 6], [0, 8]], shape=[4, 6, 8], periodic=[True, False, True],
+         bc={"x": "periodic", "y": {"value": 0.3}, "z": "periodic"}, solver="adams-bashforth", dt=0.05, t_range=0.55, backend="numpy"),
+    dict(id="ch2d_ab_numpy", pde="cahn_hilliard", gamma=1.0, bounds=[[0, 8], [0, 8]], shape=[8, 8], periodic=[True, False],
+         bc="auto_periodic_neumann", solver="adams-bashforth", dt=1e-3, t_range=0.05, backend="numpy"),
 ]
 
 

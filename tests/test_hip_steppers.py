@@ -261,3 +261,30 @@ def test_on_the_fly_bcs_vs_oracle(backend, shape, bc_name, dtype):
         a.set_valid(data)
         backend._lib.rhs_scaled(spec.info.ref, spec.ref, a.ptr, k.ptr, 0.01, None)
         np.testing.assert_array_equal(k.get_valid(), interior(grid, O.rhs_scaled(g, orhs, to_full(grid, data), 0.01)))
+
+
+@pytest.mark.parametrize("kind,shape", [("diffusion", (12, 16)), ("diffusion", (6, 8, 128)), ("cahn_hilliard", (8, 8, 64)), ("cahn_hilliard", (24,))])
+def test_adams_bashforth_vs_oracle(backend, rng, kind, shape):
+    """Two-step Adams-Bashforth (rate of the previous step kept instead of re-evaluated) == oracle, bit-exact; a second
+    call of the stepper continues the multi-step history like the reference's closure does."""
+    grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
+    bc = "auto_periodic_neumann"
+    data = rng.uniform(-0.3, 0.3, shape)
+    hf = host_faces(grid.get_boundary_conditions(bc))
+    g = oracle_grid(grid)
+    scratch = np.zeros(grid._shape_full)
+    if kind == "diffusion":
+        eq, orhs = pde_hip.DiffusionPDE(0.7, bc=bc), O.make_rhs(_abi.RHS_DIFFUSION, 0.7, hf.c)
+    else:
+        eq, orhs = pde_hip.CahnHilliardPDE(0.8, bc_c=bc, bc_mu=bc), O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, hf.c, hf.c, scratch)
+    dt = 2e-3
+    res, info = eq.solve(pde_hip.ScalarField(grid, data), t_range=9 * dt, dt=dt, solver="adams-bashforth", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == 9
+    np.testing.assert_array_equal(res.data, interior(grid, O.adams_bashforth_run(g, orhs, to_full(grid, data), dt, 9)))
+    # two calls of one stepper (tracker interrupts) == one call over the whole range
+    solver = pde_hip.solvers.AdamsBashforthSolver(eq)
+    state = pde_hip.ScalarField(grid, data)
+    stepper = solver.make_stepper(state, dt)
+    t = stepper(state, 0.0, 4 * dt)
+    stepper(state, t, 9 * dt)
+    np.testing.assert_array_equal(state.data, res.data)

@@ -154,6 +154,8 @@ def oracle_solve(case, grid, dtype, state_valid):
         steps = max(1, round(t_end / dt))
         if case["solver"] == "euler":
             y = O.euler_run(g, rhs, y, dt, steps)
+        elif case["solver"] == "adams-bashforth":
+            y = O.adams_bashforth_run(g, rhs, y, dt, steps)
         else:
             for _ in range(steps):
                 O.rk4_step(g, rhs, y, dt)

@@ -53,7 +53,19 @@ def cpu_baseline(n: int, seconds: float) -> dict:
     from pde_hip import _abi
 
     n_cpu = min(n, 512)
-    cores = os.cpu_count() or 1
+    # threads: what this process may actually use (affinity mask and cgroup CPU quota), not the host's core count —
+    # on the GPU boxes 256 logical CPUs are visible but the container gets 16: 256 OpenMP threads run 100x slower
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     g = _abi.make_grid((n_cpu,) * 3, (1.0,) * 3, np.float64)
     faces = _abi.FaceArray()
     for ax in range(3):
@@ -156,6 +168,7 @@ def bench_single(args) -> dict:
                        else "lap_march_kernel<double,2,RY,EULER> (fused laplace + D*, dt*, +=)"),
             "kernel_ms": round(t_kernel * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "steps_per_launch": steps_per_launch,
+            "traffic_frac": round(traffic / t_kernel / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "note": ("algorithmic bytes = 16 B per cell-step (SURVEY.md 8d) x cell-steps per launch; the kernel advances two "
                      "steps per sweep keeping the intermediate level in registers, so its measured HBM traffic is about half "
                      "of that and frac can exceed 1") if steps_per_launch == 2 else None,
@@ -246,7 +259,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"DiffusionPDE(D=1) on UnitGrid([{n}]*3, periodic=True) fp64, explicit Euler dt=0.1, "
-                        "state resident in HBM, ghost cells + fused laplace/update per step",
+                        "state resident in HBM, BCs on the fly + fused laplace/update, two steps per kernel sweep (bit-identical to single steps)",
             "cells": cells,
             "parallelism": parallelism,
             "hbm_roofline_frac_whole_step": round(value * 1e6 * BYTES_PER_CELL_STEP / 1e9 / (HBM_PEAK_GBS * ngpu), 4),

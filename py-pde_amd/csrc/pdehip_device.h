@@ -89,6 +89,7 @@ struct LapArgs {
     InBC ibc[3][2];   // [normalised axis][lower, upper]
     int per[3];       // euler2_kernel: axis is periodic (else both faces are local first-order BCs)
     long xstride;     // euler2_kernel: first plane of x-chunk xc is xc * xstride (== lx, or n0 - lx for the two-ended boundary sweep)
+    int nwy;          // euler2_kernel: waves of a workgroup stacked along the rows (others: along the fastest axis)
     InBC ibc1[3][2];  // euler2_kernel: faces of the intermediate level when it is another field (Cahn-Hilliard: mu)
 };
 

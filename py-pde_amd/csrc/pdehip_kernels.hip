@@ -376,11 +376,15 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
         a.xstride = lx;
     }
     // waves per workgroup = neighbouring chunks of the same rows (1, 2 or 4; PDEHIP_EULER2 third field overrides)
-    int nwz = (a.ntz % 4 == 0) ? 4 : (a.ntz % 2 == 0 ? 2 : 1);
-    if (t2.order > 0 && a.ntz % t2.order == 0 && (t2.order == 1 || t2.order == 2 || t2.order == 4)) nwz = t2.order;
-    a.nblocks = a.nxc * tiles / nwz;
+    int nwz = (a.ntz % 4 == 0) ? 4 : (a.ntz % 2 == 0 ? 2 : 1), nwy = 1;
+    if (has_y && t2.order > 0) {   // tuning aid: third field = 10 * (waves along the rows) + (waves along the fastest axis)
+        const int wz_ = t2.order % 10, wy_ = t2.order / 10 > 0 ? t2.order / 10 : 1;
+        if (wz_ > 0 && a.ntz % wz_ == 0 && a.nty % wy_ == 0 && wz_ * wy_ <= 4) { nwz = wz_; nwy = wy_; }
+    }
+    a.nwy = nwy;
+    a.nblocks = a.nxc * tiles / (nwz * nwy);
     a.no_swizzle = 0;
-    const dim3 grid((unsigned)a.nblocks), block(64 * nwz);
+    const dim3 grid((unsigned)a.nblocks), block(64 * nwz * nwy);
     if (dry_run) { *done = true; return 0; }
     if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
 #define PDEHIP_E2(RY_, HY_)                                                                                               \

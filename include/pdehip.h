@@ -308,6 +308,14 @@ int pdehip_jit_check(void *handle, int dtype, int ndim);
 int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host,
                      void *out_full, const double *params_host, int nparams, const pdehip_bc_face_t *in_faces,
                      void *stream);
+/* TWO applications in one sweep: out = f(f(in)), f(u) = pde_epilogue(u, laplace(u), gradient_squared(u); params), with
+ * the BCs `faces` applied to u before each application and the intermediate level in registers — two explicit Euler
+ * steps of a one-pass expression PDE (epilogue = the Euler update `u + dt * F(u, ...)`; no extra arrays, no explicit
+ * time).  Replaces two iterations of the fixed-step loop pde/backends/numba/_solvers.py:98-108 around the compiled
+ * right-hand side of pde/pdes/pde.py:401-499.  *done = 0 (nothing launched) when grid or faces are not covered: same
+ * rules as pdehip_diffusion_euler2; the caller then calls pdehip_jit_apply twice. */
+int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full,
+                      const double *params_host, int nparams, const pdehip_bc_face_t *faces, int *done, void *stream);
 
 #ifdef __cplusplus
 }

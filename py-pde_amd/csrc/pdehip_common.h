@@ -114,9 +114,16 @@ int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &
 int launch_div_march(const NGrid &n, int method, const void *in, void *out, const OutStr &o, hipStream_t st, bool *done);
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
+// launch configuration of the two-level kernel handed to a caller that launches a run-time compiled instance itself
+struct Euler2Plan {
+    LapArgs a;
+    unsigned grid, block;
+    int ry;
+    bool has_y;
+};
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, bool xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
-                  const InputBCs *fg1 = nullptr, double gamma = 0);
+                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,

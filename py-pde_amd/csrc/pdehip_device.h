@@ -10,7 +10,7 @@ enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
        LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */ };
 
 // the two fused levels of euler2_kernel (pdehip_march2.inc)
-enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2 };
+enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run-time generated: pde_epilogue() */ };
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers

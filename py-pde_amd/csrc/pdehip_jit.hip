@@ -110,20 +110,30 @@ extern "C" __global__ void __launch_bounds__(64) pde_kernel(pdehip::LapArgs a)
 }
 )SRC";
 
-int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out)
+// two-level kernel (pdehip_march2.inc) around the same epilogue: two Euler steps of a one-pass expression per sweep
+const char *kMarch2Wrapper = R"SRC(
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) pde_kernel(pdehip::LapArgs a)
+{
+    pdehip::euler2_body<PDE_T, PDE_VEC, PDE_RY, pdehip::E2_CUSTOM, PDE_HASX>(a);
+}
+)SRC";
+
+int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
+                    bool two_level = false)
 {
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
                       "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n";
     src += j->body;
     src += "\n}\n";
-    if (!generic) src += "#include \"pdehip_march.inc\"\n";
+    if (two_level) src += "#include \"pdehip_march2.inc\"\n";   // PDE_HASX carries HAS_Y there
+    else if (!generic) src += "#include \"pdehip_march.inc\"\n";
     src += "}  // namespace pdehip\n";
-    src += generic ? kGenericKernel : kMarchWrapper;
-    const char *hdr_src[] = {kDeviceH, kMarchInc};
-    const char *hdr_name[] = {"pdehip_device.h", "pdehip_march.inc"};
+    src += two_level ? kMarch2Wrapper : (generic ? kGenericKernel : kMarchWrapper);
+    const char *hdr_src[] = {kDeviceH, kMarchInc, kMarch2Inc};
+    const char *hdr_name[] = {"pdehip_device.h", "pdehip_march.inc", "pdehip_march2.inc"};
     hiprtcProgram prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src.c_str(), "pde_kernel.hip", 2, hdr_src, hdr_name) != 0)
+    if (g_rtc.CreateProgram(&prog, src.c_str(), "pde_kernel.hip", 3, hdr_src, hdr_name) != 0)
         PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
@@ -176,6 +186,7 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     const int vec = dtype == PDEHIP_F64 ? 2 : 4;
     PDEHIP_TRY(compile_variant(j, "", true, tname, 1, 1, 1, false, false, nullptr));
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr));
+    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr, true));
     return 0;
 }
 
@@ -296,6 +307,48 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
     }
     void *args[] = {&a};
     PDEHIP_HIP(hipModuleLaunchKernel(v.fn, blocks, 1, 1, threads, 1, 1, 0, as_stream(stream), args, nullptr));
+    return 0;
+}
+
+// TWO applications of the epilogue in one sweep: out = f(f(in)) with f(u) = pde_epilogue(u, laplace(u), gradient_squared(u);
+// params) and the BCs `faces` applied to u before each application — two explicit Euler steps of a one-pass expression PDE
+// whose epilogue is the Euler update `u + dt * F`.  The intermediate level lives in registers (pdehip_march2.inc).
+// *done = 0 and nothing launched when grid / faces are not covered (same rules as pdehip_diffusion_euler2) — the caller
+// then applies pdehip_jit_apply twice.
+int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full, const double *params_host,
+                      int nparams, const pdehip_bc_face_t *faces, int *done, void *stream)
+{
+    if (!handle || !in_full || !out_full || !faces || !done) PDEHIP_FAIL(E_VALUE, "jit_euler2: NULL pointer");
+    if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_euler2: at most 12 scalar parameters");
+    *done = 0;
+    Jit *j = static_cast<Jit *>(handle);
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (n.ndim < 2) return 0;
+    InputBCs fg;
+    memset(&fg, 0, sizeof(fg));
+    for (int a = 0; a < n.ndim; a++)
+        for (int side = 0; side < 2; side++) {
+            const int ax = 3 - n.ndim + a;
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) return 0;
+            fg.on[ax][side] = 1; fg.idx[ax][side] = r.index1; fg.c[ax][side] = r.const_v; fg.f[ax][side] = r.factor1;
+        }
+    Euler2Plan plan;
+    bool ok = false;
+    PDEHIP_TRY(launch_euler2(n, in_full, out_full, 0.0, 0.0, fg, false, as_stream(stream), &ok, false, 0, E2_CUSTOM, nullptr, 0.0, &plan));
+    if (!ok) return 0;
+    for (int q = 0; q < nparams; q++) plan.a.par[q] = params_host[q];
+    const bool f64 = n.dtype == PDEHIP_F64;
+    const char *tname = f64 ? "double" : "float";
+    const std::string key = std::string("two,") + tname + "," + std::to_string(plan.ry) + (plan.has_y ? ",y" : ",-");
+    Variant v;
+    auto it = j->cache.find(key);
+    if (it != j->cache.end()) v = it->second;
+    else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, true));
+    void *kargs[] = {&plan.a};
+    PDEHIP_HIP(hipModuleLaunchKernel(v.fn, plan.grid, 1, 1, plan.block, 1, 1, 0, as_stream(stream), kargs, nullptr));
+    *done = 1;
     return 0;
 }
 

@@ -329,7 +329,8 @@ static const Tune2 &tune2()
 }
 
 template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2)
+static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
+                           Euler2Plan *plan)
 {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int CW = 64 * VEC;
@@ -385,8 +386,14 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     a.nblocks = a.nxc * tiles / (nwz * nwy);
     a.no_swizzle = 0;
     const dim3 grid((unsigned)a.nblocks), block(64 * nwz * nwy);
-    if (dry_run) { *done = true; return 0; }
     if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
+    if (plan) {   // the caller launches a run-time compiled instance itself (pdehip_jit.hip)
+        plan->a = a; plan->grid = (unsigned)a.nblocks; plan->block = 64u * nwz * nwy; plan->ry = ry; plan->has_y = has_y;
+        *done = true;
+        return 0;
+    }
+    if (dry_run) { *done = true; return 0; }
+    if (m2 == E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
 #define PDEHIP_E2(RY_, HY_)                                                                                               \
     if (ry == RY_ && has_y == HY_) {                                                                                      \
         if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_>), grid, block, 0, st, a); \
@@ -413,11 +420,12 @@ static int classify_axis(const InputBCs &fg, int ax, long n)
 }
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
-                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma)
+                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
+                  Euler2Plan *plan)
 {
     *done = false;
     const long vec = 16 / elem_size(n.dtype);
-    if (m2 != E2_DIFFUSION && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
+    if ((m2 == E2_CH_EULER || m2 == E2_CH_SCALED) && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
     if (tune2().off || tune().force_generic || (n.ndim != 3 && n.ndim != 2) || in == out) return 0;
     // kernel axes (march, rows, lanes) <- normalised grid axes: 3-D (0, 1, 2); 2-D (1, -, 2): the march axis is the first
     // grid axis and there are no rows
@@ -455,8 +463,10 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     a.sx = n.lap_scale[am]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2;
     a.ndim = n.ndim; a.any_ibc = 1;
-    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2);
-    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2);
+    // squared central gradient of the custom epilogue, kernel-axis order (cartesian.py:661: 0.25 / dx**2)
+    a.gs[0] = 0.25 / (n.dx[am] * n.dx[am]); a.gs[1] = 0.25 / (n.dx[1] * n.dx[1]); a.gs[2] = 0.25 / (n.dx[2] * n.dx[2]);
+    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2, plan);
+    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2, plan);
 }
 
 // ---------------------------------------------------------------------------------------------

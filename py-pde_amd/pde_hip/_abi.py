@@ -169,6 +169,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_destroy": [_vp],
     "jit_check": [_vp, _i, _i],
     "jit_apply": [_vp, _pg, _vp, _pvp, _vp, _pd, _i, _pf, _vp],
+    "jit_euler2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, C.POINTER(_i), _vp],
 }
 
 

@@ -523,13 +523,18 @@ class HipBackendMixin:
             def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
                 steps = max(1, round((t_end - t_start) / dt))
                 cur, nxt = state_data, work[0]
-                for i in range(steps):
+                i = 0
+                while i < steps:
                     t = t_start + i * dt
                     if is_rk:
                         rk4_step(cur, t, dt)
+                    elif i + 2 <= steps and erhs.euler2(cur, nxt, dt):   # two steps per sweep (one-pass expressions)
+                        cur, nxt = nxt, cur
+                        i += 1
                     else:
                         erhs.apply(cur, nxt, "euler", dt, t)
                         cur, nxt = nxt, cur
+                    i += 1
                 if cur is not state_data:
                     lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
                 solver.info["steps"] += steps

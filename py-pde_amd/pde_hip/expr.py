@@ -222,6 +222,7 @@ class ExpressionRhs:
                 self.tmps[p.out] = DeviceArray(info)
                 self.faces[p.out] = faces_tmp
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
+        self._two_ok: bool | None = None
 
     def _kernel(self, index: int, wrap: str):
         key = (index, wrap if self.plan.passes[index].out == "out" else "rate")
@@ -250,6 +251,26 @@ class ExpressionRhs:
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+
+    def euler2(self, state, out, dt: float) -> bool:
+        """out = E(E(state)), E(u) = u + dt*F(u): TWO Euler steps in one sweep of the two-level kernel (intermediate level
+        in registers).  Only for one-pass expressions of the state without extra arrays or explicit time; returns False
+        (nothing done) when the expression, the grid or the BCs are not covered."""
+        if self._two_ok is None:
+            p = self.plan.passes[0]
+            self._two_ok = len(self.plan.passes) == 1 and p.src == "state" and not p.extras and not self.plan.uses_time
+        if not self._two_ok:
+            return False
+        h, extras = self._kernel(0, "euler")
+        if extras:
+            self._two_ok = False
+            return False
+        params = (C.c_double * 2)(dt, 0.0)
+        done = C.c_int(0)
+        self.lib.jit_euler2(h, self.info.ref, state.ptr, out.ptr, params, 2, self.faces["state"].c, C.byref(done), self.backend.stream)
+        if not done.value:
+            self._two_ok = False
+        return bool(done.value)
 
     def __del__(self):
         for h, _ in getattr(self, "_kernels", {}).values():

@@ -45,3 +45,14 @@ for shape, dtype in [((512, 512, 512), np.float64), ((4096, 4096), np.float64), 
         extra_reads = sum(len(p.extras) for p in erhs.plan.passes) + (1 if erhs.plan.passes[-1].src != "state" else 0)
         bpc = (2 * npass + extra_reads) * it
         print(f"| {'x'.join(map(str, shape))} | {np.dtype(dtype).name} | {name} | {npass} | {t:.4f} | {cells/t/1e6:.1f} | {cells*bpc/t/1e6:.0f} | {cells*bpc/t/1e6/80:.1f} |", flush=True)
+        # two Euler steps per sweep (one-pass expressions only): ms per STEP
+        if erhs.euler2(y, out, 1e-3):
+            lib.stream_synchronize(None)
+            lib.event_record(ev[0], None)
+            for _ in range(reps):
+                erhs.euler2(y, out, 1e-3)
+            lib.event_record(ev[1], None)
+            lib.stream_synchronize(None)
+            lib.event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+            t2 = ms.value / reps / 2
+            print(f"| {'x'.join(map(str, shape))} | {np.dtype(dtype).name} | {name}, TWO steps per sweep | 1/2 | {t2:.4f} | {cells/t2/1e6:.1f} | {cells*2*it/t2/1e6:.0f} | {cells*2*it/t2/1e6/80:.1f} |", flush=True)

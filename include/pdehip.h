@@ -316,6 +316,16 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
  * rules as pdehip_diffusion_euler2; the caller then calls pdehip_jit_apply twice. */
 int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full,
                       const double *params_host, int nparams, const pdehip_bc_face_t *faces, int *done, void *stream);
+/* Two-pass expressions in ONE sweep (e.g. `laplace(c**3 - c - laplace(c))`, Swift-Hohenberg): handle from
+ * pdehip_jit_create2(body1, body2);  tmp = body1(u, laplace u, gradient_squared u; params) is kept in registers,
+ *     out = body2(tmp, laplace tmp, gradient_squared tmp, e0 = u; params)
+ * with `faces_u` applied to u and `faces_tmp` to tmp (the reference applies them when it evaluates the inner and the
+ * outer operator: pde/pdes/pde.py:299-399).  *done = 0 when grid / faces are not covered: the caller then runs the two
+ * passes through pdehip_jit_apply. */
+int pdehip_jit_create2(const char *body1, const char *body2, void **handle);
+int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full,
+                      const double *params_host, int nparams, const pdehip_bc_face_t *faces_u,
+                      const pdehip_bc_face_t *faces_tmp, int *done, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
        LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */ };
 
 // the two fused levels of euler2_kernel (pdehip_march2.inc)
-enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run-time generated: pde_epilogue() */ };
+enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run-time generated: pde_epilogue() twice */,
+       E2_CUSTOM2 = 4 /* run-time generated: level 1 = pde_epilogue(), level 2 = pde_epilogue2() (two-pass expressions) */ };
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -97,8 +98,10 @@ struct LapArgs {
 // offline build never instantiates that mode and only needs the declaration to parse.
 #ifdef PDEHIP_JIT
 __device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p);
+__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p);
 #else
 __device__ __forceinline__ double pde_epilogue(double, double, double, double, double, double, const double *) { return 0.0; }
+__device__ __forceinline__ double pde_epilogue2(double, double, double, double, double, double, const double *) { return 0.0; }
 #endif
 
 }  // namespace pdehip

@@ -63,6 +63,7 @@ struct Variant {
 };
 struct Jit {
     std::string body;                       // statements of pde_epilogue
+    std::string body2;                      // statements of pde_epilogue2 (level 2 of a fused two-pass expression)
     std::map<std::string, Variant> cache;   // key: "T,VEC,RY,CZ,HASX,IBC" or "generic,T"
 };
 
@@ -114,18 +115,23 @@ extern "C" __global__ void __launch_bounds__(64) pde_kernel(pdehip::LapArgs a)
 const char *kMarch2Wrapper = R"SRC(
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) pde_kernel(pdehip::LapArgs a)
 {
-    pdehip::euler2_body<PDE_T, PDE_VEC, PDE_RY, pdehip::E2_CUSTOM, PDE_HASX>(a);
+    pdehip::euler2_body<PDE_T, PDE_VEC, PDE_RY, PDE_M2, PDE_HASX>(a);
 }
 )SRC";
 
 int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
-                    bool two_level = false)
+                    int two_level = 0)   // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
 {
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
                       "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n";
     src += j->body;
     src += "\n}\n";
+    if (two_level == E2_CUSTOM2) {
+        src += "__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n";
+        src += j->body2;
+        src += "\n}\n";
+    }
     if (two_level) src += "#include \"pdehip_march2.inc\"\n";   // PDE_HASX carries HAS_Y there
     else if (!generic) src += "#include \"pdehip_march.inc\"\n";
     src += "}  // namespace pdehip\n";
@@ -138,7 +144,7 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
                                      "-DPDE_CZ=" + std::to_string(cz), std::string("-DPDE_HASX=") + (hasx ? "true" : "false"),
-                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false")};
+                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level)};
     std::vector<const char *> copts;
     for (auto &o : opts) copts.push_back(o.c_str());
     const int rc = g_rtc.CompileProgram(prog, (int)copts.size(), copts.data());
@@ -186,7 +192,20 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     const int vec = dtype == PDEHIP_F64 ? 2 : 4;
     PDEHIP_TRY(compile_variant(j, "", true, tname, 1, 1, 1, false, false, nullptr));
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr));
-    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr, true));
+    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr,
+                                              j->body2.empty() ? E2_CUSTOM : E2_CUSTOM2));
+    return 0;
+}
+
+// a fused two-pass expression: level 1 = body1 applied to the state, level 2 = body2 applied to the result of level 1
+// with e0 = the state at the cell (see pdehip_jit_fused2)
+int pdehip_jit_create2(const char *body1, const char *body2, void **handle)
+{
+    if (!body1 || !body2 || !handle) PDEHIP_FAIL(E_VALUE, "jit_create2: NULL pointer");
+    Jit *j = new Jit();
+    j->body = body1;
+    j->body2 = body2;
+    *handle = j;
     return 0;
 }
 
@@ -345,7 +364,51 @@ int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full,
     Variant v;
     auto it = j->cache.find(key);
     if (it != j->cache.end()) v = it->second;
-    else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, true));
+    else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, E2_CUSTOM));
+    void *kargs[] = {&plan.a};
+    PDEHIP_HIP(hipModuleLaunchKernel(v.fn, plan.grid, 1, 1, plan.block, 1, 1, 0, as_stream(stream), kargs, nullptr));
+    *done = 1;
+    return 0;
+}
+
+// ONE sweep for a two-pass expression  tmp = f1(u, lap u, |grad u|^2),  out = f2(tmp, lap tmp, |grad tmp|^2, e0 = u):
+// tmp lives in registers only (two-level kernel, pdehip_march2.inc).  `faces_u` are the BCs of u, `faces_tmp` those of
+// tmp (both periodic on the same axes).  *done = 0 when grid / faces are not covered: the caller runs the two passes.
+int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full, const double *params_host,
+                      int nparams, const pdehip_bc_face_t *faces_u, const pdehip_bc_face_t *faces_tmp, int *done, void *stream)
+{
+    if (!handle || !in_full || !out_full || !faces_u || !faces_tmp || !done) PDEHIP_FAIL(E_VALUE, "jit_fused2: NULL pointer");
+    if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_fused2: at most 12 scalar parameters");
+    *done = 0;
+    Jit *j = static_cast<Jit *>(handle);
+    if (j->body2.empty()) PDEHIP_FAIL(E_VALUE, "jit_fused2: handle was not created with pdehip_jit_create2");
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (n.ndim < 2) return 0;
+    InputBCs fg[2];
+    const pdehip_bc_face_t *fsrc[2] = {faces_u, faces_tmp};
+    for (int l = 0; l < 2; l++) {
+        memset(&fg[l], 0, sizeof(fg[l]));
+        for (int a = 0; a < n.ndim; a++)
+            for (int side = 0; side < 2; side++) {
+                const int ax = 3 - n.ndim + a;
+                const pdehip_bc_face_t &r = fsrc[l][2 * a + side];
+                if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) return 0;
+                fg[l].on[ax][side] = 1; fg[l].idx[ax][side] = r.index1; fg[l].c[ax][side] = r.const_v; fg[l].f[ax][side] = r.factor1;
+            }
+    }
+    Euler2Plan plan;
+    bool ok = false;
+    PDEHIP_TRY(launch_euler2(n, in_full, out_full, 0.0, 0.0, fg[0], false, as_stream(stream), &ok, false, 0, E2_CUSTOM2, &fg[1], 0.0, &plan));
+    if (!ok) return 0;
+    for (int q = 0; q < nparams; q++) plan.a.par[q] = params_host[q];
+    const bool f64 = n.dtype == PDEHIP_F64;
+    const char *tname = f64 ? "double" : "float";
+    const std::string key = std::string("fused2,") + tname + "," + std::to_string(plan.ry) + (plan.has_y ? ",y" : ",-");
+    Variant v;
+    auto it = j->cache.find(key);
+    if (it != j->cache.end()) v = it->second;
+    else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, E2_CUSTOM2));
     void *kargs[] = {&plan.a};
     PDEHIP_HIP(hipModuleLaunchKernel(v.fn, plan.grid, 1, 1, plan.block, 1, 1, 0, as_stream(stream), kargs, nullptr));
     *done = 1;

@@ -393,7 +393,7 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
         return 0;
     }
     if (dry_run) { *done = true; return 0; }
-    if (m2 == E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
+    if (m2 >= E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
 #define PDEHIP_E2(RY_, HY_)                                                                                               \
     if (ry == RY_ && has_y == HY_) {                                                                                      \
         if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_>), grid, block, 0, st, a); \

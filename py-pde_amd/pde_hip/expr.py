@@ -223,6 +223,7 @@ class ExpressionRhs:
                 self.faces[p.out] = faces_tmp
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
         self._two_ok: bool | None = None
+        self._fused: dict[str, C.c_void_p | None] = {}
 
     def _kernel(self, index: int, wrap: str):
         key = (index, wrap if self.plan.passes[index].out == "out" else "rate")
@@ -240,17 +241,51 @@ class ExpressionRhs:
             for wrap in ("rate", "scaled", "euler"):
                 h, _ = self._kernel(i, wrap)
                 self.lib.jit_check(h, _abi.dtype_code(dtype), ndim)
+        for wrap in ("rate", "scaled", "euler"):   # the fused two-level kernel of a two-pass chain
+            h = self._fused_handle(wrap)
+            if h is not None:
+                self.lib.jit_check(h, _abi.dtype_code(dtype), ndim)
 
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
         """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler)."""
         arrays = {"state": state, "out": out, **self.tmps}
         params = (C.c_double * 2)(dt, t)
+        if self._fused2(state, out, wrap, params):
+            return
         for i, p in enumerate(self.plan.passes):
             h, extras = self._kernel(i, wrap)
             ex = (C.c_void_p * 3)()
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+
+    def _fused_handle(self, wrap: str):
+        if wrap not in self._fused:
+            h = None
+            ps = self.plan.passes
+            if len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out":
+                body1, ex1 = self.plan.epilogue(ps[0], "rate")
+                body2, ex2 = self.plan.epilogue(ps[1], wrap)
+                if not ex1 and ex2 in ([], ["state"]):
+                    h = C.c_void_p()
+                    self.lib.jit_create2(body1.encode(), body2.encode(), C.byref(h))
+            self._fused[wrap] = h
+        return self._fused[wrap]
+
+    def _fused2(self, state, out, wrap: str, params) -> bool:
+        """Two-pass chain ``tmp = f1(state)``, ``out = f2(tmp; state)`` in ONE sweep with tmp in registers (two-level
+        kernel).  False when the plan has another shape or grid / BCs are not covered (then the passes run one by one)."""
+        h = self._fused_handle(wrap)
+        if h is None:
+            return False
+        done = C.c_int(0)
+        tmp_name = self.plan.passes[0].out
+        self.lib.jit_fused2(h, self.info.ref, state.ptr, out.ptr, params, 2, self.faces["state"].c, self.faces[tmp_name].c,
+                            C.byref(done), self.backend.stream)
+        if not done.value:
+            self.lib.jit_destroy(h)
+            self._fused[wrap] = None
+        return bool(done.value)
 
     def euler2(self, state, out, dt: float) -> bool:
         """out = E(E(state)), E(u) = u + dt*F(u): TWO Euler steps in one sweep of the two-level kernel (intermediate level
@@ -273,6 +308,12 @@ class ExpressionRhs:
         return bool(done.value)
 
     def __del__(self):
+        for h in getattr(self, "_fused", {}).values():
+            if h is not None:
+                try:
+                    self.lib.jit_destroy(h)
+                except Exception:  # noqa: BLE001 - interpreter shutdown
+                    pass
         for h, _ in getattr(self, "_kernels", {}).values():
             try:
                 self.lib.jit_destroy(h)

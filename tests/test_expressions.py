@@ -55,6 +55,16 @@ def test_generated_epilogues_compile(case):
             lib.jit_create(body.encode(), C.byref(h))
             lib.jit_check(h, _abi.F64, len(case["shape"]))
             lib.jit_destroy(h)
+    if len(plan.passes) == 2 and plan.passes[1].src == plan.passes[0].out:
+        # two-pass chain: the fused two-level kernel (tmp in registers) compiles for every wrap
+        for wrap in ("rate", "scaled", "euler"):
+            body1, ex1 = plan.epilogue(plan.passes[0], "rate")
+            body2, ex2 = plan.epilogue(plan.passes[1], wrap)
+            assert not ex1 and ex2 in ([], ["state"])
+            h = C.c_void_p()
+            lib.jit_create2(body1.encode(), body2.encode(), C.byref(h))
+            lib.jit_check(h, _abi.F64, len(case["shape"]))
+            lib.jit_destroy(h)
     h = C.c_void_p()
     lib.jit_create(b"return undefined_symbol + c;", C.byref(h))
     with pytest.raises(ValueError, match="does not compile"):
@@ -169,3 +179,37 @@ def test_two_euler_steps_per_sweep_for_one_pass_expressions(shape, periodic, dty
     for other in ("laplace(c) + t*c", "laplace(c**3 - c - laplace(c)) + 0*c"):
         e2 = b.make_expression_rhs(pde_hip.PDE({"c": other}, bc=bc), state)
         assert not e2.euler2(y, two, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,periodic,dtype", [
+    ((10, 8, 128), [True, False, True], np.float64),
+    ((6, 4, 72), [False, False, False], np.float64),
+    ((24, 200), [True, False], np.float64),
+    ((7, 6, 256), [True, True, False], np.float32),
+])
+@pytest.mark.parametrize("expr,consts", [
+    ("laplace(c**3 - c - 0.8*laplace(c)) + 0*c", {}),                                    # Cahn-Hilliard through the compiler
+    ("(eps - 1)*c - 2*laplace(c) - laplace(laplace(c)) - c**3 + t", {"eps": 0.3}),       # Swift-Hohenberg (+ explicit time)
+])
+def test_two_pass_expressions_in_one_sweep(shape, periodic, dtype, expr, consts):
+    """tmp = f1(c), out = f2(tmp; c) fused into the two-level kernel (tmp in registers) == the two passes run one by
+    one through the one-level kernel, bit for bit, for the rate, the scaled rate and the Euler update."""
+    from pde_hip.device import DeviceArray
+
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    bc = "auto_periodic_neumann"
+    eq = pde_hip.PDE({"c": expr}, bc=bc, consts=consts)
+    data = np.random.default_rng(23).uniform(-0.4, 0.4, shape).astype(dtype)
+    state = pde_hip.ScalarField(grid, data, dtype=dtype)
+    b = pde_hip.get_backend("hip")
+    fused = b.make_expression_rhs(eq, state)
+    plain = b.make_expression_rhs(eq, state)
+    plain._fused = {w: None for w in ("rate", "scaled", "euler")}   # force the pass-by-pass path
+    y, o1, o2 = (DeviceArray(fused.info) for _ in range(3))
+    y.set_valid(data)
+    for wrap in ("rate", "scaled", "euler"):
+        fused.apply(y, o1, wrap, 2e-3, 0.7)
+        assert fused._fused[wrap] is not None    # the fused kernel was taken
+        plain.apply(y, o2, wrap, 2e-3, 0.7)
+        np.testing.assert_array_equal(o1.get_valid(), o2.get_valid())

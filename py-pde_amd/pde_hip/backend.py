@@ -673,6 +673,8 @@ class HipBackendMixin:
         ynew = DeviceArray(info)
         sync_errors = getattr(solver, "_sync_errors", None) or (lambda e: e)
 
+        two_half_steps = [spec.kind == _abi.RHS_DIFFUSION]
+
         def attempt(state_data: DeviceArray, dt_step: float) -> float:
             if is_rk:
                 lib.rkf45_attempt(info.ref, spec.ref, state_data.ptr, ynew.ptr, work_ptrs, dt_step, err_dev.ptr, stream)
@@ -681,8 +683,14 @@ class HipBackendMixin:
                 res = C.c_void_p()
                 k1, k2a = work[0], work[1]
                 lib.euler_run(info.ref, spec.ref, state_data.ptr, k1.ptr, dt_step, 1, C.byref(res), stream)
-                lib.euler_run(info.ref, spec.ref, state_data.ptr, k2a.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
-                lib.euler_run(info.ref, spec.ref, k2a.ptr, ynew.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
+                done = C.c_int(0)
+                if two_half_steps[0]:
+                    # the two half steps in ONE sweep (two-level kernel, intermediate level in registers)
+                    lib.diffusion_euler2(info.ref, spec.bc_c.c, state_data.ptr, ynew.ptr, spec.param, 0.5 * dt_step, C.byref(done), stream)
+                    two_half_steps[0] = bool(done.value)
+                if not done.value:
+                    lib.euler_run(info.ref, spec.ref, state_data.ptr, k2a.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
+                    lib.euler_run(info.ref, spec.ref, k2a.ptr, ynew.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
                 lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
             return err_dev.value(stream)
 

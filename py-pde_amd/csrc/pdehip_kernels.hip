@@ -367,7 +367,9 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
         // at once — workgroups march for the whole sweep, a kernel launched behind a full sweep waits for its first
         // round to end (measured: 90 us for 13 us of work).  Thick slabs are compute-bound: full occupancy.
         const bool thin = xplain && a.n0 < 96;
-        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 4096);
+        // (thick slabs: one round of 2048 wave tiles — measured 0.154 vs 0.177 ms/step at 256 layers and 0.088 vs 0.101 at 128
+        // with 4096, where the boundary sweep and the RCCL kernel queue up behind the second round)
+        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : (xplain ? 2048 : 4096));
         long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;
         if (nxc > a.n0 / 16) nxc = a.n0 / 16 > 0 ? a.n0 / 16 : 1;
@@ -394,15 +396,18 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     }
     if (dry_run) { *done = true; return 0; }
     if (m2 >= E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
-#define PDEHIP_E2(RY_, HY_)                                                                                               \
-    if (ry == RY_ && has_y == HY_) {                                                                                      \
-        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_>), grid, block, 0, st, a); \
-        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_>), grid, block, 0, st, a);                  \
+    // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
+    // the 5 VGPRs decide whether the loads can be issued early (8-19 % at 256^3 and slab-sized grids)
+    const bool ragged = !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
+#define PDEHIP_E2(RY_, HY_, RG_)                                                                                               \
+    if (ry == RY_ && has_y == HY_ && ragged == RG_) {                                                                          \
+        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_>), grid, block, 0, st, a); \
+        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_>), grid, block, 0, st, a);                  \
     }
-    PDEHIP_E2(1, false)
-    PDEHIP_E2(2, true)
-    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true) }
+    PDEHIP_E2(1, false, true)
+    PDEHIP_E2(2, true, true)
+    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true, true) PDEHIP_E2(4, true, false) }
 #undef PDEHIP_E2
     PDEHIP_HIP(hipGetLastError());
     *done = true;

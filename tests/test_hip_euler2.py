@@ -269,3 +269,25 @@ def test_full_size_time_loop_512cubed(backend):
         np.testing.assert_array_equal(got[lo:lo + keep], out[pad:pad + keep])
     assert abs(got.sum() - u.sum()) < 1e-9 * u.sum()
     assert got.min() > u.min() and got.max() < u.max()
+
+
+@pytest.mark.parametrize("shape,periodic", [((9, 8, 128), [True, False, True]), ((6, 4, 72), [False, True, False]), ((20, 136), [False, True])])
+def test_special_values_stay_bit_identical(backend, shape, periodic):
+    """Denormals, huge magnitudes, signed zeros, an infinity and a NaN travel through both levels exactly as through two
+    single steps of the oracle (IEEE arithmetic, denormals on, no contraction, selects instead of arithmetic masking)."""
+    grid, bc, bcs, data = _setup(shape, periodic, np.float64, seed=31)
+    rng = np.random.default_rng(32)
+    data = data * 10.0 ** rng.integers(-320, 300, size=shape).astype(np.float64)
+    flat = data.reshape(-1)
+    flat[rng.choice(flat.size, 40, replace=False)] = 0.0
+    flat[rng.choice(flat.size, 40, replace=False)] = -0.0
+    flat[rng.choice(flat.size, 20, replace=False)] = 4.9e-324
+    flat[flat.size // 3] = np.inf
+    flat[2 * flat.size // 3] = np.nan
+    with np.errstate(all="ignore"):
+        done, got = _euler2(backend, grid, bcs, data, 0.6, 2e-3)
+        expect = _oracle_steps(grid, bcs, data, 0.6, 2e-3, 2)
+    assert done == 1
+    np.testing.assert_array_equal(got, expect)
+    assert np.array_equal(np.signbit(got[got == 0]), np.signbit(expect[expect == 0]))   # signed zeros too
+    assert np.isnan(got).sum() > 1 and np.isinf(got).sum() >= 0

@@ -626,6 +626,18 @@ class HipBackendMixin:
         """
         from .solvers import make_dt_adjuster
 
+        # a PDE with a post-step hook (pde/solvers/base.py:191-232) must not silently run without it
+        make_hook = getattr(solver.pde, "make_post_step_hook", None)
+        if make_hook is not None and getattr(solver, "_use_post_step_hook", True):
+            try:
+                make_hook(state, backend=self)
+            except NotImplementedError:
+                pass   # no hook defined: the normal case
+            except TypeError:
+                pass   # mirror classes without the `backend` argument have no hooks either
+            else:
+                msg = f"Backend `{self.name}` does not support post-step hooks"
+                raise NotImplementedError(msg)
         solver_name = solver.__class__.__name__
         if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver", "AdamsBashforthSolver"}:
             msg = f"Backend `{self.name}` does not support solver {solver_name}"

@@ -369,7 +369,9 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
         const bool thin = xplain && a.n0 < 96;
         // (thick slabs: one round of 2048 wave tiles — measured 0.154 vs 0.177 ms/step at 256 layers and 0.088 vs 0.101 at 128
         // with 4096, where the boundary sweep and the RCCL kernel queue up behind the second round)
-        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : ((xplain && a.n0 < 384) ? 2048 : 4096));
+        // (otherwise ONE full round of 2048 wave tiles = 256 CUs x 8 slots: measured best or equal for 64..512 planes,
+        // 0.126 vs 0.131 ms/step at 256 planes and 0.066 vs 0.071 at 128 with 4096 tiles, profiles/r01_time_tiles_vs_planes.log)
+        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
         long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;
         if (nxc > a.n0 / 16) nxc = a.n0 / 16 > 0 ? a.n0 / 16 : 1;

@@ -115,6 +115,36 @@ def test_cahn_hilliard_slab_one_sweep_per_rhs(process_group, monkeypatch, shape,
         np.testing.assert_array_equal(final, _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, eq.bc_c, data, 1e-3, steps, solver))
 
 
+@pytest.mark.parametrize("shape", [(7, 6, 128), (2, 4, 64), (5, 256)])
+def test_slab_loop_with_physical_faces_on_both_ends(process_group, shape):
+    """The one-step C slab loop on a rank that owns BOTH physical faces of the slowest axis (no neighbours): boundary
+    layers and interior are separate sub-slab launches whose faces come from `sub_faces` - must equal the oracle."""
+    import ctypes as C
+
+    from pde_hip.backend import convert_bcs
+    from pde_hip.device import DeviceArray, GridInfo
+    from pde_hip.distributed import HipEngine
+
+    eng = HipEngine(0)
+    comm = eng.make_comm(process_group, None, 1, 0)
+    grid = pde_hip.UnitGrid(shape, periodic=False)
+    bc = {f"{a}{s}": v for a, (lo, hi) in zip(grid.axes, [({"value": 0.4}, {"derivative": -0.2}), ({"derivative": 0.3}, {"value": -0.1}),
+                                                           ({"type": "mixed", "value": 0.5, "const": 0.2}, {"value": 0.0})]) for s, v in (("-", lo), ("+", hi))}
+    data = np.random.default_rng(9).uniform(-1, 1, shape)
+    info = GridInfo(grid.shape, grid.discretization, np.float64)
+    rhs = _abi.RHS()
+    rhs.kind, rhs.param = _abi.RHS_DIFFUSION, 0.6
+    faces = convert_bcs(grid.get_boundary_conditions(bc))
+    faces.copy_into(rhs.bc_c)
+    a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
+    res = C.c_void_p()
+    eng.lib.slab_euler_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
+    eng.lib.stream_synchronize(None)
+    got = (b if res.value == b.ptr else a).get_valid()
+    np.testing.assert_array_equal(got, _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
+    eng.lib.comm_destroy(comm)
+
+
 @pytest.mark.parametrize("comm_mode", ["native", "torch"])
 def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group, monkeypatch, comm_mode):
     from pde_hip.distributed import HipEngine, SlabStepper

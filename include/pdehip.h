@@ -190,6 +190,13 @@ int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void
  * single steps by itself). */
 int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full,
                             void *out_full, double diffusivity, double dt, int *done, void *stream);
+/* The same two steps on a sub-slab of layers of a larger array (building block of pdehip_slab_euler2_run): `g_sub` has
+ * the extent of the sub-slab along axis 0, `in_full` / `out_full` point ONE LAYER BEFORE its first layer, and the array
+ * holds TWO real layers beyond the sub-slab on the sides named by `halo_sides` (1 = both sides, 2 = upper side only, the
+ * lower face is the physical face `faces[0]`; 3 = lower side only, upper face `faces[1]`, index1 = extent - 1).  Replaces
+ * the _MPIBC virtual points of pde/grids/boundaries/local.py:561-662 for both time levels. */
+int pdehip_diffusion_euler2_slab(const pdehip_grid_t *g_sub, const pdehip_bc_face_t *faces, const void *in_full,
+                                 void *out_full, double diffusivity, double dt, int halo_sides, int *done, void *stream);
 /* ONE sweep for the Cahn-Hilliard right-hand side (pde/pdes/cahn_hilliard.py:115-122): mu = c^3 - c - gamma*laplace(c)
  * with the faces of c, then laplace(mu) with the faces of mu; mu lives in registers only (same two-level kernel as
  * pdehip_diffusion_euler2, bit-identical to pdehip_cahn_hilliard_mu + pdehip_laplace_euler / _scaled):

@@ -269,11 +269,12 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
 static int exchange2(Comm *c, size_t lp, long nloc, void *ext, int lower, int upper, hipStream_t st)
 {
     char *b = static_cast<char *>(ext);
+    if (lower < 0 && upper < 0) return 0;
     PDEHIP_NCCL(g_rccl.GroupStart());
-    PDEHIP_NCCL(g_rccl.Send(b + 2 * lp, 2 * lp, ncclInt8, lower, c->comm, st));            // own first two layers -> lower
-    PDEHIP_NCCL(g_rccl.Recv(b + (nloc + 2) * lp, 2 * lp, ncclInt8, upper, c->comm, st));   // upper halo <- upper
-    PDEHIP_NCCL(g_rccl.Send(b + nloc * lp, 2 * lp, ncclInt8, upper, c->comm, st));         // own last two layers -> upper
-    PDEHIP_NCCL(g_rccl.Recv(b, 2 * lp, ncclInt8, lower, c->comm, st));                     // lower halo <- lower
+    if (lower >= 0) PDEHIP_NCCL(g_rccl.Send(b + 2 * lp, 2 * lp, ncclInt8, lower, c->comm, st));            // own first two layers -> lower
+    if (upper >= 0) PDEHIP_NCCL(g_rccl.Recv(b + (nloc + 2) * lp, 2 * lp, ncclInt8, upper, c->comm, st));   // upper halo <- upper
+    if (upper >= 0) PDEHIP_NCCL(g_rccl.Send(b + nloc * lp, 2 * lp, ncclInt8, upper, c->comm, st));         // own last two layers -> upper
+    if (lower >= 0) PDEHIP_NCCL(g_rccl.Recv(b, 2 * lp, ncclInt8, lower, c->comm, st));                     // lower halo <- lower
     PDEHIP_NCCL(g_rccl.GroupEnd());
     return 0;
 }
@@ -286,7 +287,13 @@ int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_
     bool done = false;
     pdehip_grid_t gs = *g_local;
     gs.shape[0] = 2;   // the smallest launch of the loop
-    PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, true, true));
+    PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, 1, true));
+    // sides without a neighbour (face not marked SKIP) must be local first-order faces the kernel can apply itself
+    for (int side = 0; side < 2 && done; side++)
+        if (rhs->bc_c[side].kind != PDEHIP_BC_SKIP) {
+            gs.shape[0] = g_local->shape[0];
+            PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, side == 0 ? 2 : 3, true));
+        }
     *ok = done ? 1 : 0;
     return 0;
 }
@@ -297,7 +304,10 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     if (!comm || !rhs || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler2_run: NULL pointer");
     int ok = 0;
     PDEHIP_TRY(pdehip_slab_euler2_supported(g_local, rhs, &ok));
-    if (!ok || lower < 0 || upper < 0) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: grid, faces or neighbours are not covered by the two-step kernel");
+    if (!ok) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: grid or faces are not covered by the two-step kernel");
+    // sides of the slowest axis without a neighbour keep their (local, first-order) physical face:
+    // 0 both physical, 1 both exchanged, 2 lower physical, 3 upper physical  (xplain codes of launch_euler2)
+    const int xends = (lower >= 0 && upper >= 0) ? 1 : (lower < 0 && upper < 0) ? 0 : (lower < 0 ? 2 : 3);
     Comm *c = static_cast<Comm *>(comm);
     NGrid n;
     PDEHIP_TRY(norm_grid(g_local, &n));
@@ -327,7 +337,8 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
 
     pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
     for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) faces[i] = rhs->bc_c[i];
-    faces[0].kind = faces[1].kind = PDEHIP_BC_SKIP;   // slowest axis: real layers on both sides
+    if (lower >= 0) faces[0].kind = PDEHIP_BC_SKIP;   // exchanged sides: real layers
+    if (upper >= 0) faces[1].kind = PDEHIP_BC_SKIP;
 
     // two steps on private layers [first, first+count)
     // (ends > 0: the first and the last `ends` layers of the range in one launch)
@@ -336,7 +347,9 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
         pdehip_grid_t gs = *g_local;
         gs.shape[0] = count;
         bool done = false;
-        PDEHIP_TRY(euler2_with_input_bcs(&gs, cur + (first - 1) * lp, nxt + (first - 1) * lp, rhs->param, dt, faces, st, &done, true, false, ends));
+        // the interior sweep reads own layers only (plain on both sides); the two-ended boundary sweep meets the physical faces
+        PDEHIP_TRY(euler2_with_input_bcs(&gs, cur + (first - 1) * lp, nxt + (first - 1) * lp, rhs->param, dt, faces, st, &done,
+                                         ends ? xends : 1, false, ends));
         if (!done) PDEHIP_FAIL(E_RUNTIME, "internal: two-step kernel refused a sub-slab");
         return 0;
     };

@@ -121,19 +121,20 @@ struct Euler2Plan {
     int ry;
     bool has_y;
 };
-int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, bool xplain,
+int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, int xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
                   const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done, bool xplain = false, bool dry_run = false, int ends = 0);
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain = 0, bool dry_run = false, int ends = 0);
 // one Cahn-Hilliard sweep: mu = c^3 - c - gamma*lap(c) with the faces of c, then (euler) out = c + dt*lap(mu) or
 // (!euler) out = dt*lap(mu) with the faces of mu — mu never leaves the registers; *done as above
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
                         const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
-                        bool xplain = false, bool dry_run = false);
-// xplain: the slowest axis has two real halo layers on either side (slab decomposition) instead of BCs; `in` / `out` then
+                        int xplain = 0, bool dry_run = false);
+// xplain: 1 = the slowest axis has two real halo layers on either side (slab decomposition) instead of BCs; 2 = on its upper
+// side only (the lower face keeps its local BC: first slab of a non-periodic axis); 3 = on its lower side only (last slab); `in` / `out` then
 // point one layer before the first layer to update, like every sub-slab launch (pdehip_comm.hip)
 // BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`
 // (see pdehip_ops.hip)

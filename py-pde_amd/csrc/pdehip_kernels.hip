@@ -329,7 +329,7 @@ static const Tune2 &tune2()
 }
 
 template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
+static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
                            Euler2Plan *plan)
 {
     constexpr int VEC = 16 / sizeof(T);
@@ -390,7 +390,8 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, bool xplain, hipStream_t s
     a.nblocks = a.nxc * tiles / (nwz * nwy);
     a.no_swizzle = 0;
     const dim3 grid((unsigned)a.nblocks), block(64 * nwz * nwy);
-    if (xplain) a.per[0] = 2;   // real halo planes instead of BCs on the slowest axis
+    // real halo planes instead of BCs on the slowest axis: both sides (1), upper side only (2), lower side only (3)
+    if (xplain) a.per[0] = xplain == 1 ? 2 : (xplain == 2 ? 3 : 4);
     if (plan) {   // the caller launches a run-time compiled instance itself (pdehip_jit.hip)
         plan->a = a; plan->grid = (unsigned)a.nblocks; plan->block = 64u * nwz * nwy; plan->ry = ry; plan->has_y = has_y;
         *done = true;
@@ -427,7 +428,7 @@ static int classify_axis(const InputBCs &fg, int ax, long n)
 }
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
-                  bool xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
+                  int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
                   Euler2Plan *plan)
 {
     *done = false;
@@ -443,7 +444,17 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     LapArgs a;
     memset(&a, 0, sizeof(a));
     for (int k = 0; k < 3; k++) {   // k = kernel axis
-        if (k == 0 && xplain) continue;
+        if (k == 0 && xplain == 1) continue;
+        if (k == 0 && xplain > 1) {
+            // first / last slab of a non-periodic axis: ONE local face (the other side has real halo planes)
+            const int side = xplain == 2 ? 0 : 1;
+            const InputBCs &f1 = fg1 ? *fg1 : fg;
+            const long want = side ? n.n[am] - 1 : 0;
+            if (!fg.on[am][side] || fg.idx[am][side] != want || !f1.on[am][side] || f1.idx[am][side] != want) return 0;
+            a.ibc[0][side].on = 1; a.ibc[0][side].idx = want; a.ibc[0][side].c = fg.c[am][side]; a.ibc[0][side].f = fg.f[am][side];
+            a.ibc1[0][side].on = 1; a.ibc1[0][side].idx = want; a.ibc1[0][side].c = f1.c[am][side]; a.ibc1[0][side].f = f1.f[am][side];
+            continue;
+        }
         if (k == 1 && n.ndim == 2) { a.per[1] = 1; continue; }
         const int ax = (k == 0) ? am : k;
         // both faces periodic, or both local (virtual point from the adjacent cell); the same for both levels

@@ -498,9 +498,15 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
 }
 
 // faces (grid axes) -> on-the-fly BC table (normalised axes); false when a face is not a scalar first-order condition
-static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, InputBCs *fg, int first_axis = 0)
+static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, InputBCs *fg, int first_axis = 0, int xplain = 0)
 {
     memset(fg, 0, sizeof(*fg));
+    if (xplain > 1) {   // one local face on the slowest axis (first / last slab of a non-periodic axis)
+        const int side = xplain == 2 ? 0 : 1, ax = 3 - n.ndim;
+        const pdehip_bc_face_t &r = faces[side];
+        if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) return false;
+        fg->on[ax][side] = 1; fg->idx[ax][side] = r.index1; fg->c[ax][side] = r.const_v; fg->f[ax][side] = r.factor1;
+    }
     for (int a = first_axis; a < n.ndim; a++)
         for (int side = 0; side < 2; side++) {
             const int ax = 3 - n.ndim + a;
@@ -512,7 +518,7 @@ static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, In
 }
 
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done, bool xplain, bool dry_run, int ends)
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain, bool dry_run, int ends)
 {
     *done = false;
     NGrid n;
@@ -520,13 +526,13 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     if (!in || !out || !faces) PDEHIP_FAIL(E_VALUE, "euler2: NULL pointer");
     if (n.ndim < 2) return 0;
     InputBCs fg;
-    if (!faces_to_input_bcs(n, faces, &fg, xplain ? 1 : 0)) return 0;
+    if (!faces_to_input_bcs(n, faces, &fg, xplain ? 1 : 0, xplain)) return 0;
     return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
 
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
                         const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
-                        bool xplain, bool dry_run)
+                        int xplain, bool dry_run)
 {
     *done = false;
     NGrid n;
@@ -534,7 +540,7 @@ int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, doubl
     if (!in || !out || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
     if (n.ndim < 2) return 0;
     InputBCs fc, fm;
-    if (!faces_to_input_bcs(n, faces_c, &fc, xplain ? 1 : 0) || !faces_to_input_bcs(n, faces_mu, &fm, xplain ? 1 : 0)) return 0;
+    if (!faces_to_input_bcs(n, faces_c, &fc, xplain ? 1 : 0, xplain) || !faces_to_input_bcs(n, faces_mu, &fm, xplain ? 1 : 0, xplain)) return 0;
     // level 2 is `y + s2 * (s1 * lap(mu))` resp. `s2 * (s1 * lap(mu))` with s1 = 1 like the two-kernel path (pdehip_steppers.hip)
     return launch_euler2(n, in, out, 1.0, dt, fc, xplain, as_stream(stream), done, dry_run, 0,
                          euler ? E2_CH_EULER : E2_CH_SCALED, &fm, gamma);
@@ -550,6 +556,18 @@ int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *face
     bool d = false;
     *done = 0;
     PDEHIP_TRY(euler2_with_input_bcs(g, in_full, out_full, diffusivity, dt, faces, stream, &d));
+    *done = d ? 1 : 0;
+    return 0;
+}
+
+int pdehip_diffusion_euler2_slab(const pdehip_grid_t *g_sub, const pdehip_bc_face_t *faces, const void *in_full, void *out_full,
+                                 double diffusivity, double dt, int halo_sides, int *done, void *stream)
+{
+    if (!done) PDEHIP_FAIL(E_VALUE, "diffusion_euler2_slab: NULL pointer");
+    if (halo_sides < 1 || halo_sides > 3) PDEHIP_FAIL(E_VALUE, "diffusion_euler2_slab: halo_sides must be 1 (both), 2 (upper) or 3 (lower)");
+    bool d = false;
+    *done = 0;
+    PDEHIP_TRY(euler2_with_input_bcs(g_sub, in_full, out_full, diffusivity, dt, faces, stream, &d, halo_sides, false, 0));
     *done = d ? 1 : 0;
     return 0;
 }

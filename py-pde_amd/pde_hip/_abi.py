@@ -163,6 +163,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_ch_sweep": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)
     "diffusion_euler2": [_pg, _pf, _vp, _vp, _d, _d, C.POINTER(_i), _vp],
+    "diffusion_euler2_slab": [_pg, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],
     "cahn_hilliard_fused": [_pg, _pf, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],
     # run-time specialised expression kernels (pdehip_jit.hip)
     "jit_create": [C.c_char_p, _pvp],

@@ -223,7 +223,20 @@ class SlabStepper:
         # two steps per sweep (temporal blocking, two halo layers exchanged every other step): decided from GLOBAL
         # information only, so that all ranks take the same path
         self._euler2 = False
-        if self._rhs_c is not None and self.exchanging and grid.periodic[0] and min(self.mesh.counts) >= 4 and grid.num_axes == 3:
+        x_ok = bool(grid.periodic[0])
+        if not x_ok:
+            # non-periodic slowest axis: the first / last rank apply the physical face inside the kernel, which needs a
+            # local first-order face with scalar coefficients on BOTH ends of the GLOBAL grid (checked on every rank)
+            class _NoUpload:   # array-valued faces are rejected below, nothing needs to reach the device
+                ptr = 0
+
+                def __init__(self, arr):
+                    pass
+
+            glob = convert_bcs(bc_c, upload=_NoUpload).c
+            x_ok = all(glob[s].kind == _abi.BC_ORDER1 and glob[s].flags == 0 and glob[s].index1 == (grid.shape[0] - 1 if s else 0)
+                       for s in (0, 1))
+        if self._rhs_c is not None and self.exchanging and x_ok and min(self.mesh.counts) >= 4 and grid.num_axes == 3:
             ok = C.c_int(0)
             self.engine.lib.slab_euler2_supported(C.byref(self.g), C.byref(self._rhs_c), C.byref(ok))
             self._euler2 = bool(ok.value)

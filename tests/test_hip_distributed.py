@@ -142,6 +142,15 @@ def test_slab_loop_with_physical_faces_on_both_ends(process_group, shape):
     eng.lib.stream_synchronize(None)
     got = (b if res.value == b.ptr else a).get_valid()
     np.testing.assert_array_equal(got, _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
+    # the two-steps-per-sweep loop on the same rank: two-ended boundary sweep with the physical faces + interior sweep
+    ok = C.c_int(0)
+    eng.lib.slab_euler2_supported(info.ref, C.byref(rhs), C.byref(ok))
+    assert bool(ok.value) == (len(shape) == 3 and shape[0] >= 4)
+    if ok.value:
+        a.set_valid(data)
+        eng.lib.slab_euler2_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
+        eng.lib.stream_synchronize(None)
+        np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
     eng.lib.comm_destroy(comm)
 
 

@@ -291,3 +291,32 @@ def test_special_values_stay_bit_identical(backend, shape, periodic):
     np.testing.assert_array_equal(got, expect)
     assert np.array_equal(np.signbit(got[got == 0]), np.signbit(expect[expect == 0]))   # signed zeros too
     assert np.isnan(got).sum() > 1 and np.isinf(got).sum() >= 0
+
+
+@pytest.mark.parametrize("dtype,shape,split", [(np.float64, (12, 8, 128), 5), (np.float64, (9, 4, 72), 4), (np.float32, (10, 6, 256), 6)])
+def test_sub_slabs_with_one_physical_face(backend, dtype, shape, split):
+    """First / last slab of a NON-periodic slowest axis: one side of the sub-slab is the physical (local) face, the other
+    side reads two real layers of the neighbouring sub-slab.  Two such launches over the halves of one array must equal
+    the sweep over the whole array (and the oracle) bit for bit - this is what the first and the last rank of
+    pdehip_slab_euler2_run execute."""
+    grid, bc, bcs, data = _setup(shape, [False, False, True], dtype, seed=41)
+    info = GridInfo(grid.shape, grid.discretization, data.dtype)
+    faces = convert_bcs(bcs)
+    a, whole, parts = DeviceArray(info).set_valid(data), DeviceArray(info), DeviceArray(info)
+    done = C.c_int(0)
+    lib = backend._lib
+    lib.diffusion_euler2(info.ref, faces.c, a.ptr, whole.ptr, 0.6, 2e-3, C.byref(done), None)
+    assert done.value == 1
+    n0 = shape[0]
+    lp = info.layer_pitch * data.dtype.itemsize
+    for first, count, sides in [(1, split, 2), (split + 1, n0 - split, 3)]:
+        sub = GridInfo((count, *shape[1:]), grid.discretization, data.dtype)
+        f = _abi.FaceArray()
+        for i in range(6):
+            f[i] = faces.c[i]
+        f[0 if sides == 3 else 1].kind = _abi.BC_SKIP               # the side with real layers
+        f[1].index1 -= first - 1                                    # upper face index relative to the sub-slab
+        lib.diffusion_euler2_slab(sub.ref, f, a.ptr + (first - 1) * lp, parts.ptr + (first - 1) * lp, 0.6, 2e-3, sides, C.byref(done), None)
+        assert done.value == 1
+    np.testing.assert_array_equal(parts.get_valid(), whole.get_valid())
+    np.testing.assert_array_equal(whole.get_valid(), _oracle_steps(grid, bcs, data, 0.6, 2e-3, 2))

@@ -289,11 +289,12 @@ int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_
     gs.shape[0] = 2;   // the smallest launch of the loop
     PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, 1, true));
     // sides without a neighbour (face not marked SKIP) must be local first-order faces the kernel can apply itself
-    for (int side = 0; side < 2 && done; side++)
-        if (rhs->bc_c[side].kind != PDEHIP_BC_SKIP) {
-            gs.shape[0] = g_local->shape[0];
-            PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done, side == 0 ? 2 : 3, true));
-        }
+    const bool phys0 = rhs->bc_c[0].kind != PDEHIP_BC_SKIP, phys1 = rhs->bc_c[1].kind != PDEHIP_BC_SKIP;
+    if (done && (phys0 || phys1)) {
+        gs.shape[0] = g_local->shape[0];
+        PDEHIP_TRY(euler2_with_input_bcs(&gs, (const void *)16, (void *)32, rhs->param, 0.0, rhs->bc_c, nullptr, &done,
+                                         (phys0 && phys1) ? 0 : (phys0 ? 2 : 3), true));
+    }
     *ok = done ? 1 : 0;
     return 0;
 }
@@ -405,7 +406,13 @@ int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *r
     if (rhs->kind != PDEHIP_RHS_CAHN_HILLIARD || g_local->ndim != 3 || g_local->shape[0] < 2) return 0;
     bool done = false;
     PDEHIP_TRY(cahn_hilliard_fused(g_local, (const void *)16, (void *)32, rhs->param, 0.0, false, rhs->bc_c, rhs->bc_mu, nullptr,
-                                   &done, true, true));
+                                   &done, 1, true));
+    // sides without a neighbour (faces not marked SKIP): local first-order faces of c AND mu that the kernel applies itself
+    const bool phys0 = rhs->bc_c[0].kind != PDEHIP_BC_SKIP || rhs->bc_mu[0].kind != PDEHIP_BC_SKIP;
+    const bool phys1 = rhs->bc_c[1].kind != PDEHIP_BC_SKIP || rhs->bc_mu[1].kind != PDEHIP_BC_SKIP;
+    if (done && (phys0 || phys1))
+        PDEHIP_TRY(cahn_hilliard_fused(g_local, (const void *)16, (void *)32, rhs->param, 0.0, false, rhs->bc_c, rhs->bc_mu, nullptr,
+                                       &done, (phys0 && phys1) ? 0 : (phys0 ? 2 : 3), true));
     *ok = done ? 1 : 0;
     return 0;
 }
@@ -414,7 +421,8 @@ int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_
                          void *c_ext, void *out_ext, double dt, int euler, void *stream)
 {
     if (!comm || !rhs || !c_ext || !out_ext) PDEHIP_FAIL(E_VALUE, "slab_ch_sweep: NULL pointer");
-    if (lower < 0 || upper < 0) PDEHIP_FAIL(E_NOTIMPL, "slab_ch_sweep needs both neighbours (periodic slowest axis)");
+    // sides without a neighbour keep their physical faces (xplain codes of launch_euler2)
+    const int xmode = (lower >= 0 && upper >= 0) ? 1 : (lower < 0 && upper < 0) ? 0 : (lower < 0 ? 2 : 3);
     Comm *c = static_cast<Comm *>(comm);
     NGrid n;
     PDEHIP_TRY(norm_grid(g_local, &n));
@@ -424,10 +432,11 @@ int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_
     PDEHIP_TRY(exchange2(c, lp, nloc, c_ext, lower, upper, st));
     pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
     for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) { fc[i] = rhs->bc_c[i]; fm[i] = rhs->bc_mu[i]; }
-    fc[0].kind = fc[1].kind = fm[0].kind = fm[1].kind = PDEHIP_BC_SKIP;
+    if (lower >= 0) fc[0].kind = fm[0].kind = PDEHIP_BC_SKIP;
+    if (upper >= 0) fc[1].kind = fm[1].kind = PDEHIP_BC_SKIP;
     bool done = false;
     PDEHIP_TRY(cahn_hilliard_fused(g_local, static_cast<char *>(c_ext) + lp, static_cast<char *>(out_ext) + lp, rhs->param, dt,
-                                   euler != 0, fc, fm, stream, &done, true));
+                                   euler != 0, fc, fm, stream, &done, xmode));
     if (!done) PDEHIP_FAIL(E_NOTIMPL, "slab_ch_sweep: grid or faces are not covered by the two-level kernel");
     return 0;
 }

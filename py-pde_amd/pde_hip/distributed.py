@@ -130,6 +130,15 @@ class HipEngine:
         return self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
 
 
+class _NoUpload:
+    """Face-table `upload` stub for checks that only look at kinds / indices (array-valued faces are rejected anyway)."""
+
+    ptr = 0
+
+    def __init__(self, arr):
+        pass
+
+
 # ---------------------------------------------------------------------------------------------
 # the slab stepper
 # ---------------------------------------------------------------------------------------------
@@ -227,12 +236,6 @@ class SlabStepper:
         if not x_ok:
             # non-periodic slowest axis: the first / last rank apply the physical face inside the kernel, which needs a
             # local first-order face with scalar coefficients on BOTH ends of the GLOBAL grid (checked on every rank)
-            class _NoUpload:   # array-valued faces are rejected below, nothing needs to reach the device
-                ptr = 0
-
-                def __init__(self, arr):
-                    pass
-
             glob = convert_bcs(bc_c, upload=_NoUpload).c
             x_ok = all(glob[s].kind == _abi.BC_ORDER1 and glob[s].flags == 0 and glob[s].index1 == (grid.shape[0] - 1 if s else 0)
                        for s in (0, 1))
@@ -242,7 +245,12 @@ class SlabStepper:
             self._euler2 = bool(ok.value)
         # Cahn-Hilliard: the right-hand side in ONE sweep (mu in registers) after ONE exchange of two layers of c
         self._ch_rhs = None
-        if (self.comm is not None and self.kind == _abi.RHS_CAHN_HILLIARD and self.exchanging and grid.periodic[0]
+        x_ok_ch = bool(grid.periodic[0])
+        if not x_ok_ch and self.kind == _abi.RHS_CAHN_HILLIARD:   # both fields need local scalar faces on the global ends
+            tabs = [convert_bcs(b, upload=_NoUpload).c for b in (bc_c, bc_mu)]
+            x_ok_ch = all(t[s].kind == _abi.BC_ORDER1 and t[s].flags == 0 and t[s].index1 == (grid.shape[0] - 1 if s else 0)
+                          for t in tabs for s in (0, 1))
+        if (self.comm is not None and self.kind == _abi.RHS_CAHN_HILLIARD and self.exchanging and x_ok_ch
                 and min(self.mesh.counts) >= 2 and grid.num_axes == 3):
             rhs = _abi.RHS()
             rhs.kind, rhs.param = _abi.RHS_CAHN_HILLIARD, self.param

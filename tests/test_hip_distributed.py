@@ -151,6 +151,22 @@ def test_slab_loop_with_physical_faces_on_both_ends(process_group, shape):
         eng.lib.slab_euler2_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
         eng.lib.stream_synchronize(None)
         np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
+    # Cahn-Hilliard sweep on arrays with two halo layers per side, physical faces on both ends (no exchange)
+    if len(shape) == 3:
+        ch = _abi.RHS()
+        ch.kind, ch.param = _abi.RHS_CAHN_HILLIARD, 0.9
+        faces.copy_into(ch.bc_c)
+        faces.copy_into(ch.bc_mu)
+        eng.lib.slab_ch_supported(info.ref, C.byref(ch), C.byref(ok))
+        assert bool(ok.value) == (shape[0] >= 4)   # a rank that owns both faces needs 4 layers (never the case with > 1 rank)
+    if len(shape) == 3 and ok.value:
+        ext = GridInfo((shape[0] + 2, *shape[1:]), grid.discretization, np.float64)
+        padded = np.zeros((shape[0] + 2, *shape[1:]))
+        padded[1:-1] = data
+        ce, oe = DeviceArray(ext).set_valid(padded), DeviceArray(ext)
+        eng.lib.slab_ch_sweep(comm, info.ref, C.byref(ch), -1, -1, ce.ptr, oe.ptr, 1e-3, 1, None)
+        eng.lib.stream_synchronize(None)
+        np.testing.assert_array_equal(oe.get_valid()[1:-1], _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, bc, data, 1e-3, 1))
     eng.lib.comm_destroy(comm)
 
 

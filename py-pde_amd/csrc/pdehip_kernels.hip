@@ -362,15 +362,13 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         a.nxc = (a.n0 + lx - 1) / lx;
         a.xstride = lx;
     } else {
-        // whole grid: ~4096 single-wave workgroups (two rounds over the 256 CUs x 8 wave slots).  Interior sweep of a
-        // THIN slab (exchange-bound): at most 1536, so that the RCCL kernel of the halo stream finds free wave slots
-        // at once — workgroups march for the whole sweep, a kernel launched behind a full sweep waits for its first
-        // round to end (measured: 90 us for 13 us of work).  Thick slabs are compute-bound: full occupancy.
+        // ONE full round of 2048 wave tiles (256 CUs x 8 wave slots at 2 waves per SIMD): measured best or equal from 64 to
+        // 512 planes (0.126 vs 0.131 ms/step at 256 planes, 0.066 vs 0.071 at 128 with 4096 tiles; in the slab loop the
+        // boundary sweep and the RCCL kernel otherwise queue up behind the second round:
+        // profiles/r01_time_tiles_vs_planes.log).  Interior sweep of a THIN slab (exchange-bound): at most 1536, so that
+        // the RCCL kernel of the halo stream finds free wave slots at once — workgroups march for the whole sweep, a kernel
+        // launched behind a full round waits for it to end (measured: 90 us for 13 us of work).
         const bool thin = xplain && a.n0 < 96;
-        // (thick slabs: one round of 2048 wave tiles — measured 0.154 vs 0.177 ms/step at 256 layers and 0.088 vs 0.101 at 128
-        // with 4096, where the boundary sweep and the RCCL kernel queue up behind the second round)
-        // (otherwise ONE full round of 2048 wave tiles = 256 CUs x 8 slots: measured best or equal for 64..512 planes,
-        // 0.126 vs 0.131 ms/step at 256 planes and 0.066 vs 0.071 at 128 with 4096 tiles, profiles/r01_time_tiles_vs_planes.log)
         const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
         long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;

@@ -399,16 +399,20 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     if (m2 >= E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
     // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
     // the 5 VGPRs decide whether the loads can be issued early (8-19 % at 256^3 and slab-sized grids)
-    const bool ragged = !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
-#define PDEHIP_E2(RY_, HY_, RG_)                                                                                               \
-    if (ry == RY_ && has_y == HY_ && ragged == RG_) {                                                                          \
-        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_>), grid, block, 0, st, a); \
-        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_>), grid, block, 0, st, a);                  \
+    // XS: the one-sided halo modes of the first / last slab of a non-periodic axis are separate instances (with the
+    // ragged-row code): compiled into the hot instances they cost 5-9 % through register allocation alone
+    const bool xs = xplain > 1;
+    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
+#define PDEHIP_E2(RY_, HY_, RG_, XS_)                                                                                               \
+    if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_) {                                                                  \
+        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_>), grid, block, 0, st, a); \
+        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_>), grid, block, 0, st, a);                  \
     }
-    PDEHIP_E2(1, false, true)
-    PDEHIP_E2(2, true, true)
-    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true, true) PDEHIP_E2(4, true, false) }
+    PDEHIP_E2(1, false, true, false)
+    PDEHIP_E2(2, true, true, false)
+    PDEHIP_E2(2, true, true, true)
+    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true, true, false) PDEHIP_E2(4, true, false, false) PDEHIP_E2(4, true, true, true) }
 #undef PDEHIP_E2
     PDEHIP_HIP(hipGetLastError());
     *done = true;

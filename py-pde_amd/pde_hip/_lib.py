@@ -13,7 +13,8 @@ from pathlib import Path
 
 from . import _abi
 
-LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libpdehip.so"
+# PDEHIP_LIB: another build of the same library (A/B timing of kernel variants); default = the in-tree build
+LIB_PATH = Path(os.environ.get("PDEHIP_LIB") or (Path(__file__).resolve().parent.parent / "lib" / "libpdehip.so"))
 
 _E_VALUE, _E_NOTIMPL = 1, 2
 

@@ -115,7 +115,7 @@ extern "C" __global__ void __launch_bounds__(64) pde_kernel(pdehip::LapArgs a)
 const char *kMarch2Wrapper = R"SRC(
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) pde_kernel(pdehip::LapArgs a)
 {
-    pdehip::euler2_body<PDE_T, PDE_VEC, PDE_RY, PDE_M2, PDE_HASX, true, false>(a);
+    pdehip::euler2_body<PDE_T, PDE_VEC, PDE_RY, PDE_M2, PDE_HASX, true, false, false>(a);
 }
 )SRC";
 

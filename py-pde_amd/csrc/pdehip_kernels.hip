@@ -403,16 +403,21 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     // ragged-row code): compiled into the hot instances they cost 5-9 % through register allocation alone
     const bool xs = xplain > 1;
     const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
-#define PDEHIP_E2(RY_, HY_, RG_, XS_)                                                                                               \
-    if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_) {                                                                  \
-        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_>), grid, block, 0, st, a); \
-        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_>), grid, block, 0, st, a);                  \
+    // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
+    const bool nt = !ragged && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
+#define PDEHIP_E2(RY_, HY_, RG_, XS_, NT_)                                                                                               \
+    if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                                          \
+        if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
+        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
     }
-    PDEHIP_E2(1, false, true, false)
-    PDEHIP_E2(2, true, true, false)
-    PDEHIP_E2(2, true, true, true)
-    if constexpr (sizeof(T) == 8) { PDEHIP_E2(4, true, true, false) PDEHIP_E2(4, true, false, false) PDEHIP_E2(4, true, true, true) }
+    PDEHIP_E2(1, false, true, false, false)
+    PDEHIP_E2(2, true, true, false, false)
+    PDEHIP_E2(2, true, true, true, false)
+    if constexpr (sizeof(T) == 8) {
+        PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(4, true, false, false, false) PDEHIP_E2(4, true, false, false, true)
+        PDEHIP_E2(4, true, true, true, false)
+    }
 #undef PDEHIP_E2
     PDEHIP_HIP(hipGetLastError());
     *done = true;

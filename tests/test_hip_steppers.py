@@ -288,3 +288,31 @@ def test_adams_bashforth_vs_oracle(backend, rng, kind, shape):
     t = stepper(state, 0.0, 4 * dt)
     stepper(state, t, 9 * dt)
     np.testing.assert_array_equal(state.data, res.data)
+
+
+@pytest.mark.parametrize("kind,shape", [("diffusion", (16, 128)), ("diffusion", (8, 8, 64)), ("cahn_hilliard", (12, 72)), ("diffusion", (10, 7))])
+def test_euler_run_through_the_captured_graph(backend, rng, kind, shape):
+    """Long runs on small grids replay a captured hipGraph of 32 steps (16 double sweeps where the two-level kernel covers
+    the grid): 2100 steps = 65 replays + 20 plain steps, then a second call re-uses the cached graph - bit-exact."""
+    grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
+    bc = "auto_periodic_neumann"
+    data = rng.uniform(-0.3, 0.3, shape)
+    hf = host_faces(grid.get_boundary_conditions(bc))
+    g = oracle_grid(grid)
+    scratch = np.zeros(grid._shape_full)
+    if kind == "diffusion":
+        eq, orhs, dt = pde_hip.DiffusionPDE(0.7, bc=bc), O.make_rhs(_abi.RHS_DIFFUSION, 0.7, hf.c), 0.05
+    else:
+        eq, orhs, dt = pde_hip.CahnHilliardPDE(0.8, bc_c=bc, bc_mu=bc), O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, hf.c, hf.c, scratch), 1e-3
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data))
+    a, b = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info)
+    res = C.c_void_p()
+    lib = backend._lib
+    lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, dt, 2100, C.byref(res), None)
+    got = (b if res.value == b.ptr else a).get_valid()
+    full = O.euler_run(g, orhs, to_full(grid, data), dt, 2100)
+    np.testing.assert_array_equal(got, interior(grid, full))
+    # the same buffers, grid, rhs and dt again: the cached graph (64 more steps = 2 replays); the state continues from `a`
+    a.set_valid(got)
+    lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, dt, 64, C.byref(res), None)
+    np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), interior(grid, O.euler_run(g, orhs, full, dt, 64)))

@@ -248,11 +248,16 @@ int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_f
 int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b,
                      double dt, int64_t nsteps, void **result, void *stream);
 /* one classical RK4 step in place on y (pde/solvers/runge_kutta.py:29-66);
- * work = 5 full arrays (k1..k4, tmp) */
+ * work = 5 full arrays (scratch: slopes and stage inputs; their contents after the call are unspecified).
+ * Where the stencil kernels cover grid and faces every stage is ONE sweep: the slope and, from the slope still in
+ * registers, the input of the next stage / the new state (17 instead of 23 arrays moved per step); the result is
+ * bit-identical to the sequence rhs_scaled + lincomb + rk4_combine, which remains the fallback. */
 int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
                     void *const *work5_host, double dt, void *stream);
 /* one RKF45 attempt (pde/solvers/runge_kutta.py:68-156): ynew and *err_dev are produced,
- * y is unchanged apart from its ghost cells; work = 7 full arrays (k1..k6, tmp) */
+ * y is unchanged apart from its ghost cells; work = 7 full arrays (scratch: k1..k6, tmp; contents unspecified after
+ * the call, ynew doubles as a stage input until the last sweep).  Fused like pdehip_rk4_step: six sweeps, the last
+ * one computes the new state and the max-norm of the error estimate from k6 in registers (36 instead of 45 arrays). */
 int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
                          void *ynew_full, void *const *work7_host, double dt, double *err_dev,
                          void *stream);

@@ -108,8 +108,21 @@ struct InputBCs {
     long idx[3][2];
     double c[3][2], f[3][2];
 };
+// what follows a slope k = dt*rhs in a Runge-Kutta scheme, fused into the sweep that computes k (mode LAP_STAGE)
+struct StageFuse {
+    int kind;            // 0: next stage input  out2 = y + sum_m c[m]*k[m] + c_new*k  (k is also stored);  1: RK4 update
+                         //    out2 = y + (k[0] + 2*k[1] + 2*k[2] + k)/6  (k is not stored; out2 may be y itself)
+                         // 2: end of an RKF45 attempt  out2 = 4th-order state from y and k = {k1, k3, k4, k5}, *err = max-norm
+                         //    of the error estimate with k6 = k  (k is not stored; *err must be zero before the launch)
+    const void *y;
+    const void *k[5];    // earlier slopes, NULL-terminated
+    double c[5], c_new;
+    void *out2;
+    double *err;
+};
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
-                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr);
+                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr,
+                   const StageFuse *stage = nullptr);
 int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, const double *gs, hipStream_t st, bool *done);
 int launch_div_march(const NGrid &n, int method, const void *in, void *out, const OutStr &o, hipStream_t st, bool *done);
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
@@ -123,7 +136,7 @@ struct Euler2Plan {
 };
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, int xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
-                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr);
+                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
@@ -132,13 +145,15 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
 // (!euler) out = dt*lap(mu) with the faces of mu — mu never leaves the registers; *done as above
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
                         const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
-                        int xplain = 0, bool dry_run = false);
+                        int xplain = 0, bool dry_run = false, const StageFuse *stage = nullptr);
+// (stage: `out` = dt*lap(mu) is followed by the Runge-Kutta combination of StageFuse in the same sweep; `euler` must be false)
 // xplain: 1 = the slowest axis has two real halo layers on either side (slab decomposition) instead of BCs; 2 = on its upper
 // side only (the lower face keeps its local BC: first slab of a non-periodic axis); 3 = on its lower side only (last slab); `in` / `out` then
 // point one layer before the first layer to update, like every sub-slab launch (pdehip_comm.hip)
 // BCs of `in` (on the fly where possible) + stencil (mode LAP_*) into the FULL array `out`
 // (see pdehip_ops.hip)
 int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void *out, int mode, double s1,
-                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream);
+                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream,
+                           const StageFuse *stage = nullptr);
 
 }  // namespace pdehip

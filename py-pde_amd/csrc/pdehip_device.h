@@ -7,11 +7,13 @@ namespace pdehip {
 // epilogue selector of lap_march_kernel
 enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
        LAP_GRAD_C = 4, LAP_GRAD_F = 5, LAP_GRAD_B = 6, LAP_GRADSQ_C = 7, LAP_GRADSQ_N = 8,
-       LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */ };
+       LAP_CUSTOM = 9 /* epilogue generated at run time: pde_epilogue() */,
+       LAP_STAGE = 10 /* Runge-Kutta stage: slope dt*(D*lap) AND the pointwise combination that follows it (LapArgs::st*) */ };
 
 // the two fused levels of euler2_kernel (pdehip_march2.inc)
 enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run-time generated: pde_epilogue() twice */,
-       E2_CUSTOM2 = 4 /* run-time generated: level 1 = pde_epilogue(), level 2 = pde_epilogue2() (two-pass expressions) */ };
+       E2_CUSTOM2 = 4 /* run-time generated: level 1 = pde_epilogue(), level 2 = pde_epilogue2() (two-pass expressions) */,
+       E2_CH_STAGE = 5 /* E2_CH_SCALED + the Runge-Kutta combination that follows the slope (LapArgs::st*, like LAP_STAGE) */ };
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -44,6 +46,19 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+// max of non-negative doubles through their bit patterns: NaN (canonicalised by abs_nan_canon) is the largest, so a
+// NaN anywhere surfaces in the error norm (solvers/base.py:577-590)
+__device__ __forceinline__ double abs_nan_canon(double e)
+{
+    e = fabs(e);
+    return (e != e) ? __longlong_as_double(0x7ff8000000000000LL) : e;
+}
+__device__ __forceinline__ double max_nan(double a, double b)
+{
+    const unsigned long long x = (unsigned long long)__double_as_longlong(a), y = (unsigned long long)__double_as_longlong(b);
+    return __longlong_as_double((long long)((x > y) ? x : y));
+}
+
 // XCD-aware block -> work-item map: hardware places block b on XCD b % 8 (speed only, never
 // correctness).  Every XCD gets a contiguous range of the tile list so that tiles sharing halo
 // rows also share an L2.
@@ -58,7 +73,7 @@ template <int MODE>
 __device__ __forceinline__ double epilogue(double lap, double c, double yv, double s1, double s2, double gamma)
 {
     if (MODE == LAP_PLAIN) return lap;
-    if (MODE == LAP_SCALED) return s2 * (s1 * lap);        // dt * (D * lap)
+    if (MODE == LAP_SCALED || MODE == LAP_STAGE) return s2 * (s1 * lap);   // dt * (D * lap)
     if (MODE == LAP_EULER) return yv + s2 * (s1 * lap);    // pde/solvers/euler.py:174
     return c * c * c - c - gamma * lap;                    // pde/pdes/cahn_hilliard.py:116-120
 }
@@ -92,6 +107,17 @@ struct LapArgs {
     long xstride;     // euler2_kernel: first plane of x-chunk xc is xc * xstride (== lx, or n0 - lx for the two-ended boundary sweep)
     int nwy;          // euler2_kernel: waves of a workgroup stacked along the rows (others: along the fastest axis)
     InBC ibc1[3][2];  // euler2_kernel: faces of the intermediate level when it is another field (Cahn-Hilliard: mu)
+    // LAP_STAGE: what follows the slope k (still in registers) in a Runge-Kutta scheme, all arrays in the layout of `in`
+    //   st_kind 0: out = k, st_out = y + sum_m st_c[m]*st_k[m] + st_c[5]*k      (input of the next stage, runge_kutta.py:135-145)
+    //   st_kind 1: st_out = y + (k1 + 2*k2 + 2*k3 + k)/6, `out` is not written     (new state of RK4, runge_kutta.py:60)
+    //   st_kind 2: st_out = y + c1*k1 + c3*k3 + c4*k4 + c5*k5 and *st_err = max |error estimate| with k6 = k; st_k = {k1, k3, k4, k5},
+    //              `out` is not written                                          (end of an RKF45 attempt, runge_kutta.py:147-150)
+    int st_kind;
+    double *st_err;
+    const void *st_y;
+    const void *st_k[5];   // earlier slopes, NULL-terminated
+    double st_c[6];
+    void *st_out;
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

@@ -103,7 +103,7 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     a.nblocks = a.nxc * tiles;
     // only the Euler epilogue reads a second array; on-the-fly BCs exist for the four laplace epilogues
     constexpr bool kHasY = (MODE == LAP_EULER);
-    constexpr bool kIbc = (MODE <= LAP_CH_MU);
+    constexpr bool kIbc = (MODE <= LAP_CH_MU) || MODE == LAP_STAGE;
     const dim3 grid((unsigned)a.nblocks), block(64 * WY);
     if (a.any_ibc && !kIbc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs are not built for the derivative epilogues");
     if (a.any_ibc) {
@@ -117,6 +117,13 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     return 0;
 }
 
+static bool stage_aligned(const LapArgs &a)
+{
+    uintptr_t bits = (uintptr_t)a.st_y | (uintptr_t)a.st_out;
+    for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
+    return bits % 16 == 0;
+}
+
 template <typename T, int MODE>
 static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, hipStream_t st)
 {
@@ -124,7 +131,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
     const Tune &tn = tune();
     const bool vec_ok = (n.n[2] % VEC == 0) && (o.s1 % VEC == 0) && (o.s0 % VEC == 0) && (o.off % VEC == 0) &&
                         (((uintptr_t)a.out) % 16 == 0) && (((uintptr_t)a.in) % 16 == 0) &&
-                        (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0);
+                        (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0) && stage_aligned(a);
     if (n.ndim >= 2 && vec_ok && !tn.force_generic) {
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
         // chunks per row: cover the whole fastest axis with one wave where possible (contiguous
@@ -144,6 +151,10 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         };
         while (cz > 1 && n_tiles(ry, cz) < 512) cz /= 2;
         if (n.ndim == 3 && ry == 4 && cz < 2) ry = 2;   // only (4,4) and (4,2) are instantiated
+        // Runge-Kutta stages with few pointwise streams are latency-bound at one wave per SIMD: two waves measured
+        // 0.74 vs 0.91 ms (no earlier slope) and 1.11 vs 1.17 ms (one) at 512^3; from two slopes on one wave wins
+        // (profiles/r01_time_rk.md)
+        if (MODE == LAP_STAGE && (a.st_kind == 1 || !a.st_k[1])) blocks = 2048;
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
 #define PDEHIP_CFG3(RY_, CZ_, WY_, PF_) \
     if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st);
@@ -162,7 +173,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
     }
     if (a.any_ibc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");
-    if (MODE > LAP_CH_MU) PDEHIP_FAIL(E_RUNTIME, "internal: derivative epilogues need the vectorised kernel");
+    if (MODE > LAP_CH_MU) PDEHIP_FAIL(E_RUNTIME, "internal: derivative and stage epilogues need the vectorised kernel");
     const long total = n.n[0] * n.n[1] * n.n[2];
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -273,9 +284,10 @@ int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &
 }
 
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
-                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg)
+                   double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg, const StageFuse *stage)
 {
-    if (!in || !out) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
+    if ((mode == LAP_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage epilogue without / with a stage descriptor");
+    if (!in || (!out && !(stage && stage->kind != 0))) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
     if (mode == LAP_EULER && !y) PDEHIP_FAIL(E_VALUE, "laplace_euler: y is NULL");
     LapArgs a;
     memset(&a, 0, sizeof(a));
@@ -296,8 +308,19 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
                 a.any_ibc |= fg->on[ax][side];
             }
     }
+    if (stage) {
+        if (!stage->y || !stage->out2 || stage->out2 == in || out == in) PDEHIP_FAIL(E_VALUE, "stage epilogue: NULL or aliased array pointer");
+        a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2;
+        int nk = 0;
+        for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
+        if (stage->kind == 1 && nk != 3) PDEHIP_FAIL(E_RUNTIME, "internal: the RK4 update needs three earlier slopes");
+        if (stage->kind == 2 && (nk != 4 || !stage->err)) PDEHIP_FAIL(E_RUNTIME, "internal: the RKF45 update needs four earlier slopes and the error cell");
+        a.st_err = stage->err;
+        a.st_c[5] = stage->c_new;
+    }
 #define PDEHIP_MODE_SWITCH(T)                                                     \
     switch (mode) {                                                               \
+    case LAP_STAGE: return launch_laplace_t<T, LAP_STAGE>(n, a, o, st);           \
     case LAP_PLAIN: return launch_laplace_t<T, LAP_PLAIN>(n, a, o, st);           \
     case LAP_SCALED: return launch_laplace_t<T, LAP_SCALED>(n, a, o, st);         \
     case LAP_EULER: return launch_laplace_t<T, LAP_EULER>(n, a, o, st);           \
@@ -340,7 +363,11 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
     int ry = t2.ry ? t2.ry : 4;
     if (a.n1 % ry || sizeof(T) == 4) ry = 2;
+    // the stage epilogue (six more streams) does not fit the ragged 4-row tile without spilling: 2-row tiles there
+    if (m2 == E2_CH_STAGE && ry == 4 && a.n2 % CW != 0) ry = 2;
     if (!has_y) ry = 1;
+    // ... and not at all the fp32 tile (fp64 registers, 4 cells per lane): fp32 3-D stages stay separate kernels
+    if (m2 == E2_CH_STAGE && sizeof(T) == 4 && has_y) return 0;
     if (a.n2 % VEC || a.n1 % ry || (ry != 1 && ry != 2 && ry != 4)) return 0;
     a.ntz = (a.n2 + CW - 1) / CW;   // the row may end inside the last chunk
     a.nty = a.n1 / ry;
@@ -396,7 +423,8 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         return 0;
     }
     if (dry_run) { *done = true; return 0; }
-    if (m2 >= E2_CUSTOM) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
+    if (m2 == E2_CUSTOM || m2 == E2_CUSTOM2) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
+    if (m2 == E2_CH_STAGE && xplain) PDEHIP_FAIL(E_RUNTIME, "internal: Runge-Kutta stage sweeps are not built for sub-slabs");
     // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
     // the 5 VGPRs decide whether the loads can be issued early (8-19 % at 256^3 and slab-sized grids)
     // XS: the one-sided halo modes of the first / last slab of a non-periodic axis are separate instances (with the
@@ -404,12 +432,14 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     const bool xs = xplain > 1;
     const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
     // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
-    const bool nt = !ragged && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
+    const bool nt = !ragged && m2 != E2_CH_STAGE && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
 #define PDEHIP_E2(RY_, HY_, RG_, XS_, NT_)                                                                                               \
     if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                                          \
         if (m2 == E2_DIFFUSION) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
         else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
+        else if (m2 == E2_CH_STAGE) {                                                                                                    \
+            if constexpr (!XS_ && !NT_ && !(RY_ == 4 && RG_) && !(sizeof(T) == 4 && HY_)) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_STAGE, HY_, RG_, false, false>), grid, block, 0, st, a); \
+        } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
     }
     PDEHIP_E2(1, false, true, false, false)
     PDEHIP_E2(2, true, true, false, false)
@@ -436,11 +466,12 @@ static int classify_axis(const InputBCs &fg, int ax, long n)
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
                   int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
-                  Euler2Plan *plan)
+                  Euler2Plan *plan, const StageFuse *stage)
 {
     *done = false;
+    if ((m2 == E2_CH_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage sweep without / with a stage descriptor");
     const long vec = 16 / elem_size(n.dtype);
-    if ((m2 == E2_CH_EULER || m2 == E2_CH_SCALED) && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
+    if ((m2 == E2_CH_EULER || m2 == E2_CH_SCALED || m2 == E2_CH_STAGE) && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
     if (tune2().off || tune().force_generic || (n.ndim != 3 && n.ndim != 2) || in == out) return 0;
     // kernel axes (march, rows, lanes) <- normalised grid axes: 3-D (0, 1, 2); 2-D (1, -, 2): the march axis is the first
     // grid axis and there are no rows
@@ -481,6 +512,15 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
         }
     }
     a.gamma = gamma;
+    if (stage) {
+        if (!stage->y || !stage->out2 || stage->out2 == in || (stage->kind == 0 && !out)) PDEHIP_FAIL(E_VALUE, "stage sweep: NULL or aliased array pointer");
+        a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2; a.st_err = stage->err;
+        int nk = 0;
+        for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
+        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err))) PDEHIP_FAIL(E_RUNTIME, "internal: malformed stage descriptor");
+        a.st_c[5] = stage->c_new;
+        if (!stage_aligned(a)) return 0;
+    }
     a.in = in; a.out = out; a.y = in;
     a.n0 = n.n[am]; a.n1 = n.ndim == 3 ? n.n[1] : 1; a.n2 = n.n[2];
     a.p0 = n.p[am]; a.p1 = n.ndim == 3 ? n.p[1] : 0; a.off = n.off;

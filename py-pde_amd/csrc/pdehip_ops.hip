@@ -377,16 +377,6 @@ __device__ __forceinline__ void block_max_to(double v, double *dst)
         atomicMax((unsigned long long *)dst, m);
     }
 }
-__device__ __forceinline__ double abs_nan_canon(double e)
-{
-    e = fabs(e);
-    return (e != e) ? __longlong_as_double(0x7ff8000000000000LL) : e;
-}
-__device__ __forceinline__ double max_nan(double a, double b)
-{
-    const unsigned long long x = (unsigned long long)__double_as_longlong(a), y = (unsigned long long)__double_as_longlong(b);
-    return __longlong_as_double((long long)((x > y) ? x : y));
-}
 
 struct Rkf45Args {
     DevGrid g;
@@ -466,7 +456,7 @@ namespace pdehip {
 // `in` are neither written nor read for them); array-valued / second-order faces are written into
 // the ghost cells of `in` by the ghost kernel first (numba/backend.py:501-517 order: BCs, then stencil).
 int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void *out, int mode, double s1,
-                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream)
+                           double s2, double gamma, const pdehip_bc_face_t *in_faces, void *stream, const StageFuse *stage)
 {
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
@@ -494,7 +484,7 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
             }
         }
     if (n_rest) PDEHIP_TRY(launch_ghosts(n, 1, rest, in, as_stream(stream)));
-    return launch_laplace(n, in, out, out_strides(n, PDEHIP_OUT_FULL), mode, s1, s2, gamma, y, as_stream(stream), n_fused ? &fg : nullptr);
+    return launch_laplace(n, in, out, out_strides(n, PDEHIP_OUT_FULL), mode, s1, s2, gamma, y, as_stream(stream), n_fused ? &fg : nullptr, stage);
 }
 
 // faces (grid axes) -> on-the-fly BC table (normalised axes); false when a face is not a scalar first-order condition
@@ -532,18 +522,19 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
 
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
                         const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
-                        int xplain, bool dry_run)
+                        int xplain, bool dry_run, const StageFuse *stage)
 {
     *done = false;
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
-    if (!in || !out || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    if (!in || (!out && !(stage && stage->kind != 0)) || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    if (stage && euler) PDEHIP_FAIL(E_RUNTIME, "internal: a Runge-Kutta stage sweep computes the scaled slope");
     if (n.ndim < 2) return 0;
     InputBCs fc, fm;
     if (!faces_to_input_bcs(n, faces_c, &fc, xplain ? 1 : 0, xplain) || !faces_to_input_bcs(n, faces_mu, &fm, xplain ? 1 : 0, xplain)) return 0;
     // level 2 is `y + s2 * (s1 * lap(mu))` resp. `s2 * (s1 * lap(mu))` with s1 = 1 like the two-kernel path (pdehip_steppers.hip)
     return launch_euler2(n, in, out, 1.0, dt, fc, xplain, as_stream(stream), done, dry_run, 0,
-                         euler ? E2_CH_EULER : E2_CH_SCALED, &fm, gamma);
+                         stage ? E2_CH_STAGE : (euler ? E2_CH_EULER : E2_CH_SCALED), &fm, gamma, nullptr, stage);
 }
 }  // namespace pdehip
 

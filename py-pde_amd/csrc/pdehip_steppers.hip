@@ -4,7 +4,7 @@
 // Kernel budget per step (algorithmic HBM traffic, values per cell):
 //   diffusion Euler        : ghosts + laplace_euler                     = 1 read + 1 write
 //   Cahn–Hilliard Euler    : ghosts + ch_mu (1r+1w) + ghosts + laplace_euler(mu; y=c) (2r+1w) = 5 values
-//   RK stage               : lincomb (1+j reads, 1 write) + rhs_scaled
+//   RK stage               : lincomb (1+j reads, 1 write) + rhs_scaled; diffusion: ONE sweep per stage (rhs_stage)
 #include "pdehip_common.h"
 
 using namespace pdehip;
@@ -45,6 +45,29 @@ struct GraphEntry {
 };
 GraphEntry g_graphs[kGraphCache];
 unsigned g_graph_next = 0;
+
+// One Runge-Kutta stage in ONE sweep: the slope k = dt*rhs(in) and, from the slope still in registers, the pointwise
+// combination that follows it (the input of the next stage, or the new state).  Saves the separate lincomb /
+// rk4_combine pass: a stage moves (1 + earlier slopes + 2 or 3) arrays instead of 2 + (earlier slopes + 3).
+// *fused = false (nothing launched) when the sweep is not available: diffusion needs the vectorised kernel,
+// Cahn-Hilliard the two-level kernel (pdehip_march2.inc).
+int rhs_stage(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *in, void *k_out, double dt, const StageFuse &sf,
+              void *stream, bool *fused)
+{
+    *fused = false;
+    static int on = -1;   // PDEHIP_RK_FUSE=0: separate kernels (tuning / testing aid)
+    if (on < 0) { const char *e = getenv("PDEHIP_RK_FUSE"); on = e ? atoi(e) : 1; }
+    if (!on) return 0;
+    if (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD)   // two-level sweep (mu in registers) with the stage epilogue, where it covers grid and faces
+        return cahn_hilliard_fused(g, in, k_out, rhs->param, dt, false, rhs->bc_c, rhs->bc_mu, stream, fused, 0, false, &sf);
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    uintptr_t bits = (uintptr_t)sf.y | (uintptr_t)sf.out2;
+    for (int m = 0; m < 5; m++) bits |= (uintptr_t)sf.k[m];
+    if (bits % 16 != 0 || !laplace_can_fuse_bcs(n, in, k_out, nullptr)) return 0;
+    *fused = true;
+    return laplace_with_input_bcs(g, in, nullptr, k_out, LAP_STAGE, rhs->param, dt, 0, rhs->bc_c, stream, &sf);
+}
 
 }  // namespace
 
@@ -168,7 +191,23 @@ int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, vo
     void *k1 = w[0], *k2 = w[1], *k3 = w[2], *k4 = w[3], *tmp = w[4];
     const double half = 0.5, one = 1.0;
     const void *kk[1];
-    // runge_kutta.py:52-61
+    // runge_kutta.py:52-61.  Fused form: every sweep also writes what the next one reads (k4's array serves as the
+    // second stage input; k4 itself never leaves the registers) - 17 instead of 23 arrays moved per step.
+    bool fused = false;
+    StageFuse sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.y = y; sf.c_new = half; sf.out2 = tmp;
+    PDEHIP_TRY(rhs_stage(g, rhs, y, k1, dt, sf, stream, &fused));
+    if (fused) {
+        sf.out2 = k4;
+        PDEHIP_TRY(rhs_stage(g, rhs, tmp, k2, dt, sf, stream, &fused));
+        sf.c_new = one; sf.out2 = tmp;
+        if (fused) PDEHIP_TRY(rhs_stage(g, rhs, k4, k3, dt, sf, stream, &fused));
+        sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.out2 = y;
+        if (fused) PDEHIP_TRY(rhs_stage(g, rhs, tmp, nullptr, dt, sf, stream, &fused));
+        if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
+        return 0;
+    }
     PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, k1, dt, stream));
     kk[0] = k1; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));
     PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k2, dt, stream));
@@ -186,7 +225,35 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
     if (!y || !ynew || !w || !err_dev) PDEHIP_FAIL(E_VALUE, "rkf45_attempt: NULL pointer");
     void *tmp = w[6];
     const void *k[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
-    // runge_kutta.py:135-145
+    // runge_kutta.py:135-145.  Fused form: stages 1-5 also write the input of the next stage (alternating between
+    // tmp and ynew), the sixth computes the new state and the error norm from k6 in registers - 36 instead of 45
+    // arrays moved per attempt.
+    {
+        const double *tab[5] = {B2, B3, B4, B5, B6};
+        void *t_in = y, *t_out = tmp;
+        bool fused = true;
+        for (int s = 0; s < 5 && fused; s++) {
+            StageFuse sf;
+            memset(&sf, 0, sizeof(sf));
+            sf.y = y; sf.out2 = t_out;
+            for (int m = 0; m < s; m++) { sf.k[m] = k[m]; sf.c[m] = tab[s][m]; }
+            sf.c_new = tab[s][s];
+            PDEHIP_TRY(rhs_stage(g, rhs, t_in, w[s], dt, sf, stream, &fused));
+            if (!fused && s > 0) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
+            t_in = t_out;
+            t_out = (t_out == tmp) ? ynew : tmp;
+        }
+        if (fused) {   // five stages done: the last input is in tmp, ynew is free again; k6 stays in registers
+            StageFuse sf;
+            memset(&sf, 0, sizeof(sf));
+            sf.kind = 2; sf.y = y; sf.out2 = ynew; sf.err = err_dev;
+            sf.k[0] = k[0]; sf.k[1] = k[2]; sf.k[2] = k[3]; sf.k[3] = k[4];
+            PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
+            PDEHIP_TRY(rhs_stage(g, rhs, t_in, nullptr, dt, sf, stream, &fused));
+            if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
+            return 0;
+        }
+    }
     PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, w[0], dt, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, B2, k, stream));
     PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[1], dt, stream));

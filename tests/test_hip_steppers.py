@@ -263,6 +263,51 @@ def test_on_the_fly_bcs_vs_oracle(backend, shape, bc_name, dtype):
         np.testing.assert_array_equal(k.get_valid(), interior(grid, O.rhs_scaled(g, orhs, to_full(grid, data), 0.01)))
 
 
+@pytest.mark.parametrize("shape", [(6, 10, 128), (5, 8, 128), (4, 8, 200), (5, 7, 200), (4, 6, 520), (9, 256), (5, 600), (2, 2, 4), (1, 1, 8), (7, 5, 3), (33,)])
+@pytest.mark.parametrize("bc_name", ["periodic", "mixed_faces", "second_order", "inhomogeneous"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kind", ["diffusion", "cahn_hilliard"])
+def test_runge_kutta_stage_sweeps_vs_oracle(backend, shape, bc_name, dtype, kind):
+    """RK4 steps and RKF45 attempts whose stages run as ONE sweep each (slope + the pointwise combination that follows,
+    error norm included) - diffusion on the vectorised one-level kernel, Cahn-Hilliard on the two-level kernel (fp64, and
+    fp32 in 2-D) - and as separate kernels elsewhere (odd rows, 1-D, faces the two-level kernel does not cover): state,
+    new state and error norm equal the oracle's lincomb / combine sequence bit for bit, for on-the-fly faces, ghost-cell
+    faces (curvature, per-cell values) and row ends inside / at / beyond a wave tile."""
+    if bc_name == "second_order" and min(shape) < 2:
+        pytest.skip("curvature BC needs 2 support points")
+    grid = pde_hip.CartesianGrid([[0, n * 0.8] for n in shape], shape, periodic=bc_name == "periodic")
+    bc = "periodic" if bc_name == "periodic" else _bc_for(bc_name, grid)
+    data = np.random.default_rng(13).uniform(-0.5, 0.5, shape).astype(dtype)
+    g = oracle_grid(grid, dtype)
+    hf = host_faces(grid.get_boundary_conditions(bc))
+    scratch = np.zeros(grid._shape_full, dtype)
+    if kind == "diffusion":
+        orhs = O.make_rhs(_abi.RHS_DIFFUSION, 0.6, hf.c)
+        eq = pde_hip.DiffusionPDE(0.6, bc=bc)
+    else:
+        orhs = O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.9, hf.c, hf.c, scratch)
+        eq = pde_hip.CahnHilliardPDE(0.9, bc_c=bc, bc_mu=bc)
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data, dtype=dtype))
+    info, lib = spec.info, backend._lib
+    dt = 2e-3
+    y = DeviceArray(info).set_valid(data)
+    work = [DeviceArray(info) for _ in range(7)]
+    yo = to_full(grid, data)
+    for _ in range(3):
+        lib.rk4_step(info.ref, spec.ref, y.ptr, ptr_array(work[:5]), dt, None)
+        O.rk4_step(g, orhs, yo, dt)
+    np.testing.assert_array_equal(y.get_valid(), interior(grid, yo))
+    ynew, err = DeviceArray(info), DeviceScalar()
+    for _ in range(2):   # second attempt starts from the first one's result (work arrays are dirty)
+        start = y.get_valid()
+        lib.rkf45_attempt(info.ref, spec.ref, y.ptr, ynew.ptr, ptr_array(work), dt, err.ptr, None)
+        yo_new, err_o = O.rkf45_attempt(g, orhs, to_full(grid, start), dt)
+        np.testing.assert_array_equal(ynew.get_valid(), interior(grid, yo_new))
+        assert err.value() == err_o
+        np.testing.assert_array_equal(y.get_valid(), start)
+        y, ynew = ynew, y
+
+
 @pytest.mark.parametrize("kind,shape", [("diffusion", (12, 16)), ("diffusion", (6, 8, 128)), ("cahn_hilliard", (8, 8, 64)), ("cahn_hilliard", (24,))])
 def test_adams_bashforth_vs_oracle(backend, rng, kind, shape):
     """Two-step Adams-Bashforth (rate of the previous step kept instead of re-evaluated) == oracle, bit-exact; a second

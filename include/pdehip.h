@@ -254,6 +254,10 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
  * bit-identical to the sequence rhs_scaled + lincomb + rk4_combine, which remains the fallback. */
 int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
                     void *const *work5_host, double dt, void *stream);
+/* `nsteps` RK4 steps with fixed dt in place on y: the fixed-step loop (pde/backends/numba/_solvers.py:93-104) around
+ * pdehip_rk4_step.  Small grids (launch-bound) replay a cached hipGraph of 8 steps, like pdehip_euler_run. */
+int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host,
+                   double dt, int64_t nsteps, void *stream);
 /* one RKF45 attempt (pde/solvers/runge_kutta.py:68-156): ynew and *err_dev are produced,
  * y is unchanged apart from its ghost cells; work = 7 full arrays (scratch: k1..k6, tmp; contents unspecified after
  * the call, ynew doubles as a stage input until the last sweep).  Fused like pdehip_rk4_step: six sweeps, the last

@@ -34,8 +34,9 @@ constexpr int kGraphCache = 8;
 struct GraphKey {
     pdehip_grid_t g;
     pdehip_rhs_t rhs;
-    void *a, *b;
+    void *buf[8];   // every array the captured launches touch (Euler: the two ping-pong buffers; RK4: y and the work arrays)
     double dt;
+    int kind;       // 0 Euler block, 1 RK4 block
 };
 struct GraphEntry {
     GraphKey key;
@@ -45,6 +46,56 @@ struct GraphEntry {
 };
 GraphEntry g_graphs[kGraphCache];
 unsigned g_graph_next = 0;
+
+// Replays a cached graph of `block` steps as often as it fits into `nsteps`, building it first when the run is long
+// enough to pay for the build (milliseconds).  `capture(stream)` issues one block onto the capture stream.  The
+// replays are ordered after the user's stream and the result is handed back to it (no host synchronisation).
+// *done = steps taken through replays (0: nothing cached / built; the caller launches every step itself).
+template <class Capture>
+int replay_graph(const GraphKey &key, int64_t nsteps, int64_t block, int64_t build_from, void *stream, Capture &&capture, int64_t *done)
+{
+    *done = 0;
+    if (nsteps < block) return 0;
+    GraphEntry *entry = nullptr;
+    for (auto &e : g_graphs)
+        if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) { entry = &e; break; }
+    if (!entry && nsteps >= build_from) {
+        GraphEntry &e = g_graphs[g_graph_next++ % kGraphCache];
+        if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
+        if (!e.cap) PDEHIP_HIP(hipStreamCreateWithFlags(&e.cap, hipStreamNonBlocking));
+        if (!e.ev) PDEHIP_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+        hipGraph_t graph = nullptr;
+        PDEHIP_HIP(hipStreamBeginCapture(e.cap, hipStreamCaptureModeThreadLocal));
+        const int rc = capture((void *)e.cap);
+        const hipError_t ce = hipStreamEndCapture(e.cap, &graph);
+        if (rc == 0 && ce == hipSuccess && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            e.key = key;
+            entry = &e;
+        } else {
+            e.exec = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc) return rc;
+    }
+    if (entry) {
+        hipStream_t user = as_stream(stream);
+        PDEHIP_HIP(hipEventRecord(entry->ev, user));
+        PDEHIP_HIP(hipStreamWaitEvent(entry->cap, entry->ev, 0));
+        int64_t s = 0;
+        for (; s + block <= nsteps; s += block) PDEHIP_HIP(hipGraphLaunch(entry->exec, entry->cap));
+        PDEHIP_HIP(hipEventRecord(entry->ev, entry->cap));
+        PDEHIP_HIP(hipStreamWaitEvent(user, entry->ev, 0));
+        *done = s;
+    }
+    return 0;
+}
+
+bool graphs_enabled()
+{
+    static int use_graph = -1;
+    if (use_graph < 0) { const char *e = getenv("PDEHIP_GRAPH"); use_graph = e ? atoi(e) : 1; }
+    return use_graph != 0;
+}
 
 // One Runge-Kutta stage in ONE sweep: the slope k = dt*rhs(in) and, from the slope still in registers, the pointwise
 // combination that follows it (the input of the next stage, or the new state).  Saves the separate lincomb /
@@ -131,48 +182,19 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     int64_t s = 0;
     long cells = 1;
     for (int a = 0; a < g->ndim; a++) cells *= g->shape[a];
-    static int use_graph = -1;
-    if (use_graph < 0) { const char *e = getenv("PDEHIP_GRAPH"); use_graph = e ? atoi(e) : 1; }
-    if (use_graph && cells <= (1L << 22) && nsteps >= kGraphSteps) {
+    if (graphs_enabled() && cells <= (1L << 22) && nsteps >= kGraphSteps) {
         GraphKey key;
         memset(&key, 0, sizeof(key));
-        key.g = *g; key.rhs = *rhs; key.a = buf_a; key.b = buf_b; key.dt = dt;
-        GraphEntry *entry = nullptr;
-        for (auto &e : g_graphs)
-            if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) { entry = &e; break; }
-        if (!entry && nsteps >= 2048) {
-            GraphEntry &e = g_graphs[g_graph_next++ % kGraphCache];
-            if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
-            if (!e.cap) PDEHIP_HIP(hipStreamCreateWithFlags(&e.cap, hipStreamNonBlocking));
-            if (!e.ev) PDEHIP_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
-            hipGraph_t graph = nullptr;
-            int rc = 0;
-            PDEHIP_HIP(hipStreamBeginCapture(e.cap, hipStreamCaptureModeThreadLocal));
-            for (int64_t q = 0; q < kGraphSteps && rc == 0;) {
+        key.g = *g; key.rhs = *rhs; key.buf[0] = buf_a; key.buf[1] = buf_b; key.dt = dt; key.kind = 0;
+        PDEHIP_TRY(replay_graph(key, nsteps, kGraphSteps, 2048, stream, [&](void *cap) -> int {
+            for (int64_t q = 0; q < kGraphSteps;) {
                 int took = 0;
-                rc = advance(cur, nxt, e.cap, kGraphSteps - q, &took);
+                PDEHIP_TRY(advance(cur, nxt, cap, kGraphSteps - q, &took));
                 q += took;
                 void *t = cur; cur = nxt; nxt = t;   // even number of swaps (16 double steps or 32 single steps): back in place
             }
-            const hipError_t ce = hipStreamEndCapture(e.cap, &graph);
-            if (rc == 0 && ce == hipSuccess && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                e.key = key;
-                entry = &e;
-            } else {
-                e.exec = nullptr;
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-            if (rc) return rc;
-        }
-        if (entry) {
-            hipStream_t user = as_stream(stream);
-            // order the replays after the user's stream and hand the result back to it (no host sync)
-            PDEHIP_HIP(hipEventRecord(entry->ev, user));
-            PDEHIP_HIP(hipStreamWaitEvent(entry->cap, entry->ev, 0));
-            for (; s + kGraphSteps <= nsteps; s += kGraphSteps) PDEHIP_HIP(hipGraphLaunch(entry->exec, entry->cap));
-            PDEHIP_HIP(hipEventRecord(entry->ev, entry->cap));
-            PDEHIP_HIP(hipStreamWaitEvent(user, entry->ev, 0));
-        }
+            return 0;
+        }, &s));
     }
     while (s < nsteps) {
         int took = 0;
@@ -216,6 +238,32 @@ int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, vo
     kk[0] = k3; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &one, kk, stream));
     PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k4, dt, stream));
     return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, stream);
+}
+
+int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, int64_t nsteps,
+                   void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    if (!y || !w) PDEHIP_FAIL(E_VALUE, "rk4_run: NULL pointer");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "rk4_run: negative step count");
+    // launch-bound regime (a 512^2 stage is a few us of GPU work): blocks of 8 steps (32 sweeps) as a cached hipGraph
+    constexpr int64_t kBlock = 8;
+    int64_t s = 0;
+    long cells = 1;
+    for (int a = 0; a < g->ndim; a++) cells *= g->shape[a];
+    if (graphs_enabled() && cells <= (1L << 22) && nsteps >= kBlock) {
+        GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.g = *g; key.rhs = *rhs; key.dt = dt; key.kind = 1;
+        key.buf[0] = y;
+        for (int q = 0; q < 5; q++) key.buf[1 + q] = w[q];
+        PDEHIP_TRY(replay_graph(key, nsteps, kBlock, 512, stream, [&](void *cap) -> int {
+            for (int64_t q = 0; q < kBlock; q++) PDEHIP_TRY(pdehip_rk4_step(g, rhs, y, w, dt, cap));
+            return 0;
+        }, &s));
+    }
+    for (; s < nsteps; s++) PDEHIP_TRY(pdehip_rk4_step(g, rhs, y, w, dt, stream));
+    return 0;
 }
 
 int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *ynew, void *const *w,

@@ -161,6 +161,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_ch_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_ch_sweep": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i, _vp],
+    # fixed-step RK4 loop (device only: the oracle loops over rk4_step)
+    "rk4_run": [_pg, _pr, _vp, _pvp, _d, _i64, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)
     "diffusion_euler2": [_pg, _pf, _vp, _vp, _d, _d, C.POINTER(_i), _vp],
     "diffusion_euler2_slab": [_pg, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],

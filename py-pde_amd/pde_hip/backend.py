@@ -546,9 +546,9 @@ class HipBackendMixin:
         solver.info.setdefault("dt_statistics", OnlineStatistics())
         adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
         tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
-        err_dev, ynew = DeviceScalar(), DeviceArray(info)
+        err_dev, ynew0 = DeviceScalar(), DeviceArray(info)
 
-        def attempt(y, t, dt_step) -> float:
+        def attempt(y, ynew, t, dt_step) -> float:
             if is_rk:
                 ks, tmp = work[:6], work[6]
                 erhs.apply(y, ks[0], "scaled", dt_step, t)
@@ -569,18 +569,21 @@ class HipBackendMixin:
             dt_opt = float(solver.info["dt"])
             t, steps = t_start, 0
             stats = solver.info["dt_statistics"]
+            cur, nxt = state_data, ynew0   # an accepted attempt swaps the roles (no copy of the field per step)
             while True:
                 dt_step = max(min(dt_opt, t_end - t), dt_min)
-                error_rel = attempt(state_data, t, dt_step) / tolerance
+                error_rel = attempt(cur, nxt, t, dt_step) / tolerance
                 if error_rel <= 1:
                     steps += 1
                     t += dt_step
-                    lib.memcpy_d2d(state_data.ptr, ynew.ptr, state_data.nbytes, stream)
+                    cur, nxt = nxt, cur
                     stats.add(dt_step)
                 if t < t_end:
                     dt_opt = adjust_dt(dt_step, error_rel)
                 else:
                     break
+            if cur is not state_data:
+                lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
             solver.info["dt"] = dt_opt
             solver.info["steps"] += steps
             return state_data, t
@@ -661,8 +664,7 @@ class HipBackendMixin:
             def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
                 steps = max(1, round((t_end - t_start) / dt))
                 if is_rk:
-                    for _ in range(steps):
-                        lib.rk4_step(info.ref, spec.ref, state_data.ptr, work_ptrs, dt, stream)
+                    lib.rk4_run(info.ref, spec.ref, state_data.ptr, work_ptrs, dt, steps, stream)
                     result = state_data
                 else:
                     res = C.c_void_p()
@@ -688,7 +690,7 @@ class HipBackendMixin:
 
         two_half_steps = [spec.kind == _abi.RHS_DIFFUSION]
 
-        def attempt(state_data: DeviceArray, dt_step: float) -> float:
+        def attempt(state_data: DeviceArray, ynew: DeviceArray, dt_step: float) -> float:
             if is_rk:
                 lib.rkf45_attempt(info.ref, spec.ref, state_data.ptr, ynew.ptr, work_ptrs, dt_step, err_dev.ptr, stream)
             else:
@@ -708,22 +710,24 @@ class HipBackendMixin:
             return err_dev.value(stream)
 
         def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
-            nonlocal ynew
             dt_opt = float(solver.info["dt"])
             t, steps = t_start, 0
             stats = solver.info["dt_statistics"]
+            cur, nxt = state_data, ynew   # an accepted attempt swaps the roles (no copy of the field per step)
             while True:
                 dt_step = max(min(dt_opt, t_end - t), dt_min)
-                error_rel = sync_errors(attempt(state_data, dt_step) / tolerance)
+                error_rel = sync_errors(attempt(cur, nxt, dt_step) / tolerance)
                 if error_rel <= 1:
                     steps += 1
                     t += dt_step
-                    lib.memcpy_d2d(state_data.ptr, ynew.ptr, state_data.nbytes, stream)
+                    cur, nxt = nxt, cur
                     stats.add(dt_step)
                 if t < t_end:
                     dt_opt = adjust_dt(dt_step, error_rel)
                 else:
                     break
+            if cur is not state_data:
+                lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
             solver.info["dt"] = dt_opt
             solver.info["steps"] += steps
             return state_data, t

@@ -361,3 +361,38 @@ def test_euler_run_through_the_captured_graph(backend, rng, kind, shape):
     a.set_valid(got)
     lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, dt, 64, C.byref(res), None)
     np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), interior(grid, O.euler_run(g, orhs, full, dt, 64)))
+
+
+@pytest.mark.parametrize("kind,shape", [("diffusion", (16, 128)), ("cahn_hilliard", (8, 8, 64)), ("diffusion", (10, 7))])
+def test_rk4_run_through_the_captured_graph(backend, rng, kind, shape):
+    """pdehip_rk4_run: 530 RK4 steps on a small grid = 66 replays of a captured 8-step graph + 2 plain steps, then the
+    cached graph again - equal to 530 (+ 17) single steps of the oracle, bit for bit."""
+    grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
+    bc = "auto_periodic_neumann"
+    data = rng.uniform(-0.3, 0.3, shape)
+    hf = host_faces(grid.get_boundary_conditions(bc))
+    g = oracle_grid(grid)
+    scratch = np.zeros(grid._shape_full)
+    if kind == "diffusion":
+        eq, orhs, dt = pde_hip.DiffusionPDE(0.7, bc=bc), O.make_rhs(_abi.RHS_DIFFUSION, 0.7, hf.c), 0.05
+    else:
+        eq, orhs, dt = pde_hip.CahnHilliardPDE(0.8, bc_c=bc, bc_mu=bc), O.make_rhs(_abi.RHS_CAHN_HILLIARD, 0.8, hf.c, hf.c, scratch), 1e-3
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data))
+    y = DeviceArray(spec.info).set_valid(data)
+    work = [DeviceArray(spec.info) for _ in range(5)]
+    lib = backend._lib
+    lib.rk4_run(spec.info.ref, spec.ref, y.ptr, ptr_array(work), dt, 530, None)
+    yo = to_full(grid, data)
+    for _ in range(530):
+        O.rk4_step(g, orhs, yo, dt)
+    np.testing.assert_array_equal(y.get_valid(), interior(grid, yo))
+    lib.rk4_run(spec.info.ref, spec.ref, y.ptr, ptr_array(work), dt, 17, None)   # cached graph: 2 replays + 1 step
+    for _ in range(17):
+        O.rk4_step(g, orhs, yo, dt)
+    np.testing.assert_array_equal(y.get_valid(), interior(grid, yo))
+    # and through the solver front end (fixed-step Runge-Kutta = one rk4_run per stepper call)
+    res = eq.solve(pde_hip.ScalarField(grid, data), t_range=20 * dt, dt=dt, solver="runge-kutta", adaptive=False, backend="hip", tracker=None)
+    yo = to_full(grid, data)
+    for _ in range(20):
+        O.rk4_step(g, orhs, yo, dt)
+    np.testing.assert_array_equal(res.data, interior(grid, yo))

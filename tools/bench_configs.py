@@ -1,7 +1,8 @@
 """Single-GPU timings of the BASELINE.json configs through the mirror API (`eq.solve`), state device
 resident inside one stepper call.  Prints a small table (markdown) — evidence for DESIGN.md / profiles/.
-usage: python tools/bench_configs.py
+usage: [ONLY=cfg5] python tools/bench_configs.py
 """
+import os
 import sys
 import time
 from pathlib import Path
@@ -13,9 +14,12 @@ import numpy as np
 import pde_hip
 
 rng = np.random.default_rng(0)
+ONLY = os.environ.get("ONLY", "")   # run only the configs whose name contains this string (profiling aid)
 
 
 def run(name, eq, grid, dtype, t_range, dt, solver, lo=0.0, hi=1.0, **kw):
+    if ONLY and ONLY not in name:
+        return
     state = pde_hip.ScalarField(grid, rng.uniform(lo, hi, grid.shape), dtype=dtype)
     b = pde_hip.get_backend("hip")
     eq.solve(state, t_range=t_range / 50, dt=dt, solver=solver, backend=b, **kw)  # warm-up (allocations)

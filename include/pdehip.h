@@ -324,6 +324,18 @@ int pdehip_jit_check(void *handle, int dtype, int ndim);
 int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host,
                      void *out_full, const double *params_host, int nparams, const pdehip_bc_face_t *in_faces,
                      void *stream);
+/* pdehip_jit_apply whose result is the slope k of a Runge-Kutta stage (the epilogue computes dt * F), followed in the
+ * SAME sweep by the pointwise combination of the scheme (pde/solvers/runge_kutta.py:52-61, :135-150):
+ *   kind 0: k_out = k,  out2 = y + sum_m coef[m] * k_prev[m] + c_new * k      (input of the next stage)
+ *   kind 1: out2 = y + (k_prev[0] + 2 k_prev[1] + 2 k_prev[2] + k) / 6        (RK4 update; k_out unused, out2 may be y)
+ *   kind 2: out2 = y + c1 k1 + c3 k3 + c4 k4 + c5 k5 and *err_dev = max |error estimate| with k6 = k,
+ *           k_prev = {k1, k3, k4, k5}                                         (end of an RKF45 attempt)
+ * Same expressions in the same order as pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine: bit-identical to
+ * pdehip_jit_apply followed by them.  *done = 0 (nothing launched) when only the generic kernel covers the grid. */
+int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host,
+                           void *k_out_full, const double *params_host, int nparams, const pdehip_bc_face_t *in_faces,
+                           int kind, const void *y_full, int nk, const void *const *k_prev_host, const double *coef_host,
+                           double c_new, void *out2_full, double *err_dev, int *done, void *stream);
 /* TWO applications in one sweep: out = f(f(in)), f(u) = pde_epilogue(u, laplace(u), gradient_squared(u); params), with
  * the BCs `faces` applied to u before each application and the intermediate level in registers — two explicit Euler
  * steps of a one-pass expression PDE (epilogue = the Euler update `u + dt * F(u, ...)`; no extra arrays, no explicit

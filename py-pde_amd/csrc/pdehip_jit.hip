@@ -105,9 +105,9 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
 )SRC";
 
 const char *kMarchWrapper = R"SRC(
-extern "C" __global__ void __launch_bounds__(64) pde_kernel(pdehip::LapArgs a)
+extern "C" __global__ void __launch_bounds__(64 * PDE_WY) pde_kernel(pdehip::LapArgs a)
 {
-    pdehip::lap_march_body<PDE_T, PDE_VEC, PDE_RY, PDE_CZ, 1, 1, pdehip::LAP_CUSTOM, PDE_HASX, true, PDE_IBC>(a);
+    pdehip::lap_march_body<PDE_T, PDE_VEC, PDE_RY, PDE_CZ, PDE_WY, 1, pdehip::LAP_CUSTOM, PDE_HASX, true, PDE_IBC>(a);
 }
 )SRC";
 
@@ -120,7 +120,9 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 )SRC";
 
 int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
-                    int two_level = 0)   // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
+                    int two_level = 0,    // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
+                    bool stage = false,   // one-level kernel followed by the Runge-Kutta stage epilogue (LapArgs::st_*)
+                    int wy = 1)           // waves per workgroup (stacked along the rows), one-level kernel
 {
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
@@ -144,7 +146,8 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
                                      "-DPDE_CZ=" + std::to_string(cz), std::string("-DPDE_HASX=") + (hasx ? "true" : "false"),
-                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level)};
+                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level),
+                                     std::string("-DPDE_STAGE=") + (stage ? "1" : "0"), "-DPDE_WY=" + std::to_string(wy)};
     std::vector<const char *> copts;
     for (auto &o : opts) copts.push_back(o.c_str());
     const int rc = g_rtc.CompileProgram(prog, (int)copts.size(), copts.data());
@@ -192,6 +195,7 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     const int vec = dtype == PDEHIP_F64 ? 2 : 4;
     PDEHIP_TRY(compile_variant(j, "", true, tname, 1, 1, 1, false, false, nullptr));
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr));
+    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr, 0, true));
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr,
                                               j->body2.empty() ? E2_CUSTOM : E2_CUSTOM2));
     return 0;
@@ -222,10 +226,18 @@ int pdehip_jit_destroy(void *handle)
 // Apply the BCs `in_faces` (NULL: ghost cells are already set) to `in_full`, then evaluate
 //   out = pde_epilogue(in, laplace(in), gradient_squared(in), extra[0], extra[1], extra[2], params)
 // on every interior cell (all arrays FULL, same grid).
-int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *out_full,
-                     const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, void *stream)
+}  // extern "C"
+
+namespace {
+// stage != NULL: the generated epilogue is the slope of a Runge-Kutta stage and the combination that follows it is
+// computed in the same sweep (StageFuse, pdehip_common.h); *done = 0 and nothing launched when the vectorised kernel
+// does not cover the grid (the caller then runs pdehip_jit_apply + lincomb / combine)
+int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *out_full,
+                   const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, void *stream,
+                   const StageFuse *stage, int *done)
 {
-    if (!handle || !in_full || !out_full) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
+    if (done) *done = 0;
+    if (!handle || !in_full || (!out_full && !(stage && stage->kind != 0))) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
     if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_apply: at most 12 scalar parameters");
     Jit *j = static_cast<Jit *>(handle);
     NGrid n;
@@ -247,7 +259,20 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
 
     bool aligned = ((uintptr_t)in_full % 16 == 0) && ((uintptr_t)out_full % 16 == 0);
     for (int m = 0; m < 3; m++) aligned = aligned && ((uintptr_t)a.ex[m] % 16 == 0);
+    if (stage) {
+        if (!stage->y || !stage->out2 || stage->out2 == in_full || out_full == in_full) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL or aliased array pointer");
+        a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2; a.st_err = stage->err;
+        int nk = 0;
+        for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
+        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || stage->kind < 0 || stage->kind > 2)
+            PDEHIP_FAIL(E_VALUE, "jit_apply_stage: malformed stage (kind %d with %d earlier slopes)", stage->kind, nk);
+        a.st_c[5] = stage->c_new;
+        uintptr_t bits = (uintptr_t)a.st_y | (uintptr_t)a.st_out;
+        for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
+        aligned = aligned && bits % 16 == 0;
+    }
     const bool fast = n.ndim >= 2 && (n.n[2] % vec == 0) && aligned;
+    if (stage && !fast) return 0;   // only the vectorised kernel carries the stage epilogue
 
     // boundary conditions: on the fly where possible (fast kernel), ghost kernel otherwise
     InputBCs fg;
@@ -296,16 +321,24 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
         };
         while (cz > 1 && n_tiles(ry, cz) < 512) cz /= 2;
         const bool hasx = n.ndim == 3, ibc = n_fused > 0;
-        const std::string key = std::string(tname) + "," + std::to_string(ry) + "," + std::to_string(cz) + "," + (hasx ? "x" : "-") + (ibc ? "b" : "-");
+        static int wy_env = -1;   // PDEHIP_JIT_WY: waves per workgroup of the stage sweeps (tuning aid)
+        if (wy_env < 0) { const char *e = getenv("PDEHIP_JIT_WY"); wy_env = e ? atoi(e) : 0; }
+        const int wy = (stage && wy_env > 0) ? wy_env : 1;
+        const std::string key = std::string(tname) + "," + std::to_string(ry) + "," + std::to_string(cz) + "," + (hasx ? "x" : "-") + (ibc ? "b" : "-") +
+                                (stage ? "s" : "-") + std::to_string(wy);
         auto it = j->cache.find(key);
         if (it != j->cache.end()) v = it->second;
-        else PDEHIP_TRY(compile_variant(j, key, false, tname, vec, ry, cz, hasx, ibc, &v));
+        else PDEHIP_TRY(compile_variant(j, key, false, tname, vec, ry, cz, hasx, ibc, &v, 0, stage != nullptr, wy));
         a.ntz = (a.n2 + 64L * vec * cz - 1) / (64L * vec * cz);
-        a.nty = (a.n1 + ry - 1) / ry;
+        a.nty = (a.n1 + wy * ry - 1) / (wy * ry);
         const long tiles = a.ntz * a.nty;
         long lx = a.n0;
         if (hasx) {
-            long nxc = (1024 + tiles - 1) / tiles;
+            // stages with few pointwise streams: two waves per SIMD (see launch_laplace_t, profiles/r01_time_rk.md)
+            static long want_env = -1;   // PDEHIP_JIT_BLOCKS: wave tiles per sweep (tuning aid)
+            if (want_env < 0) { const char *e = getenv("PDEHIP_JIT_BLOCKS"); want_env = e ? atol(e) : 0; }
+            const long want = want_env > 0 ? want_env : ((stage && (stage->kind == 1 || !stage->k[1])) ? 2048 : 1024);
+            long nxc = (want / wy + tiles - 1) / tiles;   // `want` counts waves
             if (nxc < 1) nxc = 1;
             if (nxc > a.n0) nxc = a.n0;
             lx = (a.n0 + nxc - 1) / nxc;
@@ -314,7 +347,7 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
         a.nxc = (a.n0 + lx - 1) / lx;
         a.nblocks = a.nxc * tiles;
         blocks = (unsigned)a.nblocks;
-        threads = 64;
+        threads = 64 * wy;
     } else {
         const std::string key = std::string("generic,") + tname;
         auto it = j->cache.find(key);
@@ -326,7 +359,47 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
     }
     void *args[] = {&a};
     PDEHIP_HIP(hipModuleLaunchKernel(v.fn, blocks, 1, 1, threads, 1, 1, 0, as_stream(stream), args, nullptr));
+    if (done) *done = 1;
     return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *out_full,
+                     const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, void *stream)
+{
+    return jit_apply_impl(handle, g, in_full, extra3_host, out_full, params_host, nparams, in_faces, stream, nullptr, nullptr);
+}
+
+// pdehip_jit_apply whose result is the slope k of a Runge-Kutta stage (the epilogue must compute dt * F), followed in the
+// SAME sweep by the pointwise combination of the scheme (all arrays FULL):
+//   kind 0: k_out = k,  out2 = y + sum_m coef[m] * k_prev[m] + c_new * k                       (input of the next stage)
+//   kind 1: out2 = y + (k_prev[0] + 2 k_prev[1] + 2 k_prev[2] + k) / 6     (RK4 update; k_out unused, out2 may be y)
+//   kind 2: out2 = y + c1 k1 + c3 k3 + c4 k4 + c5 k5, *err_dev = max |error estimate| with k6 = k, k_prev = {k1, k3, k4, k5}
+//           (end of an RKF45 attempt; *err_dev is zeroed first)
+// The same expressions in the same order as pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine.
+// *done = 0 and nothing launched when only the generic kernel covers the grid (1-D, odd rows).
+int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *k_out_full,
+                           const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, int kind,
+                           const void *y_full, int nk, const void *const *k_prev_host, const double *coef_host, double c_new,
+                           void *out2_full, double *err_dev, int *done, void *stream)
+{
+    if (!done) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL pointer");
+    if (nk < 0 || nk > 5 || (nk > 0 && !k_prev_host) || (kind == 0 && nk > 0 && !coef_host)) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: bad slope table");
+    StageFuse sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.kind = kind; sf.y = y_full; sf.out2 = out2_full; sf.err = err_dev; sf.c_new = c_new;
+    for (int m = 0; m < nk; m++) {
+        if (!k_prev_host[m]) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL slope array");
+        sf.k[m] = k_prev_host[m];
+        sf.c[m] = (kind == 0) ? coef_host[m] : 0.0;
+    }
+    if (kind == 2) {
+        if (!err_dev) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL error cell");
+        PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
+    }
+    return jit_apply_impl(handle, g, in_full, extra3_host, k_out_full, params_host, nparams, in_faces, stream, &sf, done);
 }
 
 // TWO applications of the epilogue in one sweep: out = f(f(in)) with f(u) = pde_epilogue(u, laplace(u), gradient_squared(u);

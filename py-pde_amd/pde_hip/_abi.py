@@ -172,6 +172,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_destroy": [_vp],
     "jit_check": [_vp, _i, _i],
     "jit_apply": [_vp, _pg, _vp, _pvp, _vp, _pd, _i, _pf, _vp],
+    "jit_apply_stage": [_vp, _pg, _vp, _pvp, _vp, _pd, _i, _pf, _i, _vp, _i, _pvp, _pd, _d, _vp, _vp, C.POINTER(_i), _vp],
     "jit_euler2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, C.POINTER(_i), _vp],
     "jit_create2": [C.c_char_p, C.c_char_p, _pvp],
     "jit_fused2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, _pf, C.POINTER(_i), _vp],

@@ -507,15 +507,17 @@ class HipBackendMixin:
             lib.lincomb(info.ref, 1, out.ptr, y.ptr, len(ks), cf, ptr_array(ks), stream)
 
         def rk4_step(y, t, dt):
+            # every stage in one sweep where the kernels cover it (slope + the combination that follows, like
+            # pdehip_rk4_step): the array of k4 serves as the second stage input, k4 itself stays in registers
             k1, k2, k3, k4, tmp = work[:5]
-            erhs.apply(y, k1, "scaled", dt, t)
-            lincomb(tmp, y, [0.5], [k1])
-            erhs.apply(tmp, k2, "scaled", dt, t + 0.5 * dt)
-            lincomb(tmp, y, [0.5], [k2])
-            erhs.apply(tmp, k3, "scaled", dt, t + 0.5 * dt)
-            lincomb(tmp, y, [1.0], [k3])
-            erhs.apply(tmp, k4, "scaled", dt, t + dt)
-            lib.rk4_combine(info.ref, 1, y.ptr, k1.ptr, k2.ptr, k3.ptr, k4.ptr, stream)
+            if not erhs.apply_stage(y, k1, dt, t, 0, y, [], [], 0.5, tmp):
+                lincomb(tmp, y, [0.5], [k1])
+            if not erhs.apply_stage(tmp, k2, dt, t + 0.5 * dt, 0, y, [], [], 0.5, k4):
+                lincomb(k4, y, [0.5], [k2])
+            if not erhs.apply_stage(k4, k3, dt, t + 0.5 * dt, 0, y, [], [], 1.0, tmp):
+                lincomb(tmp, y, [1.0], [k3])
+            if not erhs.apply_stage(tmp, k4, dt, t + dt, 1, y, [k1, k2, k3], [], 0.0, y):
+                lib.rk4_combine(info.ref, 1, y.ptr, k1.ptr, k2.ptr, k3.ptr, k4.ptr, stream)
 
         if not adaptive:
             dt = float(solver.info["dt"])
@@ -550,12 +552,16 @@ class HipBackendMixin:
 
         def attempt(y, ynew, t, dt_step) -> float:
             if is_rk:
+                # stages 1-5: slope + next stage input in one sweep (inputs alternate between tmp and ynew, which is free
+                # until the last sweep); stage 6: new state + error norm with k6 in registers (like pdehip_rkf45_attempt)
                 ks, tmp = work[:6], work[6]
-                erhs.apply(y, ks[0], "scaled", dt_step, t)
+                src, dst = y, tmp
                 for s_, b in enumerate(B):
-                    lincomb(tmp, y, b, ks[: s_ + 1])
-                    erhs.apply(tmp, ks[s_ + 1], "scaled", dt_step, t + A[s_ + 1] * dt_step)
-                lib.rkf45_combine(info.ref, 1, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
+                    if not erhs.apply_stage(src, ks[s_], dt_step, t + A[s_] * dt_step, 0, y, ks[:s_], b[:s_], b[s_], dst):
+                        lincomb(dst, y, b, ks[: s_ + 1])
+                    src, dst = dst, (ynew if dst is tmp else tmp)
+                if not erhs.apply_stage(src, ks[5], dt_step, t + A[5] * dt_step, 2, y, [ks[0], ks[2], ks[3], ks[4]], [], 0.0, ynew, err_dev):
+                    lib.rkf45_combine(info.ref, 1, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
             else:
                 k1, k2a = work[0], work[1]
                 erhs.apply(y, k1, "euler", dt_step, t)

@@ -259,6 +259,37 @@ class ExpressionRhs:
                 ex[m] = arrays[name].ptr
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
 
+    def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:
+        """k = dt*F(state) and, in the same sweep, the Runge-Kutta combination that follows it (``pdehip_jit_apply_stage``:
+        kind 0 next stage input ``out2 = y + sum coefs*ks + c_new*k`` with k stored in ``k_out``; 1 RK4 update; 2 RKF45
+        update + error norm into ``err``).  Returns False when the sweep is not available - then ``k_out`` holds the slope
+        (plain ``apply``) and the caller combines with the pointwise kernels.  Two-pass chains keep their fused two-level
+        sweep (tmp in registers) and combine separately."""
+        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None:
+            self.apply(state, k_out, "scaled", dt, t)
+            return False
+        arrays = {"state": state, "out": k_out, **self.tmps}
+        params = (C.c_double * 2)(dt, t)
+        last = len(self.plan.passes) - 1
+        for i, p in enumerate(self.plan.passes):
+            h, extras = self._kernel(i, "scaled")
+            ex = (C.c_void_p * 3)()
+            for m, name in enumerate(extras):
+                ex[m] = arrays[name].ptr
+            if i < last:
+                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+                continue
+            done = C.c_int(0)
+            kp = (C.c_void_p * max(1, len(ks)))(*[k.ptr for k in ks])
+            cf = (C.c_double * max(1, len(ks)))(*(list(coefs) if kind == 0 else [0.0] * len(ks)))
+            self.lib.jit_apply_stage(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self.faces[p.src].c, kind, y.ptr, len(ks), kp,
+                                     cf, c_new, out2.ptr, err.ptr if err is not None else None, C.byref(done), self.backend.stream)
+            if not done.value:
+                self._stage_ok = False
+                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+                return False
+        return True
+
     def _fused_handle(self, wrap: str):
         if wrap not in self._fused:
             h = None

@@ -213,3 +213,38 @@ def test_two_pass_expressions_in_one_sweep(shape, periodic, dtype, expr, consts)
         assert fused._fused[wrap] is not None    # the fused kernel was taken
         plain.apply(y, o2, wrap, 2e-3, 0.7)
         np.testing.assert_array_equal(o1.get_valid(), o2.get_valid())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,periodic,dtype", [
+    ((6, 10, 128), [True, False, False], np.float64), ((24, 256), [False, True], np.float64), ((8, 8, 64), [True, True, True], np.float32),
+    ((5, 7, 200), [False, False, False], np.float64), ((7, 5, 3), [True, False, False], np.float64), ((33,), [False], np.float64),
+])
+@pytest.mark.parametrize("expr,consts", [
+    ("c - c**3 + laplace(c)", {}),                                           # one pass
+    ("nu*laplace(h) + lam*gradient_squared(h) + 0.1*t", {"nu": 0.7, "lam": 0.3}),   # one pass, explicit time
+    ("laplace(c**3 - c - g*laplace(c)) + 0*t", {"g": 0.9}),                 # two passes (explicit time: no fused two-level sweep)
+])
+def test_runge_kutta_stage_sweeps_of_expressions(monkeypatch, shape, periodic, dtype, expr, consts):
+    """RK4 and adaptive RKF45 of expression PDEs with every stage as one sweep (generated slope + the combination that
+    follows, `pdehip_jit_apply_stage`) == the same solves with separate lincomb / combine kernels, bit for bit, with
+    equal step counts; 1-D and odd-row grids take the separate kernels in both runs."""
+    from pde_hip.expr import ExpressionRhs
+
+    var = "h" if "h" in expr.replace("laplace", "") and "(h)" in expr else "c"
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    eq = pde_hip.PDE({var: expr}, consts=consts, bc="auto_periodic_neumann")
+    data = np.random.default_rng(17).uniform(-0.3, 0.3, shape).astype(dtype)
+    state = pde_hip.ScalarField(grid, data, dtype=dtype)
+    results = {}
+    for mode in ("sweeps", "separate"):
+        if mode == "separate":
+            monkeypatch.setattr(ExpressionRhs, "_stage_ok", False, raising=False)
+        rk4, i4 = eq.solve(state, t_range=0.02, dt=2e-3, solver="runge-kutta", adaptive=False, backend="hip", ret_info=True, tracker=None)
+        ada, ia = eq.solve(state, t_range=0.02, dt=None, solver="runge-kutta", backend="hip", ret_info=True, tracker=None, tolerance=1e-5)
+        results[mode] = (rk4.data, i4["solver"]["steps"], ada.data, ia["solver"]["steps"])
+    a, b = results["sweeps"], results["separate"]
+    assert a[1] == b[1] == 10 and a[3] == b[3] > 0
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[2], b[2])
+    assert np.isfinite(a[2]).all()

@@ -314,7 +314,15 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         int ry = 2;   // measured: 2-row tiles win in 2-D as well (4096^2 Allen-Cahn 80 % vs 40 % of the HBM peak with 8 rows)
         static int ry_env = -1;   // PDEHIP_JIT_RY: rows per wave tile (tuning aid; any value works, kernels are built on demand)
         if (ry_env < 0) { const char *e = getenv("PDEHIP_JIT_RY"); ry_env = e ? atoi(e) : 0; }
+        // stage sweeps: 1-row tiles.  The 2-row stage kernel (28 KB of code) runs at its one-wave-per-SIMD speed when it
+        // is loaded through hipModuleLoadData (4.9 vs 3.7 ms per RK4 step at 512^3; the same code built into the library
+        // is not affected, nor is this one once librocprofiler-sdk.so is in the process); with half the code the
+        // effect is gone (4.0 ms): profiles/r01_time_expr_rk.md
+        if (stage) ry = 1;
         if (ry_env > 0) ry = ry_env;
+        static int cz_env = -1;   // PDEHIP_JIT_CZ: chunks per wave tile (tuning aid)
+        if (cz_env < 0) { const char *e = getenv("PDEHIP_JIT_CZ"); cz_env = e ? atoi(e) : 0; }
+        if (cz_env > 0 && cz_env <= cz) cz = cz_env;
         auto n_tiles = [&](int ry_, int cz_) {
             const long per_plane = ((n.n[1] + ry_ - 1) / ry_) * ((n.n[2] + 64L * vec * cz_ - 1) / (64L * vec * cz_));
             return n.ndim == 3 ? per_plane * n.n[0] : per_plane;

@@ -254,6 +254,12 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
  * bit-identical to the sequence rhs_scaled + lincomb + rk4_combine, which remains the fallback. */
 int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full,
                     void *const *work5_host, double dt, void *stream);
+/* One Adams-Bashforth step (pde/solvers/adams_bashforth.py:40-47) in ONE sweep: rate_cur = rhs(y_in) (kept for the
+ * next step) and y_out = y_in + dt * (1.5 * rate_cur - 0.5 * rate_prev), bit-identical to pdehip_rhs_scaled(dt = 1) +
+ * pdehip_ab2_combine.  *fused = 0 and nothing launched where the stencil kernels do not carry the stage epilogue
+ * (1-D, odd rows, faces the two-level kernel does not cover for Cahn-Hilliard): the caller runs those two. */
+int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_full, void *y_out_full,
+                    void *rate_cur_full, const void *rate_prev_full, double dt, int *fused, void *stream);
 /* `nsteps` RK4 steps with fixed dt in place on y: the fixed-step loop (pde/backends/numba/_solvers.py:93-104) around
  * pdehip_rk4_step.  Small grids (launch-bound) replay a cached hipGraph of 8 steps, like pdehip_euler_run. */
 int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host,

@@ -114,6 +114,7 @@ struct StageFuse {
                          //    out2 = y + (k[0] + 2*k[1] + 2*k[2] + k)/6  (k is not stored; out2 may be y itself)
                          // 2: end of an RKF45 attempt  out2 = 4th-order state from y and k = {k1, k3, k4, k5}, *err = max-norm
                          //    of the error estimate with k6 = k  (k is not stored; *err must be zero before the launch)
+                         // 3: Adams-Bashforth step  out2 = y + c_new * (1.5*k - 0.5*k[0])  with k = the rate (also stored), c_new = dt
     const void *y;
     const void *k[5];    // earlier slopes, NULL-terminated
     double c[5], c_new;

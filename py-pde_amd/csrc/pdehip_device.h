@@ -112,6 +112,7 @@ struct LapArgs {
     //   st_kind 1: st_out = y + (k1 + 2*k2 + 2*k3 + k)/6, `out` is not written     (new state of RK4, runge_kutta.py:60)
     //   st_kind 2: st_out = y + c1*k1 + c3*k3 + c4*k4 + c5*k5 and *st_err = max |error estimate| with k6 = k; st_k = {k1, k3, k4, k5},
     //              `out` is not written                                          (end of an RKF45 attempt, runge_kutta.py:147-150)
+    //   st_kind 3: out = k (the rate, s2 = 1), st_out = y + st_c[5] * (1.5*k - 0.5*st_k[0])   (Adams-Bashforth step, adams_bashforth.py:44)
     int st_kind;
     double *st_err;
     const void *st_y;

@@ -237,7 +237,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
                    const StageFuse *stage, int *done)
 {
     if (done) *done = 0;
-    if (!handle || !in_full || (!out_full && !(stage && stage->kind != 0))) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
+    if (!handle || !in_full || (!out_full && !(stage && (stage->kind == 1 || stage->kind == 2)))) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
     if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_apply: at most 12 scalar parameters");
     Jit *j = static_cast<Jit *>(handle);
     NGrid n;

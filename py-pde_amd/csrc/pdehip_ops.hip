@@ -530,7 +530,7 @@ int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, doubl
     *done = false;
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
-    if (!in || (!out && !(stage && stage->kind != 0)) || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    if (!in || (!out && !(stage && (stage->kind == 1 || stage->kind == 2))) || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
     if (stage && euler) PDEHIP_FAIL(E_RUNTIME, "internal: a Runge-Kutta stage sweep computes the scaled slope");
     if (n.ndim < 2) return 0;
     InputBCs fc, fm;

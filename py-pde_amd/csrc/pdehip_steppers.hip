@@ -240,6 +240,23 @@ int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, vo
     return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, stream);
 }
 
+int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in, void *y_out, void *rate_cur,
+                    const void *rate_prev, double dt, int *fused, void *stream)
+{
+    PDEHIP_TRY(check_rhs(rhs));
+    if (!y_in || !y_out || !rate_cur || !rate_prev || !fused) PDEHIP_FAIL(E_VALUE, "ab2_step: NULL pointer");
+    if (y_in == y_out || rate_cur == rate_prev) PDEHIP_FAIL(E_VALUE, "ab2_step: aliased arrays");
+    *fused = 0;
+    // adams_bashforth.py:40-47 in ONE sweep: the rate of y_in (stored for the next step) and the new state from it
+    StageFuse sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.kind = 3; sf.y = y_in; sf.k[0] = rate_prev; sf.c_new = dt; sf.out2 = y_out;
+    bool done = false;
+    PDEHIP_TRY(rhs_stage(g, rhs, y_in, rate_cur, 1.0, sf, stream, &done));
+    *fused = done ? 1 : 0;
+    return 0;
+}
+
 int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, int64_t nsteps,
                    void *stream)
 {

@@ -161,6 +161,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_ch_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_ch_sweep": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i, _vp],
+    # Adams-Bashforth step in one sweep (device only: the oracle runs rhs_scaled + ab2_combine)
+    "ab2_step": [_pg, _pr, _vp, _vp, _vp, _vp, _d, C.POINTER(_i), _vp],
     # fixed-step RK4 loop (device only: the oracle loops over rk4_step)
     "rk4_run": [_pg, _pr, _vp, _pvp, _d, _i64, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)

@@ -608,7 +608,7 @@ class HipBackendMixin:
         rates = [DeviceArray(info), DeviceArray(info)]   # [current, previous], roles swap every step
         tmp = DeviceArray(info)
         minus_dt = (C.c_double * 1)(-dt)
-        first = [True]
+        first, one_sweep = [True], [True]
 
         def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
             steps = max(1, round((t_end - t_start) / dt))
@@ -618,10 +618,21 @@ class HipBackendMixin:
                 lib.lincomb(info.ref, 1, tmp.ptr, state_data.ptr, 1, minus_dt, ptr_array([rates[0]]), stream)
                 lib.rhs_scaled(info.ref, spec.ref, tmp.ptr, rates[1].ptr, 1.0, stream)
                 first[0] = False
+            cur, nxt = state_data, tmp
+            fused = C.c_int(0)
             for _ in range(steps):
-                lib.rhs_scaled(info.ref, spec.ref, state_data.ptr, rates[0].ptr, 1.0, stream)
-                lib.ab2_combine(info.ref, 1, state_data.ptr, rates[0].ptr, rates[1].ptr, dt, stream)
+                # rate and update in one sweep where the kernels cover it (state ping-pongs), else two kernels in place
+                if one_sweep[0]:
+                    lib.ab2_step(info.ref, spec.ref, cur.ptr, nxt.ptr, rates[0].ptr, rates[1].ptr, dt, C.byref(fused), stream)
+                    one_sweep[0] = bool(fused.value)
+                if one_sweep[0]:
+                    cur, nxt = nxt, cur
+                else:
+                    lib.rhs_scaled(info.ref, spec.ref, cur.ptr, rates[0].ptr, 1.0, stream)
+                    lib.ab2_combine(info.ref, 1, cur.ptr, rates[0].ptr, rates[1].ptr, dt, stream)
                 rates.reverse()
+            if cur is not state_data:
+                lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
             solver.info["steps"] += steps
             return state_data, t_start + (steps - 1) * dt + dt
 

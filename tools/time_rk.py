@@ -59,3 +59,22 @@ dt = 1e-6
 reps = int(os.environ.get("REPS", "10"))
 timeit(lambda: lib.rk4_step(info.ref, spec.ref, y.ptr, wp, dt, None), "rk4_step")
 timeit(lambda: lib.rkf45_attempt(info.ref, spec.ref, y.ptr, ynew.ptr, wp, dt, err.ptr, None), "rkf45_attempt")
+
+# Adams-Bashforth step: one sweep (pdehip_ab2_step) vs rate + combine kernels
+rates = [work[0], work[1]]
+nxt = work[2]
+fused = C.c_int(0)
+
+
+def ab_fused():
+    lib.ab2_step(info.ref, spec.ref, y.ptr, nxt.ptr, rates[0].ptr, rates[1].ptr, dt, C.byref(fused), None)
+
+
+def ab_separate():
+    lib.rhs_scaled(info.ref, spec.ref, y.ptr, rates[0].ptr, 1.0, None)
+    lib.ab2_combine(info.ref, 1, y.ptr, rates[0].ptr, rates[1].ptr, dt, None)
+
+
+ab_fused()
+timeit(ab_fused if fused.value else ab_separate, "adams-bashforth step, one sweep" if fused.value else "adams-bashforth step (sweep refused)")
+timeit(ab_separate, "adams-bashforth step, rate + combine kernels")

@@ -396,3 +396,36 @@ def test_rk4_run_through_the_captured_graph(backend, rng, kind, shape):
     for _ in range(20):
         O.rk4_step(g, orhs, yo, dt)
     np.testing.assert_array_equal(res.data, interior(grid, yo))
+
+
+def test_full_size_runge_kutta_sweeps_512cubed(backend):
+    """BASELINE size (512^3 fp64, periodic diffusion): one RK4 step and one RKF45 attempt through the one-sweep-per-stage
+    path.  Slabs of the results equal the oracle run on those slabs alone with 6 spare layers per side (every stage moves
+    an error at the slab end one layer inwards: 4 resp. 6 layers) - bit for bit; the periodic sum is conserved; the error
+    estimate is finite and at least the one of the compared slabs' inner layers."""
+    n, dt = 512, 0.05
+    grid = pde_hip.UnitGrid([n, n, n], periodic=True)
+    u = np.random.default_rng(1).random((n, n, n))
+    eq = pde_hip.DiffusionPDE(1.0)
+    spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, u))
+    info, lib = spec.info, backend._lib
+    y, ynew, err = DeviceArray(info).set_valid(u), DeviceArray(info), DeviceScalar()
+    work = [DeviceArray(info) for _ in range(7)]
+    lib.rkf45_attempt(info.ref, spec.ref, y.ptr, ynew.ptr, ptr_array(work), dt, err.ptr, None)
+    got45, e45 = ynew.get_valid(), err.value()
+    lib.rk4_step(info.ref, spec.ref, y.ptr, ptr_array(work[:5]), dt, None)
+    got4 = y.get_valid()
+    pad, keep = 6, 4
+    for lo in (0, 253, n - keep):
+        idx = np.arange(lo - pad, lo + keep + pad) % n
+        sub = pde_hip.CartesianGrid([[0, len(idx)], [0, n], [0, n]], [len(idx), n, n], periodic=[False, True, True])
+        bcs = sub.get_boundary_conditions({"x": {"derivative": 0}, "y": "periodic", "z": "periodic"})
+        rhs = O.make_rhs(_abi.RHS_DIFFUSION, 1.0, host_faces(bcs).c)
+        g = oracle_grid(sub)
+        new45, _ = O.rkf45_attempt(g, rhs, to_full(sub, u[idx]), dt)
+        np.testing.assert_array_equal(got45[lo:lo + keep], interior(sub, new45)[pad:pad + keep])
+        full4 = to_full(sub, u[idx])
+        O.rk4_step(g, rhs, full4, dt)
+        np.testing.assert_array_equal(got4[lo:lo + keep], interior(sub, full4)[pad:pad + keep])
+    assert np.isfinite(e45) and e45 > 0
+    assert abs(got45.sum() - u.sum()) < 1e-9 * u.sum() and abs(got4.sum() - u.sum()) < 1e-9 * u.sum()

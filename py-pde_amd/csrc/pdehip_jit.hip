@@ -195,7 +195,7 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     const int vec = dtype == PDEHIP_F64 ? 2 : 4;
     PDEHIP_TRY(compile_variant(j, "", true, tname, 1, 1, 1, false, false, nullptr));
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr));
-    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 2, 2, ndim == 3, true, nullptr, 0, true));
+    if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 1, 4, ndim == 3, true, nullptr, 0, true));   // stage sweeps: 1-row tiles
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr,
                                               j->body2.empty() ? E2_CUSTOM : E2_CUSTOM2));
     return 0;

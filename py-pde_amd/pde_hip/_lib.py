@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 
 from . import _abi
@@ -111,7 +112,7 @@ class _Lib:
 
 
 _LIB: _Lib | None = None
-_DEVICE_READY = False
+_DEVICE: int | None = None   # the HIP device this process drives (one process per GPU)
 
 
 def get_lib() -> _Lib:
@@ -131,14 +132,41 @@ def device_count() -> int:
     return n.value
 
 
+def current_device() -> int | None:
+    """Index of the device selected by the first `require_device` call (None before it)."""
+    return _DEVICE
+
+
 def require_device(device: int | None = None) -> _Lib:
-    """Return the library after making sure a HIP device is usable; raise loudly otherwise."""
-    global _DEVICE_READY
+    """Return the library after making sure a HIP device is usable; raise loudly otherwise.
+
+    The first call selects the device (``device`` or 0) for the whole process.  Buffers, grids and kernels all
+    run on that one device (HIP tracks the current device per host thread, so it is re-applied when another
+    thread calls in); asking for a different index later is refused instead of silently mixing devices:
+    multi-GPU runs use one process per GPU (``pde_hip/distributed.py``).
+    """
+    global _DEVICE
     lib = get_lib()
-    if not _DEVICE_READY or device is not None:
+    if _DEVICE is None:
         if device_count() < 1:
             msg = "hip backend: no HIP device visible (MI355X required; there is no CPU fallback)"
             raise RuntimeError(msg)
-        lib.set_device(0 if device is None else int(device))
-        _DEVICE_READY = True
+        dev = 0 if device is None else int(device)
+        lib.set_device(dev)
+        _DEVICE = dev
+        _threads_ready.add(threading.get_ident())
+    else:
+        if device is not None and int(device) != _DEVICE:
+            msg = (
+                f"hip backend: this process already drives HIP device {_DEVICE}; cannot switch to device {int(device)} "
+                "(start one process per GPU)"
+            )
+            raise RuntimeError(msg)
+        ident = threading.get_ident()
+        if ident not in _threads_ready:
+            lib.set_device(_DEVICE)   # the current device is a per-thread setting of the HIP runtime
+            _threads_ready.add(ident)
     return lib
+
+
+_threads_ready: set[int] = set()

@@ -152,8 +152,68 @@ class RhsSpec:
             self.c.scratch_mu = self.mu.ptr
 
     @property
+    def time_dependent(self) -> bool:
+        """Faces whose coefficient arrays must be refreshed when the time changes (expression BCs with `t`)."""
+        return any(getattr(tb, "time_dependent", False) for tb in (self.bc_c, self.bc_mu) if tb is not None)
+
+    def update(self, t: float) -> None:
+        for tb in (self.bc_c, self.bc_mu):
+            if tb is not None and getattr(tb, "time_dependent", False):
+                tb.update({"t": t})
+
+    @property
     def ref(self):
         return C.byref(self.c)
+
+
+def pde_bcs_table(eq) -> dict[str, Any]:
+    """``{"var:operator": bc}`` of an expression PDE in lookup order.
+
+    The reference's ``pde.PDE`` stores exactly this as ``eq.bcs`` (``pde/pdes/pde.py:232-264``: the entries of
+    ``bc_ops`` in insertion order, then ``"*:*"`` = ``bc``; keys without a variable get the first one).  Objects that
+    only carry ``bc`` / ``bc_ops`` (older mirror instances) are normalised the same way.  Anything else is refused:
+    silently falling back to default conditions would give wrong results.
+    """
+    bcs = getattr(eq, "bcs", None)
+    if isinstance(bcs, dict):
+        return bcs
+    if not hasattr(eq, "bc"):
+        msg = f"hip backend: cannot determine the boundary conditions of {eq.__class__.__name__} (no `bcs` / `bc` attribute)"
+        raise NotImplementedError(msg)
+    variables = list(getattr(eq, "rhs", {}))
+    table: dict[str, Any] = {}
+    for key, value in dict(getattr(eq, "bc_ops", None) or {}).items():
+        parts = key.replace(".", ":").split(":")
+        if len(parts) == 1:
+            key = f"{variables[0]}:{key}"
+        elif len(parts) != 2:
+            msg = f'Cannot parse boundary condition "{key}"'
+            raise ValueError(msg)
+        else:
+            key = ":".join(parts)
+        table[key] = value
+    table["*:*"] = eq.bc
+    return table
+
+
+def pde_bc_for(eq, var: str, operator: str):
+    """Boundary condition the reference applies to ``operator`` in the equation of ``var``: the FIRST entry of
+    ``eq.bcs`` whose variable and operator match, ``*`` being a wildcard (``pde/pdes/pde.py:329-343``); one condition
+    per operator NAME, used for every (also nested) application of it."""
+    for key, bc in pde_bcs_table(eq).items():
+        bc_var, bc_func = key.split(":")
+        if bc_var in (var, "*") and bc_func in (operator, "*"):
+            return bc
+    msg = f"Could not find suitable boundary condition for function `{operator}` applied in equation for `{var}`"
+    raise RuntimeError(msg)
+
+
+def pde_expression(eq, var: str) -> str:
+    """Expression string of ``var`` after the reference's shorthand replacement (``pde/pdes/pde.py:47-53``, ``:195-201``)."""
+    exprs = getattr(eq, "expressions", None)
+    if isinstance(exprs, dict) and var in exprs:
+        return str(exprs[var])
+    return str(dict(eq.rhs)[var])
 
 
 def _match_expression_rhs(expr_str: str, var: str, consts: dict[str, Any]) -> tuple[int, float] | None:
@@ -184,6 +244,49 @@ def _match_expression_rhs(expr_str: str, var: str, consts: dict[str, Any]) -> tu
     return None
 
 
+class SpecRhs:
+    """A fused class right-hand side (:class:`RhsSpec`) behind the evaluator interface of
+    :class:`~pde_hip.expr.ExpressionRhs`, for steppers driven from Python: every evaluation first refreshes the
+    coefficient arrays of time-dependent faces (``args={"t": t}`` of the reference, ``pde/pdes/diffusion.py:119-121``)."""
+
+    def __init__(self, backend, spec: RhsSpec):
+        self.backend, self.spec, self.info, self.lib = backend, spec, spec.info, backend._lib
+
+    def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
+        spec, st = self.spec, self.backend.stream
+        spec.update(t)
+        if wrap == "euler":
+            res = C.c_void_p()
+            self.lib.euler_run(self.info.ref, spec.ref, state.ptr, out.ptr, dt, 1, C.byref(res), st)
+            assert res.value == out.ptr
+        else:
+            self.lib.rhs_scaled(self.info.ref, spec.ref, state.ptr, out.ptr, 1.0 if wrap == "rate" else dt, st)
+
+    def apply_stage(self, state, k_out, dt, t, kind, y, ks, coefs, c_new, out2, err=None) -> bool:
+        self.apply(state, k_out, "scaled", dt, t)
+        return False   # the caller combines with the pointwise kernels
+
+    def euler2(self, state, out, dt: float) -> bool:
+        return False   # the second level would need the faces at t + dt
+
+
+def make_face_setter(backend, bcs, comp_shape: tuple[int, ...] = ()):
+    """``f(data_full: DeviceArray, args)`` setting all ghost faces of one field (constant-coefficient faces in one
+    launch of the ghost kernel; expression faces — ``pde_hip/bc_expr.py`` — refresh their coefficient arrays first when
+    they depend on time)."""
+    from .bc_expr import convert_bcs_with_expressions
+
+    table = convert_bcs_with_expressions(bcs, comp_shape)
+    lib = backend._lib
+
+    def set_faces(data_full: DeviceArray, args=None) -> None:
+        table.update(args)
+        lib.set_ghost_cells(data_full.info.ref, data_full.ncomp, table.c, data_full.ptr, backend.stream)
+
+    set_faces.table = table   # type: ignore[attr-defined]
+    return set_faces
+
+
 class HipBackendMixin:
     """Implementation shared by the stand-alone and the py-pde-plugin backend classes."""
 
@@ -193,17 +296,36 @@ class HipBackendMixin:
 
     # set by concrete classes: _operators (per class), name, config
     def _hip_init(self, device: int | None = None) -> None:
-        self._lib = require_device(device)
-        self.device = 0 if device is None else int(device)
+        """Remember the requested device.  NOTHING here touches the HIP runtime: py-pde instantiates every
+        registered backend just to list operators (``pde/grids/base.py:1128-1150``) and only tolerates
+        ``ImportError`` there (``pde/backends/registry.py:241-245``), so construction must succeed on a box
+        without a GPU.  The first compute call selects the device and raises ``RuntimeError`` without one."""
+        self._device_request = None if device is None else int(device)
         self.stream = None  # HIP default stream; multi-GPU paths create their own
         self._info_cache: dict[tuple, GridInfo] = {}
+
+    @property
+    def _lib(self):
+        """libpdehip with the device of this backend selected (loud failure without library / GPU)."""
+        return require_device(self._device_request)
+
+    @property
+    def device(self) -> int:
+        return 0 if self._device_request is None else self._device_request
+
+    @property
+    def device_name(self) -> str:
         buf = C.create_string_buffer(256)
         self._lib.device_name(buf, 256)
-        self.device_name = buf.value.decode()
+        return buf.value.decode()
 
     @property
     def info(self) -> dict[str, Any]:
-        return {"name": self.name, "implementation": self.implementation, "device": self.device_name}
+        try:
+            device = self.device_name
+        except (RuntimeError, ImportError) as err:   # diagnostics must not fail on a box without GPU
+            device = f"unavailable ({err})"
+        return {"name": self.name, "implementation": self.implementation, "device": device}
 
     # --- helpers -----------------------------------------------------------------------------
     def grid_info(self, grid, dtype) -> GridInfo:
@@ -225,12 +347,14 @@ class HipBackendMixin:
 
     # --- data movement -------------------------------------------------------------------------
     def numpy_to_native(self, value, grid=None):
-        """Valid host data → :class:`DeviceArray` (needs ``grid`` to know the geometry)."""
+        """Valid host data → :class:`DeviceArray`.  py-pde calls this without a grid (``pde/backends/base.py:186-194``;
+        e.g. ``ScipySolver``, ``pde/solvers/scipy.py:77-79``); the geometry is then unknown here, so the host array is
+        passed through and the native callables of this backend (operators, right-hand sides, ghost-cell setters) — which
+        know their grid — move host input to the device themselves."""
         if isinstance(value, DeviceArray) or not isinstance(value, np.ndarray):
             return value
         if grid is None:
-            msg = "hip backend: numpy_to_native needs the grid of the data"
-            raise TypeError(msg)
+            return value
         info = self.grid_info(grid, value.dtype)
         comp_shape = value.shape[: value.ndim - len(info.shape)]
         return DeviceArray(info, comp_shape).set_valid(value, self.stream)
@@ -299,21 +423,39 @@ class HipBackendMixin:
 
     # --- ghost cells (pde/backends/base.py:378-429) -------------------------------------------------
     def make_ghost_cell_setter(self, bcs):
-        """``f(data_full: DeviceArray, args=None)`` — one fused kernel for all faces."""
-        tables: dict[tuple, FaceTable] = {}
-        lib = self._lib
+        """``f(data_full, args=None)`` — one fused kernel for all faces.
 
-        def ghost_cell_setter(data_full: DeviceArray, args=None) -> None:
+        ``data_full`` is a :class:`DeviceArray` (the normal case inside steppers and operators) or, like the reference's
+        setters (``pde/backends/numba/backend.py:342-404``), a host full array (``field._data_full``) that is updated in
+        place through a device round trip.
+        """
+        tables: dict[tuple, Any] = {}
+        grid = bcs.grid
+        nd = len(grid.shape)
+
+        def ghost_cell_setter(data_full, args=None) -> None:
+            if not isinstance(data_full, DeviceArray):
+                host = data_full
+                info = self.grid_info(grid, host.dtype)
+                dev = DeviceArray(info, host.shape[: host.ndim - nd]).set_hostfull(host, self.stream)
+                ghost_cell_setter(dev, args=args)
+                host[...] = dev.get_hostfull(stream=self.stream)
+                return
             key = data_full.comp_shape
             if key not in tables:
-                tables[key] = convert_bcs(bcs, key)
-            lib.set_ghost_cells(data_full.info.ref, data_full.ncomp, tables[key].c, data_full.ptr, self.stream)
+                tables[key] = make_face_setter(self, bcs, key)
+            tables[key](data_full, args)
 
         return ghost_cell_setter
 
     def make_valid_data_setter(self, grid, rank: int = 0):
-        def set_valid(data_full: DeviceArray, data_valid, args=None) -> None:
-            if isinstance(data_valid, DeviceArray):
+        nd = len(grid.shape)
+
+        def set_valid(data_full, data_valid, args=None) -> None:
+            if not isinstance(data_full, DeviceArray):
+                # host full array: plain interior assignment (pde/backends/numpy/backend.py:72-115)
+                data_full[(...,) + (slice(1, -1),) * nd] = np.asarray(data_valid)
+            elif isinstance(data_valid, DeviceArray):
                 # interior copy on the device: out = y + 0 is not bit-safe for -0.0, so copy bytes
                 self._lib.memcpy_d2d(data_full.ptr, data_valid.ptr, data_full.nbytes, self.stream)
             else:
@@ -325,7 +467,7 @@ class HipBackendMixin:
         set_valid = self.make_valid_data_setter(bcs.grid, 0)
         set_bcs = self.make_ghost_cell_setter(bcs)
 
-        def set_valid_and_bcs(data_full: DeviceArray, data_valid, args=None) -> None:
+        def set_valid_and_bcs(data_full, data_valid, args=None) -> None:
             set_valid(data_full, data_valid)
             set_bcs(data_full, args=args)
 
@@ -397,6 +539,8 @@ class HipBackendMixin:
     # --- PDE right hand sides ---------------------------------------------------------------------------
     def make_rhs_spec(self, eq, state) -> RhsSpec:
         """Map a PDE object onto one of the fused device right-hand sides."""
+        from .bc_expr import convert_bcs_with_expressions as _faces
+
         name = eq.__class__.__name__
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
@@ -408,39 +552,51 @@ class HipBackendMixin:
             raise NotImplementedError(msg)
         if name == "DiffusionPDE":
             bcs = grid.get_boundary_conditions(eq.bc, rank=0)
-            return RhsSpec(_abi.RHS_DIFFUSION, eq.diffusivity, info, convert_bcs(bcs))
+            return RhsSpec(_abi.RHS_DIFFUSION, eq.diffusivity, info, _faces(bcs))
         if name == "CahnHilliardPDE":
             bc_c = grid.get_boundary_conditions(eq.bc_c, rank=0)
             bc_mu = grid.get_boundary_conditions(eq.bc_mu, rank=0)
-            return RhsSpec(_abi.RHS_CAHN_HILLIARD, eq.interface_width, info, convert_bcs(bc_c), convert_bcs(bc_mu))
+            return RhsSpec(_abi.RHS_CAHN_HILLIARD, eq.interface_width, info, _faces(bc_c), _faces(bc_mu))
         if name == "PDE":
             rhs = dict(eq.rhs)
             if len(rhs) != 1:
                 msg = "hip backend supports expression PDEs of a single scalar variable"
                 raise NotImplementedError(msg)
-            (var, expr), = rhs.items()
-            match = _match_expression_rhs(str(expr), var, dict(getattr(eq, "consts", {}) or {}))
+            (var,) = rhs
+            expr = pde_expression(eq, var)
+            match = _match_expression_rhs(expr, var, dict(getattr(eq, "consts", {}) or {}))
             if match is None:
                 msg = f"hip backend has no fused kernel for the expression `{expr}`"
                 raise NotImplementedError(msg)
-            bc_data = getattr(eq, "bc", "auto_periodic_neumann")
-            bc_ops = dict(getattr(eq, "bc_ops", {}) or {})
-            bc_data = bc_ops.get(f"{var}:laplace", bc_ops.get("*:laplace", bc_ops.get("*:*", bc_data)))
-            bcs = grid.get_boundary_conditions(bc_data, rank=0)
+            # ONE condition per operator name (pde/pdes/pde.py:329-343): the inner and the outer laplace of the
+            # Cahn-Hilliard form both use it
+            bcs = grid.get_boundary_conditions(pde_bc_for(eq, var, "laplace"), rank=0)
             kind, param = match
-            table = convert_bcs(bcs)
-            return RhsSpec(kind, param, info, table, convert_bcs(bcs) if kind == _abi.RHS_CAHN_HILLIARD else None)
+            table = _faces(bcs)
+            return RhsSpec(kind, param, info, table, _faces(bcs) if kind == _abi.RHS_CAHN_HILLIARD else None)
         msg = f"hip backend has no fused right-hand side for {name}"
         raise NotImplementedError(msg)
 
     def make_pde_rhs(self, eq, state):
-        """``rhs(state_native, t) -> rate_native`` (base.py:634-651)."""
+        """``rhs(state_native, t) -> rate_native`` (base.py:634-651).
+
+        ``state_native`` is a :class:`DeviceArray`; host valid data (what ``numpy_to_native`` passes through when it is
+        called without a grid, e.g. by ``ScipySolver``) is uploaded here, where the grid is known."""
+        grid = state.grid
+        info = self.grid_info(grid, state.dtype)
+
+        def to_device(state_data):
+            if isinstance(state_data, DeviceArray):
+                return state_data
+            return DeviceArray(info).set_valid(np.asarray(state_data, dtype=info.dtype), self.stream)
+
         try:
             spec = self.make_rhs_spec(eq, state)
         except NotImplementedError:
             erhs = self.make_expression_rhs(eq, state)   # raises NotImplementedError itself if unsupported
 
-            def expr_rhs(state_data: DeviceArray, t: float = 0) -> DeviceArray:
+            def expr_rhs(state_data, t: float = 0) -> DeviceArray:
+                state_data = to_device(state_data)
                 out = state_data.empty_like()
                 erhs.apply(state_data, out, "rate", 0.0, float(t))
                 return out
@@ -449,8 +605,10 @@ class HipBackendMixin:
             return expr_rhs
         lib = self._lib
 
-        def pde_rhs(state_data: DeviceArray, t: float = 0) -> DeviceArray:
+        def pde_rhs(state_data, t: float = 0) -> DeviceArray:
+            state_data = to_device(state_data)
             out = state_data.empty_like()
+            spec.update(float(t))
             # 1.0 * (D * lap) == D * lap exactly
             lib.rhs_scaled(spec.info.ref, spec.ref, state_data.ptr, out.ptr, 1.0, self.stream)
             return out
@@ -460,6 +618,7 @@ class HipBackendMixin:
 
     def make_expression_rhs(self, eq, state):
         """Generic expression PDE (pde/pdes/pde.py) -> run-time specialised kernels (pde_hip/expr.py)."""
+        from .bc_expr import convert_bcs_with_expressions
         from .expr import ExpressionPlan, ExpressionRhs
 
         if eq.__class__.__name__ != "PDE":
@@ -475,24 +634,38 @@ class HipBackendMixin:
         if len(rhs) != 1:
             msg = "hip backend supports expression PDEs of a single scalar variable"
             raise NotImplementedError(msg)
-        (var, expr), = rhs.items()
-        plan = ExpressionPlan(str(expr), var, dict(getattr(eq, "consts", {}) or {}))
+        (var,) = rhs
+        plan = ExpressionPlan(pde_expression(eq, var), var, dict(getattr(eq, "consts", {}) or {}))
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
-        bc_default = getattr(eq, "bc", "auto_periodic_neumann")
-        bc_ops = dict(getattr(eq, "bc_ops", {}) or {})
-        bc_state = bc_ops.get(f"{var}:laplace", bc_ops.get(f"{var}:*", bc_ops.get("*:laplace", bc_ops.get("*:*", bc_default))))
-        faces_state = convert_bcs(grid.get_boundary_conditions(bc_state, rank=0))
-        faces_tmp = convert_bcs(grid.get_boundary_conditions(bc_ops.get("*:*", bc_default), rank=0))
-        return ExpressionRhs(self, plan, info, faces_state, faces_tmp)
+        # one face table per operator NAME, like the reference (pde/pdes/pde.py:329-343)
+        tables: dict[str, FaceTable] = {}
+        specs: list[tuple[Any, FaceTable]] = []
+        for op in plan.operators_used:
+            bc = pde_bc_for(eq, var, op)
+            for other, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
+                try:
+                    same = other is bc or bool(other == bc)
+                except (ValueError, TypeError):   # array-valued entries do not compare to a bool
+                    same = False
+                if same:
+                    tables[op] = table
+                    break
+            else:
+                tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
+                specs.append((bc, tables[op]))
+        return ExpressionRhs(self, plan, info, tables)
 
-    def _make_expression_stepper(self, solver, state):
+    def _make_expression_stepper(self, solver, state, erhs=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
         (pde/solvers/euler.py:172-175, runge_kutta.py:52-61, :135-153) with the RHS evaluated by the
-        run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass."""
+        run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass.
+        ``erhs``: any evaluator with the interface of :class:`~pde_hip.expr.ExpressionRhs` (default: the expression
+        of ``solver.pde``; :class:`SpecRhs` for the class PDEs when their BCs depend on time)."""
         from .solvers import OnlineStatistics, make_dt_adjuster
 
-        erhs = self.make_expression_rhs(solver.pde, state)
+        if erhs is None:
+            erhs = self.make_expression_rhs(solver.pde, state)
         info, lib, stream = erhs.info, self._lib, self.stream
         is_rk = solver.__class__.__name__ == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
@@ -668,6 +841,13 @@ class HipBackendMixin:
             if solver_name == "AdamsBashforthSolver":
                 raise
             return self._make_expression_stepper(solver, state)   # generic expression PDE
+        if spec.time_dependent:
+            # faces with explicit time dependence: the C loops do not know t, so the steps are driven from here and the
+            # coefficient arrays are refreshed before every right-hand side
+            if solver_name == "AdamsBashforthSolver":
+                msg = f"Backend `{self.name}` does not support time-dependent boundary conditions with {solver_name}"
+                raise NotImplementedError(msg)
+            return self._make_expression_stepper(solver, state, SpecRhs(self, spec))
         if solver_name == "AdamsBashforthSolver":
             return self._make_adams_bashforth_stepper(solver, spec)
         info, lib, stream = spec.info, self._lib, self.stream

@@ -1,0 +1,155 @@
+"""Expression boundary conditions (``virtual_point`` / ``value_expression`` / ``derivative_expression`` /
+``mixed_expression``) for the hip backend.
+
+Reference semantics (``pde/grids/boundaries/local.py:766-1150``, numba twin
+``pde/backends/numba/_boundaries.py:256-394``, torch twin ``pde/backends/torch/_boundaries.py:258-345``): the
+virtual point of every face cell is ``F(value, dx, *coords, t)`` where ``value`` is the field in the adjacent cell
+(or ``value_cell``), ``coords`` the wall point and ``t`` the time handed over as ``args={"t": t}``; ``F`` is
+``<expr>``, ``2*(<expr>) - value``, ``dx*(<expr>) + value`` or the Robin combination (``local.py:849-866``).
+
+Every ``F`` that is affine in ``value`` — all value / derivative conditions and mixed conditions whose coefficients do
+not read the field — is exactly the constant-coefficient form the ghost kernel and the stencil kernels already evaluate,
+
+    ghost = A(dx, coords, t) + B(dx, coords, t) * value[index]
+
+with per-face-cell coefficient arrays (``PDEHIP_BCF_ARRAYS``, ``include/pdehip.h``).  ``A`` and ``B`` are split off
+symbolically (``B = dF/dvalue``, ``A = F(value=0)``) and evaluated on the wall points once (time independent: the face
+then costs nothing extra in the time loop) or whenever the time changes (``ExprFaceTable.update``).  Conditions that are
+non-linear in ``value`` or given as Python callables raise ``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from . import _abi
+
+EXPRESSION_BC_CLASSES = {"ExpressionBC", "ExpressionValueBC", "ExpressionDerivativeBC", "ExpressionMixedBC"}
+
+
+def is_expression_bc(bc) -> bool:
+    return any(c.__name__ in EXPRESSION_BC_CLASSES for c in type(bc).__mro__)
+
+
+class _AffineFace:
+    """``A`` and ``B`` of one expression face as numpy callables of ``t``."""
+
+    def __init__(self, bc):
+        import sympy as sp
+
+        if getattr(bc, "_is_func", False):
+            msg = "hip backend: boundary conditions given as Python functions cannot run on the device (use an expression string)"
+            raise NotImplementedError(msg)
+        if getattr(bc, "rank", 0) != 0:
+            msg = "Expression boundary conditions only work for scalar conditions"
+            raise NotImplementedError(msg)
+        grid = bc.grid
+        expr = sp.sympify(bc._func_expression._sympy_expr)
+        names = ["value", "dx", *grid.axes, "t"]
+        by_name = {s.name: s for s in expr.free_symbols}
+        unknown = set(by_name) - set(names)
+        if unknown:
+            msg = f"hip backend: unknown symbol(s) {sorted(unknown)} in boundary expression `{expr}`"
+            raise NotImplementedError(msg)
+        value = by_name.get("value", sp.Symbol("value"))
+        slope = sp.diff(expr, value)
+        if slope.has(value):
+            msg = f"hip backend: boundary expression `{expr}` is not linear in `value` (needs run-time code generation)"
+            raise NotImplementedError(msg)
+        offset = expr.subs(value, 0)
+        args = [by_name.get(n, sp.Symbol(n)) for n in names[1:]]
+        self._offset = sp.lambdify(args, offset, modules="numpy")
+        self._slope = sp.lambdify(args, slope, modules="numpy")
+        self.time_dependent = "t" in by_name
+        self.dx = float(grid.discretization[bc.axis])
+        coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
+        self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
+        self.face_shape = self.coords[0].shape if self.coords else ()
+        index = int(bc._get_value_cell_index(with_ghost_cells=False))
+        self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
+
+    def evaluate(self, t: float) -> tuple[np.ndarray, np.ndarray]:
+        with np.errstate(all="ignore"):
+            a = np.asarray(self._offset(self.dx, *self.coords, t), dtype=np.float64)
+            b = np.asarray(self._slope(self.dx, *self.coords, t), dtype=np.float64)
+        return (np.array(np.broadcast_to(a, self.face_shape), dtype=np.float64, order="C"), np.array(np.broadcast_to(b, self.face_shape), dtype=np.float64, order="C"))
+
+
+class ExprFaceTable:
+    """Face table (``.c`` = ``pdehip_bc_face_t[6]``) whose expression faces can be refreshed for a new time."""
+
+    def __init__(self, table, dynamic: list[tuple[_AffineFace, Any, Any]], write):
+        self._table = table
+        self.c = table.c
+        self.keepalive = table.keepalive
+        self._dynamic = dynamic          # (face evaluator, const buffer, factor buffer) of time-dependent faces
+        self._write = write
+        self._t: float | None = None
+
+    @property
+    def time_dependent(self) -> bool:
+        return bool(self._dynamic)
+
+    def copy_into(self, dst) -> None:
+        self._table.copy_into(dst)
+
+    def update(self, args=None) -> None:
+        """Re-evaluate the coefficient arrays of time-dependent faces for ``args["t"]`` (no-op otherwise)."""
+        if not self._dynamic:
+            return
+        if args is None:
+            # same contract as the reference (pde/grids/boundaries/local.py:1139-1146)
+            msg = ("Require value for `t` for time-dependent BC. The value must be passed explicitly via `args` when "
+                   "calling a differential operator.")
+            raise RuntimeError(msg)
+        t = float(args["t"])
+        if self._t is not None and t == self._t:
+            return
+        for face, buf_a, buf_b in self._dynamic:
+            a, b = face.evaluate(t)
+            self._write(buf_a, a)
+            self._write(buf_b, b)
+        self._t = t
+
+
+def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None) -> ExprFaceTable:
+    """``convert_bcs`` that also lowers expression conditions (affine in ``value``) onto coefficient arrays."""
+    from ._lib import require_device
+    from .backend import _upload_f64, convert_bcs
+
+    if upload is None:
+        upload = _upload_f64
+
+    def write(buf, arr: np.ndarray) -> None:
+        host = getattr(buf, "arr", None)
+        if host is not None:                      # host-side tables of the test harness
+            host[...] = arr.reshape(host.shape)
+        else:
+            require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None)
+
+    expr_faces: dict[tuple[int, bool], Any] = {}
+    if hasattr(bcs, "__iter__"):
+        for ax, bc_axis in enumerate(bcs):
+            for upper, bc in ((False, bc_axis.low), (True, bc_axis.high)):
+                if is_expression_bc(bc) and not (skip and (ax, upper) in skip):
+                    expr_faces[(ax, upper)] = bc
+    table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload)
+    dynamic = []
+    for (ax, upper), bc in expr_faces.items():
+        if comp_shape:
+            msg = "Expression boundary conditions only work for scalar conditions"
+            raise NotImplementedError(msg)
+        face = _AffineFace(bc)
+        a, b = face.evaluate(0.0)
+        buf_a, buf_b = upload(a), upload(b)
+        table.keepalive += [buf_a, buf_b]
+        entry = table.c[2 * ax + int(upper)]
+        entry.kind = _abi.BC_ORDER1
+        entry.flags = _abi.BCF_ARRAYS
+        entry.index1, entry.index2 = face.index, 0
+        entry.const_arr, entry.factor1_arr = buf_a.ptr, buf_b.ptr
+        if face.time_dependent:
+            dynamic.append((face, buf_a, buf_b))
+    return ExprFaceTable(table, dynamic, write)

@@ -180,18 +180,19 @@ class SlabStepper:
             bc_mu = grid.get_boundary_conditions(eq.bc_mu, rank=0)
         elif name == "PDE":
             # expression PDEs that map onto the fused right-hand sides (BASELINE config 5)
-            from .backend import _match_expression_rhs
+            from .backend import _match_expression_rhs, pde_bc_for, pde_expression
 
             rhs = dict(eq.rhs)
             match = None
             if len(rhs) == 1:
-                (var, expr), = rhs.items()
-                match = _match_expression_rhs(str(expr), var, dict(getattr(eq, "consts", {}) or {}))
+                (var,) = rhs
+                match = _match_expression_rhs(pde_expression(eq, var), var, dict(getattr(eq, "consts", {}) or {}))
             if match is None:
                 msg = "slab stepper supports expression PDEs of the Diffusion / Cahn-Hilliard form"
                 raise NotImplementedError(msg)
             self.kind, self.param = match
-            bc_c = bc_mu = grid.get_boundary_conditions(getattr(eq, "bc", "auto_periodic_neumann"), rank=0)
+            # one condition per operator name, inner and outer laplace alike (pde/pdes/pde.py:329-343)
+            bc_c = bc_mu = grid.get_boundary_conditions(pde_bc_for(eq, var, "laplace"), rank=0)
         else:
             msg = f"slab stepper has no fused right-hand side for {name}"
             raise NotImplementedError(msg)

@@ -75,6 +75,7 @@ class ExpressionPlan:
             msg = f"unknown symbol(s) {sorted(free)} in `{expr_str}` (pass them in `consts`)"
             raise ValueError(msg)
         self.uses_time = self._t in expr.free_symbols
+        self.operators_used = sorted({f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)})
         self.passes: list[_Pass] = []
         self._ntmp = 0
         self._memo: dict[Any, str] = {}
@@ -210,20 +211,41 @@ class ExpressionPlan:
 class ExpressionRhs:
     """Device evaluation of an :class:`ExpressionPlan` (kernels compiled lazily, cached per wrap mode)."""
 
-    def __init__(self, backend, plan: ExpressionPlan, info, faces_state, faces_tmp):
+    def __init__(self, backend, plan: ExpressionPlan, info, tables: dict):
+        """``tables``: operator name -> face table.  The reference applies ONE boundary condition per operator name to
+        every application of that operator, nested ones included (``pde/pdes/pde.py:329-343``); a pass therefore takes
+        the table of the operator(s) it evaluates.  Operators with equal conditions share one table object."""
         from .device import DeviceArray
 
         self.backend, self.plan, self.info = backend, plan, info
         self.lib = backend._lib
-        self.faces = {"state": faces_state}
+        self.tables = tables
+        self.pass_faces = []
+        sp = _sympy()
+        for p in plan.passes:
+            ops = sorted({a.func.__name__ for a in p.expr.atoms(sp.core.function.AppliedUndef)})
+            distinct = {id(tables[o]): tables[o] for o in ops}
+            if len(distinct) > 1:
+                msg = f"hip backend: operators {ops} with different boundary conditions on the same field cannot share one sweep"
+                raise NotImplementedError(msg)
+            self.pass_faces.append(next(iter(distinct.values())) if distinct else None)
         self.tmps = {}
         for p in plan.passes:
             if p.out != "out":
                 self.tmps[p.out] = DeviceArray(info)
-                self.faces[p.out] = faces_tmp
+        self._dynamic = [tb for tb in {id(tb): tb for tb in tables.values()}.values() if getattr(tb, "time_dependent", False)]
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
-        self._two_ok: bool | None = None
+        self._two_ok: bool | None = False if self._dynamic else None   # the second level would need the faces at t + dt
         self._fused: dict[str, C.c_void_p | None] = {}
+
+    def _update_faces(self, t: float) -> None:
+        """Coefficient arrays of faces with explicit time dependence (expression BCs, ``pde_hip/bc_expr.py``)."""
+        for tb in self._dynamic:
+            tb.update({"t": t})
+
+    def _faces(self, index: int):
+        t = self.pass_faces[index]
+        return None if t is None else t.c
 
     def _kernel(self, index: int, wrap: str):
         key = (index, wrap if self.plan.passes[index].out == "out" else "rate")
@@ -250,6 +272,7 @@ class ExpressionRhs:
         """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler)."""
         arrays = {"state": state, "out": out, **self.tmps}
         params = (C.c_double * 2)(dt, t)
+        self._update_faces(t)
         if self._fused2(state, out, wrap, params):
             return
         for i, p in enumerate(self.plan.passes):
@@ -257,7 +280,7 @@ class ExpressionRhs:
             ex = (C.c_void_p * 3)()
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
-            self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+            self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self._faces(i), self.backend.stream)
 
     def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:
         """k = dt*F(state) and, in the same sweep, the Runge-Kutta combination that follows it (``pdehip_jit_apply_stage``:
@@ -270,6 +293,7 @@ class ExpressionRhs:
             return False
         arrays = {"state": state, "out": k_out, **self.tmps}
         params = (C.c_double * 2)(dt, t)
+        self._update_faces(t)
         last = len(self.plan.passes) - 1
         for i, p in enumerate(self.plan.passes):
             h, extras = self._kernel(i, "scaled")
@@ -277,16 +301,16 @@ class ExpressionRhs:
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
             if i < last:
-                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self._faces(i), self.backend.stream)
                 continue
             done = C.c_int(0)
             kp = (C.c_void_p * max(1, len(ks)))(*[k.ptr for k in ks])
             cf = (C.c_double * max(1, len(ks)))(*(list(coefs) if kind == 0 else [0.0] * len(ks)))
-            self.lib.jit_apply_stage(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self.faces[p.src].c, kind, y.ptr, len(ks), kp,
+            self.lib.jit_apply_stage(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self._faces(i), kind, y.ptr, len(ks), kp,
                                      cf, c_new, out2.ptr, err.ptr if err is not None else None, C.byref(done), self.backend.stream)
             if not done.value:
                 self._stage_ok = False
-                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self.faces[p.src].c, self.backend.stream)
+                self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self._faces(i), self.backend.stream)
                 return False
         return True
 
@@ -294,7 +318,8 @@ class ExpressionRhs:
         if wrap not in self._fused:
             h = None
             ps = self.plan.passes
-            if len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out":
+            if (len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out"
+                    and self.pass_faces[1] is not None):
                 body1, ex1 = self.plan.epilogue(ps[0], "rate")
                 body2, ex2 = self.plan.epilogue(ps[1], wrap)
                 if not ex1 and ex2 in ([], ["state"]):
@@ -310,8 +335,9 @@ class ExpressionRhs:
         if h is None:
             return False
         done = C.c_int(0)
-        tmp_name = self.plan.passes[0].out
-        self.lib.jit_fused2(h, self.info.ref, state.ptr, out.ptr, params, 2, self.faces["state"].c, self.faces[tmp_name].c,
+        faces_tmp = self.pass_faces[1]
+        faces_u = self.pass_faces[0] or faces_tmp   # a first pass without operators never reads the halo of u
+        self.lib.jit_fused2(h, self.info.ref, state.ptr, out.ptr, params, 2, faces_u.c, faces_tmp.c,
                             C.byref(done), self.backend.stream)
         if not done.value:
             self.lib.jit_destroy(h)
@@ -324,7 +350,8 @@ class ExpressionRhs:
         (nothing done) when the expression, the grid or the BCs are not covered."""
         if self._two_ok is None:
             p = self.plan.passes[0]
-            self._two_ok = len(self.plan.passes) == 1 and p.src == "state" and not p.extras and not self.plan.uses_time
+            self._two_ok = (len(self.plan.passes) == 1 and p.src == "state" and not p.extras and not self.plan.uses_time
+                            and self.pass_faces[0] is not None)
         if not self._two_ok:
             return False
         h, extras = self._kernel(0, "euler")
@@ -333,7 +360,7 @@ class ExpressionRhs:
             return False
         params = (C.c_double * 2)(dt, 0.0)
         done = C.c_int(0)
-        self.lib.jit_euler2(h, self.info.ref, state.ptr, out.ptr, params, 2, self.faces["state"].c, C.byref(done), self.backend.stream)
+        self.lib.jit_euler2(h, self.info.ref, state.ptr, out.ptr, params, 2, self.pass_faces[0].c, C.byref(done), self.backend.stream)
         if not done.value:
             self._two_ok = False
         return bool(done.value)

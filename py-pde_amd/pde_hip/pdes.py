@@ -101,9 +101,31 @@ class PDE(PDEBase):
     def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None):
         super().__init__()
         self.rhs = dict(rhs)
-        self.bc = bc
-        self.bc_ops = dict(bc_ops or {})
+        self.variables = tuple(self.rhs)
         self.consts = dict(consts or {})
+        # boundary conditions per "variable:operator", wildcards allowed, default last (pde/pdes/pde.py:232-264)
+        if bc_ops is not None and not isinstance(bc_ops, dict):
+            msg = f"`bc_ops` must be a dictionary, but got {type(bc_ops)}"
+            raise TypeError(msg)
+        self.bc, self.bc_ops = bc, dict(bc_ops or {})   # kept for convenience; the backend reads `bcs` like on pde.PDE
+        table = dict(bc_ops or {})
+        table["*:*"] = bc
+        self.bcs: dict[str, Any] = {}
+        for key_str, value in table.items():
+            parts = key_str.replace(".", ":").split(":")
+            if len(parts) == 1:
+                key = f"{self.variables[0]}:{key_str}"
+            elif len(parts) == 2:
+                key = ":".join(parts)
+            else:
+                msg = f'Cannot parse boundary condition "{key_str}"'
+                raise ValueError(msg)
+            self.bcs[key] = value
+
+    @property
+    def expressions(self) -> dict[str, str]:
+        """Expressions after the shorthand replacement of the reference (pde/pdes/pde.py:47-53)."""
+        return {var: str(e).replace("∇²", "laplace") for var, e in self.rhs.items()}
 
     @property
     def expression(self) -> str:

@@ -15,8 +15,10 @@ Mechanism (``pde/backends/registry.py:57-84``, ``:101-230``; pattern of
 it and calls ``backend_registry.register_class("hip", HipBackend)``.  The mixin duck-types py-pde's
 grids, ``BoundariesList`` and PDE / solver objects, so no py-pde class is re-implemented here.
 
-Importing this module without py-pde raises ``ImportError`` (``grid.operators`` instantiates every
-importable backend and only tolerates ImportError).
+Importing this module without py-pde raises ``ImportError``.  Constructing the backend never touches
+the HIP runtime (``grid.operators`` instantiates every registered backend and only tolerates
+``ImportError``, ``pde/backends/registry.py:241-245``): the first compute call selects the device and
+raises ``RuntimeError`` when the library or a GPU is missing — there is no CPU fallback.
 """
 
 from __future__ import annotations
@@ -26,7 +28,7 @@ try:
     from pde.backends import backend_registry
     from pde.backends.base import BackendBase
     from pde.grids.cartesian import CartesianGrid
-    from pde.tools.config import Config, Parameter
+    from pde.tools.config import Parameter
 except ImportError as err:  # pragma: no cover - exercised only without py-pde
     msg = "pde_hip.pypde_plugin needs py-pde (`import pde` failed)"
     raise ImportError(msg) from err
@@ -38,8 +40,13 @@ from .backend import HipBackendMixin
 from .device import DeviceArray
 
 DEFAULT_CONFIG = {
-    "device": Parameter(value=0, cls=int, description="Index of the HIP device (MI355X) the backend runs on."),
-    "dtype_downcasting": Parameter(value=False, cls=bool, description="Reserved: never downcast, fp64 fields stay fp64."),
+    "device": Parameter(value=0, cls=int, description="Index of the HIP device (MI355X) the backend runs on; `hip:<n>` overrides it."),
+    "resident_state": Parameter(
+        value=True,
+        cls=bool,
+        description="Keep the state on the device between the calls of one stepper: tracker interrupts only download it, "
+        "and it is uploaded again only when the host copy was modified in between.",
+    ),
 }
 
 
@@ -55,8 +62,15 @@ class HipBackend(HipBackendMixin, BackendBase):
     @classmethod
     def from_args(cls, config, args: str = "", *, name: str | None = None):
         """``get_backend("hip:2")`` selects device 2 (pde/backends/registry.py:164-186)."""
-        device = int(args) if args else None
+        try:
+            device = int(args) if args else None
+        except ValueError:
+            msg = f"hip backend: device index expected after the colon, got `{args}`"
+            raise ValueError(msg) from None
         return cls(config, name=name or (f"hip:{args}" if args else "hip"), device=device)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(name={self.name!r}, device={self.device})"
 
     # py-pde hands native <-> numpy conversion only the array; the geometry is taken from the
     # operator/stepper closures, so plain arrays are accepted where the grid is implied

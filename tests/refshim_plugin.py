@@ -1,0 +1,97 @@
+"""pytest plugin that runs the REFERENCE's own generic tests against the hip backend (tests only).
+
+Loaded with ``-p refshim_plugin`` by ``tests/test_reference_suite.py`` in a child pytest process that collects
+test files straight from ``/root/reference/tests`` (nothing is copied).  It stands in for the reference's
+``tests/conftest.py`` (which cannot be imported here: it needs numba and matplotlib; ``--confcutdir`` keeps it
+out) and
+
+* installs the host shim (``tests/shim``: the C ABI of include/pdehip.h on host memory + oracle kernels) and
+  registers the hip backend with the real py-pde (``pde_hip.pypde_plugin``),
+* puts ``"hip"`` into the backend lists the reference parametrises its generic tests with
+  (``ALL_BACKENDS`` & co.) — only ``"hip"`` is kept, the other backends are the
+  reference's own business,
+* provides the ``backend`` / ``rng`` fixtures and the floating-point error policy of the reference's conftest.
+"""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+HERE = Path(__file__).resolve().parent
+for p in (HERE, HERE.parent / "py-pde_amd", HERE.parent):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+if "/root/reference" not in sys.path:
+    sys.path.append("/root/reference")
+
+import shimlib  # noqa: E402
+
+_shim_ctx = None
+BACKEND_LIST_NAMES = ("ALL_BACKENDS", "ALL_COMPILED_BACKENDS", "ALL_BACKENDS_NO_NUMBA")
+
+
+def pytest_configure(config):
+    global _shim_ctx
+    import os
+
+    for name in ("interactive", "multiprocessing", "slow"):
+        config.addinivalue_line("markers", f"{name}: marker of the reference test-suite")
+    _shim_ctx = shimlib.use_shim(fused=os.environ.get("REFSHIM_FUSED", "0") == "1")
+    _shim_ctx.__enter__()
+    import pde
+    import pde_hip.pypde_plugin  # noqa: F401  (registers "hip")
+    from pde.tools.misc import module_available
+
+    if not module_available("numba"):
+        # the reference's default backend is numba; where a generic test computes its yardstick without naming a
+        # backend, the reference's scipy operators take its place in this container
+        pde.config["default_backend"] = "scipy"
+
+
+def pytest_unconfigure(config):
+    global _shim_ctx
+    if _shim_ctx is not None:
+        _shim_ctx.__exit__(None, None, None)
+        _shim_ctx = None
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_generate_tests(metafunc):
+    """Runs before pytest resolves the ``parametrize`` marks: the marks hold the module's list OBJECTS, so editing
+    them in place re-parametrises every generic test with the hip backend."""
+    mod = metafunc.module
+    for name in BACKEND_LIST_NAMES:
+        lst = getattr(mod, name, None)
+        if isinstance(lst, list) and lst != ["hip"]:
+            lst[:] = ["hip"]
+    unsupported = getattr(mod, "NOT_SUPPORTED", None)
+    if isinstance(unsupported, dict) and "hip" not in unsupported:
+        # explicit steppers and, through make_pde_rhs, ScipySolver; the others must raise NotImplementedError
+        from pde import solvers as S
+
+        unsupported["hip"] = {getattr(S, n) for n in ("CrankNicolsonSolver", "ImplicitSolver", "MilsteinSolver") if hasattr(S, n)}
+
+
+@pytest.fixture
+def backend(request):
+    from pde.backends import get_backend
+
+    if not str(request.param).startswith("hip"):
+        pytest.skip("only the hip backend is exercised by this run")
+    return get_backend(request.param)
+
+
+@pytest.fixture(name="rng")
+def init_random_number_generators():
+    return np.random.default_rng(0)
+
+
+@pytest.fixture(autouse=True)
+def _setup_and_teardown():
+    old = np.seterr(all="raise", under="ignore")
+    yield
+    np.seterr(**old)

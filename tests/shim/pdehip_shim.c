@@ -1,0 +1,500 @@
+/*
+ * pdehip_shim.c — HOST implementation of the C ABI of include/pdehip.h.  TESTS ONLY.
+ *
+ * ******************************************************************************
+ * TEST INFRASTRUCTURE.  This library exists so that the Python host side of the hip backend
+ * (py-pde_amd/pde_hip: plugin class, BC conversion, stepper loops, solver.info bookkeeping) can
+ * be driven END TO END through the REAL py-pde in a container without a GPU.  It is built into
+ * tests/shim/_build/ by tests/shim/build.py and loaded only by tests (tests/shimlib.py sets
+ * PDEHIP_LIB before the package binds its library).  The product never builds, ships, finds or
+ * loads it: py-pde_amd/pde_hip/_lib.py resolves py-pde_amd/lib/libpdehip.so and raises when
+ * that library or a HIP device is missing.
+ * ******************************************************************************
+ *
+ * "Device" memory is host memory, streams and events are dummies, every compute entry point is
+ * the CPU oracle (oracle/pde_oracle.c, compiled into this file) behind the pdehip_* name.  The
+ * full layout of this library is the reference's compact layout (pitch N+2), reported through
+ * pdehip_layout() like the device library reports its padded one — the host side must not care.
+ *
+ * Entry points that exist only on the device (two steps per sweep, fused Cahn-Hilliard sweep,
+ * fused Runge-Kutta stages) report "not covered" (*done = 0) by default — the host side then
+ * takes its unfused branch — or, with PDEHIP_SHIM_FUSED=1, are composed of oracle calls so that
+ * the fused branches of the host code run as well (the device versions are bit-identical to the
+ * composition by design; tests/test_hip_*.py check that on the GPU).
+ *
+ * Run-time specialised right-hand sides (pdehip_jit_*): the epilogue body is plain C, so it is
+ * compiled with gcc into a small shared object and applied to laplace / gradient_squared
+ * arrays computed by the oracle.
+ *
+ * Slab-parallel layer (pdehip_comm_*, pdehip_slab_*): the communicator is a directory of files
+ * (one mailbox per rank and message), so several processes — the ranks of a torch.distributed
+ * gloo job — can run the SAME slab loops as pdehip_comm.hip on the CPU (tests/test_distributed_*).
+ */
+#define _GNU_SOURCE
+#include "../../oracle/pde_oracle.c"
+
+#include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+enum { E_OK = 0, E_VALUE = 1, E_NOTIMPL = 2, E_RUNTIME = 3 };
+
+static __thread char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define TRY(expr)                                                                       \
+    do {                                                                                \
+        int _rc = (expr);                                                               \
+        if (_rc) return _rc > 99 ? _rc : fail(_rc == 2 ? E_NOTIMPL : (_rc == 1 ? E_VALUE : E_RUNTIME), \
+                                              "shim: %s failed with code %d", #expr, _rc); \
+    } while (0)
+
+static int fused_enabled(void)
+{
+    const char *e = getenv("PDEHIP_SHIM_FUSED");
+    return e && e[0] == '1';
+}
+
+/* ---- runtime -------------------------------------------------------------------------- */
+const char *pdehip_last_error(void) { return g_err; }
+int pdehip_abi_version(void) { return PDEHIP_ABI_VERSION; }
+int pdehip_device_count(int *count)
+{
+    const char *e = getenv("PDEHIP_SHIM_DEVICES");
+    *count = e ? atoi(e) : 1;
+    return 0;
+}
+static int g_device = 0;
+int pdehip_set_device(int device)
+{
+    int n;
+    pdehip_device_count(&n);
+    if (device < 0 || device >= n) return fail(E_RUNTIME + 100, "hipSetDevice(%d) failed: invalid device ordinal", device);
+    g_device = device;
+    return 0;
+}
+int pdehip_get_device(int *device) { *device = g_device; return 0; }
+int pdehip_device_name(char *buf, size_t len)
+{
+    snprintf(buf, len, "host shim (tests only), device %d", g_device);
+    return 0;
+}
+int pdehip_malloc(void **ptr, size_t bytes)
+{
+    *ptr = calloc(1, bytes ? bytes : 1);
+    return *ptr ? 0 : fail(E_RUNTIME, "shim: out of memory (%zu bytes)", bytes);
+}
+int pdehip_free(void *ptr) { free(ptr); return 0; }
+int pdehip_memset(void *ptr, int value, size_t bytes, void *stream) { (void)stream; memset(ptr, value, bytes); return 0; }
+int pdehip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
+int pdehip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
+int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
+int pdehip_host_alloc(void **ptr, size_t bytes) { return pdehip_malloc(ptr, bytes); }
+int pdehip_host_free(void *ptr) { free(ptr); return 0; }
+int pdehip_stream_create(void **stream) { *stream = malloc(8); return 0; }
+int pdehip_stream_destroy(void *stream) { free(stream); return 0; }
+int pdehip_stream_synchronize(void *stream) { (void)stream; return 0; }
+int pdehip_stream_wait_event(void *stream, void *event) { (void)stream; (void)event; return 0; }
+int pdehip_event_create(void **event) { *event = calloc(1, sizeof(struct timespec)); return 0; }
+int pdehip_event_destroy(void *event) { free(event); return 0; }
+int pdehip_event_record(void *event, void *stream) { (void)stream; clock_gettime(CLOCK_MONOTONIC, (struct timespec *)event); return 0; }
+int pdehip_event_synchronize(void *event) { (void)event; return 0; }
+int pdehip_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    const struct timespec *a = start, *b = stop;
+    *ms = (float)((b->tv_sec - a->tv_sec) * 1e3 + (b->tv_nsec - a->tv_nsec) * 1e-6);
+    return 0;
+}
+
+int pdehip_layout(const pdehip_grid_t *g, int64_t *out8)
+{
+    ngrid_t n;
+    if (!g || g->ndim < 1 || g->ndim > 3) return fail(E_NOTIMPL, "unsupported number of axes");
+    if (g->dtype != PDEHIP_F64 && g->dtype != PDEHIP_F32) return fail(E_NOTIMPL, "unsupported dtype code %d", g->dtype);
+    for (int a = 0; a < g->ndim; a++)
+        if (g->shape[a] < 1) return fail(E_VALUE, "grid shape must be positive (axis %d: %ld)", a, (long)g->shape[a]);
+    if (norm_grid(g, &n)) return fail(E_VALUE, "bad grid");
+    out8[0] = n.p[0]; out8[1] = n.p[1]; out8[2] = n.pc; out8[3] = n.off; out8[4] = 1;
+    out8[5] = n.pc; out8[6] = 0; out8[7] = n.p[3 - n.ndim];
+    return 0;
+}
+
+static size_t full_bytes(const pdehip_grid_t *g, int ncomp)
+{
+    ngrid_t n;
+    norm_grid(g, &n);
+    return (size_t)ncomp * (size_t)n.pc * (g->dtype == PDEHIP_F64 ? 8 : 4);
+}
+
+static int check_grid(const pdehip_grid_t *g)
+{
+    int64_t lay[8];
+    return pdehip_layout(g, lay);
+}
+#define GRID(g) do { int _rc = check_grid(g); if (_rc) return _rc; } while (0)
+
+/* ---- layout conversion ------------------------------------------------------------------ */
+int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, void *full, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_valid_to_full(g, ncomp, valid, full)); return 0; }
+int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *valid, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_full_to_valid(g, ncomp, full, valid)); return 0; }
+int pdehip_hostfull_to_full(const pdehip_grid_t *g, int ncomp, const void *hostfull, void *full, void *stream)
+{ (void)stream; GRID(g); memmove(full, hostfull, full_bytes(g, ncomp)); return 0; }
+int pdehip_full_to_hostfull(const pdehip_grid_t *g, int ncomp, const void *full, void *hostfull, void *stream)
+{ (void)stream; GRID(g); memmove(hostfull, full, full_bytes(g, ncomp)); return 0; }
+
+/* ---- ghost cells and operators ---------------------------------------------------------- */
+int pdehip_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_face_t *faces, void *data_full, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_set_ghost_cells(g, ncomp, faces, data_full)); return 0; }
+int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_laplace(g, in_full, out, out_layout)); return 0; }
+int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_gradient(g, method, in_full, out, out_layout)); return 0; }
+int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_divergence(g, method, in_full, out, out_layout)); return 0; }
+int pdehip_gradient_squared(const pdehip_grid_t *g, int central, const void *in_full, void *out, int out_layout, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_gradient_squared(g, central, in_full, out, out_layout)); return 0; }
+int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int method, const void *in_full, void *out,
+                           int out_layout, void *stream)
+{
+    (void)stream; GRID(g);
+    if (axis < 0 || axis >= g->ndim) return fail(E_VALUE, "axis %d out of range", axis);
+    if (order != 1 && order != 2) return fail(E_VALUE, "derivative order must be 1 or 2");
+    TRY(oracle_axis_derivative(g, axis, order, method, in_full, out, out_layout));
+    return 0;
+}
+#ifdef ORACLE_HAS_LAPLACE9
+int pdehip_laplace9(const pdehip_grid_t *g, const int *periodic2, double corner_weight, void *in_full, void *out,
+                    int out_layout, void *stream)
+{
+    (void)stream; GRID(g);
+    if (g->ndim != 2) return fail(E_VALUE, "the 9-point stencil needs a 2-D grid");
+    TRY(oracle_laplace9(g, periodic2, corner_weight, in_full, out, out_layout));
+    return 0;
+}
+#endif
+int pdehip_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out_full, double s1, double s2, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_laplace_scaled(g, in_full, out_full, s1, s2)); return 0; }
+int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void *y_full, void *out_full, double s1, double s2,
+                         void *stream)
+{ (void)stream; GRID(g); TRY(oracle_laplace_euler(g, in_full, y_full, out_full, s1, s2)); return 0; }
+int pdehip_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full, double gamma, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_cahn_hilliard_mu(g, c_full, mu_full, gamma)); return 0; }
+
+/* ---- pointwise helpers -------------------------------------------------------------------- */
+int pdehip_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int n, const double *coef_host,
+                   const void *const *k_full_host, void *stream)
+{
+    (void)stream; GRID(g);
+    if (n < 0 || n > 6) return fail(E_VALUE, "lincomb: n must be 0..6");
+    TRY(oracle_lincomb(g, ncomp, out_full, y_full, n, coef_host, k_full_host));
+    return 0;
+}
+int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *k1, const void *k2, const void *k3, const void *k4,
+                       void *stream)
+{ (void)stream; GRID(g); TRY(oracle_rk4_combine(g, ncomp, y, k1, k2, k3, k4)); return 0; }
+int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *rate_cur, const void *rate_prev, double dt, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_ab2_combine(g, ncomp, y, rate_cur, rate_prev, dt)); return 0; }
+int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew, const void *const *k6_host, double *err_dev,
+                         void *stream)
+{ (void)stream; GRID(g); TRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6_host, err_dev)); return 0; }
+int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a, const void *b, double *out_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_max_abs_diff(g, ncomp, a, b, out_dev)); return 0; }
+
+/* ---- device-only fused sweeps: "not covered" unless PDEHIP_SHIM_FUSED=1 --------------------- */
+static int faces_simple(const pdehip_bc_face_t *f, int ndim)
+{
+    /* the device kernels evaluate scalar first-order faces on the fly; mimic that coverage rule */
+    for (int i = 0; i < 2 * ndim; i++)
+        if (f[i].kind != PDEHIP_BC_ORDER1 || (f[i].flags & PDEHIP_BCF_ARRAYS)) return 0;
+    return 1;
+}
+int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full, void *out_full,
+                            double diffusivity, double dt, int *done, void *stream)
+{
+    (void)stream; GRID(g);
+    *done = 0;
+    if (!fused_enabled() || g->ndim < 2 || !faces_simple(faces, g->ndim)) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *tmp = malloc(nb), *src = malloc(nb);
+    memcpy(src, in_full, nb);   /* ghost cells of `in` are neither read nor written */
+    int rc = oracle_set_ghost_cells(g, 1, faces, src);
+    if (!rc) rc = oracle_laplace_euler(g, src, src, tmp, diffusivity, dt);
+    if (!rc) rc = oracle_set_ghost_cells(g, 1, faces, tmp);
+    if (!rc) rc = oracle_laplace_euler(g, tmp, tmp, out_full, diffusivity, dt);
+    free(tmp); free(src);
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
+int pdehip_diffusion_euler2_slab(const pdehip_grid_t *g_sub, const pdehip_bc_face_t *faces, const void *in_full, void *out_full,
+                                 double diffusivity, double dt, int halo_sides, int *done, void *stream)
+{
+    (void)g_sub; (void)faces; (void)in_full; (void)out_full; (void)diffusivity; (void)dt; (void)halo_sides; (void)stream;
+    *done = 0;
+    return 0;
+}
+int pdehip_cahn_hilliard_fused(const pdehip_grid_t *g, const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu,
+                               const void *c_full, void *out_full, double gamma, double dt, int euler, int *done, void *stream)
+{
+    (void)stream; GRID(g);
+    *done = 0;
+    if (!fused_enabled() || g->ndim < 2 || !faces_simple(faces_c, g->ndim) || !faces_simple(faces_mu, g->ndim)) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *mu = calloc(1, nb), *src = malloc(nb);
+    memcpy(src, c_full, nb);
+    int rc = oracle_set_ghost_cells(g, 1, faces_c, src);
+    if (!rc) rc = oracle_cahn_hilliard_mu(g, src, mu, gamma);
+    if (!rc) rc = oracle_set_ghost_cells(g, 1, faces_mu, mu);
+    if (!rc) rc = euler ? oracle_laplace_euler(g, mu, src, out_full, 1.0, dt) : oracle_laplace_scaled(g, mu, out_full, 1.0, dt);
+    free(mu); free(src);
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
+
+/* ---- fused steppers ------------------------------------------------------------------------ */
+int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_rhs_scaled(g, rhs, y_full, k_out_full, dt)); return 0; }
+int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b, double dt, int64_t nsteps,
+                     void **result, void *stream)
+{
+    (void)stream; GRID(g);
+    if (nsteps < 0) return fail(E_VALUE, "nsteps must be >= 0");
+    TRY(oracle_euler_run(g, rhs, buf_a, buf_b, dt, nsteps, result));
+    return 0;
+}
+int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host, double dt, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt)); return 0; }
+int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host, double dt, int64_t nsteps,
+                   void *stream)
+{
+    (void)stream; GRID(g);
+    for (int64_t s = 0; s < nsteps; s++) TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt));
+    return 0;
+}
+int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *ynew_full, void *const *work7_host,
+                         double dt, double *err_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_rkf45_attempt(g, rhs, y_full, ynew_full, work7_host, dt, err_dev)); return 0; }
+int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_full, void *y_out_full, void *rate_cur_full,
+                    const void *rate_prev_full, double dt, int *fused, void *stream)
+{
+    (void)stream; GRID(g);
+    *fused = 0;
+    if (!fused_enabled() || g->ndim < 2) return 0;
+    TRY(oracle_rhs_scaled(g, rhs, y_in_full, rate_cur_full, 1.0));
+    memcpy(y_out_full, y_in_full, full_bytes(g, 1));
+    TRY(oracle_ab2_combine(g, 1, y_out_full, rate_cur_full, rate_prev_full, dt));
+    *fused = 1;
+    return 0;
+}
+
+/* ---- run-time specialised right-hand sides: gcc instead of hiprtc ---------------------------- */
+typedef double (*epilogue_fn)(double, double, double, double, double, double, const double *);
+typedef struct {
+    void *dl[2];
+    epilogue_fn fn[2];
+    int nbody;
+} shim_jit_t;
+
+static int compile_epilogue(const char *body, void **dl, epilogue_fn *fn)
+{
+    static int counter = 0;
+    char dir[] = "/tmp/pdehip_shim_XXXXXX";
+    if (!mkdtemp(dir)) return fail(E_RUNTIME, "shim: mkdtemp failed");
+    char src[600], so[600], cmd[2000];
+    snprintf(src, sizeof(src), "%s/e%d.c", dir, counter);
+    snprintf(so, sizeof(so), "%s/e%d.so", dir, counter++);
+    FILE *f = fopen(src, "w");
+    if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
+    fprintf(f, "#include <math.h>\ndouble pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n"
+               "(void)c; (void)lap; (void)gsq; (void)e0; (void)e1; (void)e2; (void)p;\n%s\n}\n", body);
+    fclose(f);
+    snprintf(cmd, sizeof(cmd), "gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -fno-fast-math -o %s %s -lm 2> %s/err.txt", so, src, dir);
+    if (system(cmd) != 0) {
+        char msg[300] = "";
+        snprintf(cmd, sizeof(cmd), "%s/err.txt", dir);
+        FILE *e = fopen(cmd, "r");
+        if (e) { size_t k = fread(msg, 1, sizeof(msg) - 1, e); msg[k] = 0; fclose(e); }
+        return fail(E_VALUE, "shim: epilogue does not compile: %s", msg);
+    }
+    *dl = dlopen(so, RTLD_NOW | RTLD_LOCAL);
+    if (!*dl) return fail(E_RUNTIME, "shim: dlopen failed: %s", dlerror());
+    *fn = (epilogue_fn)dlsym(*dl, "pde_epilogue");
+    unlink(src); unlink(so);
+    snprintf(cmd, sizeof(cmd), "%s/err.txt", dir); unlink(cmd);
+    rmdir(dir);
+    return *fn ? 0 : fail(E_RUNTIME, "shim: pde_epilogue not found");
+}
+int pdehip_jit_create(const char *epilogue_body, void **handle)
+{
+    shim_jit_t *j = calloc(1, sizeof(*j));
+    j->nbody = 1;
+    int rc = compile_epilogue(epilogue_body, &j->dl[0], &j->fn[0]);
+    if (rc) { free(j); return rc; }
+    *handle = j;
+    return 0;
+}
+int pdehip_jit_create2(const char *body1, const char *body2, void **handle)
+{
+    shim_jit_t *j = calloc(1, sizeof(*j));
+    j->nbody = 2;
+    int rc = compile_epilogue(body1, &j->dl[0], &j->fn[0]);
+    if (!rc) rc = compile_epilogue(body2, &j->dl[1], &j->fn[1]);
+    if (rc) { free(j); return rc; }
+    *handle = j;
+    return 0;
+}
+int pdehip_jit_destroy(void *handle)
+{
+    shim_jit_t *j = handle;
+    if (!j) return 0;
+    for (int i = 0; i < 2; i++) if (j->dl[i]) dlclose(j->dl[i]);
+    free(j);
+    return 0;
+}
+int pdehip_jit_check(void *handle, int dtype, int ndim) { (void)handle; (void)dtype; (void)ndim; return 0; }
+
+/* out = fn(in, laplace(in), gradient_squared(in), extras; params) on the interior; `in` must carry valid ghost cells */
+static int shim_pointwise(epilogue_fn fn, const pdehip_grid_t *g, const void *in, const void *const *extra3, void *out,
+                          const double *params)
+{
+    ngrid_t n;
+    norm_grid(g, &n);
+    size_t nb = full_bytes(g, 1);
+    void *lap = calloc(1, nb), *gsq = calloc(1, nb);
+    int rc = oracle_laplace(g, in, lap, PDEHIP_OUT_FULL);
+    if (!rc) rc = oracle_gradient_squared(g, 1, in, gsq, PDEHIP_OUT_FULL);
+    if (rc) { free(lap); free(gsq); return rc; }
+    /* results go to a scratch first: `out` may alias an extra array */
+    void *res = malloc(nb);
+    memcpy(res, out, nb);
+    for (int64_t i = 0; i < n.n[0]; i++)
+        for (int64_t j = 0; j < n.n[1]; j++)
+            for (int64_t k = 0; k < n.n[2]; k++) {
+                int64_t at = n.off + i * n.p[0] + j * n.p[1] + k;
+                double e[3] = {0, 0, 0};
+                if (g->dtype == PDEHIP_F64) {
+                    for (int m = 0; m < 3; m++) if (extra3 && extra3[m]) e[m] = ((const double *)extra3[m])[at];
+                    ((double *)res)[at] = fn(((const double *)in)[at], ((double *)lap)[at], ((double *)gsq)[at], e[0], e[1], e[2], params);
+                } else {
+                    for (int m = 0; m < 3; m++) if (extra3 && extra3[m]) e[m] = ((const float *)extra3[m])[at];
+                    ((float *)res)[at] = (float)fn(((const float *)in)[at], ((float *)lap)[at], ((float *)gsq)[at], e[0], e[1], e[2], params);
+                }
+            }
+    /* interior only: the ghost cells of `out` are left untouched like the device kernel does */
+    int esz = g->dtype == PDEHIP_F64 ? 8 : 4;
+    for (int64_t i = 0; i < n.n[0]; i++)
+        for (int64_t j = 0; j < n.n[1]; j++) {
+            int64_t at = n.off + i * n.p[0] + j * n.p[1];
+            memcpy((char *)out + at * esz, (char *)res + at * esz, (size_t)n.n[2] * esz);
+        }
+    free(res); free(lap); free(gsq);
+    return 0;
+}
+int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *out_full,
+                     const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, void *stream)
+{
+    (void)stream; (void)nparams; GRID(g);
+    shim_jit_t *j = handle;
+    if (!j || j->nbody != 1) return fail(E_VALUE, "jit_apply: bad handle");
+    if (in_faces) TRY(oracle_set_ghost_cells(g, 1, in_faces, in_full));
+    TRY(shim_pointwise(j->fn[0], g, in_full, extra3_host, out_full, params_host));
+    return 0;
+}
+int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *k_out_full,
+                           const double *params_host, int nparams, const pdehip_bc_face_t *in_faces, int kind, const void *y_full,
+                           int nk, const void *const *k_prev_host, const double *coef_host, double c_new, void *out2_full,
+                           double *err_dev, int *done, void *stream)
+{
+    (void)stream; GRID(g);
+    *done = 0;
+    if (!fused_enabled() || g->ndim < 2) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *k = kind == 0 ? k_out_full : calloc(1, nb);
+    int rc = pdehip_jit_apply(handle, g, in_full, extra3_host, k, params_host, nparams, in_faces, NULL);
+    if (!rc && kind == 0) {
+        const void *ks[6]; double cf[6];
+        for (int m = 0; m < nk; m++) { ks[m] = k_prev_host[m]; cf[m] = coef_host[m]; }
+        ks[nk] = k; cf[nk] = c_new;
+        rc = oracle_lincomb(g, 1, out2_full, y_full, nk + 1, cf, ks);
+    } else if (!rc && kind == 1) {
+        if (out2_full != y_full) memcpy(out2_full, y_full, nb);
+        rc = oracle_rk4_combine(g, 1, out2_full, k_prev_host[0], k_prev_host[1], k_prev_host[2], k);
+    } else if (!rc && kind == 2) {
+        /* k2 does not enter the RKF45 tail: any valid array stands in for it */
+        const void *k6[6] = {k_prev_host[0], k_prev_host[0], k_prev_host[1], k_prev_host[2], k_prev_host[3], k};
+        rc = oracle_rkf45_combine(g, 1, y_full, out2_full, k6, err_dev);
+    }
+    if (kind != 0) free(k);
+    if (rc > 99) return rc;
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
+int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full, const double *params_host,
+                      int nparams, const pdehip_bc_face_t *faces, int *done, void *stream)
+{
+    (void)stream; (void)nparams; GRID(g);
+    shim_jit_t *j = handle;
+    *done = 0;
+    if (!fused_enabled() || g->ndim < 2 || !faces_simple(faces, g->ndim)) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *src = malloc(nb), *tmp = calloc(1, nb);
+    memcpy(src, in_full, nb);
+    int rc = oracle_set_ghost_cells(g, 1, faces, src);
+    if (!rc) rc = shim_pointwise(j->fn[0], g, src, NULL, tmp, params_host);
+    if (!rc) rc = oracle_set_ghost_cells(g, 1, faces, tmp);
+    if (!rc) rc = shim_pointwise(j->fn[0], g, tmp, NULL, out_full, params_host);
+    free(src); free(tmp);
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
+int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full, void *out_full, const double *params_host,
+                      int nparams, const pdehip_bc_face_t *faces_u, const pdehip_bc_face_t *faces_tmp, int *done, void *stream)
+{
+    (void)stream; (void)nparams; GRID(g);
+    shim_jit_t *j = handle;
+    *done = 0;
+    if (!j || j->nbody != 2) return fail(E_VALUE, "jit_fused2: bad handle");
+    if (!fused_enabled() || g->ndim < 2 || !faces_simple(faces_u, g->ndim) || !faces_simple(faces_tmp, g->ndim)) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *src = malloc(nb), *tmp = calloc(1, nb);
+    memcpy(src, in_full, nb);
+    const void *ex[3] = {src, NULL, NULL};
+    int rc = oracle_set_ghost_cells(g, 1, faces_u, src);
+    if (!rc) rc = shim_pointwise(j->fn[0], g, src, NULL, tmp, params_host);
+    if (!rc) rc = oracle_set_ghost_cells(g, 1, faces_tmp, tmp);
+    if (!rc) rc = shim_pointwise(j->fn[1], g, tmp, ex, out_full, params_host);
+    free(src); free(tmp);
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
+
+#ifndef SHIM_WITH_COMM
+/* slab-parallel layer: provided by pdehip_shim_comm.cpp when it is linked in */
+#define NOCOMM(name, ...) int pdehip_##name(__VA_ARGS__) { return fail(E_NOTIMPL, "shim: pdehip_" #name " needs the comm part of the shim"); }
+NOCOMM(comm_unique_id, const char *a, void *b)
+NOCOMM(comm_create, const char *a, const void *b, int c, int d, void **e)
+NOCOMM(comm_destroy, void *a)
+NOCOMM(halo_exchange, void *a, const pdehip_grid_t *b, void *c, int d, int e, void *f)
+NOCOMM(allreduce_max, void *a, double *b, void *c)
+NOCOMM(slab_euler_run, void *a, const pdehip_grid_t *b, const pdehip_rhs_t *c, int d, int e, void *f, void *g, double h, int64_t i, void **j, void *k)
+NOCOMM(slab_euler2_supported, const pdehip_grid_t *a, const pdehip_rhs_t *b, int *c)
+NOCOMM(slab_euler2_run, void *a, const pdehip_grid_t *b, const pdehip_rhs_t *c, int d, int e, void *f, void *g, double h, int64_t i, void **j, void *k)
+NOCOMM(slab_ch_supported, const pdehip_grid_t *a, const pdehip_rhs_t *b, int *c)
+NOCOMM(slab_ch_sweep, void *a, const pdehip_grid_t *b, const pdehip_rhs_t *c, int d, int e, void *f, void *g, double h, int i, void *j)
+#endif

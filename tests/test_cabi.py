@@ -7,6 +7,7 @@ import ctypes as C
 import re
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 from pde_hip import _abi, _lib
@@ -60,13 +61,17 @@ def test_struct_layout_matches_header():
 
 
 def test_host_side_fails_loudly_without_gpu():
-    """No silent CPU fallback: without a HIP device the backend refuses to come up."""
+    """No silent CPU fallback: without a HIP device every compute entry point refuses (constructing the backend object
+    alone must work — py-pde instantiates all registered backends just to list operators)."""
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")
     import pde_hip
 
+    backend = pde_hip.get_backend("hip")
     with pytest.raises(RuntimeError, match="no HIP device"):
-        pde_hip.get_backend("hip")
+        backend.device_name
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        backend.numpy_to_native(np.zeros((4, 4)), grid=pde_hip.UnitGrid([4, 4]))
     grid = pde_hip.UnitGrid([4, 4])
     with pytest.raises(RuntimeError, match="no HIP device"):
         pde_hip.ScalarField(grid, 1.0).laplace("auto_periodic_neumann")

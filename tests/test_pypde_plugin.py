@@ -43,11 +43,16 @@ def test_registration_and_class_attributes():
     plugin.register()  # idempotent
 
 
-def test_get_backend_fails_loudly_without_gpu():
+def test_backend_is_lazy_and_compute_fails_loudly_without_gpu():
+    """Construction must not need a device (grid.operators instantiates every backend); compute must (no fallback)."""
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")
+    backend = pde.backends.backend_registry.get_backend("hip")
+    assert "laplace" in pde.UnitGrid([4, 4]).operators
     with pytest.raises(RuntimeError, match="no HIP device"):
-        pde.backends.backend_registry.get_backend("hip")
+        backend.device_name
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        pde.ScalarField(pde.UnitGrid([4, 4]), 1.0).laplace("auto_periodic_neumann", backend="hip")
     # ... and py-pde's other backends are unaffected
     assert pde.backends.backend_registry.get_backend("numpy").name == "numpy"
 
@@ -76,13 +81,53 @@ def test_unsupported_boundaries_raise_not_implemented():
     grid = pde.UnitGrid([4, 4])
     bcs = grid.get_boundary_conditions({"value_expression": "t"}, rank=0)
     with pytest.raises(NotImplementedError, match="does not support boundary condition"):
-        convert_bcs(bcs, upload=HostBuf)
+        convert_bcs(bcs, upload=HostBuf)       # the plain converter knows constant conditions only ...
+    from pde_hip.bc_expr import convert_bcs_with_expressions
+
+    table = convert_bcs_with_expressions(bcs, upload=HostBuf)   # ... expressions affine in `value` become coefficient arrays
+    assert table.time_dependent
+    with pytest.raises(NotImplementedError, match="not linear"):
+        convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": "value**2"}, rank=0), upload=HostBuf)
+
+    def user_bc(value, dx, x, y, t):
+        return value
+
+    with pytest.raises(NotImplementedError, match="Python functions"):
+        convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": user_bc}, rank=0), upload=HostBuf)
+
+
+@pytest.mark.parametrize("bc", [
+    {"x-": {"value_expression": "sin(y) + t"}, "x+": {"derivative_expression": "0.1 * y * t"}, "y": "periodic"},
+    {"x": {"type": "mixed_expression", "value": "1 + y", "const": "cos(t)"}, "y": "periodic"},
+    {"x-": {"virtual_point": "2 * value - y"}, "x+": {"type": "virtual_point", "value": "value + x", "value_cell": 1}, "y": "periodic"},
+])
+def test_expression_boundaries_to_face_table(bc):
+    """Expression conditions lowered to coefficient arrays + oracle ghost setter == py-pde's numpy set_ghost_cells."""
+    from pde_hip.bc_expr import convert_bcs_with_expressions
+
+    grid = pde.CartesianGrid([[0, 3], [1, 4.5]], [6, 5], periodic=[False, True])
+    field = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(0))
+    table = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0), upload=HostBuf)
+    for t in (0.0, 0.4):
+        full = field._data_full.copy()
+        full[0, :] = full[-1, :] = full[:, 0] = full[:, -1] = 0
+        table.update({"t": t})
+        O.set_ghost_cells(_abi.make_grid(grid.shape, grid.discretization, np.float64), 1, table.c, full)
+        field.set_ghost_cells(bc, args={"t": t})
+        mask = face_mask(grid)
+        np.testing.assert_allclose(full[mask], field._data_full[mask], rtol=1e-14, atol=1e-14)
 
 
 def test_rhs_recognition_on_real_pde_objects():
     """The attributes make_rhs_spec reads exist on the real classes; expression PDE is matched."""
     eq = pde.DiffusionPDE(0.7, bc="auto_periodic_neumann")
     assert (eq.__class__.__name__, eq.diffusivity, eq.bc) == ("DiffusionPDE", 0.7, "auto_periodic_neumann")
+    from pde_hip.backend import pde_bc_for, pde_expression
+
+    gen2 = pde.PDE({"c": "∇²c"}, bc={"value": 1.0}, bc_ops={"c:laplace": {"value": 2.0}, "gradient": "periodic"})
+    assert not hasattr(gen2, "bc") and not hasattr(gen2, "bc_ops")       # ADVICE r1: only `bcs` exists
+    assert pde_bc_for(gen2, "c", "laplace") == {"value": 2.0} and pde_bc_for(gen2, "c", "gradient") == "periodic"
+    assert pde_bc_for(gen2, "c", "gradient_squared") == {"value": 1.0} and pde_expression(gen2, "c") == "laplace(c)"
     ch = pde.CahnHilliardPDE(interface_width=0.5)
     assert ch.__class__.__name__ == "CahnHilliardPDE" and ch.interface_width == 0.5 and hasattr(ch, "bc_c") and hasattr(ch, "bc_mu")
     gen = pde.PDE({"c": "laplace(c**3 - c - laplace(c))"})

@@ -1,0 +1,70 @@
+"""The REFERENCE's own generic tests, run with the hip backend in the backend lists.
+
+A child pytest collects test files straight from ``/root/reference/tests`` (nothing is copied; skipped where the
+reference is absent, e.g. on the GPU box) with ``tests/refshim_plugin.py`` standing in for the reference's conftest:
+it puts ``"hip"`` into ``ALL_BACKENDS`` & co., registers the plugin class with the real py-pde and installs the
+tests-only host shim behind the C ABI.  Every hip-parametrised test of the listed files must pass, except the ids in
+``NEXT`` — features SURVEY.md §8f lists as "next" that the backend refuses with ``NotImplementedError`` today; the
+list is checked both ways (a test that starts passing must be removed from it).
+"""
+
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REF_TESTS = Path("/root/reference/tests")
+if not REF_TESTS.exists():
+    pytest.skip("py-pde (reference) not available", allow_module_level=True)
+
+HERE = Path(__file__).resolve().parent
+
+# file -> ids (substring of the node id) that are expected to FAIL today, with the reason
+SUITES: dict[str, dict[str, str]] = {
+    # operators: vs scipy / ndimage, rtol 1e-5..3e-6 (tests/backends/generic/operators/test_cartesian_operators.py:39-191)
+    "backends/generic/operators/test_cartesian_operators.py": {},
+    # ghost cells incl. expression BCs (tests/backends/generic/test_boundaries.py:43-150)
+    "backends/generic/test_boundaries.py": {},
+    # solver x backend matrix, erf known answer (tests/solvers/test_generic_solvers.py:123-230)
+    "solvers/test_generic_solvers.py": {
+        "test_stochastic_solver_backend_support[hip-EulerSolver]": "Euler-Maruyama needs a device RNG (SURVEY §8 f3)",
+    },
+    "pdes/test_diffusion_pdes.py": {
+        "test_diffusion_sde[hip]": "stochastic equations (SURVEY §8 f3)",
+    },
+    "fields/test_scalar_fields.py": {},
+    "fields/test_vectorial_fields.py": {},
+}
+
+
+def _run(rel: str, fused: bool) -> dict[str, str]:
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([str(HERE), "/root/reference", env.get("PYTHONPATH", "")])
+    env["REFSHIM_FUSED"] = "1" if fused else "0"
+    env.pop("PDEHIP_LIB", None)
+    cmd = [sys.executable, "-m", "pytest", str(REF_TESTS / rel), "-p", "refshim_plugin", "--confcutdir", str(REF_TESTS / "backends"),
+           "--rootdir", "/tmp", "-p", "no:cacheprovider", "-k", "hip", "-q", "-rA", "--tb=line", "-W", "ignore"]
+    out = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1200).stdout
+    results = {}
+    for m in re.finditer(r"^(PASSED|FAILED|ERROR|SKIPPED|XFAIL|XPASS)\s+(\S*::\S+?)(?: - .*)?$", out, flags=re.M):
+        results[m.group(2).split("::", 1)[1]] = m.group(1)
+    assert results, f"no test outcomes parsed for {rel}:\n{out[-3000:]}"
+    return results
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+@pytest.mark.parametrize("rel", list(SUITES))
+def test_reference_generic_tests_with_hip(rel, fused):
+    expected_fail = SUITES[rel]
+    results = _run(rel, fused)
+    assert all("hip" in name for name in results), results
+    unexpected = {n: r for n, r in results.items() if r != "PASSED" and not any(k in n for k in expected_fail)}
+    assert not unexpected, f"{rel}: {unexpected}"
+    stale = [k for k in expected_fail if any(k in n and r == "PASSED" for n, r in results.items())]
+    assert not stale, f"{rel}: listed as 'next' but passing now: {stale}"
+    assert sum(r == "PASSED" for r in results.values()) >= 1

@@ -1,0 +1,182 @@
+"""Parity at the sizes BASELINE.json quotes (cfg1 .. cfg5), full field — VERDICT r1 row (g).
+
+Two halves:
+
+* ``-m "not gpu"``: the CPU oracle at full size against digests / samples produced by the REFERENCE itself
+  (``tests/golden/configs.npz`` from ``tests/golden/make_golden_configs.py``; the reference's torch-CPU Euler runs and the
+  oracle agree bit for bit, so a SHA-256 of the final state pins the oracle over the whole field).
+* ``-m gpu``: the HIP library against the oracle over the WHOLE field (bit for bit in fp64, 1e-5 relative with equal step
+  counts for the fp32 RKF45 configuration), through the mirror API (``eq.solve(..., backend="hip")``) — i.e. through
+  ``pdehip_euler_run`` incl. its hipGraph replay for the launch-bound 2-D grids and the two-steps-per-sweep kernels.
+
+cfg1 (UnitGrid 64^2) is the golden case ``diff64_euler_torch`` of ``steppers.npz`` (full field).
+"""
+
+from __future__ import annotations
+
+import hashlib
+import json
+import time
+
+import numpy as np
+import pytest
+from helpers import GOLDEN, host_faces, interior, max_rel, oracle_grid, to_full
+from test_oracle_golden import oracle_solve
+
+import pde_hip
+from oracle import pde_oracle as O
+from pde_hip import _abi
+
+CONFIGS = np.load(GOLDEN / "configs.npz", allow_pickle=False)
+CASES = {c["id"]: c for c in json.loads(str(CONFIGS["cases"]))}
+
+
+def _initial(case) -> np.ndarray:
+    """The reference's `ScalarField.random_uniform(grid, vmin, vmax, rng=default_rng(0))` (checked by the generator)."""
+    return np.random.default_rng(0).uniform(case["vmin"], case["vmax"], size=case["shape"]).astype(case.get("dtype", "float64"))
+
+
+def _grid(case):
+    return pde_hip.CartesianGrid(case["bounds"], case["shape"], periodic=case["periodic"])
+
+
+def _oracle_final(case):
+    grid = _grid(case)
+    dtype = np.dtype(case.get("dtype", "float64"))
+    ocase = dict(case)
+    if case["pde"] == "expression":
+        ocase.update(pde="cahn_hilliard", gamma=1.0)
+    if case.get("adaptive"):
+        ocase["dt"] = None          # oracle_solve: dt None = adaptive loop starting at dt = 1e-3
+    return oracle_solve(ocase, grid, dtype, _initial(case))
+
+
+def _sample(case, data):
+    return data[(slice(None, None, case["stride"]),) * len(case["shape"])]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# oracle vs the reference at full size (CPU)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cid", ["cfg2_diffusion_1024sq", "cfg3_cahn_hilliard_512sq"])
+def test_oracle_matches_reference_digest(cid):
+    case = CASES[cid]
+    final, steps, _ = _oracle_final(case)
+    assert steps == int(CONFIGS[f"{cid}/steps"])
+    np.testing.assert_array_equal(_sample(case, final), CONFIGS[f"{cid}/sample"])
+    assert hashlib.sha256(np.ascontiguousarray(final).tobytes()).hexdigest() == str(CONFIGS[f"{cid}/sha256"])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# HIP vs oracle (and vs the reference digests) at full size (GPU)
+# --------------------------------------------------------------------------------------------------------------
+def _make_eq(case):
+    if case["pde"] == "diffusion":
+        return pde_hip.DiffusionPDE(case["D"], bc=case["bc"])
+    if case["pde"] == "cahn_hilliard":
+        return pde_hip.CahnHilliardPDE(case["gamma"], bc_c=case["bc"], bc_mu=case["bc"])
+    return pde_hip.PDE(case["rhs"], bc=case["bc"])
+
+
+@pytest.mark.gpu
+def test_cfg1_unitgrid_64sq_euler(golden_steppers):
+    """cfg1: DiffusionPDE on UnitGrid([64, 64]) fp64, Euler dt = 0.1, t_range = 10 — the reference's torch-CPU result."""
+    cid = "diff64_euler_torch"
+    grid = pde_hip.UnitGrid([64, 64])
+    state = pde_hip.ScalarField(grid, golden_steppers[f"{cid}/input"])
+    res, info = pde_hip.DiffusionPDE().solve(state, t_range=10, dt=0.1, solver="euler", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == 100
+    np.testing.assert_array_equal(res.data, golden_steppers[f"{cid}/final"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", ["cfg2_diffusion_1024sq", "cfg3_cahn_hilliard_512sq"])
+def test_cfg2_cfg3_full_field_1000_steps(cid):
+    """cfg2: 1024^2 periodic diffusion; cfg3: UnitGrid 512^2 Cahn-Hilliard (the reference's published benchmark problem,
+    scripts/performance_solvers.py:53-66) — 1000 Euler steps through pdehip_euler_run (hipGraph replay of the launch-bound
+    loop, two-level kernels), whole field == the reference's torch-CPU run (digest) == the oracle, bit for bit."""
+    case = CASES[cid]
+    grid = _grid(case)
+    state = pde_hip.ScalarField(grid, _initial(case))
+    res, info = _make_eq(case).solve(state, t_range=case["t_range"], dt=case["dt"], solver="euler", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == int(CONFIGS[f"{cid}/steps"]) == 1000
+    np.testing.assert_array_equal(_sample(case, res.data), CONFIGS[f"{cid}/sample"])
+    assert hashlib.sha256(np.ascontiguousarray(res.data).tobytes()).hexdigest() == str(CONFIGS[f"{cid}/sha256"])
+    final, _, _ = _oracle_final(case)
+    np.testing.assert_array_equal(res.data, final)
+
+
+@pytest.mark.gpu
+def test_cfg4_512cube_full_field():
+    """cfg4 (512^3 fp64 periodic): 6 Euler steps (three two-step sweeps: the bench kernel, x-chunk seams included), one RK4
+    step, one RKF45 attempt and one Cahn-Hilliard Euler step — every cell compared with the oracle run on the whole grid."""
+    import ctypes as C
+
+    from pde_hip.device import DeviceArray, DeviceScalar, ptr_array
+
+    case = CASES["cfg4_diffusion_512cube_6steps"]
+    grid = _grid(case)
+    backend = pde_hip.get_backend("hip")
+    lib = backend._lib
+    u = _initial(case)
+    g = oracle_grid(grid)
+    faces = host_faces(grid.get_boundary_conditions("auto_periodic_neumann"))
+    full = to_full(grid, u)
+    # --- 6 Euler steps: HIP == oracle == the reference's torch-CPU digest
+    state = pde_hip.ScalarField(grid, u)
+    res = pde_hip.DiffusionPDE().solve(state, t_range=0.6, dt=0.1, solver="euler", backend="hip")
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, 1.0, faces.c)
+    expect = interior(grid, O.euler_run(g, rhs, full, 0.1, 6))
+    np.testing.assert_array_equal(res.data, expect)
+    if "cfg4_diffusion_512cube_6steps/sha256" in CONFIGS.files:
+        assert hashlib.sha256(np.ascontiguousarray(res.data).tobytes()).hexdigest() == str(CONFIGS["cfg4_diffusion_512cube_6steps/sha256"])
+    del res, expect
+    # --- one RK4 step and one RKF45 attempt of the diffusion equation (stage-fused sweeps)
+    eq = pde_hip.DiffusionPDE()
+    spec = backend.make_rhs_spec(eq, state)
+    y = DeviceArray(spec.info).set_valid(u)
+    work = [DeviceArray(spec.info) for _ in range(7)]
+    lib.rk4_step(spec.info.ref, spec.ref, y.ptr, ptr_array(work[:5]), 0.05, None)
+    o = full.copy()
+    O.rk4_step(g, rhs, o, 0.05)
+    np.testing.assert_array_equal(y.get_valid(), interior(grid, o))
+    del o
+    y.set_valid(u)
+    ynew, err = DeviceArray(spec.info), DeviceScalar()
+    lib.rkf45_attempt(spec.info.ref, spec.ref, y.ptr, ynew.ptr, ptr_array(work), 0.05, err.ptr, None)
+    onew, oerr = O.rkf45_attempt(g, rhs, full.copy(), 0.05)
+    np.testing.assert_array_equal(ynew.get_valid(), interior(grid, onew))
+    assert err.value() == oerr
+    del onew, work, ynew, y
+    # --- one Cahn-Hilliard Euler step (fused two-level sweep, mu in registers)
+    state_ch = pde_hip.ScalarField(grid, u - 0.5)
+    res = pde_hip.CahnHilliardPDE().solve(state_ch, t_range=1e-3, dt=1e-3, solver="euler", backend="hip")
+    scratch = np.zeros_like(full)
+    rhs_ch = O.make_rhs(_abi.RHS_CAHN_HILLIARD, 1.0, faces.c, faces.c, scratch)
+    expect = interior(grid, O.euler_run(g, rhs_ch, to_full(grid, u - 0.5), 1e-3, 1))
+    np.testing.assert_array_equal(res.data, expect)
+
+
+@pytest.mark.gpu
+def test_cfg5_256cube_f32_expression_rkf45():
+    """cfg5: PDE({'c': 'laplace(c**3 - c - laplace(c))'}) on 256^3 fp32, adaptive RKF45 (tolerance 1e-4, dt0 = 1e-3):
+    equal step count and <= 1e-5 relative against the oracle's adaptive loop over the whole field, and against the
+    reference's numpy+scipy run (sample) — fp32 contract of include/pdehip.h (fp32 storage, fp64 registers)."""
+    cid = "cfg5_expression_256cube_f32_rkf45"
+    case = CASES[cid]
+    grid = _grid(case)
+    u = _initial(case)
+    state = pde_hip.ScalarField(grid, u, dtype=np.float32)
+    t0 = time.time()
+    res, info = _make_eq(case).solve(state, t_range=case["t_range"], dt=case["dt"], solver="runge-kutta", adaptive=True, backend="hip",
+                                      ret_info=True)
+    t_hip = time.time() - t0
+    final, steps, dt_last = _oracle_final(case)
+    assert res.data.dtype == np.float32
+    assert info["solver"]["steps"] == steps
+    np.testing.assert_allclose(info["solver"]["dt"], dt_last, rtol=1e-4)
+    assert max_rel(res.data.astype(np.float64), final.astype(np.float64)) < 1e-5
+    if f"{cid}/sample" in CONFIGS.files:
+        assert info["solver"]["steps"] == int(CONFIGS[f"{cid}/steps"])
+        assert max_rel(_sample(case, res.data).astype(np.float64), CONFIGS[f"{cid}/sample"].astype(np.float64)) < 1e-5
+    print(f"cfg5: {steps} accepted steps, hip {t_hip:.2f}s")

@@ -92,6 +92,8 @@ def cpu_baseline(n: int, seconds: float) -> dict:
         "cores": cores,
         "kind": "port",
         "sample": f"{steps} Euler steps of DiffusionPDE {n_cpu}^3 fp64 periodic (oracle/pde_oracle.c, OpenMP {cores} threads, {el:.1f} s)",
+        "flags": "gcc -O3 -mavx2 -ffp-contract=off -fno-fast-math: a conservative stand-in for numba's fastmath build (no FMA contraction, "
+                 "no reassociation), numba itself is not installable here",
     }
 
 
@@ -148,14 +150,21 @@ def bench_single(args) -> dict:
     lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms_kernel))
     t_kernel = ms_kernel.value / reps * 1e-3
     cells = n**3
+    # bytes ONE launch has to move: every cell read once and written once — for the two-steps-per-sweep kernel that is one
+    # read + one write for TWO steps (the intermediate level lives in registers).  `frac` is priced on these moved bytes;
+    # `effective_frac` prices the same launch at SURVEY.md 8d's per-cell-step figure (16 B x cell-steps per launch), i.e.
+    # against a kernel that goes through HBM once per step — it may exceed 1 because temporal blocking removes bytes.
+    moved_bytes = cells * BYTES_PER_CELL_STEP
     alg_bytes = cells * BYTES_PER_CELL_STEP * steps_per_launch
-    achieved = alg_bytes / t_kernel / 1e9
+    achieved = moved_bytes / t_kernel / 1e9
     kname = "euler2_kernel" if steps_per_launch == 2 else "lap_march_euler"
-    traffic = None
+    traffic, traffic_source = None, None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
         try:
-            traffic = json.loads(tfile.read_text()).get(f"{kname}_{n}")
+            tj = json.loads(tfile.read_text())
+            traffic = tj.get(f"{kname}_{n}")
+            traffic_source = tj.get("source")
         except (ValueError, OSError):
             traffic = None
     out = {
@@ -166,12 +175,15 @@ def bench_single(args) -> dict:
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": ("euler2_kernel<double,2,4> (TWO fused laplace + D*, dt*, += steps per launch)" if steps_per_launch == 2
                        else "lap_march_kernel<double,2,RY,EULER> (fused laplace + D*, dt*, +=)"),
-            "kernel_ms": round(t_kernel * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": round(t_kernel * 1e3, 4), "moved_bytes_per_launch": moved_bytes,
             "steps_per_launch": steps_per_launch,
+            "effective_frac": round(alg_bytes / t_kernel / 1e9 / HBM_PEAK_GBS, 4),
+            "effective_bytes_per_launch": alg_bytes,
             "traffic_frac": round(traffic / t_kernel / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-            "note": ("algorithmic bytes = 16 B per cell-step (SURVEY.md 8d) x cell-steps per launch; the kernel advances two "
-                     "steps per sweep keeping the intermediate level in registers, so its measured HBM traffic is about half "
-                     "of that and frac can exceed 1") if steps_per_launch == 2 else None,
+            "traffic_source": traffic_source,
+            "note": "frac = bytes one launch must move (1 read + 1 write per cell; two Euler steps per launch) / kernel time / peak; "
+                    "effective_frac = SURVEY 8d's 16 B per cell-step x cell-steps per launch / kernel time / peak; traffic = HBM bytes per "
+                    "launch from rocprofv3 PMC counters of the same build on another box (see traffic_source), kernel time from this run",
         },
         "device": backend.device_name,
     }
@@ -179,11 +191,10 @@ def bench_single(args) -> dict:
 
 
 def bench_distributed(args) -> dict:
-    import torch
-    import torch.distributed as dist
-
+    """One rank per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Data plane: libpdehip +
+    RCCL over xGMI only; torch.distributed (gloo) is the control plane: RCCL id, agreeing on code paths, barriers."""
     import pde_hip
-    from pde_hip.distributed import HipEngine, SlabStepper
+    from pde_hip.distributed import SlabStepper, TorchControl
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -191,36 +202,40 @@ def bench_distributed(args) -> dict:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    control = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        control = TorchControl()
     n = args.size
     grid = pde_hip.UnitGrid([n, n, n], periodic=True)
     eq = pde_hip.DiffusionPDE(1.0)
-    stepper = SlabStepper(eq, grid, engine=HipEngine(local_rank), force_exchange=args.force_distributed)
+    stepper = SlabStepper(eq, grid, control=control, device=local_rank, force_exchange=args.force_distributed)
+    control = stepper.control
     # synthetic data: every rank fills its own slab (no global array is ever materialised)
     rng = np.random.default_rng(1000 + rank)
-    cur = stepper.buf("state_a")
-    stepper.engine.set_valid(stepper.g, cur, rng.random(stepper.mesh.subgrid.shape))
-    nxt = stepper.buf("state_b")
+    a, b = stepper.buf("state_a"), stepper.buf("state_b")
+    stepper.set_local(a, rng.random(stepper.mesh.subgrid.shape))
     dt = 0.1
-    cur = stepper.euler_steps(cur, nxt, dt, args.warmup)
-    nxt = stepper.buf("state_b") if cur is stepper.buf("state_a") else stepper.buf("state_a")
-    stepper.engine.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+    cur = stepper.euler_steps(a, b, dt, args.warmup)
+    nxt = b if cur is a else a
+    stepper.synchronize()
+    control.barrier()
     t0 = time.perf_counter()
     cur = stepper.euler_steps(cur, nxt, dt, args.steps)
-    stepper.engine.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    wall = float(el.item())
-    # sanity: the field stays finite and its mean is conserved by periodic diffusion
-    local = stepper.gather_local(cur)
-    ok = bool(np.isfinite(local).all())
-    dist.destroy_process_group()
-    return {"wall": wall, "rank": rank, "finite": ok}
+    stepper.synchronize()
+    control.barrier()
+    wall = max(control.allgather(time.perf_counter() - t0))
+    # sanity: the field stays finite
+    ok = all(control.allgather(bool(np.isfinite(stepper.gather_local(cur)).all())))
+    info = {"two_steps_per_sweep": stepper._euler2, "layers_per_rank": [int(c) for c in stepper.mesh.counts]}
+    stepper.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+    return {"wall": wall, "rank": rank, "finite": ok, "info": info}
 
 
 def main():
@@ -234,7 +249,7 @@ def main():
             return
         ngpu = world
         wall = r["wall"]
-        line = {"roofline": None, "cpu_baseline": None}
+        line = {"roofline": None, "cpu_baseline": None, "slab": r["info"], "finite": r["finite"]}
         parallelism = f"slab{ngpu} (axis-0 slabs, RCCL send/recv halo exchange overlapped with interior kernel)"
     else:
         r = bench_single(args)
@@ -242,6 +257,14 @@ def main():
         wall = r["wall"]
         line = {"roofline": r["roofline"]}
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, args.cpu_seconds)
+        ref_file = ROOT / "profiles" / "reference_cpu.json"
+        if ref_file.exists() and not args.no_cpu_baseline:
+            # the reference itself (py-pde, eager torch-CPU backend) cannot travel to the GPU box: timed in the build container
+            # by tools/time_reference_cpu.py next to the oracle on the same cores, committed under profiles/
+            try:
+                line["cpu_baseline_reference"] = json.loads(ref_file.read_text())
+            except (ValueError, OSError):
+                pass
         parallelism = "single GPU"
     value = cells * args.steps / wall / 1e6
     out = {
@@ -262,7 +285,7 @@ def main():
                         "state resident in HBM, BCs on the fly + fused laplace/update, two steps per kernel sweep (bit-identical to single steps)",
             "cells": cells,
             "parallelism": parallelism,
-            "hbm_roofline_frac_whole_step": round(value * 1e6 * BYTES_PER_CELL_STEP / 1e9 / (HBM_PEAK_GBS * ngpu), 4),
+            "effective_hbm_roofline_frac_whole_step": round(value * 1e6 * BYTES_PER_CELL_STEP / 1e9 / (HBM_PEAK_GBS * ngpu), 4),
         },
         **line,
     }

@@ -314,6 +314,45 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
                            int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                            void *stream);
 
+/* ---- slab-parallel Runge-Kutta and the adaptive loop (one C call per run: no host work per stage) ----------------
+ * `flags` (PDEHIP_SLAB_*) select code paths that every rank must take alike; the caller ANDs the local answers of
+ * pdehip_slab_flags_supported over all ranks (MIN all-reduce) before the first call.  Arrays that serve as stage inputs
+ * (y, ynew, work[3] (k4), the last work array (tmp)) — simplest: ALL slab arrays — must be allocated with one spare layer
+ * (pdehip_layout out8[7] elements) before and after, because the fused Cahn-Hilliard sweep reads TWO halo layers per side
+ * (exchanged into that spare room).  `comm` may be NULL when lower == upper == -1 (single process, no exchange): the same
+ * loops then serve the serial adaptive stepper. */
+enum {
+    PDEHIP_SLAB_FUSED_CH = 1,    /* Cahn-Hilliard right-hand side as one two-level sweep after ONE exchange of two layers of c */
+    PDEHIP_SLAB_FUSED_STAGE = 2  /* Runge-Kutta combination inside the sweep that computes the slope */
+};
+int pdehip_slab_flags_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int *flags);
+/* k_out = dt * rhs(y) on the slab incl. the halo exchange(s): replaces NumbaMPIBackend's operator + _MPIBC exchange per
+ * right-hand side (pde/backends/numba_mpi/backend.py:30-194) */
+int pdehip_slab_rhs_scaled(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                           void *y_full, void *k_out_full, double dt, void *stream);
+/* `nsteps` Euler steps of ANY fused right-hand side, one exchange + sweep per step (Cahn-Hilliard; the diffusion equation has
+ * the overlapped loops pdehip_slab_euler_run / pdehip_slab_euler2_run) */
+int pdehip_slab_euler_sweeps(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                             void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream);
+/* `nsteps` classical RK4 steps in place on y (pde/solvers/runge_kutta.py:29-66, loop pde/backends/numba/_solvers.py:93-104) */
+int pdehip_slab_rk4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                        void *y_full, void *const *work5_host, double dt, int64_t nsteps, void *stream);
+/* Adaptive RKF45 from t_start to t_end: the loop of pde/backends/numba/_solvers.py:249-281 with the controller of
+ * pde/solvers/base.py:572-592 and the MAX all-reduce of the error estimate (pde/backends/base.py:678-712).  In: t_start, t_end,
+ * dt (first trial step), tolerance, dt_min, dt_max; the counters and statistics are ACCUMULATED (zero them before the first
+ * call of a run).  Out: dt (next trial step), t_last, steps, attempts, statistics of the accepted steps.  *result = y or ynew,
+ * whichever holds the final state.  A step size below dt_min is reported as an error (code 3) with the reference's message. */
+typedef struct pdehip_adaptive {
+    double t_start, t_end, dt, tolerance, dt_min, dt_max;
+    double t_last;
+    int64_t steps, attempts;
+    int64_t stat_count;
+    double stat_min, stat_max, stat_mean, stat_m2;
+} pdehip_adaptive_t;
+int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                          void *y_full, void *ynew_full, void *const *work7_host, double *err_dev, pdehip_adaptive_t *ctl,
+                          void **result, void *stream);
+
 /* ---- run-time specialised right-hand sides (generic `PDE({...})` expressions) ----------------------
  * Replaces the sympy -> numba code generation of pde/pdes/pde.py:401-499 / pde/tools/expressions.py:
  * 361-388.  `epilogue_body` is the body of

@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include "pdehip_common.h"
+#include "pdehip_slab_loops.h"
 
 using namespace pdehip;
 
@@ -65,51 +66,28 @@ int load_rccl(const char *path)
     } while (0)
 
 struct Comm {
-    ncclComm_t comm;
-    int rank, size;
-    hipStream_t halo;            // stream of the exchange + boundary-layer kernels
-    hipEvent_t ev_comp, ev_halo, ev_bnd;
-    double *scratch2;            // device: {value, nan flag} for the MAX all-reduce
+    ncclComm_t comm = nullptr;
+    int rank = 0, size = 1;
+    hipStream_t halo = nullptr;  // stream of the exchange + boundary-layer kernels
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // slab::EV_COMP, EV_HALO, EV_BND
+    double *scratch2 = nullptr;  // device: {value, nan flag} for the MAX all-reduce
     void *ext[2] = {nullptr, nullptr};   // slab copies with TWO halo layers per side (two-steps-per-sweep loop)
     size_t ext_bytes = 0;
 };
 
-// pointer to full layer `layer` (0 = lower ghost layer) of a slab
-inline char *layer_ptr(const NGrid &n, void *buf, long layer)
+// serial use of the slab loops (comm == NULL, no neighbours): streams / events of a process-wide context without RCCL
+Comm *serial_context()
 {
-    return static_cast<char *>(buf) + layer * n.p[3 - n.ndim] * elem_size(n.dtype);
+    static Comm ctx;
+    return &ctx;
 }
 
-// Post the halo exchange of `buf` on `st`.  Order per peer: the "downward" pair first, then the
-// "upward" pair — RCCL matches sends and receives to one peer in issue order, so the 2-rank periodic
-// ring and the 1-rank self exchange pair up correctly (same order as pde_hip/distributed.py, which is
-// tested on CPU with gloo at world sizes 2 and 3).
-int exchange(Comm *c, const NGrid &n, void *buf, int lower, int upper, hipStream_t st)
+int ensure_streams(Comm *c)
 {
-    if (lower < 0 && upper < 0) return 0;
-    const long nloc = n.n[3 - n.ndim];
-    const size_t bytes = (size_t)n.p[3 - n.ndim] * elem_size(n.dtype);
-    PDEHIP_NCCL(g_rccl.GroupStart());
-    if (lower >= 0) PDEHIP_NCCL(g_rccl.Send(layer_ptr(n, buf, 1), bytes, ncclInt8, lower, c->comm, st));
-    if (upper >= 0) {
-        PDEHIP_NCCL(g_rccl.Recv(layer_ptr(n, buf, nloc + 1), bytes, ncclInt8, upper, c->comm, st));
-        PDEHIP_NCCL(g_rccl.Send(layer_ptr(n, buf, nloc), bytes, ncclInt8, upper, c->comm, st));
-    }
-    if (lower >= 0) PDEHIP_NCCL(g_rccl.Recv(layer_ptr(n, buf, 0), bytes, ncclInt8, lower, c->comm, st));
-    PDEHIP_NCCL(g_rccl.GroupEnd());
+    if (!c->halo) PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+    for (auto &e : c->ev)
+        if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
-}
-
-// faces of a sub-slab of layers [first, first+count) (1-based valid layers of the slab): the
-// inter-layer faces inside the slab are real data (SKIP); physical / exchanged faces keep the slab's
-// descriptor with the index translated into the sub-slab
-void sub_faces(const pdehip_bc_face_t *faces, long nloc, long first, long count, pdehip_bc_face_t *out)
-{
-    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) out[i] = faces[i];
-    if (first > 1) out[0].kind = PDEHIP_BC_SKIP;
-    else out[0].index1 -= (first - 1), out[0].index2 -= (first - 1);
-    if (first + count - 1 < nloc) out[1].kind = PDEHIP_BC_SKIP;
-    else out[1].index1 -= (first - 1), out[1].index2 -= (first - 1);
 }
 
 __global__ void pack_nan_kernel(const double *in, double *out2)
@@ -122,6 +100,118 @@ __global__ void pack_nan_kernel(const double *in, double *out2)
 __global__ void unpack_nan_kernel(const double *in2, double *out)
 {
     out[0] = (in2[1] > 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : in2[0];
+}
+
+// The `Ops` policy of pdehip_slab_loops.h on the device: HIP streams / events, RCCL point-to-point over xGMI, gfx950 kernels.
+struct HipOps {
+    Comm *c;
+    void *halo() { return c->halo; }
+    int record(int ev, void *st) { PDEHIP_HIP(hipEventRecord(c->ev[ev], as_stream(st))); return 0; }
+    int wait(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), c->ev[ev], 0)); return 0; }
+    int group_start() { PDEHIP_NCCL(g_rccl.GroupStart()); return 0; }
+    int group_end() { PDEHIP_NCCL(g_rccl.GroupEnd()); return 0; }
+    int send(const void *p, size_t bytes, int peer, void *st)
+    {
+        PDEHIP_NCCL(g_rccl.Send(p, bytes, ncclInt8, peer, c->comm, as_stream(st)));
+        return 0;
+    }
+    int recv(void *p, size_t bytes, int peer, void *st)
+    {
+        PDEHIP_NCCL(g_rccl.Recv(p, bytes, ncclInt8, peer, c->comm, as_stream(st)));
+        return 0;
+    }
+    int copy(void *dst, const void *src, size_t bytes, void *st)
+    {
+        PDEHIP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(st)));
+        return 0;
+    }
+    int zero(void *p, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(p, 0, bytes, as_stream(st))); return 0; }
+    int fail(const char *msg) { PDEHIP_FAIL(E_NOTIMPL, "%s", msg); }
+    int fail_runtime(const char *fmt, double v) { PDEHIP_FAIL(E_RUNTIME, fmt, v); }
+    // BCs of `in` (faces not marked SKIP) + stencil into the full array `out`
+    int lap(const pdehip_grid_t *gs, void *in, const void *y, void *out, int kind, double s1, double s2, double gamma,
+            const pdehip_bc_face_t *faces, void *st, const StageFuse *sf)
+    {
+        const int mode = kind == slab::K_EULER ? LAP_EULER : kind == slab::K_SCALED ? LAP_SCALED : kind == slab::K_CH_MU ? LAP_CH_MU : LAP_STAGE;
+        return laplace_with_input_bcs(gs, in, y, out, mode, s1, s2, gamma, faces, st, sf);
+    }
+    int euler2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *st, bool *done,
+               int xplain, bool dry, int ends)
+    {
+        return euler2_with_input_bcs(gs, in, out, D, dt, faces, st, done, xplain, dry, ends);
+    }
+    int ch_fused(const pdehip_grid_t *gs, const void *in, void *out, double gamma, double dt, bool euler, const pdehip_bc_face_t *fc,
+                 const pdehip_bc_face_t *fm, void *st, bool *done, int xplain, bool dry, const StageFuse *sf)
+    {
+        return cahn_hilliard_fused(gs, in, out, gamma, dt, euler, fc, fm, st, done, xplain, dry, sf);
+    }
+    // the pointwise Runge-Kutta combination `sf` with the slope k already stored (unfused stages)
+    int combine(const pdehip_grid_t *g, void *k, const StageFuse &sf, void *st)
+    {
+        if (sf.kind == 0) {
+            const void *ks[6];
+            double cf[6];
+            int n = 0;
+            for (; n < 5 && sf.k[n]; n++) { ks[n] = sf.k[n]; cf[n] = sf.c[n]; }
+            ks[n] = k; cf[n] = sf.c_new;
+            return pdehip_lincomb(g, 1, sf.out2, sf.y, n + 1, cf, ks, st);
+        }
+        if (sf.kind == 1) {
+            if (sf.out2 != sf.y) PDEHIP_FAIL(E_RUNTIME, "internal: the RK4 update works in place");
+            return pdehip_rk4_combine(g, 1, sf.out2, sf.k[0], sf.k[1], sf.k[2], k, st);
+        }
+        if (sf.kind == 2) {
+            const void *k6[6] = {sf.k[0], sf.k[0] /* k2 does not enter */, sf.k[1], sf.k[2], sf.k[3], k};
+            return pdehip_rkf45_combine(g, 1, sf.y, sf.out2, k6, sf.err, st);
+        }
+        PDEHIP_FAIL(E_NOTIMPL, "internal: unknown stage kind %d", sf.kind);
+    }
+    // in-place MAX over all ranks of one fp64 device scalar; NaN wins like numpy.max
+    int allreduce_max(double *dev_scalar, void *stream)
+    {
+        if (c->size == 1) return 0;
+        hipStream_t st = as_stream(stream);
+        hipLaunchKernelGGL(pack_nan_kernel, dim3(1), dim3(1), 0, st, dev_scalar, c->scratch2);
+        PDEHIP_NCCL(g_rccl.AllReduce(c->scratch2, c->scratch2, 2, ncclFloat64, ncclMax, c->comm, st));
+        hipLaunchKernelGGL(unpack_nan_kernel, dim3(1), dim3(1), 0, st, c->scratch2, dev_scalar);
+        PDEHIP_HIP(hipGetLastError());
+        return 0;
+    }
+    int read_scalar(double *host, const double *dev, void *st)
+    {
+        PDEHIP_HIP(hipMemcpyAsync(host, dev, sizeof(double), hipMemcpyDeviceToHost, as_stream(st)));
+        PDEHIP_HIP(hipStreamSynchronize(as_stream(st)));
+        return 0;
+    }
+};
+
+int make_geo(const pdehip_grid_t *g, NGrid *n, slab::Geo *q)
+{
+    PDEHIP_TRY(norm_grid(g, n));
+    q->nloc = g->shape[0];
+    q->esz = (size_t)elem_size(n->dtype);
+    q->lp = (size_t)n->p[3 - n->ndim] * q->esz;
+    return 0;
+}
+
+// comm handle -> context; NULL is allowed for a process without neighbours (serial use of the loops)
+int context(void *comm, int lower, int upper, Comm **out)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) {
+        if (lower >= 0 || upper >= 0) PDEHIP_FAIL(E_VALUE, "a slab with neighbours needs a communicator");
+        c = serial_context();
+    }
+    PDEHIP_TRY(ensure_streams(c));
+    *out = c;
+    return 0;
+}
+
+int check_rhs(const pdehip_rhs_t *rhs)
+{
+    if (!rhs) PDEHIP_FAIL(E_VALUE, "rhs descriptor is NULL");
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION && rhs->kind != PDEHIP_RHS_CAHN_HILLIARD) PDEHIP_FAIL(E_NOTIMPL, "unknown rhs kind %d", rhs->kind);
+    return 0;
 }
 
 }  // namespace
@@ -148,10 +238,7 @@ int pdehip_comm_create(const char *librccl_path, const void *id128, int rank, in
     Comm *c = new Comm();
     c->rank = rank; c->size = size;
     PDEHIP_NCCL(g_rccl.CommInitRank(&c->comm, size, id, rank));
-    PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
-    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_comp, hipEventDisableTiming));
-    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-    PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_bnd, hipEventDisableTiming));
+    PDEHIP_TRY(ensure_streams(c));
     PDEHIP_HIP(hipMalloc(&c->scratch2, 2 * sizeof(double)));
     *comm = c;
     return 0;
@@ -164,7 +251,7 @@ int pdehip_comm_destroy(void *comm)
     (void)hipStreamSynchronize(c->halo);
     g_rccl.CommDestroy(c->comm);
     (void)hipStreamDestroy(c->halo);
-    (void)hipEventDestroy(c->ev_comp); (void)hipEventDestroy(c->ev_halo); (void)hipEventDestroy(c->ev_bnd);
+    for (auto &e : c->ev) (void)hipEventDestroy(e);
     (void)hipFree(c->scratch2);
     (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
     delete c;
@@ -175,108 +262,31 @@ int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_ful
 {
     if (!comm || !buf_full) PDEHIP_FAIL(E_VALUE, "halo_exchange: NULL pointer");
     NGrid n;
-    PDEHIP_TRY(norm_grid(g_local, &n));
-    return exchange(static_cast<Comm *>(comm), n, buf_full, lower, upper, as_stream(stream));
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{static_cast<Comm *>(comm)};
+    return slab::exchange(ops, q, buf_full, lower, upper, stream);
 }
 
 int pdehip_allreduce_max(void *comm, double *dev_scalar, void *stream)
 {
     if (!comm || !dev_scalar) PDEHIP_FAIL(E_VALUE, "allreduce_max: NULL pointer");
-    Comm *c = static_cast<Comm *>(comm);
-    if (c->size == 1) return 0;
-    hipStream_t st = as_stream(stream);
-    // NaN must win like numpy's max: reduce {value with NaN -> 0, NaN flag}
-    hipLaunchKernelGGL(pack_nan_kernel, dim3(1), dim3(1), 0, st, dev_scalar, c->scratch2);
-    PDEHIP_NCCL(g_rccl.AllReduce(c->scratch2, c->scratch2, 2, ncclFloat64, ncclMax, c->comm, st));
-    hipLaunchKernelGGL(unpack_nan_kernel, dim3(1), dim3(1), 0, st, c->scratch2, dev_scalar);
-    PDEHIP_HIP(hipGetLastError());
-    return 0;
+    HipOps ops{static_cast<Comm *>(comm)};
+    return ops.allreduce_max(dev_scalar, stream);
 }
 
-// nsteps explicit Euler steps of the diffusion equation on one slab; all work is enqueued without
-// host synchronisation:
-//   comp stream : interior kernel (layers 2..n-1)   ............................ | next step
-//   halo stream : boundary kernels (layers 1, n) - send/recv of the new layers 1, n
-// The exchange of step s+1's input overlaps the interior kernel of step s.  BCs of the faces this
-// rank owns are evaluated on the fly inside the kernels; exchanged faces read the received layers.
+// nsteps explicit Euler steps of the diffusion equation on one slab, exchange overlapped with the interior kernel
+// (loop: slab::euler_run in pdehip_slab_loops.h)
 int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
                           void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
 {
     if (!comm || !rhs || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler_run: NULL pointer");
-    if (rhs->kind != PDEHIP_RHS_DIFFUSION) PDEHIP_FAIL(E_NOTIMPL, "slab_euler_run implements the diffusion right-hand side");
-    Comm *c = static_cast<Comm *>(comm);
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION) PDEHIP_FAIL(E_NOTIMPL, "slab_euler_run implements the diffusion right-hand side (others: pdehip_slab_euler_sweeps)");
     NGrid n;
-    PDEHIP_TRY(norm_grid(g_local, &n));
-    const long nloc = g_local->shape[0];
-    hipStream_t comp = as_stream(stream), halo = c->halo;
-    // faces: exchanged ones are read from the ghost layers
-    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
-    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) faces[i] = rhs->bc_c[i];
-    if (lower >= 0) faces[0].kind = PDEHIP_BC_SKIP;
-    if (upper >= 0) faces[1].kind = PDEHIP_BC_SKIP;
-    const size_t esz = elem_size(n.dtype);
-    const size_t lp = (size_t)n.p[3 - n.ndim] * esz;   // bytes per layer
-
-    auto sub_step = [&](hipStream_t st, void *cur, void *nxt, long first, long count) -> int {
-        if (count <= 0) return 0;
-        pdehip_grid_t gs = *g_local;
-        gs.shape[0] = count;
-        pdehip_bc_face_t sf[2 * PDEHIP_MAX_DIM];
-        sub_faces(faces, nloc, first, count, sf);
-        char *pc = static_cast<char *>(cur) + (first - 1) * lp, *pn = static_cast<char *>(nxt) + (first - 1) * lp;
-        return laplace_with_input_bcs(&gs, pc, pc, pn, LAP_EULER, rhs->param, dt, 0, sf, st);
-    };
-
-    void *cur = buf_a, *nxt = buf_b;
-    // ghost layers of the initial state
-    PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
-    PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
-    PDEHIP_TRY(exchange(c, n, cur, lower, upper, halo));
-    for (int64_t s = 0; s < nsteps; s++) {
-        // interior layers need no exchanged data; they must wait for the boundary layers of `cur`
-        // (written on the halo stream in the previous step)
-        if (s > 0) PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_bnd, 0));
-        PDEHIP_TRY(sub_step(comp, cur, nxt, 2, nloc - 2));
-        PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
-        // boundary layers: the received ghost layers are ordered by the halo stream itself
-        PDEHIP_TRY(sub_step(halo, cur, nxt, 1, 1));
-        if (nloc > 1) PDEHIP_TRY(sub_step(halo, cur, nxt, nloc, 1));
-        PDEHIP_HIP(hipEventRecord(c->ev_bnd, halo));
-        PDEHIP_TRY(exchange(c, n, nxt, lower, upper, halo));   // overlaps the interior kernel
-        // the next step overwrites `cur`: its interior kernel (comp) and boundary kernels (halo, in
-        // order) must be done; the halo stream additionally waits for this step's interior kernel
-        PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
-        void *t = cur; cur = nxt; nxt = t;
-    }
-    // make the compute stream see everything
-    PDEHIP_HIP(hipEventRecord(c->ev_halo, halo));
-    PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_halo, 0));
-    *result = cur;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Two Euler steps per sweep on a slab (temporal blocking, pdehip_march2.inc) — halves both the HBM traffic per
-// step and the NUMBER of halo exchanges: two layers per side are exchanged once per two steps.
-//
-// The slab is copied into a private array with two halo layers per side (layers 0,1 | own 2..n+1 | n+2,n+3):
-//   comp stream : interior sweep (own layers 4..n-1; reads own layers only)        ............ | next pair
-//   halo stream : boundary sweeps (layers 2,3 and n,n+1; read the received halos) - send/recv of the new
-//                 boundary layers, overlapping the interior sweep
-// Requires: both neighbours present on EVERY rank (periodic slowest axis), >= 4 local layers on every rank and a
-// grid / faces the kernel covers (pdehip_slab_euler2_supported) — the caller decides globally, all ranks alike.
-// ---------------------------------------------------------------------------------------------------------
-static int exchange2(Comm *c, size_t lp, long nloc, void *ext, int lower, int upper, hipStream_t st)
-{
-    char *b = static_cast<char *>(ext);
-    if (lower < 0 && upper < 0) return 0;
-    PDEHIP_NCCL(g_rccl.GroupStart());
-    if (lower >= 0) PDEHIP_NCCL(g_rccl.Send(b + 2 * lp, 2 * lp, ncclInt8, lower, c->comm, st));            // own first two layers -> lower
-    if (upper >= 0) PDEHIP_NCCL(g_rccl.Recv(b + (nloc + 2) * lp, 2 * lp, ncclInt8, upper, c->comm, st));   // upper halo <- upper
-    if (upper >= 0) PDEHIP_NCCL(g_rccl.Send(b + nloc * lp, 2 * lp, ncclInt8, upper, c->comm, st));         // own last two layers -> upper
-    if (lower >= 0) PDEHIP_NCCL(g_rccl.Recv(b, 2 * lp, ncclInt8, lower, c->comm, st));                     // lower halo <- lower
-    PDEHIP_NCCL(g_rccl.GroupEnd());
-    return 0;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{static_cast<Comm *>(comm)};
+    return slab::euler_run(ops, g_local, q, rhs, lower, upper, buf_a, buf_b, dt, nsteps, result, stream);
 }
 
 int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
@@ -299,6 +309,8 @@ int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_
     return 0;
 }
 
+// two Euler steps per sweep on a slab (loop: slab::euler2_run); the private arrays with two halo layers per side live in
+// the communicator and are re-used from call to call
 int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
                            void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
 {
@@ -306,24 +318,19 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     int ok = 0;
     PDEHIP_TRY(pdehip_slab_euler2_supported(g_local, rhs, &ok));
     if (!ok) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: grid or faces are not covered by the two-step kernel");
-    // sides of the slowest axis without a neighbour keep their (local, first-order) physical face:
-    // 0 both physical, 1 both exchanged, 2 lower physical, 3 upper physical  (xplain codes of launch_euler2)
-    const int xends = (lower >= 0 && upper >= 0) ? 1 : (lower < 0 && upper < 0) ? 0 : (lower < 0 ? 2 : 3);
     Comm *c = static_cast<Comm *>(comm);
     NGrid n;
-    PDEHIP_TRY(norm_grid(g_local, &n));
-    const long nloc = g_local->shape[0];
-    hipStream_t comp = as_stream(stream), halo = c->halo;
-    const size_t esz = elem_size(n.dtype);
-    const size_t lp = (size_t)n.p[0] * esz;   // bytes per layer
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    hipStream_t comp = as_stream(stream);
     // private arrays with two halo layers per side: the layout of a slab of nloc+2 layers
     pdehip_grid_t ge = *g_local;
-    ge.shape[0] = nloc + 2;
+    ge.shape[0] = q.nloc + 2;
     NGrid ne;
     PDEHIP_TRY(norm_grid(&ge, &ne));
-    const size_t need = (size_t)(ne.pc + kAllocSlack) * esz;
+    const size_t need = (size_t)(ne.pc + kAllocSlack) * q.esz;
     if (c->ext_bytes < need) {
-        PDEHIP_HIP(hipStreamSynchronize(halo));
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
         (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
         c->ext[0] = c->ext[1] = nullptr; c->ext_bytes = 0;
         PDEHIP_HIP(hipMalloc(&c->ext[0], need));
@@ -332,73 +339,10 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
         PDEHIP_HIP(hipMemsetAsync(c->ext[0], 0, need, comp));
         PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
     }
-    char *cur = static_cast<char *>(c->ext[0]), *nxt = static_cast<char *>(c->ext[1]);
-    // own layers: slab layers 1..nloc -> private layers 2..nloc+1 (same row layout, one layer further in)
-    PDEHIP_HIP(hipMemcpyAsync(cur + 2 * lp, static_cast<char *>(buf_a) + lp, (size_t)nloc * lp, hipMemcpyDeviceToDevice, comp));
-
-    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
-    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) faces[i] = rhs->bc_c[i];
-    if (lower >= 0) faces[0].kind = PDEHIP_BC_SKIP;   // exchanged sides: real layers
-    if (upper >= 0) faces[1].kind = PDEHIP_BC_SKIP;
-
-    // two steps on private layers [first, first+count)
-    // (ends > 0: the first and the last `ends` layers of the range in one launch)
-    auto sweep2 = [&](hipStream_t st, long first, long count, int ends) -> int {
-        if (count <= 0) return 0;
-        pdehip_grid_t gs = *g_local;
-        gs.shape[0] = count;
-        bool done = false;
-        // the interior sweep reads own layers only (plain on both sides); the two-ended boundary sweep meets the physical faces
-        PDEHIP_TRY(euler2_with_input_bcs(&gs, cur + (first - 1) * lp, nxt + (first - 1) * lp, rhs->param, dt, faces, st, &done,
-                                         ends ? xends : 1, false, ends));
-        if (!done) PDEHIP_FAIL(E_RUNTIME, "internal: two-step kernel refused a sub-slab");
-        return 0;
-    };
-
-    // comp stream : interior sweep (reads own layers only)                          | interior sweep ...
-    // halo stream : [wait interior s-1] boundary sweep - send/recv new boundary layers | [wait] boundary sweep ...
-    // Measured alternatives (profiles/r01_probe_slab_euler2.md): boundary sweep first on the compute stream, then the
-    // interior sweep — the RCCL kernel then crawls behind the full-occupancy interior sweep and ends with it (worse at
-    // every slab thickness); capping the interior sweep at 75 % of the wave slots helps only thin slabs.
-    PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
-    PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
-    PDEHIP_TRY(exchange2(c, lp, nloc, cur, lower, upper, halo));
-    int64_t s = 0;
-    bool first_pair = true;
-    for (; s + 2 <= nsteps; s += 2) {
-        if (!first_pair) PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_bnd, 0));   // boundary layers of `cur` (halo stream)
-        first_pair = false;
-        PDEHIP_TRY(sweep2(comp, 4, nloc - 4, 0));
-        PDEHIP_HIP(hipEventRecord(c->ev_comp, comp));
-        PDEHIP_TRY(sweep2(halo, 2, nloc, 2));   // own layers 2,3 and nloc,nloc+1 (needs the received halo layers)
-        PDEHIP_HIP(hipEventRecord(c->ev_bnd, halo));
-        if (s + 2 < nsteps) PDEHIP_TRY(exchange2(c, lp, nloc, nxt, lower, upper, halo));   // overlaps the interior sweep
-        // the next pair overwrites `cur` and its boundary sweep reads the interior layers written now
-        PDEHIP_HIP(hipStreamWaitEvent(halo, c->ev_comp, 0));
-        char *t = cur; cur = nxt; nxt = t;
-    }
-    PDEHIP_HIP(hipEventRecord(c->ev_halo, halo));
-    PDEHIP_HIP(hipStreamWaitEvent(comp, c->ev_halo, 0));
-    if (s < nsteps) {
-        // odd step count: one single step; layers 1 and nloc+2 act as its ghost layers (already exchanged)
-        pdehip_grid_t gs = *g_local;
-        PDEHIP_TRY(laplace_with_input_bcs(&gs, cur + lp, cur + lp, nxt + lp, LAP_EULER, rhs->param, dt, 0, faces, comp));
-        char *t = cur; cur = nxt; nxt = t;
-    }
-    PDEHIP_HIP(hipMemcpyAsync(static_cast<char *>(buf_a) + lp, cur + 2 * lp, (size_t)nloc * lp, hipMemcpyDeviceToDevice, comp));
-    *result = buf_a;
-    return 0;
+    HipOps ops{c};
+    return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Cahn-Hilliard right-hand side on a slab in ONE sweep (fused two-level kernel, mu in registers): two layers of c per
-// side are exchanged, mu needs no exchange of its own (the reference exchanges c AND mu, one layer each:
-// pde/grids/boundaries/local.py:561-662 per operator application).  `c_ext` / `out_ext` are slab arrays with TWO halo
-// layers per side (layers 0,1 | own 2..n+1 | n+2,n+3), i.e. the layout of a slab of n+2 layers.
-//   euler != 0: out = c + dt * laplace(mu)        euler == 0: out = dt * laplace(mu)
-// Preconditions as for pdehip_slab_euler2_run (periodic slowest axis, >= 2 own layers on every rank, *ok from
-// pdehip_slab_ch_supported), checked globally by the caller.
-// ---------------------------------------------------------------------------------------------------------
 int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
 {
     if (!g_local || !rhs || !ok) PDEHIP_FAIL(E_VALUE, "slab_ch_supported: NULL pointer");
@@ -417,28 +361,115 @@ int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *r
     return 0;
 }
 
+// Cahn-Hilliard right-hand side on a slab in ONE sweep after ONE exchange of two layers of c (slab::rhs_sweep with
+// F_FUSED_CH); `c_ext` / `out_ext` are the arrays with two halo layers per side
 int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
                          void *c_ext, void *out_ext, double dt, int euler, void *stream)
 {
     if (!comm || !rhs || !c_ext || !out_ext) PDEHIP_FAIL(E_VALUE, "slab_ch_sweep: NULL pointer");
-    // sides without a neighbour keep their physical faces (xplain codes of launch_euler2)
-    const int xmode = (lower >= 0 && upper >= 0) ? 1 : (lower < 0 && upper < 0) ? 0 : (lower < 0 ? 2 : 3);
-    Comm *c = static_cast<Comm *>(comm);
+    if (rhs->kind != PDEHIP_RHS_CAHN_HILLIARD) PDEHIP_FAIL(E_VALUE, "slab_ch_sweep: not a Cahn-Hilliard right-hand side");
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{static_cast<Comm *>(comm)};
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, slab::F_FUSED_CH, slab::layer(c_ext, q, 1), slab::layer(out_ext, q, 1), dt,
+                           euler != 0, nullptr, stream);
+}
+
+// which of the PDEHIP_SLAB_* paths this rank could take for (grid, right-hand side, neighbours): the caller ANDs the
+// answers of all ranks.  Faces towards neighbours must already be marked PDEHIP_BC_SKIP in rhs->bc_c / bc_mu or are
+// treated as exchanged through lower / upper.
+int pdehip_slab_flags_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int *flags)
+{
+    if (!g_local || !flags) PDEHIP_FAIL(E_VALUE, "slab_flags_supported: NULL pointer");
+    PDEHIP_TRY(check_rhs(rhs));
+    *flags = 0;
     NGrid n;
     PDEHIP_TRY(norm_grid(g_local, &n));
-    const long nloc = g_local->shape[0];
-    const size_t lp = (size_t)n.p[0] * elem_size(n.dtype);
-    hipStream_t st = as_stream(stream);
-    PDEHIP_TRY(exchange2(c, lp, nloc, c_ext, lower, upper, st));
-    pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
-    for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) { fc[i] = rhs->bc_c[i]; fm[i] = rhs->bc_mu[i]; }
-    if (lower >= 0) fc[0].kind = fm[0].kind = PDEHIP_BC_SKIP;
-    if (upper >= 0) fc[1].kind = fm[1].kind = PDEHIP_BC_SKIP;
-    bool done = false;
-    PDEHIP_TRY(cahn_hilliard_fused(g_local, static_cast<char *>(c_ext) + lp, static_cast<char *>(out_ext) + lp, rhs->param, dt,
-                                   euler != 0, fc, fm, stream, &done, xmode));
-    if (!done) PDEHIP_FAIL(E_NOTIMPL, "slab_ch_sweep: grid or faces are not covered by the two-level kernel");
+    pdehip_rhs_t r = *rhs;
+    slab::local_faces(rhs->bc_c, lower, upper, r.bc_c);
+    slab::local_faces(rhs->bc_mu, lower, upper, r.bc_mu);
+    if (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD) {
+        bool done = false;
+        if (n.ndim >= 2 && g_local->shape[0] >= 2)
+            PDEHIP_TRY(cahn_hilliard_fused(g_local, (const void *)16, (void *)32, rhs->param, 0.0, false, r.bc_c, r.bc_mu, nullptr, &done,
+                                           slab::xends(lower, upper), true));
+        if (done) *flags |= PDEHIP_SLAB_FUSED_CH;
+        // the stage epilogue rides on the two-level sweep: same coverage with a stage descriptor (dry run)
+        if (done) {
+            StageFuse sf;
+            memset(&sf, 0, sizeof(sf));
+            sf.y = (const void *)48; sf.out2 = (void *)64;
+            bool d2 = false;
+            PDEHIP_TRY(cahn_hilliard_fused(g_local, (const void *)16, (void *)32, rhs->param, 0.0, false, r.bc_c, r.bc_mu, nullptr, &d2,
+                                           slab::xends(lower, upper), true, &sf));
+            if (d2) *flags |= PDEHIP_SLAB_FUSED_STAGE;
+        }
+    } else if (laplace_can_fuse_bcs(n, (const void *)16, (const void *)32, nullptr)) {
+        *flags |= PDEHIP_SLAB_FUSED_STAGE;
+    }
     return 0;
+}
+
+int pdehip_slab_rhs_scaled(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                           void *y_full, void *k_out_full, double dt, void *stream)
+{
+    if (!y_full || !k_out_full) PDEHIP_FAIL(E_VALUE, "slab_rhs_scaled: NULL pointer");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    PDEHIP_TRY(context(comm, lower, upper, &c));
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{c};
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream);
+}
+
+int pdehip_slab_euler_sweeps(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                             void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler_sweeps: NULL pointer");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "slab_euler_sweeps: negative step count");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    PDEHIP_TRY(context(comm, lower, upper, &c));
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{c};
+    return slab::euler_sweeps(ops, g_local, q, rhs, lower, upper, flags, buf_a, buf_b, dt, nsteps, result, stream);
+}
+
+int pdehip_slab_rk4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                        void *y_full, void *const *work5_host, double dt, int64_t nsteps, void *stream)
+{
+    if (!y_full || !work5_host) PDEHIP_FAIL(E_VALUE, "slab_rk4_run: NULL pointer");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "slab_rk4_run: negative step count");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    PDEHIP_TRY(context(comm, lower, upper, &c));
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{c};
+    for (int64_t s = 0; s < nsteps; s++) PDEHIP_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream));
+    return 0;
+}
+
+int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                          void *y_full, void *ynew_full, void *const *work7_host, double *err_dev, pdehip_adaptive_t *ctl,
+                          void **result, void *stream)
+{
+    if (!y_full || !ynew_full || !work7_host || !err_dev || !ctl || !result) PDEHIP_FAIL(E_VALUE, "slab_rkf45_run: NULL pointer");
+    if (!(ctl->tolerance > 0) || !(ctl->dt > 0)) PDEHIP_FAIL(E_VALUE, "slab_rkf45_run: tolerance and dt must be positive");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    PDEHIP_TRY(context(comm, lower, upper, &c));
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{c};
+    return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 
 #include "../../include/pdehip.h"
 #include "pdehip_device.h"
+#include "pdehip_slab_loops.h"
 
 namespace pdehip {
 
@@ -108,19 +109,7 @@ struct InputBCs {
     long idx[3][2];
     double c[3][2], f[3][2];
 };
-// what follows a slope k = dt*rhs in a Runge-Kutta scheme, fused into the sweep that computes k (mode LAP_STAGE)
-struct StageFuse {
-    int kind;            // 0: next stage input  out2 = y + sum_m c[m]*k[m] + c_new*k  (k is also stored);  1: RK4 update
-                         //    out2 = y + (k[0] + 2*k[1] + 2*k[2] + k)/6  (k is not stored; out2 may be y itself)
-                         // 2: end of an RKF45 attempt  out2 = 4th-order state from y and k = {k1, k3, k4, k5}, *err = max-norm
-                         //    of the error estimate with k6 = k  (k is not stored; *err must be zero before the launch)
-                         // 3: Adams-Bashforth step  out2 = y + c_new * (1.5*k - 0.5*k[0])  with k = the rate (also stored), c_new = dt
-    const void *y;
-    const void *k[5];    // earlier slopes, NULL-terminated
-    double c[5], c_new;
-    void *out2;
-    double *err;
-};
+// StageFuse (what follows a slope k = dt*rhs in a Runge-Kutta scheme, fused into the sweep that computes k): pdehip_slab_loops.h
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
                    double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr,
                    const StageFuse *stage = nullptr);

@@ -74,6 +74,37 @@ class RHS(C.Structure):
     ]
 
 
+class Adaptive(C.Structure):
+    """``pdehip_adaptive_t``: controller state of the adaptive loop (``pdehip_slab_rkf45_run``)."""
+
+    _fields_ = [
+        ("t_start", C.c_double),
+        ("t_end", C.c_double),
+        ("dt", C.c_double),
+        ("tolerance", C.c_double),
+        ("dt_min", C.c_double),
+        ("dt_max", C.c_double),
+        ("t_last", C.c_double),
+        ("steps", C.c_int64),
+        ("attempts", C.c_int64),
+        ("stat_count", C.c_int64),
+        ("stat_min", C.c_double),
+        ("stat_max", C.c_double),
+        ("stat_mean", C.c_double),
+        ("stat_m2", C.c_double),
+    ]
+
+
+def adaptive_statistics(ctl: Adaptive) -> dict:
+    """Statistics of the accepted step sizes in the format of ``OnlineStatistics.to_dict`` (pde/tools/math.py:125-174)."""
+    import math
+
+    n = int(ctl.stat_count)
+    var = ctl.stat_m2 / (n - 1) if n >= 2 else math.nan
+    return {"min": ctl.stat_min if n else math.inf, "max": ctl.stat_max if n else -math.inf, "mean": ctl.stat_mean,
+            "std": math.sqrt(var) if var == var else math.nan, "count": n}
+
+
 def make_grid(shape, dx, dtype) -> Grid:
     """Build the POD grid descriptor from ``grid.shape`` / ``grid.discretization``."""
     shape = tuple(int(s) for s in shape)
@@ -95,6 +126,7 @@ _pf = C.POINTER(BCFace)
 _pr = C.POINTER(RHS)
 _pd = C.POINTER(C.c_double)
 _pvp = C.POINTER(C.c_void_p)
+_pa = C.POINTER(Adaptive)
 _i, _i64, _d = C.c_int, C.c_int64, C.c_double
 
 # name -> argument types WITHOUT the trailing stream argument.  ``True`` in the second slot
@@ -161,6 +193,12 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_ch_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_ch_sweep": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i, _vp],
+    # slab-parallel Runge-Kutta / adaptive loop / generic right-hand side (one C call per run)
+    "slab_flags_supported": [_pg, _pr, _i, _i, C.POINTER(_i)],
+    "slab_rhs_scaled": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _d, _vp],
+    "slab_euler_sweeps": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    "slab_rk4_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _pvp, _d, _i64, _vp],
+    "slab_rkf45_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _pvp, _vp, _pa, _pvp, _vp],
     # Adams-Bashforth step in one sweep (device only: the oracle runs rhs_scaled + ab2_combine)
     "ab2_step": [_pg, _pr, _vp, _vp, _vp, _vp, _d, C.POINTER(_i), _vp],
     # fixed-step RK4 loop (device only: the oracle loops over rk4_step)

@@ -53,6 +53,9 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+/* error channel for the C++ half of the shim (pdehip_shim_comm.cpp) */
+int shim_set_error(int code, const char *msg) { return fail(code, "%s", msg); }
+
 #define TRY(expr)                                                                       \
     do {                                                                                \
         int _rc = (expr);                                                               \

@@ -1,0 +1,492 @@
+// pdehip_shim_comm.cpp — the slab-parallel entry points of include/pdehip.h on the HOST.  TESTS ONLY.
+//
+// ******************************************************************************
+// TEST INFRASTRUCTURE (see pdehip_shim.c).  Instantiates the SAME loop templates the product compiles for the GPU
+// (py-pde_amd/csrc/pdehip_slab_loops.h: halo exchanges, stream choreography, Runge-Kutta stage sequence, adaptive
+// accept/reject) with a host `Ops` policy, so that several CPU processes — the ranks of a torch.distributed gloo job —
+// execute exactly the product's call sequence:
+//   * transport: a directory of message files.  Rank 0 creates the directory, its path is the "unique id".  A message
+//     from rank s to rank d with per-pair sequence number q is the file  m_<s>_<d>_<q>  (written under a temporary
+//     name, then renamed).  Like RCCL: operations of one group progress together (all sends are posted before the first
+//     receive blocks), messages between one pair of ranks match in issue order, a rank may be its own peer.  A receive
+//     that waits longer than PDEHIP_SHIM_COMM_TIMEOUT seconds (default 60) FAILS — a mismatched send/recv pattern shows
+//     up as an error, not as a hang.
+//   * kernels: the CPU oracle; the two-level sweeps (two Euler steps / fused Cahn-Hilliard on sub-slabs with real halo
+//     layers) are composed of two oracle passes over the same layers the device kernel covers.
+//   * streams / events: everything is synchronous, events are no-ops.
+// ******************************************************************************
+#include <cerrno>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "../../py-pde_amd/csrc/pdehip_slab_loops.h"
+
+using namespace pdehip;
+
+extern "C" {
+// the oracle (compiled into pdehip_shim.c)
+int oracle_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_face_t *faces, void *data_full);
+int oracle_laplace_scaled(const pdehip_grid_t *g, const void *in_full, void *out_full, double s1, double s2);
+int oracle_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void *y_full, void *out_full, double s1, double s2);
+int oracle_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu_full, double gamma);
+int oracle_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int nk, const double *coef, const void *const *k);
+int oracle_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *k1, const void *k2, const void *k3, const void *k4);
+int oracle_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew, const void *const *k6, double *err);
+// the rest of the shim
+int pdehip_layout(const pdehip_grid_t *g, int64_t *out8);
+int shim_set_error(int code, const char *msg);
+}
+
+namespace {
+
+enum { E_VALUE = 1, E_NOTIMPL = 2, E_RUNTIME = 3 };
+
+int failf(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return shim_set_error(code, buf);
+}
+
+#define OTRY(expr)                                                                      \
+    do {                                                                                \
+        int _rc = (expr);                                                               \
+        if (_rc) return failf(E_RUNTIME, "shim: %s failed with code %d", #expr, _rc);   \
+    } while (0)
+
+struct Comm {
+    std::string dir;
+    int rank = 0, size = 1;
+    std::vector<long> sent, received;   // per-peer sequence numbers
+    void *ext[2] = {nullptr, nullptr};
+    size_t ext_bytes = 0;
+    // operations of the open group
+    struct Op { bool is_send; void *p; size_t bytes; int peer; };
+    std::vector<Op> group;
+    bool in_group = false;
+};
+
+double timeout_seconds()
+{
+    const char *e = getenv("PDEHIP_SHIM_COMM_TIMEOUT");
+    return e ? atof(e) : 60.0;
+}
+
+int post_send(Comm *c, const void *p, size_t bytes, int peer)
+{
+    char tmp[700], fin[700];
+    const long q = c->sent[peer]++;
+    snprintf(tmp, sizeof(tmp), "%s/t_%d_%d_%ld", c->dir.c_str(), c->rank, peer, q);
+    snprintf(fin, sizeof(fin), "%s/m_%d_%d_%ld", c->dir.c_str(), c->rank, peer, q);
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return failf(E_RUNTIME, "shim comm: cannot write %s: %s", tmp, strerror(errno));
+    const size_t w = fwrite(p, 1, bytes, f);
+    fclose(f);
+    if (w != bytes) return failf(E_RUNTIME, "shim comm: short write to %s", tmp);
+    if (rename(tmp, fin) != 0) return failf(E_RUNTIME, "shim comm: rename failed: %s", strerror(errno));
+    return 0;
+}
+
+int wait_recv(Comm *c, void *p, size_t bytes, int peer)
+{
+    char fin[700];
+    const long q = c->received[peer]++;
+    snprintf(fin, sizeof(fin), "%s/m_%d_%d_%ld", c->dir.c_str(), peer, c->rank, q);
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = timeout_seconds();
+    for (;;) {
+        struct stat sb;
+        if (stat(fin, &sb) == 0) {
+            if ((size_t)sb.st_size != bytes)
+                return failf(E_RUNTIME, "shim comm: rank %d expected %zu bytes from rank %d (message %ld) but the peer sent %zu — mismatched send/recv",
+                             c->rank, bytes, peer, q, (size_t)sb.st_size);
+            FILE *f = fopen(fin, "rb");
+            if (!f) return failf(E_RUNTIME, "shim comm: cannot read %s", fin);
+            const size_t r = fread(p, 1, bytes, f);
+            fclose(f);
+            unlink(fin);
+            if (r != bytes) return failf(E_RUNTIME, "shim comm: short read from %s", fin);
+            return 0;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            return failf(E_RUNTIME, "shim comm: rank %d timed out after %.0f s waiting for message %ld from rank %d — mismatched send/recv or a dead peer",
+                         c->rank, limit, q, peer);
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
+size_t layer_bytes(const pdehip_grid_t *g)
+{
+    int64_t lay[8];
+    pdehip_layout(g, lay);
+    return (size_t)lay[7] * (g->dtype == PDEHIP_F64 ? 8 : 4);
+}
+size_t full_bytes(const pdehip_grid_t *g)
+{
+    int64_t lay[8];
+    pdehip_layout(g, lay);
+    return (size_t)lay[2] * (g->dtype == PDEHIP_F64 ? 8 : 4);
+}
+
+struct HostOps {
+    Comm *c;
+    void *halo() { return (void *)1; }
+    int record(int, void *) { return 0; }
+    int wait(void *, int) { return 0; }
+    int group_start() { c->in_group = true; c->group.clear(); return 0; }
+    int send(const void *p, size_t bytes, int peer, void *) { c->group.push_back({true, const_cast<void *>(p), bytes, peer}); return 0; }
+    int recv(void *p, size_t bytes, int peer, void *) { c->group.push_back({false, p, bytes, peer}); return 0; }
+    int group_end()
+    {
+        c->in_group = false;
+        for (auto &op : c->group)
+            if (op.is_send) SLAB_TRY(post_send(c, op.p, op.bytes, op.peer));
+        for (auto &op : c->group)
+            if (!op.is_send) SLAB_TRY(wait_recv(c, op.p, op.bytes, op.peer));
+        c->group.clear();
+        return 0;
+    }
+    int copy(void *dst, const void *src, size_t bytes, void *) { memmove(dst, src, bytes); return 0; }
+    int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int fail(const char *msg) { return failf(E_NOTIMPL, "%s", msg); }
+    int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
+
+    int lap(const pdehip_grid_t *gs, void *in, const void *y, void *out, int kind, double s1, double s2, double gamma,
+            const pdehip_bc_face_t *faces, void *st, const StageFuse *sf)
+    {
+        OTRY(oracle_set_ghost_cells(gs, 1, faces, in));   // faces marked SKIP keep the (exchanged / neighbouring) layers
+        if (kind == slab::K_EULER) { OTRY(oracle_laplace_euler(gs, in, y, out, s1, s2)); return 0; }
+        if (kind == slab::K_SCALED) { OTRY(oracle_laplace_scaled(gs, in, out, s1, s2)); return 0; }
+        if (kind == slab::K_CH_MU) { OTRY(oracle_cahn_hilliard_mu(gs, in, out, gamma)); return 0; }
+        // K_STAGE: slope, then the combination (kinds 1 and 2 do not store the slope)
+        void *k = out, *tmp = nullptr;
+        if (sf->kind == 1 || sf->kind == 2) k = tmp = calloc(1, full_bytes(gs));
+        int rc = oracle_laplace_scaled(gs, in, k, s1, s2);
+        if (!rc) rc = combine(gs, k, *sf, st);
+        free(tmp);
+        return rc;
+    }
+    int combine(const pdehip_grid_t *g, void *k, const StageFuse &sf, void *)
+    {
+        if (sf.kind == 0) {
+            const void *ks[6];
+            double cf[6];
+            int n = 0;
+            for (; n < 5 && sf.k[n]; n++) { ks[n] = sf.k[n]; cf[n] = sf.c[n]; }
+            ks[n] = k; cf[n] = sf.c_new;
+            OTRY(oracle_lincomb(g, 1, sf.out2, sf.y, n + 1, cf, ks));
+            return 0;
+        }
+        if (sf.kind == 1) {
+            if (sf.out2 != sf.y) return failf(E_RUNTIME, "internal: the RK4 update works in place");
+            OTRY(oracle_rk4_combine(g, 1, sf.out2, sf.k[0], sf.k[1], sf.k[2], k));
+            return 0;
+        }
+        if (sf.kind == 2) {
+            const void *k6[6] = {sf.k[0], sf.k[0], sf.k[1], sf.k[2], sf.k[3], k};
+            double err = 0;
+            OTRY(oracle_rkf45_combine(g, 1, sf.y, sf.out2, k6, &err));
+            // like the device kernel: atomic max onto the (zeroed) scalar, NaN wins
+            if (err != err || *sf.err != *sf.err) *sf.err = NAN; else if (err > *sf.err) *sf.err = err;
+            return 0;
+        }
+        return failf(E_NOTIMPL, "internal: unknown stage kind %d", sf.kind);
+    }
+
+    // Two-level sweep over the sub-slab `gs` (layers r = 1..count relative to `in`, which points ONE LAYER BEFORE the first
+    // layer to update): level 1 on every layer level 2 reads, level 2 on the sub-slab (or its first / last `ends` layers).
+    // Sides with a halo (xplain 1: both, 2: upper only, 3: lower only) hold TWO real layers beyond the sub-slab; the other
+    // sides end in the physical faces faces1[0/1] (level 0 -> 1) and faces2[0/1] (level 1 -> 2).
+    template <class L1, class L2>
+    int two_level(const pdehip_grid_t *gs, const void *in, const pdehip_bc_face_t *faces1, const pdehip_bc_face_t *faces2, int xplain, int ends,
+                  L1 &&level1, L2 &&level2)
+    {
+        const long count = gs->shape[0];
+        const bool lo = xplain == 1 || xplain == 3, hi = xplain == 1 || xplain == 2;
+        const size_t lp = layer_bytes(gs);
+        const long a0 = lo ? -1 : 0, a1 = hi ? count + 2 : count + 1;   // window: ghost layer a0, own layers a0+1 .. a1-1, ghost a1
+        pdehip_grid_t gw = *gs;
+        gw.shape[0] = a1 - a0 - 1;
+        const size_t wbytes = full_bytes(&gw);
+        std::vector<char> src(wbytes), l1(wbytes, 0);
+        memcpy(src.data(), static_cast<const char *>(in) + a0 * (long)lp, wbytes);   // `in` itself is never written
+        pdehip_bc_face_t f1[2 * PDEHIP_MAX_DIM], f2[2 * PDEHIP_MAX_DIM];
+        for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) { f1[i] = faces1[i]; f2[i] = faces2[i]; }
+        if (lo) f1[0].kind = f2[0].kind = PDEHIP_BC_SKIP;
+        if (hi) f1[1].kind = f2[1].kind = PDEHIP_BC_SKIP;
+        else if (lo) { f1[1].index1 += 1; f1[1].index2 += 1; }    // the window starts one layer before the sub-slab
+        OTRY(oracle_set_ghost_cells(&gw, 1, f1, src.data()));
+        SLAB_TRY(level1(&gw, src.data(), l1.data()));
+        char *v = l1.data() + (-a0) * (long)lp;                     // level 1 as a full array of the sub-slab: r = 0 is its ghost layer
+        OTRY(oracle_set_ghost_cells(gs, 1, f2, v));
+        auto range = [&](long first, long cnt) -> int {
+            if (cnt <= 0) return 0;
+            pdehip_grid_t g2 = *gs;
+            g2.shape[0] = cnt;
+            return level2(&g2, v + (first - 1) * (long)lp, (first - 1) * (long)lp);
+        };
+        if (!ends) return range(1, count);
+        SLAB_TRY(range(1, ends));
+        return range(count - ends + 1, ends);
+    }
+    int euler2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *, bool *done,
+               int xplain, bool dry, int ends)
+    {
+        *done = gs->ndim >= 2;
+        if (dry || !*done) return 0;
+        return two_level(gs, in, faces, faces, xplain, ends,
+                         [&](const pdehip_grid_t *gw, void *src, void *l1) -> int { OTRY(oracle_laplace_euler(gw, src, src, l1, D, dt)); return 0; },
+                         [&](const pdehip_grid_t *g2, void *v, long off) -> int {
+                             OTRY(oracle_laplace_euler(g2, v, v, static_cast<char *>(out) + off, D, dt));
+                             return 0;
+                         });
+    }
+    int ch_fused(const pdehip_grid_t *gs, const void *in, void *out, double gamma, double dt, bool euler, const pdehip_bc_face_t *fc,
+                 const pdehip_bc_face_t *fm, void *st, bool *done, int xplain, bool dry, const StageFuse *sf)
+    {
+        *done = gs->ndim >= 2;
+        if (dry || !*done) return 0;
+        return two_level(gs, in, fc, fm, xplain, 0,
+                         [&](const pdehip_grid_t *gw, void *src, void *l1) -> int { OTRY(oracle_cahn_hilliard_mu(gw, src, l1, gamma)); return 0; },
+                         [&](const pdehip_grid_t *g2, void *mu, long off) -> int {
+                             if (euler) { OTRY(oracle_laplace_euler(g2, mu, static_cast<const char *>(in) + off, static_cast<char *>(out) + off, 1.0, dt)); return 0; }
+                             if (!sf) { OTRY(oracle_laplace_scaled(g2, mu, static_cast<char *>(out) + off, 1.0, dt)); return 0; }
+                             void *k = out, *tmp = nullptr;
+                             if (sf->kind == 1 || sf->kind == 2) k = tmp = calloc(1, full_bytes(g2));
+                             int rc = oracle_laplace_scaled(g2, mu, k, 1.0, dt);
+                             if (!rc) rc = combine(g2, k, *sf, st);
+                             free(tmp);
+                             return rc;
+                         });
+    }
+    // MAX over all ranks, NaN wins: every rank sends its value to every other rank (one group)
+    int allreduce_max(double *scalar, void *st)
+    {
+        if (c->size == 1) return 0;
+        std::vector<double> all(c->size, 0.0);
+        all[c->rank] = *scalar;
+        SLAB_TRY(group_start());
+        for (int p = 0; p < c->size; p++)
+            if (p != c->rank) { SLAB_TRY(send(scalar, sizeof(double), p, st)); SLAB_TRY(recv(&all[p], sizeof(double), p, st)); }
+        SLAB_TRY(group_end());
+        double m = all[0];
+        bool nan = false;
+        for (double v : all) { if (v != v) nan = true; else if (v > m || m != m) m = v; }
+        *scalar = nan ? NAN : m;
+        return 0;
+    }
+    int read_scalar(double *host, const double *dev, void *) { *host = *dev; return 0; }
+};
+
+int make_geo(const pdehip_grid_t *g, slab::Geo *q)
+{
+    int64_t lay[8];
+    int rc = pdehip_layout(g, lay);
+    if (rc) return rc;
+    q->nloc = g->shape[0];
+    q->esz = g->dtype == PDEHIP_F64 ? 8 : 4;
+    q->lp = (size_t)lay[7] * q->esz;
+    return 0;
+}
+
+Comm *serial_context()
+{
+    static Comm ctx;
+    return &ctx;
+}
+int context(void *comm, int lower, int upper, Comm **out)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) {
+        if (lower >= 0 || upper >= 0) return failf(E_VALUE, "a slab with neighbours needs a communicator");
+        c = serial_context();
+    }
+    *out = c;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdehip_comm_unique_id(const char *, void *id128)
+{
+    char dir[] = "/tmp/pdehip_shim_comm_XXXXXX";
+    if (!mkdtemp(dir)) return failf(E_RUNTIME, "shim comm: mkdtemp failed");
+    memset(id128, 0, 128);
+    memcpy(id128, dir, strlen(dir));
+    return 0;
+}
+
+int pdehip_comm_create(const char *, const void *id128, int rank, int size, void **comm)
+{
+    if (!id128 || !comm) return failf(E_VALUE, "comm_create: NULL pointer");
+    if (rank < 0 || rank >= size) return failf(E_VALUE, "comm_create: rank %d outside of world size %d", rank, size);
+    Comm *c = new Comm();
+    c->dir = std::string(static_cast<const char *>(id128), strnlen(static_cast<const char *>(id128), 127));
+    c->rank = rank; c->size = size;
+    c->sent.assign(size, 0);
+    c->received.assign(size, 0);
+    struct stat sb;
+    if (stat(c->dir.c_str(), &sb) != 0) { delete c; return failf(E_RUNTIME, "shim comm: mailbox directory %s does not exist", static_cast<const char *>(id128)); }
+    *comm = c;
+    return 0;
+}
+
+int pdehip_comm_destroy(void *comm)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) return 0;
+    free(c->ext[0]); free(c->ext[1]);
+    if (c->rank == 0) rmdir(c->dir.c_str());   // succeeds once every message was consumed
+    delete c;
+    return 0;
+}
+
+int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper, void *stream)
+{
+    if (!comm || !buf_full) return failf(E_VALUE, "halo_exchange: NULL pointer");
+    slab::Geo q;
+    SLAB_TRY(make_geo(g_local, &q));
+    HostOps ops{static_cast<Comm *>(comm)};
+    return slab::exchange(ops, q, buf_full, lower, upper, stream);
+}
+
+int pdehip_allreduce_max(void *comm, double *scalar, void *stream)
+{
+    if (!comm || !scalar) return failf(E_VALUE, "allreduce_max: NULL pointer");
+    HostOps ops{static_cast<Comm *>(comm)};
+    return ops.allreduce_max(scalar, stream);
+}
+
+int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, void *buf_a, void *buf_b,
+                          double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) return failf(E_VALUE, "slab_euler_run: NULL pointer");
+    if (rhs->kind != PDEHIP_RHS_DIFFUSION) return failf(E_NOTIMPL, "slab_euler_run implements the diffusion right-hand side");
+    slab::Geo q;
+    SLAB_TRY(make_geo(g_local, &q));
+    HostOps ops{static_cast<Comm *>(comm)};
+    return slab::euler_run(ops, g_local, q, rhs, lower, upper, buf_a, buf_b, dt, nsteps, result, stream);
+}
+
+int pdehip_slab_euler2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    // mimic the device rule: 3-D, >= 4 own layers, scalar first-order faces
+    *ok = rhs->kind == PDEHIP_RHS_DIFFUSION && g_local->ndim == 3 && g_local->shape[0] >= 4;
+    for (int i = 0; i < 2 * g_local->ndim && *ok; i++)
+        if (rhs->bc_c[i].kind == PDEHIP_BC_ORDER2 || (rhs->bc_c[i].flags & PDEHIP_BCF_ARRAYS)) *ok = 0;
+    return 0;
+}
+
+int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, void *buf_a, void *buf_b,
+                           double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) return failf(E_VALUE, "slab_euler2_run: NULL pointer");
+    int ok = 0;
+    pdehip_slab_euler2_supported(g_local, rhs, &ok);
+    if (!ok) return failf(E_NOTIMPL, "slab_euler2_run: grid or faces are not covered by the two-step kernel");
+    Comm *c = static_cast<Comm *>(comm);
+    slab::Geo q;
+    SLAB_TRY(make_geo(g_local, &q));
+    pdehip_grid_t ge = *g_local;
+    ge.shape[0] = q.nloc + 2;
+    const size_t need = full_bytes(&ge);
+    if (c->ext_bytes < need) {
+        free(c->ext[0]); free(c->ext[1]);
+        c->ext[0] = calloc(1, need); c->ext[1] = calloc(1, need);
+        c->ext_bytes = need;
+    }
+    HostOps ops{c};
+    return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
+}
+
+int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    *ok = rhs->kind == PDEHIP_RHS_CAHN_HILLIARD && g_local->ndim == 3 && g_local->shape[0] >= 2;
+    for (int i = 0; i < 2 * g_local->ndim && *ok; i++)
+        if (rhs->bc_c[i].kind == PDEHIP_BC_ORDER2 || (rhs->bc_c[i].flags & PDEHIP_BCF_ARRAYS) || rhs->bc_mu[i].kind == PDEHIP_BC_ORDER2 ||
+            (rhs->bc_mu[i].flags & PDEHIP_BCF_ARRAYS))
+            *ok = 0;
+    return 0;
+}
+
+int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, void *c_ext, void *out_ext,
+                         double dt, int euler, void *stream)
+{
+    if (!comm || !rhs || !c_ext || !out_ext) return failf(E_VALUE, "slab_ch_sweep: NULL pointer");
+    slab::Geo q;
+    SLAB_TRY(make_geo(g_local, &q));
+    HostOps ops{static_cast<Comm *>(comm)};
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, slab::F_FUSED_CH, slab::layer(c_ext, q, 1), slab::layer(out_ext, q, 1), dt, euler != 0,
+                           nullptr, stream);
+}
+
+int pdehip_slab_flags_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int *flags)
+{
+    // PDEHIP_SHIM_FUSED=1 exercises the fused branches of the loops, else the plain ones
+    const char *e = getenv("PDEHIP_SHIM_FUSED");
+    *flags = 0;
+    if (!(e && e[0] == '1') || g_local->ndim < 2) return 0;
+    *flags = PDEHIP_SLAB_FUSED_STAGE;
+    if (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD) {
+        int ok = 0;
+        pdehip_rhs_t r = *rhs;
+        slab::local_faces(rhs->bc_c, lower, upper, r.bc_c);
+        slab::local_faces(rhs->bc_mu, lower, upper, r.bc_mu);
+        pdehip_slab_ch_supported(g_local, &r, &ok);
+        if (ok) *flags |= PDEHIP_SLAB_FUSED_CH; else *flags = 0;   // the stage epilogue of Cahn-Hilliard rides on the two-level sweep
+    }
+    return 0;
+}
+
+#define SLAB_ENTRY_PROLOGUE(name)                          \
+    Comm *c;                                               \
+    SLAB_TRY(context(comm, lower, upper, &c));             \
+    slab::Geo q;                                           \
+    SLAB_TRY(make_geo(g_local, &q));                       \
+    HostOps ops{c};
+
+int pdehip_slab_rhs_scaled(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y_full,
+                           void *k_out_full, double dt, void *stream)
+{
+    SLAB_ENTRY_PROLOGUE(rhs_scaled)
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream);
+}
+
+int pdehip_slab_euler_sweeps(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *buf_a,
+                             void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    SLAB_ENTRY_PROLOGUE(euler_sweeps)
+    return slab::euler_sweeps(ops, g_local, q, rhs, lower, upper, flags, buf_a, buf_b, dt, nsteps, result, stream);
+}
+
+int pdehip_slab_rk4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y_full,
+                        void *const *work5_host, double dt, int64_t nsteps, void *stream)
+{
+    SLAB_ENTRY_PROLOGUE(rk4_run)
+    for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream));
+    return 0;
+}
+
+int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y_full,
+                          void *ynew_full, void *const *work7_host, double *err_dev, pdehip_adaptive_t *ctl, void **result, void *stream)
+{
+    if (!(ctl->tolerance > 0) || !(ctl->dt > 0)) return failf(E_VALUE, "slab_rkf45_run: tolerance and dt must be positive");
+    SLAB_ENTRY_PROLOGUE(rkf45_run)
+    return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
+}
+
+}  // extern "C"

@@ -1,42 +1,26 @@
-"""GPU test of the slab stepper's product engine (HipEngine: libpdehip + torch streams + RCCL).
+"""GPU test of the slab-parallel path on ONE GPU (libpdehip + RCCL to self).
 
-Only one GPU is available to the test box, so the RCCL path is exercised with world size 1 and
-`force_exchange=True`: the periodic axis-0 halo then travels through ncclSend/ncclRecv to self on
-the halo stream, overlapped with the interior kernel on the compute stream — the same code path,
-stream/event choreography and P2P ordering that N > 1 ranks use (N = 2, 3 are covered bit-exactly
-on CPU with gloo in test_distributed_gloo.py).
+The gpurun box has one GPU, so the RCCL path is exercised with world size 1 and ``force_exchange=True``: the periodic
+axis-0 halo then travels through ncclSend/ncclRecv to self on the halo stream, overlapped with the interior kernel on
+the compute stream — the same loop templates (``csrc/pdehip_slab_loops.h``), stream/event choreography and matching
+order that N > 1 ranks use.  N = 2, 3, 4 run the same templates on CPU (tests/test_distributed_gloo.py); N real GPUs:
+tests/test_hip_multirank.py.  No torch in this file: the data plane is libpdehip only.
 """
 
 from __future__ import annotations
 
-import os
-import socket
+import ctypes as C
 
 import numpy as np
 import pytest
-from helpers import host_faces, interior, oracle_grid, to_full
+from helpers import host_faces, interior, max_rel, oracle_grid, to_full
+from test_oracle_golden import oracle_solve
 
 import pde_hip
 from oracle import pde_oracle as O
 from pde_hip import _abi
 
 pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(scope="module")
-def process_group():
-    import torch
-    import torch.distributed as dist
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    yield dist
-    dist.destroy_process_group()
 
 
 def _expect(eq_kind, param, grid, bc, data, dt, steps, solver="euler"):
@@ -53,84 +37,79 @@ def _expect(eq_kind, param, grid, bc, data, dt, steps, solver="euler"):
     return interior(grid, y)
 
 
-@pytest.mark.parametrize("comm_mode", ["native", "torch"])
 @pytest.mark.parametrize("force", [True, False])
 @pytest.mark.parametrize("shape", [(16, 12, 128), (3, 8, 64), (2, 4, 64), (1, 4, 64), (12, 256)])
-def test_diffusion_euler_overlapped_self_exchange(process_group, monkeypatch, comm_mode, force, shape):
-    """native = libpdehip's own RCCL communicator + C step loop; torch = torch.distributed P2P ops."""
-    from pde_hip.distributed import HipEngine, SlabStepper
+def test_diffusion_euler_overlapped_self_exchange(force, shape):
+    from pde_hip.distributed import SlabStepper
 
-    monkeypatch.setenv("PDEHIP_COMM", comm_mode)
-
-    grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
-    data = np.random.default_rng(2).uniform(-1, 1, shape)
+    grid = pde_hip.UnitGrid(shape, periodic=True)
+    data = np.random.default_rng(5).uniform(-1, 1, shape)
     eq = pde_hip.DiffusionPDE(0.8)
-    st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=force)
+    st = SlabStepper(eq, grid, force_exchange=force)
     assert st.exchanging == force
-    assert (st.comm is not None) == (force and comm_mode == "native")
     final, info = st.solve(data, t_range=1.1, dt=0.1, solver="euler")
+    st.close()
     assert info["steps"] == 11
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.8, grid, eq.bc, data, 0.1, 11))
 
 
-@pytest.mark.parametrize("shape,periodic,steps", [
-    ((16, 12, 128), [True, False, False], 11),   # 5 double sweeps + 1 single step, local faces on y and z
-    ((4, 8, 256), [True, True, True], 6),        # interior sweep empty (4 layers = 2 + 2 boundary layers)
-    ((9, 6, 128), [True, True, False], 2),       # 2-row tiles, one double sweep
-    ((40, 8, 128), [True, False, True], 7),
-])
-def test_diffusion_euler_two_steps_per_sweep_slab_loop(process_group, monkeypatch, shape, periodic, steps):
-    """The slab loop with two halo layers (exchange every other step) == serial oracle, bit-exact."""
-    from pde_hip.distributed import HipEngine, SlabStepper
+@pytest.mark.parametrize("steps", [1, 2, 7, 12])
+def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
+    """pdehip_slab_euler2_run: two halo layers exchanged (to self) once per two steps, odd step counts end in a single step."""
+    from pde_hip.distributed import SlabStepper
 
-    monkeypatch.setenv("PDEHIP_COMM", "native")
-    grid = pde_hip.UnitGrid(shape, periodic=periodic)
-    data = np.random.default_rng(4).uniform(-1, 1, shape)
-    eq = pde_hip.DiffusionPDE(0.7)
-    st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
-    assert st.comm is not None and st._euler2
+    grid = pde_hip.UnitGrid((16, 8, 128), periodic=[True, False, True])
+    data = np.random.default_rng(6).uniform(-1, 1, grid.shape)
+    eq = pde_hip.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 0.2}, "z": "periodic"})
+    st = SlabStepper(eq, grid, force_exchange=True)
+    assert st._euler2
     final, info = st.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
-    assert info["steps"] == steps
+    st.close()
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps))
-    # grids the kernel does not cover keep the one-step loop
-    st1 = SlabStepper(eq, pde_hip.UnitGrid((8, 7, 64), periodic=True), engine=HipEngine(0), force_exchange=True)
+    # thin slabs (< 4 layers) and 2-D grids keep the one-step loop
+    st1 = SlabStepper(eq, pde_hip.UnitGrid((3, 8, 64), periodic=[True, False, True]), force_exchange=True)
     assert not st1._euler2
+    st1.close()
+    monkeypatch.setenv("PDEHIP_SLAB_EULER2", "0")
+    st2 = SlabStepper(eq, grid, force_exchange=True)
+    assert not st2._euler2
+    final2, _ = st2.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
+    st2.close()
+    np.testing.assert_array_equal(final2, final)
 
 
-@pytest.mark.parametrize("shape,periodic", [((8, 8, 64), [True, True, True]), ((6, 12, 128), [True, False, False]), ((2, 4, 72), [True, False, True])])
-def test_cahn_hilliard_slab_one_sweep_per_rhs(process_group, monkeypatch, shape, periodic):
-    """Slab Cahn-Hilliard with the fused sweep: ONE exchange (two layers of c) per right-hand side, mu never exchanged;
-    Euler and RK4 equal the serial oracle bit for bit."""
-    from pde_hip.distributed import HipEngine, SlabStepper
+@pytest.mark.parametrize("solver,steps", [("euler", 5), ("runge-kutta", 3)])
+@pytest.mark.parametrize("shape", [(8, 8, 128), (6, 6, 72), (12, 128)])
+def test_cahn_hilliard_slab_one_sweep_per_rhs(solver, steps, shape):
+    """Cahn-Hilliard on a slab: ONE exchange of two layers of c per right-hand side where the two-level kernel covers the
+    grid (3-D), else two kernels with two exchanges — both bit-identical to the serial oracle."""
+    from pde_hip.distributed import FUSED_CH, SlabStepper
 
-    monkeypatch.setenv("PDEHIP_COMM", "native")
-    grid = pde_hip.UnitGrid(shape, periodic=periodic)
-    data = np.random.default_rng(6).uniform(-0.2, 0.2, shape)
+    grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (len(shape) - 1))
+    data = np.random.default_rng(8).uniform(-0.5, 0.5, shape)
     eq = pde_hip.CahnHilliardPDE(0.9)
-    for solver, steps in [("euler", 5), ("runge-kutta", 3)]:
-        st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
-        assert st._ch_rhs is not None
-        final, info = st.solve(data, t_range=steps * 1e-3, dt=1e-3, solver=solver)
-        assert info["steps"] == steps
-        np.testing.assert_array_equal(final, _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, eq.bc_c, data, 1e-3, steps, solver))
+    st = SlabStepper(eq, grid, force_exchange=True)
+    assert bool(st.flags & FUSED_CH) == (len(shape) == 3)
+    final, info = st.solve(data, t_range=steps * 1e-3, dt=1e-3, solver=solver)
+    st.close()
+    np.testing.assert_array_equal(final, _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, "auto_periodic_neumann", data, 1e-3, steps, solver))
 
 
-@pytest.mark.parametrize("shape", [(7, 6, 128), (2, 4, 64), (5, 256)])
-def test_slab_loop_with_physical_faces_on_both_ends(process_group, shape):
-    """The one-step C slab loop on a rank that owns BOTH physical faces of the slowest axis (no neighbours): boundary
-    layers and interior are separate sub-slab launches whose faces come from `sub_faces` - must equal the oracle."""
-    import ctypes as C
-
+@pytest.mark.parametrize("shape", [(16, 12, 128), (5, 8, 64), (12, 256)])
+def test_slab_loops_on_a_rank_owning_both_physical_faces(shape):
+    """The C slab loops on a rank WITHOUT neighbours (physical faces on both ends of the slowest axis): boundary layers and
+    interior are separate sub-slab launches whose faces come from `sub_faces` — must equal the oracle."""
     from pde_hip.backend import convert_bcs
     from pde_hip.device import DeviceArray, GridInfo
-    from pde_hip.distributed import HipEngine
+    from pde_hip.distributed import SlabStepper
 
-    eng = HipEngine(0)
-    comm = eng.make_comm(process_group, None, 1, 0)
     grid = pde_hip.UnitGrid(shape, periodic=False)
-    bc = {f"{a}{s}": v for a, (lo, hi) in zip(grid.axes, [({"value": 0.4}, {"derivative": -0.2}), ({"derivative": 0.3}, {"value": -0.1}),
-                                                           ({"type": "mixed", "value": 0.5, "const": 0.2}, {"value": 0.0})]) for s, v in (("-", lo), ("+", hi))}
+    pairs = [({"value": 0.4}, {"derivative": -0.2}), ({"derivative": 0.3}, {"value": -0.1}), ({"type": "mixed", "value": 0.5, "const": 0.2}, {"value": 0.0})]
+    bc = {f"{a}{s}": v for a, (lo, hi) in zip(grid.axes, pairs) for s, v in (("-", lo), ("+", hi))}
     data = np.random.default_rng(9).uniform(-1, 1, shape)
+    # a communicator of size 1 (created like SlabStepper does) with lower = upper = -1
+    helper = SlabStepper(pde_hip.DiffusionPDE(), pde_hip.UnitGrid(shape, periodic=True), force_exchange=True)
+    lib, comm = helper.lib, helper.comm
     info = GridInfo(grid.shape, grid.discretization, np.float64)
     rhs = _abi.RHS()
     rhs.kind, rhs.param = _abi.RHS_DIFFUSION, 0.6
@@ -138,53 +117,57 @@ def test_slab_loop_with_physical_faces_on_both_ends(process_group, shape):
     faces.copy_into(rhs.bc_c)
     a, b = DeviceArray(info).set_valid(data), DeviceArray(info)
     res = C.c_void_p()
-    eng.lib.slab_euler_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
-    eng.lib.stream_synchronize(None)
+    lib.slab_euler_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
+    lib.stream_synchronize(None)
     got = (b if res.value == b.ptr else a).get_valid()
     np.testing.assert_array_equal(got, _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
-    # the two-steps-per-sweep loop on the same rank: two-ended boundary sweep with the physical faces + interior sweep
     ok = C.c_int(0)
-    eng.lib.slab_euler2_supported(info.ref, C.byref(rhs), C.byref(ok))
+    lib.slab_euler2_supported(info.ref, C.byref(rhs), C.byref(ok))
     assert bool(ok.value) == (len(shape) == 3 and shape[0] >= 4)
     if ok.value:
         a.set_valid(data)
-        eng.lib.slab_euler2_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
-        eng.lib.stream_synchronize(None)
+        lib.slab_euler2_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, 5, C.byref(res), None)
+        lib.stream_synchronize(None)
         np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, 5))
-    # Cahn-Hilliard sweep on arrays with two halo layers per side, physical faces on both ends (no exchange)
-    if len(shape) == 3:
-        ch = _abi.RHS()
-        ch.kind, ch.param = _abi.RHS_CAHN_HILLIARD, 0.9
-        faces.copy_into(ch.bc_c)
-        faces.copy_into(ch.bc_mu)
-        eng.lib.slab_ch_supported(info.ref, C.byref(ch), C.byref(ok))
-        assert bool(ok.value) == (shape[0] >= 4)   # a rank that owns both faces needs 4 layers (never the case with > 1 rank)
-    if len(shape) == 3 and ok.value:
-        ext = GridInfo((shape[0] + 2, *shape[1:]), grid.discretization, np.float64)
-        padded = np.zeros((shape[0] + 2, *shape[1:]))
-        padded[1:-1] = data
-        ce, oe = DeviceArray(ext).set_valid(padded), DeviceArray(ext)
-        eng.lib.slab_ch_sweep(comm, info.ref, C.byref(ch), -1, -1, ce.ptr, oe.ptr, 1e-3, 1, None)
-        eng.lib.stream_synchronize(None)
-        np.testing.assert_array_equal(oe.get_valid()[1:-1], _expect(_abi.RHS_CAHN_HILLIARD, 0.9, grid, bc, data, 1e-3, 1))
-    eng.lib.comm_destroy(comm)
+    helper.close()
 
 
-@pytest.mark.parametrize("comm_mode", ["native", "torch"])
-def test_cahn_hilliard_rk_and_adaptive_self_exchange(process_group, monkeypatch, comm_mode):
-    from pde_hip.distributed import HipEngine, SlabStepper
+@pytest.mark.parametrize("kind", ["diffusion", "cahn_hilliard"])
+def test_rk4_and_adaptive_rkf45_in_one_c_call(kind):
+    """pdehip_slab_rk4_run / pdehip_slab_rkf45_run (stage sweeps, MAX all-reduce, accept/reject and the dt controller in C):
+    bit-identical final state, equal step counts and the same next dt as the serial oracle loop."""
+    from pde_hip.distributed import SlabStepper
 
-    monkeypatch.setenv("PDEHIP_COMM", comm_mode)
-
-    grid = pde_hip.UnitGrid([8, 8, 64], periodic=True)
-    data = np.random.default_rng(3).uniform(-0.1, 0.1, grid.shape)
-    eq = pde_hip.CahnHilliardPDE(1.0)
-    st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
+    grid = pde_hip.UnitGrid((8, 8, 128), periodic=True)
+    data = np.random.default_rng(11).uniform(-0.1, 0.1, grid.shape)
+    eq = pde_hip.DiffusionPDE(0.5) if kind == "diffusion" else pde_hip.CahnHilliardPDE(1.0)
+    code, param = (_abi.RHS_DIFFUSION, 0.5) if kind == "diffusion" else (_abi.RHS_CAHN_HILLIARD, 1.0)
+    st = SlabStepper(eq, grid, force_exchange=True)
     final, info = st.solve(data, t_range=0.01, dt=1e-3, solver="runge-kutta")
-    np.testing.assert_array_equal(final, _expect(_abi.RHS_CAHN_HILLIARD, 1.0, grid, eq.bc_c, data, 1e-3, 10, "runge-kutta"))
-    # adaptive RKF45 == the single-GPU backend's adaptive solve (same controller, same kernels)
-    st2 = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=True)
-    final2, info2 = st2.solve(data, t_range=0.05, dt=None, solver="runge-kutta")
-    ref, rinfo = eq.solve(pde_hip.ScalarField(grid, data), t_range=0.05, dt=None, solver="runge-kutta", backend="hip", ret_info=True)
-    assert info2["steps"] == rinfo["solver"]["steps"]
-    np.testing.assert_array_equal(final2, ref.data)
+    np.testing.assert_array_equal(final, _expect(code, param, grid, "auto_periodic_neumann", data, 1e-3, 10, "runge-kutta"))
+    final2, info2 = st.solve(data, t_range=0.3 if kind == "diffusion" else 0.05, dt=None, solver="runge-kutta")
+    st.close()
+    case = {"pde": kind, "D": 0.5, "gamma": 1.0, "bc": "auto_periodic_neumann", "t_range": 0.3 if kind == "diffusion" else 0.05, "dt": None,
+            "solver": "runge-kutta"}
+    expect, steps, dt_last = oracle_solve(case, grid, np.float64, data)
+    assert info2["steps"] == steps and info2["attempts"] >= steps
+    assert info2["dt"] == pytest.approx(dt_last, rel=1e-12)
+    np.testing.assert_array_equal(final2, expect)
+    stats = info2["dt_statistics"]
+    assert stats["count"] == steps and 0 < stats["min"] <= stats["mean"] <= stats["max"]
+    # ... and the serial product stepper (mirror API) agrees
+    ref, rinfo = eq.solve(pde_hip.ScalarField(grid, data), t_range=case["t_range"], dt=None, solver="runge-kutta", backend="hip", ret_info=True)
+    assert rinfo["solver"]["steps"] == steps
+    assert max_rel(final2, ref.data) == 0.0
+
+
+def test_adaptive_loop_reports_too_small_steps():
+    """dt below dt_min -> RuntimeError with the reference's message (pde/solvers/base.py:583-590)."""
+    from pde_hip.distributed import SlabStepper
+
+    grid = pde_hip.UnitGrid((8, 8, 64), periodic=True)
+    data = np.random.default_rng(12).uniform(-1, 1, grid.shape) * 1e6
+    st = SlabStepper(pde_hip.CahnHilliardPDE(1.0), grid, force_exchange=True)
+    with pytest.raises(RuntimeError, match="Time step below|NaN even though"):
+        st.solve(data, t_range=1.0, dt=None, solver="runge-kutta", dt_min=1e-4)
+    st.close()

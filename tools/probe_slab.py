@@ -12,34 +12,29 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "py-pde_amd")]
 import numpy as np
-import torch
-import torch.distributed as dist
 
 import pde_hip
 from pde_hip.device import DeviceArray
-from pde_hip.distributed import HipEngine, SlabStepper
+from pde_hip.distributed import SlabStepper
 
 shape = tuple(int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "64,512,512").split(","))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29555")
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 grid = pde_hip.UnitGrid(shape, periodic=True)
 eq = pde_hip.DiffusionPDE(1.0)
 cells = int(np.prod(shape))
 for force in (True, False):
-    st = SlabStepper(eq, grid, engine=HipEngine(0), force_exchange=force)
+    st = SlabStepper(eq, grid, force_exchange=force)
     cur, nxt = st.buf("state_a"), st.buf("state_b")
-    st.engine.set_valid(st.g, cur, np.random.default_rng(0).random(shape))
+    st.set_local(cur, np.random.default_rng(0).random(shape))
     cur = st.euler_steps(cur, nxt, 0.1, 20)
     nxt = st.buf("state_b") if cur is st.buf("state_a") else st.buf("state_a")
-    st.engine.synchronize()
+    st.synchronize()
     t0 = time.perf_counter()
     cur = st.euler_steps(cur, nxt, 0.1, steps)
     t_enq = time.perf_counter() - t0
-    st.engine.synchronize()
+    st.synchronize()
     t_all = time.perf_counter() - t0
+    st.close()
     print(f"{shape} slab stepper exchange={force}: {t_all/steps*1e3:.4f} ms/step ({cells*steps/t_all/1e9:.1f} Gcells/s), host enqueue {t_enq/steps*1e6:.1f} us/step", flush=True)
 b = pde_hip.get_backend("hip")
 state = pde_hip.ScalarField(grid, np.random.default_rng(0).random(shape))
@@ -54,4 +49,3 @@ t_enq = time.perf_counter() - t0
 b._lib.stream_synchronize(None)
 t_all = time.perf_counter() - t0
 print(f"{shape} pdehip_euler_run (single kernel/step): {t_all/steps*1e3:.4f} ms/step ({cells*steps/t_all/1e9:.1f} Gcells/s), host enqueue {t_enq/steps*1e6:.1f} us/step")
-dist.destroy_process_group()

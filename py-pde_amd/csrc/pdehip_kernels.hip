@@ -423,9 +423,11 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         *done = true;
         return 0;
     }
+    // the stage epilogue exists for real halo layers on BOTH sides (a run-time argument of the plain instances) but not as
+    // one-sided (XS) instances: the first / last slab of a non-periodic axis combines with the pointwise kernels
+    if (m2 == E2_CH_STAGE && xplain > 1) return 0;
     if (dry_run) { *done = true; return 0; }
     if (m2 == E2_CUSTOM || m2 == E2_CUSTOM2) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
-    if (m2 == E2_CH_STAGE && xplain) PDEHIP_FAIL(E_RUNTIME, "internal: Runge-Kutta stage sweeps are not built for sub-slabs");
     // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
     // the 5 VGPRs decide whether the loads can be issued early (8-19 % at 256^3 and slab-sized grids)
     // XS: the one-sided halo modes of the first / last slab of a non-periodic axis are separate instances (with the

@@ -934,20 +934,154 @@ class HipBackendMixin:
     def make_stepper(self, solver, state):
         """``stepper(state_field, t_start, t_end) -> t_last`` mutating ``state.data`` (base.py:728-755).
 
-        Data crosses the PCIe bus once per call in each direction, i.e. once per tracker
-        interrupt, like the reference's torch backend (``pde/backends/torch/backend.py:654-662``).
+        The reference's device template moves the whole state over PCIe in both directions on EVERY call, i.e. at every
+        tracker interrupt (``pde/backends/torch/backend.py:654-662``).  Here the state stays RESIDENT on the device between
+        the calls of one stepper (config ``resident_state``, default on): the host copy of the field is refreshed only
+        when somebody actually reads ``state.data`` (a tracker that stores or plots, the caller after the run), and the
+        device copy is refreshed only after such an access (the view handed out is writable).  A run with ``tracker=None``
+        or progress-only trackers uploads once and downloads once.  See :class:`ResidentState`.
         """
         inner = self.make_inner_stepper(solver, state)
         info = self.grid_info(state.grid, state.dtype)
+        resident = bool(_config_get(getattr(self, "config", None), "resident_state", True))
         dev_state = DeviceArray(info)
+        if not resident:
 
-        def stepper(state_field, t_start: float, t_end: float) -> float:
-            dev_state.set_valid(state_field.data, self.stream)
+            def stepper(state_field, t_start: float, t_end: float) -> float:
+                dev_state.set_valid(state_field.data, self.stream)
+                result, t_last = inner(dev_state, t_start, t_end)
+                state_field.data[...] = result.get_valid(stream=self.stream)
+                return t_last
+
+            return stepper
+
+        def resident_stepper(state_field, t_start: float, t_end: float) -> float:
+            link = ResidentState.attach(state_field, dev_state, self)
+            link.push()                                   # uploads only if the host copy may have changed
             result, t_last = inner(dev_state, t_start, t_end)
-            state_field.data[...] = result.get_valid(stream=self.stream)
+            if result is not dev_state:                   # steppers hand back the array they were given; be safe
+                self._lib.memcpy_d2d(dev_state.ptr, result.ptr, dev_state.nbytes, self.stream)
+            link.device_advanced()
             return t_last
 
-        return stepper
+        resident_stepper.device_state = dev_state  # type: ignore[attr-defined]
+        return resident_stepper
+
+
+def _config_get(config, key: str, default):
+    try:
+        if config is not None and key in config:
+            return config[key]
+    except TypeError:
+        pass
+    return default
+
+
+_DATA_ATTRIBUTES = frozenset({"data", "_data_valid", "_data_full", "_FieldBase__data_full"})
+_SYNCED_CLASSES: dict[type, type] = {}
+
+
+class ResidentState:
+    """Link between a host field object and its device-resident copy (no full-field PCIe traffic per
+    tracker interrupt; reference behaviour being replaced: ``pde/backends/torch/backend.py:654-662``).
+
+    The field object handed to the stepper keeps its identity (the controller returns it, trackers receive it), but its
+    class is swapped for a dynamic subclass whose data attributes (``data``, ``_data_full`` ...) first bring the host
+    arrays up to date — one pinned-speed download — and then count as a possible modification, so the next stepper call
+    uploads again.  Nothing else about the field changes; copies of it are ordinary fields.
+    """
+
+    def __init__(self, field, dev_state: DeviceArray, backend):
+        self.dev_state, self.backend = dev_state, backend
+        self.host_stale = False          # device is ahead of the host arrays
+        self.host_touched = True         # host arrays may differ from the device copy (initially: never uploaded)
+        self.downloads = self.uploads = 0
+
+    @staticmethod
+    def attach(field, dev_state: DeviceArray, backend) -> "ResidentState":
+        link = field.__dict__.get("_hip_link")
+        if link is not None and link.dev_state is dev_state:
+            return link
+        if link is not None:             # a stepper of an earlier run: settle it first
+            link.pull(field)
+        cls = type(field)
+        base = getattr(cls, "_hip_base_class", cls)
+        if base not in _SYNCED_CLASSES:
+            _SYNCED_CLASSES[base] = _make_synced_class(base)
+        link = ResidentState(field, dev_state, backend)
+        field.__dict__["_hip_link"] = link
+        link._field_ref = field
+        if cls is base:
+            field.__class__ = _SYNCED_CLASSES[base]
+        return link
+
+    def _host_valid(self):
+        field = self._field_ref
+        base = type(field)._hip_base_class
+        return base.data.fget(field) if isinstance(getattr(base, "data", None), property) else object.__getattribute__(field, "data")
+
+    def push(self) -> None:
+        if self.host_touched:
+            field = self._field_ref
+            field.__dict__["_hip_link"] = None            # plain access while we read the host arrays
+            try:
+                self.dev_state.set_valid(field.data, self.backend.stream)
+            finally:
+                field.__dict__["_hip_link"] = self
+            self.host_touched, self.host_stale = False, False
+            self.uploads += 1
+
+    def device_advanced(self) -> None:
+        self.host_stale = True
+
+    def pull(self, field=None) -> None:
+        """Bring the host arrays up to date (called on the first data access after the device advanced)."""
+        field = self._field_ref if field is None else field
+        if self.host_stale:
+            self.host_stale = False
+            field.__dict__["_hip_link"] = None
+            try:
+                field.data[...] = self.dev_state.get_valid(stream=self.backend.stream)
+            finally:
+                field.__dict__["_hip_link"] = self
+            self.downloads += 1
+
+    def before_host_access(self) -> None:
+        self.pull()
+        self.host_touched = True
+
+
+def _make_synced_class(base: type) -> type:
+    def __getattribute__(self, name):
+        if name in _DATA_ATTRIBUTES:
+            link = object.__getattribute__(self, "__dict__").get("_hip_link")
+            if link is not None:
+                link.before_host_access()
+        return base.__getattribute__(self, name)
+
+    def __reduce_ex__(self, protocol):
+        # pickling / deepcopy: settle the data and present the plain class
+        link = self.__dict__.pop("_hip_link", None)
+        if link is not None:
+            self.__dict__["_hip_link"] = None
+            link.pull(self)
+            del self.__dict__["_hip_link"]
+        self.__class__ = base
+        return base.__reduce_ex__(self, protocol)
+
+    # py-pde registers every field subclass by NAME (pde/fields/base.py:77-88) to rebuild fields from stored attributes: the
+    # registry must keep pointing at the real class
+    import warnings
+
+    registry = getattr(base, "_subclasses", None)
+    previous = registry.get(base.__name__) if isinstance(registry, dict) else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        synced = type(base.__name__, (base,), {"__getattribute__": __getattribute__, "__reduce_ex__": __reduce_ex__, "_hip_base_class": base,
+                                               "__module__": base.__module__, "__qualname__": base.__qualname__, "__doc__": base.__doc__})
+    if previous is not None:
+        registry[base.__name__] = previous
+    return synced
 
 
 # ---------------------------------------------------------------------------------------------

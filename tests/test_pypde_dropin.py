@@ -359,3 +359,41 @@ def test_unsupported_requests_raise_not_implemented(hip1):
         pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, solver="implicit", backend="hip", tracker=None)
     with pytest.raises(NotImplementedError):
         pde.PDE({"c": "laplace(c)", "d": "c"}).solve(pde.FieldCollection([state, state]), t_range=0.1, dt=0.01, backend="hip", tracker=None)
+
+
+def test_state_stays_resident_between_tracker_interrupts(hip1):
+    """SURVEY §8 f4 / VERDICT r1 missing #1: no full-field PCIe round trip per tracker interrupt.  Uploads / downloads are
+    counted on the link object: a run whose trackers never read `state.data` moves the field once in each direction."""
+    import pickle
+
+    grid = pde.UnitGrid([16, 16], periodic=True)
+    state = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(8))
+    eq = pde.DiffusionPDE()
+    times = []
+    quiet = pde.CallbackTracker(lambda s, t: times.append(t), interrupts=0.1)          # never touches the data
+    res = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend="hip", tracker=quiet)
+    link = res.__dict__["_hip_link"]
+    assert len(times) == 11 and (link.uploads, link.downloads) == (1, 0)                # 11 interrupts, one upload, nothing back yet
+    data = res.data                                                                     # the caller reads the result: ONE download
+    assert (link.uploads, link.downloads) == (1, 1)
+    ref = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend="hip", tracker=None)
+    np.testing.assert_array_equal(data, ref.data)
+    assert type(res).__name__ == "ScalarField" and isinstance(res, pde.ScalarField)
+    assert pde.fields.base.FieldBase._subclasses["ScalarField"] is pde.ScalarField      # py-pde's class registry is untouched
+    # derived quantities, copies and pickles behave like on any field
+    assert res.average == pytest.approx(ref.data.mean()) and res.copy().__dict__.get("_hip_link") is None
+    clone = pickle.loads(pickle.dumps(res))
+    assert type(clone) is pde.ScalarField
+    np.testing.assert_array_equal(clone.data, ref.data)
+    # a tracker that reads every second interrupt: one download per read, one re-upload after each (the view is writable)
+    seen = []
+    reader = pde.CallbackTracker(lambda s, t: seen.append(float(s.data.sum())), interrupts=0.5)
+    res2 = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend="hip", tracker=[quiet, reader])
+    link2 = res2.__dict__["_hip_link"]
+    assert len(seen) == 3 and link2.downloads == 2 and link2.uploads == 2               # the read at t=0 is on the host copy; reads at 0.5 (then re-upload) and 1.0
+    np.testing.assert_array_equal(res2.data, ref.data)
+    # resident_state = False restores the reference's behaviour (both directions on every call)
+    backend = pde.backends.get_backend("hip", config={"resident_state": False})
+    res3 = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend=backend, tracker=quiet)
+    assert "_hip_link" not in res3.__dict__
+    np.testing.assert_array_equal(res3.data, ref.data)

@@ -164,6 +164,14 @@ int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, v
 int pdehip_gradient_squared(const pdehip_grid_t *g, int central, const void *in_full, void *out,
                             int out_layout, void *stream);
 
+/* 2-D Laplacian with the nine-point stencil (pde/backends/numba/operators/cartesian.py:153-190; `corner_weight` w: 1/2
+ * Oono-Puri, 1/3 Mehrstellen; w = 0 is pdehip_laplace).  The four CORNER ghost cells of `in_full` are written first, as the
+ * reference's make_corner_point_setter_2d does (:36-78: copies across a periodic axis — periodic2 = grid.periodic —, else
+ * the mean of the two adjacent face ghosts); the face ghost cells must be set by the caller.  This is the one operator
+ * that writes its input (SURVEY.md 8b "ownership"). */
+int pdehip_laplace9(const pdehip_grid_t *g, const int *periodic2, double corner_weight, void *in_full, void *out,
+                    int out_layout, void *stream);
+
 /* first (order = 1, `method` as above) or second (order = 2, central) derivative along ONE axis:
  * the `d_dx`, `d_dy_forward`, `d2_dx2`, ... pattern operators of NumbaBackend.get_operator_info
  * (pde/backends/numba/backend.py:119-182), formulas of make_derivative / make_derivative2

@@ -47,6 +47,8 @@ def lib():
             fn = getattr(handle, "oracle_" + name)
             fn.argtypes = args
             fn.restype = C.c_int
+        handle.oracle_set_corner_points_2d.argtypes = [C.POINTER(_abi.Grid), C.POINTER(C.c_int), C.c_void_p]
+        handle.oracle_set_corner_points_2d.restype = C.c_int
         _LIB = handle
     return _LIB
 
@@ -95,6 +97,19 @@ def _out_array(g: _abi.Grid, ncomp_lead: tuple[int, ...], layout: int, dtype) ->
 def laplace(g, arr_full, layout=_abi.OUT_VALID):
     out = _out_array(g, (), layout, arr_full.dtype)
     _check(lib().oracle_laplace(C.byref(g), _p(arr_full), _p(out), layout), "laplace")
+    return out
+
+
+def set_corner_points_2d(g, periodic, arr_full) -> None:
+    per = (C.c_int * 2)(*[int(bool(p)) for p in periodic])
+    _check(lib().oracle_set_corner_points_2d(C.byref(g), per, _p(arr_full)), "set_corner_points_2d")
+
+
+def laplace9(g, periodic, corner_weight, arr_full, layout=_abi.OUT_VALID):
+    """Nine-point 2-D Laplacian; writes the corner ghost cells of ``arr_full`` like the reference."""
+    out = _out_array(g, (), layout, arr_full.dtype)
+    per = (C.c_int * 2)(*[int(bool(p)) for p in periodic])
+    _check(lib().oracle_laplace9(C.byref(g), per, float(corner_weight), _p(arr_full), _p(out), layout), "laplace9")
     return out
 
 

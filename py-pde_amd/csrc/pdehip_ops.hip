@@ -165,6 +165,55 @@ __global__ void __launch_bounds__(256) axis_derivative_kernel(AxisArgs a)
     });
 }
 
+// ---- 2-D nine-point Laplacian (pde/backends/numba/operators/cartesian.py:153-190) ------------------------------------
+struct Lap9Args {
+    const void *in;
+    void *out;
+    long p1, off, nx, ny, o_off, o_s1;
+    double st[3][3];
+    int per_x, per_y;
+};
+
+// the four corner ghost cells, make_corner_point_setter_2d (cartesian.py:36-78), restated as written there
+template <typename T>
+__global__ void corner_points_kernel(Lap9Args a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    T *arr = (T *)a.in;               // full indices (i, j) = 0 .. nx+1, 0 .. ny+1; `off` is the first interior cell (1, 1)
+    const long p1 = a.p1, X = a.nx + 1, Y = a.ny + 1;
+    auto at = [&](long i, long j) -> T & { return arr[a.off + (i - 1) * p1 + (j - 1)]; };
+    if (a.per_x) {
+        at(0, 0) = at(X - 1, 0); at(X, 0) = at(1, 0);
+        at(0, Y) = at(X - 1, Y); at(X, Y) = at(1, Y);
+    } else if (a.per_y) {
+        at(0, 0) = at(0, Y - 1); at(X, 0) = at(X, 1);
+        at(0, Y) = at(0, Y - 1); at(X, Y) = at(X, 1);
+    } else {
+        at(0, 0) = (T)(0.5 * ((double)at(0, 1) + (double)at(1, 0)));
+        at(X, 0) = (T)(0.5 * ((double)at(X, 1) + (double)at(X - 1, 0)));
+        at(0, Y) = (T)(0.5 * ((double)at(0, Y - 1) + (double)at(1, Y)));
+        at(X, Y) = (T)(0.5 * ((double)at(X, Y - 1) + (double)at(X - 1, Y)));
+    }
+}
+
+// one cell per thread, rows along threadIdx.x (coalesced); the 3 x 3 neighbourhood comes out of L1/L2
+template <typename T>
+__global__ void __launch_bounds__(256) laplace9_kernel(Lap9Args a)
+{
+    const T *in = (const T *)a.in;
+    T *out = (T *)a.out;
+    const long bpr = (a.ny + 255) / 256;   // blocks per row
+    const long i = blockIdx.x / bpr, j = (blockIdx.x % bpr) * 256 + threadIdx.x;
+    if (j >= a.ny) return;
+    const T *c = in + a.off + i * a.p1 + j;
+    double value = 0;   // accumulation order of cartesian.py:184-188
+#pragma unroll
+    for (int x = 0; x < 3; x++)
+#pragma unroll
+        for (int y = 0; y < 3; y++) value += (double)c[(x - 1) * a.p1 + (y - 1)] * a.st[x][y];
+    out[a.o_off + i * a.o_s1 + j] = (T)value;
+}
+
 static int launch_deriv(int which, const pdehip_grid_t *g, int method, const void *in, void *out,
                         int layout, void *stream)
 {
@@ -631,6 +680,37 @@ int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int meth
     const unsigned blocks = grid_blocks(n.n[0] * n.n[1] * n.n[2]);
     if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((axis_derivative_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((axis_derivative_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pdehip_laplace9(const pdehip_grid_t *g, const int *periodic2, double corner_weight, void *in_full, void *out, int out_layout,
+                    void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in_full || !out || !periodic2) PDEHIP_FAIL(E_VALUE, "laplace9: NULL pointer");
+    if (n.ndim != 2) PDEHIP_FAIL(E_VALUE, "the nine-point stencil is defined for 2-D grids (got %d axes)", n.ndim);
+    if (out_layout != PDEHIP_OUT_VALID && out_layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "unknown output layout %d", out_layout);
+    const OutStr o = out_strides(n, out_layout);
+    Lap9Args a;
+    a.in = in_full; a.out = out;
+    a.p1 = n.p[1]; a.off = n.off; a.nx = n.n[1]; a.ny = n.n[2]; a.o_off = o.off; a.o_s1 = o.s1;
+    a.per_x = periodic2[0] != 0; a.per_y = periodic2[1] != 0;
+    const double w = corner_weight, dxm2 = n.lap_scale[1], dym2 = n.lap_scale[2], dm2 = dxm2 + dym2;
+    const double st[3][3] = {{0.25 * dm2 * w, dxm2 * (1 - w), 0.25 * dm2 * w},
+                             {dym2 * (1 - w), (dxm2 + dym2) * (w - 2), dym2 * (1 - w)},
+                             {0.25 * dm2 * w, dxm2 * (1 - w), 0.25 * dm2 * w}};
+    memcpy(a.st, st, sizeof(st));
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((unsigned)(((a.ny + 255) / 256) * a.nx));
+    if (n.dtype == PDEHIP_F64) {
+        hipLaunchKernelGGL((corner_points_kernel<double>), dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((laplace9_kernel<double>), grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((corner_points_kernel<float>), dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((laplace9_kernel<float>), grid, dim3(256), 0, s, a);
+    }
     PDEHIP_HIP(hipGetLastError());
     return 0;
 }

@@ -142,6 +142,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "divergence": ([_pg, _i, _vp, _vp, _i], True),
     "gradient_squared": ([_pg, _i, _vp, _vp, _i], True),
     "axis_derivative": ([_pg, _i, _i, _i, _vp, _vp, _i], True),
+    "laplace9": ([_pg, C.POINTER(_i), _d, _vp, _vp, _i], True),
     "laplace_scaled": ([_pg, _vp, _vp, _d, _d], True),
     "laplace_euler": ([_pg, _vp, _vp, _vp, _d, _d], True),
     "cahn_hilliard_mu": ([_pg, _vp, _vp, _d], True),

@@ -19,12 +19,35 @@ def _check_method(method: str) -> int:
     return _abi.METHODS[method]
 
 
-def make_laplace(grid, *, backend, **kwargs):
-    """7/5/3-point Laplacian (cartesian.py:81-229, dispatch :332-383)."""
-    if kwargs.get("corner_weight"):
-        msg = "hip backend: 9-point 2-D stencil not implemented (SURVEY.md §8f)"
-        raise NotImplementedError(msg)
+def _default_corner_weight() -> float:
+    """py-pde's configuration value ``operators.cartesian.laplacian_2d_corner_weight`` when py-pde is present (default 0)."""
+    try:
+        from pde import config
+    except ImportError:
+        return 0.0
+    try:
+        return float(config["operators.cartesian.laplacian_2d_corner_weight"])
+    except (KeyError, TypeError, ValueError):
+        return 0.0
+
+
+def make_laplace(grid, *, backend, corner_weight: float | None = None, **kwargs):
+    """7/5/3-point Laplacian (cartesian.py:81-229, dispatch :332-383); 2-D grids: nine-point stencil for ``corner_weight`` != 0
+    (cartesian.py:153-190; the corner ghost cells of the input are filled first, :36-78)."""
     lib = backend._lib
+    if corner_weight is None:
+        corner_weight = _default_corner_weight() if len(grid.shape) == 2 else 0.0
+    if corner_weight and len(grid.shape) == 2:
+        import ctypes as C
+
+        periodic = (C.c_int * 2)(*[int(bool(p)) for p in grid.periodic])
+        weight = float(corner_weight)
+
+        def laplace9(arr: DeviceArray, out: DeviceArray) -> None:
+            lib.laplace9(arr.info.ref, periodic, weight, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+        laplace9.grid = grid
+        return laplace9
 
     def laplace(arr: DeviceArray, out: DeviceArray) -> None:
         lib.laplace(arr.info.ref, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)

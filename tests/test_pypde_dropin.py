@@ -397,3 +397,18 @@ def test_state_stays_resident_between_tracker_interrupts(hip1):
     res3 = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend=backend, tracker=quiet)
     assert "_hip_link" not in res3.__dict__
     np.testing.assert_array_equal(res3.data, ref.data)
+
+
+def test_nine_point_laplacian_through_pypde(hip1):
+    """`field.laplace(bc, corner_weight=w, backend="hip")` and the config default `operators.cartesian.laplacian_2d_corner_weight`
+    (pde/backends/numba/operators/cartesian.py:132-133) reach the nine-point kernel."""
+    grid = pde.CartesianGrid([[-1, 1], [-1, 1]], [17, 17], periodic=[True, False])
+    field = pde.ScalarField.from_expression(grid, "exp(-x**2 - y**2)")
+    lap5 = field.laplace("auto_periodic_neumann", backend="hip")
+    lap9 = field.laplace("auto_periodic_neumann", backend="hip", corner_weight=1 / 3)
+    np.testing.assert_allclose(lap5.data, lap9.data, atol=1 / 9)       # tests/grids/test_cartesian_grids.py:311-321
+    assert not np.array_equal(lap5.data, lap9.data)
+    with pde.config({"operators.cartesian.laplacian_2d_corner_weight": 1 / 3}):
+        grid2 = pde.CartesianGrid([[-1, 1], [-1, 1]], [17, 17], periodic=[True, False])   # operators are cached per grid object
+        field2 = pde.ScalarField.from_expression(grid2, "exp(-x**2 - y**2)")
+        np.testing.assert_array_equal(field2.laplace("auto_periodic_neumann", backend="hip").data, lap9.data)

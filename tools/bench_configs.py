@@ -27,15 +27,16 @@ def run(name, eq, grid, dtype, t_range, dt, solver, lo=0.0, hi=1.0, **kw):
     t0 = time.perf_counter()
     res, info = eq.solve(state, t_range=t_range, dt=dt, solver=solver, backend=b, ret_info=True, **kw)
     b.synchronize()
-    wall = time.perf_counter() - t0
-    solver_t = info["controller"]["profiler"]["solver"]
+    wall = time.perf_counter() - t0               # upload + all steps on the device (the state stays resident: no download yet)
+    data = res.data                                # first host access: ONE download
+    wall_dl = time.perf_counter() - t0
     steps = info["solver"]["steps"]
     cells = int(np.prod(grid.shape))
-    assert np.isfinite(res.data).all()
-    print(f"| {name} | {steps} | {solver_t*1e3:.1f} | {solver_t/steps*1e6:.1f} | {cells*steps/solver_t/1e6:.0f} | {wall*1e3:.1f} |", flush=True)
+    assert np.isfinite(data).all()
+    print(f"| {name} | {steps} | {wall*1e3:.1f} | {wall/steps*1e6:.1f} | {cells*steps/wall/1e6:.0f} | {wall_dl*1e3:.1f} |", flush=True)
 
 
-print("| config | steps | stepper wall (ms, incl. H2D/D2H) | us/step | Mcell-steps/s | eq.solve wall (ms) |")
+print("| config | steps | eq.solve wall until the device is done (ms; incl. state copy + upload) | us/step | Mcell-steps/s | ... incl. the download of the result (ms) |")
 print("|---|---:|---:|---:|---:|---:|")
 run("cfg1 Diffusion UnitGrid 64^2 fp64 Euler dt=0.1", pde_hip.DiffusionPDE(), pde_hip.UnitGrid([64, 64]), np.float64, 100.0, 0.1, "euler")
 run("cfg2 Diffusion 1024^2 fp64 periodic Euler dt=0.1", pde_hip.DiffusionPDE(), pde_hip.CartesianGrid([[0, 1024]] * 2, 1024, periodic=True), np.float64, 100.0, 0.1, "euler")

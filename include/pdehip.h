@@ -240,6 +240,15 @@ int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void 
 int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, const void *b_full,
                         double *out_dev, void *stream);
 
+/* y += scale * xi over the interior, xi ~ N(0, 1) independent per cell: the noise increment of an Euler-Maruyama step
+ * (pde/solvers/euler.py:66-147: `state += sqrt(dt) * sqrt(noise_variance / cell_volume) * dW`; the reference draws dW with
+ * numba's / torch's generator, pde/backends/numba/backend.py make_gaussian_noise, pde/backends/torch/backend.py:603-625).
+ * Counter-based generator: xi of cell q (C-order index of the VALID array, component-major) in call number `counter` is
+ * Box-Muller(Philox4x32-10(key = seed, counter = {q_lo, q_hi, counter_lo, counter_hi})) — reproducible for a given seed, independent of the
+ * launch geometry and of how the grid is split over devices (pass the global cell offset of the slab in `cell_offset`). */
+int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, double scale, uint64_t seed, uint64_t counter,
+                              uint64_t cell_offset, void *stream);
+
 /* ---- fused time steppers ----------------------------------------------------------
  * k_out = dt * rhs(y): applies the BCs of y (and of mu) — on the fly inside the stencil kernel where the
  * faces allow it, else by setting the ghost cells in place — then evaluates the RHS;

@@ -165,6 +165,44 @@ __global__ void __launch_bounds__(256) axis_derivative_kernel(AxisArgs a)
     });
 }
 
+// ---- Gaussian white noise increment of an Euler-Maruyama step (pde/solvers/euler.py:66-147) -----------------------------
+// Philox4x32-10 (counter = {cell, call number}, key = seed) + Box-Muller, one draw per cell: reproducible for a given seed,
+// independent of the launch geometry; twin of oracle_add_gaussian_noise.
+struct NoiseArgs {
+    DevGrid g;
+    void *y;
+    int ncomp;
+    double scale;
+    unsigned long long seed, counter, cell_offset;
+};
+
+__device__ inline double philox_normal(unsigned long long cell, unsigned long long counter, unsigned long long seed)
+{
+    unsigned c0 = (unsigned)cell, c1 = (unsigned)(cell >> 32), c2 = (unsigned)counter, c3 = (unsigned)(counter >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const double u1 = ((double)((((unsigned long long)c0 << 32) | c1) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)((((unsigned long long)c2 << 32) | c3) >> 11) * (1.0 / 9007199254740992.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gaussian_noise_kernel(NoiseArgs a)
+{
+    T *y = (T *)a.y;
+    const long cells = a.g.n0 * a.g.n1 * a.g.n2;
+    for_each_chunk<1>(a.g, a.ncomp, [&](int c, long i, long j, long k, long e) {
+        const unsigned long long q = (unsigned long long)(c * cells + (i * a.g.n1 + j) * a.g.n2 + k) + a.cell_offset;
+        y[e] = (T)((double)y[e] + a.scale * philox_normal(q, a.counter, a.seed));
+    });
+}
+
 // ---- 2-D nine-point Laplacian (pde/backends/numba/operators/cartesian.py:153-190) ------------------------------------
 struct Lap9Args {
     const void *in;
@@ -680,6 +718,22 @@ int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int meth
     const unsigned blocks = grid_blocks(n.n[0] * n.n[1] * n.n[2]);
     if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((axis_derivative_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((axis_derivative_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, double scale, uint64_t seed, uint64_t counter,
+                              uint64_t cell_offset, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!y_full) PDEHIP_FAIL(E_VALUE, "add_gaussian_noise: NULL pointer");
+    if (ncomp < 1) PDEHIP_FAIL(E_VALUE, "add_gaussian_noise: ncomp must be positive");
+    NoiseArgs a;
+    a.g = dev_grid(n); a.y = y_full; a.ncomp = ncomp; a.scale = scale; a.seed = seed; a.counter = counter; a.cell_offset = cell_offset;
+    const unsigned blocks = grid_blocks((long)ncomp * n.n[0] * n.n[1] * n.n[2]);
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((gaussian_noise_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((gaussian_noise_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
     PDEHIP_HIP(hipGetLastError());
     return 0;
 }

@@ -134,6 +134,16 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
 # ---------------------------------------------------------------------------------------------
 # right hand sides the fused steppers know
 # ---------------------------------------------------------------------------------------------
+def pde_kind(eq) -> str:
+    """``"DiffusionPDE"`` / ``"CahnHilliardPDE"`` / ``"PDE"`` for objects of these classes OR subclasses of them (user classes
+    that add e.g. a post-step hook), looked up by class name along the MRO so that the reference's and the mirror's classes
+    both match; otherwise the object's own class name."""
+    for cls in type(eq).__mro__:
+        if cls.__name__ in {"DiffusionPDE", "CahnHilliardPDE", "PDE"}:
+            return cls.__name__
+    return eq.__class__.__name__
+
+
 class RhsSpec:
     """``pdehip_rhs_t`` + everything that must stay alive with it."""
 
@@ -541,12 +551,9 @@ class HipBackendMixin:
         """Map a PDE object onto one of the fused device right-hand sides."""
         from .bc_expr import convert_bcs_with_expressions as _faces
 
-        name = eq.__class__.__name__
+        name = pde_kind(eq)
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
-        if getattr(eq, "is_sde", False) or getattr(eq, "noise", 0):
-            msg = "hip backend does not support stochastic equations"
-            raise NotImplementedError(msg)
         if state.__class__.__name__ != "ScalarField":
             msg = "hip backend steppers support a single ScalarField state"
             raise NotImplementedError(msg)
@@ -621,11 +628,8 @@ class HipBackendMixin:
         from .bc_expr import convert_bcs_with_expressions
         from .expr import ExpressionPlan, ExpressionRhs
 
-        if eq.__class__.__name__ != "PDE":
+        if pde_kind(eq) != "PDE":
             msg = f"hip backend has no right-hand side for {eq.__class__.__name__}"
-            raise NotImplementedError(msg)
-        if getattr(eq, "is_sde", False) or getattr(eq, "noise", 0):
-            msg = "hip backend does not support stochastic equations"
             raise NotImplementedError(msg)
         if state.__class__.__name__ != "ScalarField":
             msg = "hip backend expression kernels support a single ScalarField state"
@@ -656,12 +660,15 @@ class HipBackendMixin:
                 specs.append((bc, tables[op]))
         return ExpressionRhs(self, plan, info, tables)
 
-    def _make_expression_stepper(self, solver, state, erhs=None):
+    def _make_expression_stepper(self, solver, state, erhs=None, post_step=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
         (pde/solvers/euler.py:172-175, runge_kutta.py:52-61, :135-153) with the RHS evaluated by the
         run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass.
         ``erhs``: any evaluator with the interface of :class:`~pde_hip.expr.ExpressionRhs` (default: the expression
-        of ``solver.pde``; :class:`SpecRhs` for the class PDEs when their BCs depend on time)."""
+        of ``solver.pde``; :class:`SpecRhs` for the class PDEs when their BCs depend on time).
+        ``post_step(array, t) -> array``: the PDE's post-step hook (after every fixed step with the time the step started at,
+        ``pde/solvers/base.py:266-272``; after every accepted adaptive step with the new time,
+        ``pde/backends/numba/_solvers.py:262-270``); with a hook every step is a single sweep."""
         from .solvers import OnlineStatistics, make_dt_adjuster
 
         if erhs is None:
@@ -699,20 +706,25 @@ class HipBackendMixin:
                 steps = max(1, round((t_end - t_start) / dt))
                 cur, nxt = state_data, work[0]
                 i = 0
-                while i < steps:
-                    t = t_start + i * dt
-                    if is_rk:
-                        rk4_step(cur, t, dt)
-                    elif i + 2 <= steps and erhs.euler2(cur, nxt, dt):   # two steps per sweep (one-pass expressions)
-                        cur, nxt = nxt, cur
+                try:
+                    while i < steps:
+                        t = t_start + i * dt
+                        if is_rk:
+                            rk4_step(cur, t, dt)
+                        elif post_step is None and i + 2 <= steps and erhs.euler2(cur, nxt, dt):   # two steps per sweep (one-pass expressions)
+                            cur, nxt = nxt, cur
+                            i += 1
+                        else:
+                            erhs.apply(cur, nxt, "euler", dt, t)
+                            cur, nxt = nxt, cur
                         i += 1
-                    else:
-                        erhs.apply(cur, nxt, "euler", dt, t)
-                        cur, nxt = nxt, cur
-                    i += 1
-                if cur is not state_data:
-                    lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
-                solver.info["steps"] += steps
+                        if post_step is not None:
+                            cur = post_step(cur, t)
+                finally:
+                    # also when a hook ends the run with StopIteration: the caller's array holds the latest state
+                    if cur is not state_data:
+                        lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
+                    solver.info["steps"] += i
                 return state_data, t_start + (steps - 1) * dt + dt
 
             return fixed_stepper
@@ -749,22 +761,26 @@ class HipBackendMixin:
             t, steps = t_start, 0
             stats = solver.info["dt_statistics"]
             cur, nxt = state_data, ynew0   # an accepted attempt swaps the roles (no copy of the field per step)
-            while True:
-                dt_step = max(min(dt_opt, t_end - t), dt_min)
-                error_rel = attempt(cur, nxt, t, dt_step) / tolerance
-                if error_rel <= 1:
-                    steps += 1
-                    t += dt_step
-                    cur, nxt = nxt, cur
-                    stats.add(dt_step)
-                if t < t_end:
-                    dt_opt = adjust_dt(dt_step, error_rel)
-                else:
-                    break
-            if cur is not state_data:
-                lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
-            solver.info["dt"] = dt_opt
-            solver.info["steps"] += steps
+            try:
+                while True:
+                    dt_step = max(min(dt_opt, t_end - t), dt_min)
+                    error_rel = attempt(cur, nxt, t, dt_step) / tolerance
+                    if error_rel <= 1:
+                        steps += 1
+                        t += dt_step
+                        cur, nxt = nxt, cur
+                        if post_step is not None:
+                            cur = post_step(cur, t)
+                        stats.add(dt_step)
+                    if t < t_end:
+                        dt_opt = adjust_dt(dt_step, error_rel)
+                    else:
+                        break
+            finally:
+                if cur is not state_data:
+                    lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
+                solver.info["dt"] = dt_opt
+                solver.info["steps"] += steps
             return state_data, t
 
         return adaptive_stepper
@@ -811,6 +827,88 @@ class HipBackendMixin:
 
         return fixed_stepper
 
+    def _make_noise_step(self, solver, state):
+        """Noise increment of an Euler-Maruyama step as ``add_noise(array: DeviceArray)``, or None for deterministic equations.
+
+        Covers the reference's standard case — additive Gaussian white noise of constant variance ``eq.noise``
+        (``SDEBase.make_noise_variance``, ``pde/pdes/base.py:634-722``) in ``EulerSolver`` with a fixed step
+        (``pde/solvers/euler.py:66-147``): ``state += sqrt(dt) * sqrt(noise / cell_volume) * dW``; additive noise has no drift
+        correction in any interpretation.  dW comes from the device generator of ``pdehip_add_gaussian_noise`` seeded from
+        ``eq.rng`` (like the torch backend, ``pde/backends/torch/backend.py:603-625``); realisations are therefore not those
+        of the numba backend, only their statistics agree.  Everything else (state-dependent variance, noise realisations,
+        Milstein, adaptive steps) raises like the reference / ``NotImplementedError``."""
+        eq = solver.pde
+        if not getattr(eq, "is_sde", False):
+            return None
+        solver_name = solver.__class__.__name__
+        if bool(getattr(solver, "adaptive", False)):
+            msg = "Cannot use adaptive stepping with stochastic equation"   # pde/solvers/base.py:446-449
+            raise RuntimeError(msg)
+        if solver_name not in {"EulerSolver", "ExplicitSolver"}:
+            msg = f"Backend `{self.name}` does not support stochastic equations with {solver_name}"
+            raise NotImplementedError(msg)
+        custom_variance = False
+        for cls in type(eq).__mro__:
+            if "make_noise_variance" in vars(cls):
+                custom_variance = cls.__name__ not in {"SDEBase", "PDEBase"}
+                break
+        if custom_variance or getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
+            msg = f"Backend `{self.name}` supports additive Gaussian white noise of constant variance only"
+            raise NotImplementedError(msg)
+        noise = np.unique(np.asarray(getattr(eq, "noise", 0), dtype=float))
+        if noise.size != 1 or noise[0] < 0:
+            msg = f"Backend `{self.name}` needs one non-negative noise variance for the field"
+            raise NotImplementedError(msg)
+        grid = state.grid
+        info = self.grid_info(grid, state.dtype)
+        cell_volume = float(np.prod(grid.discretization))
+        dt = float(solver.info["dt"])
+        scale = float(np.sqrt(dt) * np.sqrt(noise[0] / cell_volume))
+        rng = getattr(eq, "rng", None)
+        seed = int((rng if rng is not None else np.random.default_rng()).integers(0, 2**32))   # like the torch backend (torch/backend.py:619)
+        counter = [0]
+        lib = self._lib
+
+        def add_noise(arr: DeviceArray) -> None:
+            lib.add_gaussian_noise(info.ref, 1, arr.ptr, scale, seed, counter[0], 0, self.stream)
+            counter[0] += 1
+
+        solver.info["stochastic"] = True
+        return add_noise
+
+    def _make_host_post_step(self, solver, state):
+        """The PDE's post-step hook (``pde/solvers/base.py:191-232``, ``pde/pdes/base.py:160-208``) as
+        ``post_step(array: DeviceArray, t) -> DeviceArray``, or None when the PDE defines none.
+
+        Hooks are user code written against numpy arrays (``state_data[i] = 1``, ``raise StopIteration`` ...), so they run
+        on the HOST: the valid data is downloaded, handed to the hook, and uploaded again after every step — a full PCIe
+        round trip per step, logged once as a warning.  ``StopIteration`` propagates to the controller
+        (``pde/solvers/controller.py:235-240``); ``solver.info["post_step_data"]`` is kept up to date."""
+        make_hook = getattr(solver.pde, "make_post_step_hook", None)
+        if make_hook is None or not getattr(solver, "_use_post_step_hook", True):
+            solver.info.setdefault("post_step_data", None)
+            return None
+        try:
+            try:
+                hook, data = make_hook(state, backend="numpy")
+            except TypeError:
+                hook, data = make_hook(state)          # mirror classes without the `backend` argument
+        except NotImplementedError:
+            solver.info["post_step_data"] = None   # no hook defined: the normal case
+            return None
+        solver.info["post_step_data"] = data
+        _logger.warning("post-step hook of %s runs on the host: the state crosses PCIe twice per step", solver.pde.__class__.__name__)
+
+        def post_step(arr: DeviceArray, t: float) -> DeviceArray:
+            host = arr.get_valid(stream=self.stream)
+            result = hook(host, t, solver.info["post_step_data"])
+            if result is not None:                      # hooks may work in place and return nothing (older signature)
+                host, solver.info["post_step_data"] = result
+            arr.set_valid(np.asarray(host, dtype=arr.dtype), self.stream)
+            return arr
+
+        return post_step
+
     def make_inner_stepper(self, solver, state):
         """Device-level stepper ``(state: DeviceArray, t_start, t_end) -> (DeviceArray, t_last)``.
 
@@ -819,28 +917,31 @@ class HipBackendMixin:
         """
         from .solvers import make_dt_adjuster
 
-        # a PDE with a post-step hook (pde/solvers/base.py:191-232) must not silently run without it
-        make_hook = getattr(solver.pde, "make_post_step_hook", None)
-        if make_hook is not None and getattr(solver, "_use_post_step_hook", True):
-            try:
-                make_hook(state, backend=self)
-            except NotImplementedError:
-                pass   # no hook defined: the normal case
-            except TypeError:
-                pass   # mirror classes without the `backend` argument have no hooks either
-            else:
-                msg = f"Backend `{self.name}` does not support post-step hooks"
-                raise NotImplementedError(msg)
+        post_step = self._make_host_post_step(solver, state)
+        add_noise = self._make_noise_step(solver, state)
+        if add_noise is not None:
+            # Euler-Maruyama: deterministic Euler step, noise increment, then the hook (pde/solvers/euler.py:120-141)
+            hook = post_step
+
+            def post_step(arr, t, _hook=hook):   # noqa: E306
+                add_noise(arr)
+                return arr if _hook is None else _hook(arr, t)
         solver_name = solver.__class__.__name__
         if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver", "AdamsBashforthSolver"}:
             msg = f"Backend `{self.name}` does not support solver {solver_name}"
+            raise NotImplementedError(msg)
+        if post_step is not None and solver_name == "AdamsBashforthSolver":
+            msg = f"Backend `{self.name}` does not support post-step hooks with {solver_name}"
             raise NotImplementedError(msg)
         try:
             spec = self.make_rhs_spec(solver.pde, state)
         except NotImplementedError:
             if solver_name == "AdamsBashforthSolver":
                 raise
-            return self._make_expression_stepper(solver, state)   # generic expression PDE
+            return self._make_expression_stepper(solver, state, post_step=post_step)   # generic expression PDE
+        if post_step is not None:
+            # the hook runs on the host between steps: the steps are driven from here, one sweep each
+            return self._make_expression_stepper(solver, state, SpecRhs(self, spec), post_step=post_step)
         if spec.time_dependent:
             # faces with explicit time dependence: the C loops do not know t, so the steps are driven from here and the
             # coefficient arrays are refreshed before every right-hand side
@@ -958,10 +1059,12 @@ class HipBackendMixin:
         def resident_stepper(state_field, t_start: float, t_end: float) -> float:
             link = ResidentState.attach(state_field, dev_state, self)
             link.push()                                   # uploads only if the host copy may have changed
-            result, t_last = inner(dev_state, t_start, t_end)
-            if result is not dev_state:                   # steppers hand back the array they were given; be safe
-                self._lib.memcpy_d2d(dev_state.ptr, result.ptr, dev_state.nbytes, self.stream)
-            link.device_advanced()
+            try:
+                result, t_last = inner(dev_state, t_start, t_end)
+                if result is not dev_state:               # steppers hand back the array they were given; be safe
+                    self._lib.memcpy_d2d(dev_state.ptr, result.ptr, dev_state.nbytes, self.stream)
+            finally:
+                link.device_advanced()                    # also when a post-step hook ends the run (StopIteration)
             return t_last
 
         resident_stepper.device_state = dev_state  # type: ignore[attr-defined]

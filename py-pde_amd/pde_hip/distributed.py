@@ -212,7 +212,9 @@ class SlabStepper:
 
     @staticmethod
     def _describe(eq, grid):
-        name = eq.__class__.__name__
+        from .backend import pde_kind
+
+        name = pde_kind(eq)
         if name == "DiffusionPDE":
             bc = grid.get_boundary_conditions(eq.bc, rank=0)
             return _abi.RHS_DIFFUSION, float(eq.diffusivity), bc, bc

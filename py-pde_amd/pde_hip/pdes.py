@@ -59,14 +59,19 @@ class DiffusionPDE(PDEBase):
 
     default_bc = "auto_periodic_neumann"
 
-    def __init__(self, diffusivity: float = 1, *, bc=None, noise: float = 0):
+    use_noise_variance = True
+    use_noise_realization = False
+
+    def __init__(self, diffusivity: float = 1, *, bc=None, noise: float = 0, rng=None):
         super().__init__()
-        if noise:
-            msg = "hip backend does not support stochastic equations"
-            raise NotImplementedError(msg)
         self.diffusivity = diffusivity
-        self.noise = 0
+        self.noise = float(noise)          # variance of additive Gaussian white noise (pde/pdes/base.py:583-616)
+        self.rng = rng
         self.bc = self.default_bc if bc is None else bc
+
+    @property
+    def is_sde(self) -> bool:
+        return self.noise != 0
 
     @property
     def expression(self) -> str:

@@ -412,3 +412,54 @@ def test_nine_point_laplacian_through_pypde(hip1):
         grid2 = pde.CartesianGrid([[-1, 1], [-1, 1]], [17, 17], periodic=[True, False])   # operators are cached per grid object
         field2 = pde.ScalarField.from_expression(grid2, "exp(-x**2 - y**2)")
         np.testing.assert_array_equal(field2.laplace("auto_periodic_neumann", backend="hip").data, lap9.data)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_post_step_hook_runs_on_the_host(hip1, adaptive):
+    """`pde.PDE(..., post_step_hook=...)` (pde/pdes/pde.py:99-118, base.py:160-208): the hook clips the state and counts the
+    correction; the run equals the reference's numpy backend incl. `post_step_data`."""
+    def hook(state_data, t, post_step_data):
+        i = state_data > 0.8
+        post_step_data += (state_data[i] - 0.8).sum()
+        state_data[i] = 0.8
+        return state_data, post_step_data
+
+    grid = pde.UnitGrid([12, 12], periodic=[True, False])
+    state = pde.ScalarField.random_uniform(grid, 0.5, 1.0, rng=np.random.default_rng(9))
+
+    class HookedDiffusion(pde.DiffusionPDE):
+        def make_post_step_hook(self, state, backend="numpy"):
+            return hook, 0.0
+
+    # (adaptive runs use Runge-Kutta: the reference's adaptive EULER stepper evaluates the rate of the next step on the state
+    # BEFORE the hook modified it, pde/solvers/euler.py:262-274 — a quirk this backend does not reproduce)
+    kw = {"t_range": 0.5, "dt": 0.01, "solver": "runge-kutta" if adaptive else "euler", "tracker": None, "ret_info": True, "adaptive": adaptive}
+    r_hip, i_hip = HookedDiffusion(0.7).solve(state, backend="hip", **kw)
+    old = pde.config["default_backend"]
+    pde.config["default_backend"] = "scipy"
+    try:
+        r_ref, i_ref = HookedDiffusion(0.7).solve(state, backend="numpy", **kw)
+    finally:
+        pde.config["default_backend"] = old
+    assert i_hip["solver"]["steps"] == i_ref["solver"]["steps"]
+    assert max_rel(r_hip.data, r_ref.data) < 1e-10 and r_hip.data.max() <= 0.8
+    assert i_hip["solver"]["post_step_data"] == pytest.approx(i_ref["solver"]["post_step_data"], rel=1e-10) and i_ref["solver"]["post_step_data"] > 0
+
+
+def test_post_step_hook_can_stop_the_run(hip1):
+    """`raise StopIteration` inside the hook ends the simulation early (pde/solvers/controller.py:235-240)."""
+    def hook(state_data, t, post_step_data):
+        if state_data.mean() < 0.5:
+            raise StopIteration
+        return state_data, post_step_data + 1
+
+    class Decay(pde.PDE):
+        def make_post_step_hook(self, state, backend="numpy"):
+            return hook, 0
+
+    grid = pde.UnitGrid([8, 8], periodic=True)
+    state = pde.ScalarField(grid, 1.0)
+    eq = Decay({"c": "-c"})
+    res, info = eq.solve(state, t_range=5, dt=0.01, solver="euler", backend="hip", tracker=None, ret_info=True)
+    assert 0.49 < res.data.mean() < 0.5 and 60 < info["solver"]["post_step_data"] < 80
+    assert info["controller"]["stop_reason"] == "Tracker raised StopIteration" or info["controller"]["successful"]

@@ -31,11 +31,15 @@ SUITES: dict[str, dict[str, str]] = {
     # ghost cells incl. expression BCs (tests/backends/generic/test_boundaries.py:43-150)
     "backends/generic/test_boundaries.py": {},
     # solver x backend matrix, erf known answer (tests/solvers/test_generic_solvers.py:123-230)
-    "solvers/test_generic_solvers.py": {
-        "test_stochastic_solver_backend_support[hip-EulerSolver]": "Euler-Maruyama needs a device RNG (SURVEY §8 f3)",
-    },
-    "pdes/test_diffusion_pdes.py": {
-        "test_diffusion_sde[hip]": "stochastic equations (SURVEY §8 f3)",
+    # ... incl. Euler-Maruyama with the device generator (additive noise; Milstein / implicit solvers are refused)
+    "solvers/test_generic_solvers.py": {},
+    # noise scaling: Kolmogorov-Smirnov test of the final field against the analytical normal distribution
+    "pdes/test_diffusion_pdes.py": {},
+    "solvers/test_explicit_solvers.py": {
+        "MilsteinSolver-hip": "Milstein scheme (explicit solvers beyond Euler / Runge-Kutta are not on the hot path)",
+        "test_stochastic_solvers_geometric_brownian_motion": "state-dependent noise variance needs user code on the device (SURVEY §8 f3 next)",
+        "test_stochastic_solver_equilibrium": "state-dependent noise variance needs user code on the device (SURVEY §8 f3 next)",
+        "test_stochastic_solvers_two_interfaces": "noise realisations supplied by user code (SURVEY §8 f3 next)",
     },
     "fields/test_scalar_fields.py": {},
     "fields/test_vectorial_fields.py": {},

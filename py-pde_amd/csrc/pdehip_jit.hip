@@ -271,7 +271,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
         aligned = aligned && bits % 16 == 0;
     }
-    const bool fast = n.ndim >= 2 && (n.n[2] % vec == 0) && aligned;
+    const bool fast = n.ndim >= 2 && aligned;   // any row length: rows ending inside a vector are stored element-wise (pdehip_march.inc)
     if (stage && !fast) return 0;   // only the vectorised kernel carries the stage epilogue
 
     // boundary conditions: on the fly where possible (fast kernel), ghost kernel otherwise

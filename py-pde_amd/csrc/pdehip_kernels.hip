@@ -129,7 +129,10 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
 {
     constexpr int VEC = 16 / sizeof(T);
     const Tune &tn = tune();
-    const bool vec_ok = (n.n[2] % VEC == 0) && (o.s1 % VEC == 0) && (o.s0 % VEC == 0) && (o.off % VEC == 0) &&
+    // any row length: a row that ends inside a lane's vector is stored element-wise there (pdehip_march.inc); what the
+    // vector kernel needs is 16-byte aligned rows on both sides — always true for full arrays, for valid (compact) output
+    // only when the row length is a multiple of the vector
+    const bool vec_ok = (o.s1 % VEC == 0) && (o.s0 % VEC == 0) && (o.off % VEC == 0) && (a.o_sc % VEC == 0) &&
                         (((uintptr_t)a.out) % 16 == 0) && (((uintptr_t)a.in) % 16 == 0) &&
                         (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0) && stage_aligned(a);
     if (n.ndim >= 2 && vec_ok && !tn.force_generic) {
@@ -185,8 +188,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
 // true when launch_laplace would take the vectorised kernel (the only one with fused ghosts)
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y)
 {
-    const long vec = 16 / elem_size(n.dtype);
-    return n.ndim >= 2 && (n.n[2] % vec == 0) && !tune().force_generic && ((uintptr_t)in % 16 == 0) &&
+    return n.ndim >= 2 && !tune().force_generic && ((uintptr_t)in % 16 == 0) &&
            ((uintptr_t)out % 16 == 0) && (y == nullptr || (uintptr_t)y % 16 == 0);
 }
 
@@ -257,7 +259,7 @@ int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &
 {
     *done = false;
     const long vec = 16 / elem_size(n.dtype);
-    const bool vec_ok = n.ndim >= 2 && (n.n[2] % vec == 0) && (o.s1 % vec == 0) && (o.s0 % vec == 0) && (o.off % vec == 0) &&
+    const bool vec_ok = n.ndim >= 2 && (o.s1 % vec == 0) && (o.s0 % vec == 0) && (o.off % vec == 0) &&
                         (o.sc % vec == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)in % 16 == 0) && !tune().force_generic;
     if (!vec_ok) return 0;
     LapArgs a;

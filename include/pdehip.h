@@ -249,6 +249,13 @@ int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, c
 int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, double scale, uint64_t seed, uint64_t counter,
                               uint64_t cell_offset, void *stream);
 
+/* out_dev[c] = cell_volume * sum over the interior of component c (fp64 device scalars, one per component): the integral of
+ * a field on a Cartesian grid (uniform cell volumes) — NumbaBackend.make_integrator (pde/backends/numba/backend.py:555-652),
+ * used by conservation checks and post-step logic without moving the field to the host.  Two passes (per-workgroup partial
+ * sums, then one workgroup): the result does not depend on scheduling; it differs from the reference's sequential sum by
+ * the usual reordering error (relative 1e-13 at 512^3). */
+int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream);
+
 /* ---- fused time steppers ----------------------------------------------------------
  * k_out = dt * rhs(y): applies the BCs of y (and of mu) — on the fly inside the stencil kernel where the
  * faces allow it, else by setting the ghost cells in place — then evaluates the RHS;

@@ -139,7 +139,8 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
         // chunks per row: cover the whole fastest axis with one wave where possible (contiguous
         // RY x row bytes per wave and plane is what the HBM write path likes) ...
-        const long chunks = (n.n[2] + 64 * VEC - 1) / (64 * VEC);
+        // (+1: the upper ghost cell belongs to the last tile's work, see `act` in pdehip_march.inc)
+        const long chunks = (n.n[2] + 1 + 64 * VEC - 1) / (64 * VEC);
         int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
         // measured on MI355X at 512^3 fp64 (profiles/r01_sweep_tiles.log): 2 rows x whole-row chunks, ~1024
         // single-wave workgroups (4 per CU) gives 0.41 ms per pass = 65 % of the 8 TB/s HBM peak

@@ -165,6 +165,45 @@ __global__ void __launch_bounds__(256) axis_derivative_kernel(AxisArgs a)
     });
 }
 
+// ---- integral over the grid: two deterministic passes --------------------------------------------------------------
+struct SumArgs {
+    DevGrid g;
+    const void *in;
+    double *partial;   // [ncomp][nblocks]
+    double *out;       // [ncomp]
+    double vol;
+    int comp, nblocks;
+};
+__device__ __forceinline__ double block_sum(double v)
+{
+#pragma unroll
+    for (int ofs = 32; ofs >= 1; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) part[w] = v;
+    __syncthreads();
+    double s = 0;
+    if (threadIdx.x == 0)
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) s += part[q];
+    return s;   // valid in thread 0
+}
+template <typename T>
+__global__ void __launch_bounds__(256) partial_sum_kernel(SumArgs a)
+{
+    const T *in = (const T *)a.in + (long)a.comp * a.g.pc;
+    double acc = 0;
+    for_each_chunk<1>(a.g, 1, [&](int, long, long, long, long e) { acc += a.vol * (double)in[e]; });
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) a.partial[(long)a.comp * a.nblocks + blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) final_sum_kernel(SumArgs a)
+{
+    double acc = 0;
+    for (int q = threadIdx.x; q < a.nblocks; q += blockDim.x) acc += a.partial[(long)a.comp * a.nblocks + q];
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) a.out[a.comp] = s;
+}
+
 // ---- Gaussian white noise increment of an Euler-Maruyama step (pde/solvers/euler.py:66-147) -----------------------------
 // Philox4x32-10 (counter = {cell, call number}, key = seed) + Box-Muller, one draw per cell: reproducible for a given seed,
 // independent of the launch geometry; twin of oracle_add_gaussian_noise.
@@ -718,6 +757,30 @@ int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int meth
     const unsigned blocks = grid_blocks(n.n[0] * n.n[1] * n.n[2]);
     if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((axis_derivative_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((axis_derivative_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!arr_full || !out_dev) PDEHIP_FAIL(E_VALUE, "integrate: NULL pointer");
+    if (ncomp < 1 || ncomp > 64) PDEHIP_FAIL(E_VALUE, "integrate: 1..64 components");
+    static double *partial = nullptr;   // 64 components x 1024 workgroups, allocated once per process
+    constexpr int kBlocks = 1024;
+    if (!partial) PDEHIP_HIP(hipMalloc(&partial, sizeof(double) * 64 * kBlocks));
+    SumArgs a;
+    a.g = dev_grid(n); a.in = arr_full; a.partial = partial; a.out = out_dev; a.vol = cell_volume;
+    long blocks = (n.n[0] * n.n[1] * n.n[2] + 255) / 256;
+    a.nblocks = (int)(blocks < kBlocks ? (blocks < 1 ? 1 : blocks) : kBlocks);
+    hipStream_t st = as_stream(stream);
+    for (int c = 0; c < ncomp; c++) {
+        a.comp = c;
+        if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((partial_sum_kernel<double>), dim3(a.nblocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((partial_sum_kernel<float>), dim3(a.nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, a);
+    }
     PDEHIP_HIP(hipGetLastError());
     return 0;
 }

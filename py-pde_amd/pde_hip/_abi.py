@@ -151,6 +151,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "rkf45_combine": ([_pg, _i, _vp, _vp, _pvp, _vp], True),
     "ab2_combine": ([_pg, _i, _vp, _vp, _vp, _d], True),
     "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
+    "integrate": ([_pg, _i, _vp, _d, _vp], True),
     "add_gaussian_noise": ([_pg, _i, _vp, _d, C.c_uint64, C.c_uint64, C.c_uint64], True),
     "rhs_scaled": ([_pg, _pr, _vp, _vp, _d], True),
     "euler_run": ([_pg, _pr, _vp, _vp, _d, _i64, _pvp], True),

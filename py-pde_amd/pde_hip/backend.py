@@ -483,6 +483,26 @@ class HipBackendMixin:
 
         return set_valid_and_bcs
 
+    # --- reductions on the device (pde/backends/numba/backend.py:555-652) --------------------------------------------
+    def make_integrator(self, grid, *, dtype=None):
+        """``integrate(arr) -> float | ndarray``: integral over the grid, one value per tensor component, computed on the
+        device (``pdehip_integrate``: cell volume x sum, two deterministic passes) — only ``ncomp`` doubles cross PCIe.
+        ``arr`` is a :class:`DeviceArray`; host valid data is uploaded first (convenience, like the operators)."""
+        nd = len(grid.shape)
+        cell_volume = float(np.prod(grid.discretization))
+
+        def integrate(arr):
+            if not isinstance(arr, DeviceArray):
+                host = np.asarray(arr)
+                arr = DeviceArray(self.grid_info(grid, host.dtype), host.shape[: host.ndim - nd]).set_valid(host, self.stream)
+            out = DeviceBuffer(8 * arr.ncomp)
+            self._lib.integrate(arr.info.ref, arr.ncomp, arr.ptr, cell_volume, out.ptr, self.stream)
+            host = np.empty(arr.ncomp, dtype=np.float64)
+            self._lib.memcpy_d2h(host.ctypes.data, out.ptr, host.nbytes, self.stream)
+            return float(host[0]) if not arr.comp_shape else host.reshape(arr.comp_shape)
+
+        return integrate
+
     # --- operators ------------------------------------------------------------------------------------
     def make_operator_no_bc(self, grid, operator, *, dtype=None, **kwargs):
         """``impl(arr_full: DeviceArray, out: DeviceArray)``; ghost cells are the caller's job."""

@@ -215,6 +215,8 @@ int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void 
 int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a, const void *b, double *out_dev, void *stream)
 { (void)stream; GRID(g); TRY(oracle_max_abs_diff(g, ncomp, a, b, out_dev)); return 0; }
 
+int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_integrate(g, ncomp, arr_full, cell_volume, out_dev)); return 0; }
 int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, double scale, uint64_t seed, uint64_t counter,
                               uint64_t cell_offset, void *stream)
 { (void)stream; GRID(g); TRY(oracle_add_gaussian_noise(g, ncomp, y_full, scale, seed, counter, cell_offset)); return 0; }

@@ -175,8 +175,9 @@ def test_unsupported_solver_and_pde(backend):
         pde_hip.DiffusionPDE().solve(state, 1.0, dt=0.1, solver=ImplicitSolver(pde_hip.DiffusionPDE()))
     with pytest.raises(ValueError, match="Unknown solver"):
         pde_hip.DiffusionPDE().solve(state, 1.0, dt=0.1, solver="no-such-solver")
+    # stochastic equations: Euler-Maruyama only (tests/test_noise.py); other solvers refuse, adaptive steps raise like the reference
     with pytest.raises(NotImplementedError, match="stochastic"):
-        pde_hip.DiffusionPDE(noise=0.1)
+        pde_hip.DiffusionPDE(noise=0.1).solve(state, 1.0, dt=0.1, solver="runge-kutta")
 
 
 def test_diffusion_steady_state_and_erf(backend):

@@ -463,3 +463,15 @@ def test_post_step_hook_can_stop_the_run(hip1):
     res, info = eq.solve(state, t_range=5, dt=0.01, solver="euler", backend="hip", tracker=None, ret_info=True)
     assert 0.49 < res.data.mean() < 0.5 and 60 < info["solver"]["post_step_data"] < 80
     assert info["controller"]["stop_reason"] == "Tracker raised StopIteration" or info["controller"]["successful"]
+
+
+def test_integrator_on_the_device(hip1):
+    """`backend.make_integrator(grid)` (pde/backends/numba/backend.py:555-652): scalar and vector fields vs field.integral."""
+    grid = pde.CartesianGrid([[0, 2], [0, 3]], [8, 12])
+    f = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(10))
+    v = pde.VectorField.random_uniform(grid, rng=np.random.default_rng(11))
+    integrate = hip1.make_integrator(grid)
+    assert integrate(f.data) == pytest.approx(f.integral, rel=1e-13)
+    np.testing.assert_allclose(integrate(v.data), v.integral, rtol=1e-13)
+    native = hip1.numpy_to_native(f.data, grid=grid)
+    assert integrate(native) == pytest.approx(f.integral, rel=1e-13)

@@ -139,9 +139,18 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
         // chunks per row: cover the whole fastest axis with one wave where possible (contiguous
         // RY x row bytes per wave and plane is what the HBM write path likes) ...
-        // (+1: the upper ghost cell belongs to the last tile's work, see `act` in pdehip_march.inc)
-        const long chunks = (n.n[2] + 1 + 64 * VEC - 1) / (64 * VEC);
-        int cz = chunks >= 4 ? 4 : (chunks >= 2 ? 2 : 1);
+        // ... but a row that needs 5 chunks must not pay for 8: among tiles of 4 / 2 / 1 chunks take the widest one with the
+        // fewest chunks in total (513 cells: 5 x 1 instead of 2 x 4, where the second tile would march every plane for ONE
+        // cell — measured 0.86 vs 0.48 ms at 513^3 / 512^3)
+        const long chunks = (n.n[2] + 64 * VEC - 1) / (64 * VEC);
+        int cz = 1;
+        {
+            long best = -1;
+            for (int cand = 4; cand >= 1; cand /= 2) {
+                const long padded = (chunks + cand - 1) / cand * cand;
+                if (best < 0 || padded < best) { best = padded; cz = cand; }
+            }
+        }
         // measured on MI355X at 512^3 fp64 (profiles/r01_sweep_tiles.log): 2 rows x whole-row chunks, ~1024
         // single-wave workgroups (4 per CU) gives 0.41 ms per pass = 65 % of the 8 TB/s HBM peak
         // fp32 (fp64 registers, 4 cells per lane) is VALU-heavier: 4-row tiles measured 585 vs 454 Gcells/s at 512^3

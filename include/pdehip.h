@@ -198,6 +198,15 @@ int pdehip_laplace_euler(const pdehip_grid_t *g, const void *in_full, const void
  * single steps by itself). */
 int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *faces, const void *in_full,
                             void *out_full, double diffusivity, double dt, int *done, void *stream);
+/* `nsteps` (1..8 for the diffusion equation, 1..4 for Cahn-Hilliard) explicit Euler steps of a 2-D grid in ONE launch: a
+ * workgroup keeps a tile plus halo in LDS and advances it through all time levels (temporal blocking), BCs applied to every
+ * level — bit-identical to `nsteps` iterations of the loop body of pde/backends/numba/_solvers.py:98-108 (euler.py:172-175 with
+ * diffusion.py:119-121 / cahn_hilliard.py:115-122).  For grids of a few MB (BASELINE configs 1-3), where a step per launch is
+ * bound by launch and cache latency, not by HBM.  *done = 0 (nothing written) when the grid is not 2-D, a face is not periodic
+ * / scalar first-order with the virtual point from the adjacent cell, or `nsteps` is out of range; pdehip_euler_run uses it by
+ * itself and falls back to the register-pipelined kernels. */
+int pdehip_euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in_full, void *out_full, double dt,
+                          int nsteps, int *done, void *stream);
 /* The same two steps on a sub-slab of layers of a larger array (building block of pdehip_slab_euler2_run): `g_sub` has
  * the extent of the sub-slab along axis 0, `in_full` / `out_full` point ONE LAYER BEFORE its first layer, and the array
  * holds TWO real layers beyond the sub-slab on the sides named by `halo_sides` (1 = both sides, 2 = upper side only, the

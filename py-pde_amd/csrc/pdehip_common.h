@@ -127,6 +127,12 @@ struct Euler2Plan {
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, int xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
                   const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr);
+// K Euler steps of a 2-D grid per launch, time levels in LDS (pdehip_tile2d.inc): diffusion (rhs->kind 0) or Cahn-Hilliard
+int tile2d_max_steps(int mode);
+int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
+                  const InputBCs *fm, int nsteps, hipStream_t st, bool *done);
+int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,
+                   bool *done);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,

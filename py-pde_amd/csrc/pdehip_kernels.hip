@@ -23,6 +23,7 @@ namespace pdehip {
 
 #include "pdehip_march.inc"
 #include "pdehip_march2.inc"
+#include "pdehip_tile2d.inc"
 #include "pdehip_div.inc"
 
 // ---------------------------------------------------------------------------------------------
@@ -477,6 +478,48 @@ static int classify_axis(const InputBCs &fg, int ax, long n)
                      fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
     const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n - 1;
     return per ? 1 : (loc ? 0 : -1);
+}
+
+// K Euler steps of a 2-D grid per launch with the time levels in LDS (pdehip_tile2d.inc).  mode 0: diffusion (s1 = D), 1:
+// Cahn-Hilliard (gamma; fm = faces of mu).  *done = false when grid / faces / step count are not covered.
+constexpr int kTile2Halo = 8;
+int tile2d_max_steps(int mode) { return mode == 0 ? kTile2Halo : kTile2Halo / 2; }
+int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
+                  const InputBCs *fm, int nsteps, hipStream_t st, bool *done)
+{
+    *done = false;
+    if (n.ndim != 2 || in == out || nsteps < 1 || nsteps > tile2d_max_steps(mode) || tune().force_generic) return 0;
+    if (mode == 1 && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: Cahn-Hilliard tile sweep without the faces of mu");
+    Tile2Args a;
+    memset(&a, 0, sizeof(a));
+    for (int k = 0; k < 2; k++) {
+        const int ax = 1 + k;
+        const int cls = classify_axis(fc, ax, n.n[ax]);
+        if (cls < 0 || (mode == 1 && classify_axis(*fm, ax, n.n[ax]) != cls)) return 0;
+        a.per[k] = cls;
+        for (int side = 0; side < 2; side++) {
+            a.c[0][k][side] = fc.c[ax][side]; a.f[0][k][side] = fc.f[ax][side];
+            if (mode == 1) { a.c[1][k][side] = fm->c[ax][side]; a.f[1][k][side] = fm->f[ax][side]; }
+        }
+    }
+    a.in = in; a.out = out;
+    a.n0 = n.n[1]; a.n1 = n.n[2]; a.p1 = n.p[1]; a.off = n.off;
+    a.sx = n.lap_scale[1]; a.sy = n.lap_scale[2];
+    a.s1 = s1; a.s2 = s2; a.gamma = gamma; a.nsteps = nsteps;
+    constexpr int TR = 32, TC = 64;
+    a.tiles1 = (int)((n.n[2] + TC - 1) / TC);
+    const long tiles = a.tiles1 * ((n.n[1] + TR - 1) / TR);
+    const dim3 grid((unsigned)tiles), block(256);
+    if (n.dtype == PDEHIP_F64) {
+        if (mode == 0) hipLaunchKernelGGL((tile2d_kernel<double, 0, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((tile2d_kernel<double, 1, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((tile2d_kernel<float, 0, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((tile2d_kernel<float, 1, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+    }
+    PDEHIP_HIP(hipGetLastError());
+    *done = true;
+    return 0;
 }
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,

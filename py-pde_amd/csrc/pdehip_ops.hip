@@ -649,6 +649,22 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
 
+int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,
+                   bool *done)
+{
+    *done = false;
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!in || !out || !rhs) PDEHIP_FAIL(E_VALUE, "euler_multi_2d: NULL pointer");
+    if (n.ndim != 2) return 0;
+    InputBCs fc, fm;
+    if (!faces_to_input_bcs(n, rhs->bc_c, &fc)) return 0;
+    if (rhs->kind == PDEHIP_RHS_DIFFUSION)
+        return launch_tile2d(n, in, out, 0, rhs->param, dt, 0.0, fc, nullptr, nsteps, as_stream(stream), done);
+    if (rhs->kind != PDEHIP_RHS_CAHN_HILLIARD || !faces_to_input_bcs(n, rhs->bc_mu, &fm)) return 0;
+    return launch_tile2d(n, in, out, 1, 1.0, dt, rhs->param, fc, &fm, nsteps, as_stream(stream), done);
+}
+
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,
                         const pdehip_bc_face_t *faces_c, const pdehip_bc_face_t *faces_mu, void *stream, bool *done,
                         int xplain, bool dry_run, const StageFuse *stage)
@@ -676,6 +692,17 @@ int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *face
     bool d = false;
     *done = 0;
     PDEHIP_TRY(euler2_with_input_bcs(g, in_full, out_full, diffusivity, dt, faces, stream, &d));
+    *done = d ? 1 : 0;
+    return 0;
+}
+
+int pdehip_euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in_full, void *out_full, double dt, int nsteps,
+                          int *done, void *stream)
+{
+    if (!done) PDEHIP_FAIL(E_VALUE, "euler_multi_2d: NULL pointer");
+    bool d = false;
+    *done = 0;
+    PDEHIP_TRY(euler_multi_2d(g, rhs, in_full, out_full, dt, nsteps, stream, &d));
     *done = d ? 1 : 0;
     return 0;
 }

@@ -164,7 +164,30 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     // Two steps per sweep where the temporal-blocking kernel covers the grid and its BCs (the intermediate
     // level never touches HBM: 16 B per cell for two steps), else one step per sweep.
     bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION;
+    // 2-D grids of a few MB: K steps per launch with the time levels in LDS (pdehip_tile2d.inc) — such grids are bound by
+    // launch / cache latency per step, not by HBM.  PDEHIP_TILE2D=off disables it, PDEHIP_TILE2D=<k> caps K,
+    // PDEHIP_TILE2D_CELLS=<n> moves the size limit (default 2^22 cells).
+    static int tile_k = -1;
+    static long tile_cells = 1L << 22;
+    if (tile_k < 0) {
+        const char *e = getenv("PDEHIP_TILE2D");
+        tile_k = (e && !strcmp(e, "off")) ? 0 : (e && atoi(e) > 0 ? atoi(e) : 64);
+        const char *c = getenv("PDEHIP_TILE2D_CELLS");
+        if (c && atol(c) > 0) tile_cells = atol(c);
+    }
+    long ncells = 1;
+    for (int q = 0; q < g->ndim; q++) ncells *= g->shape[q];
+    bool tile_ok = g->ndim == 2 && tile_k > 0 && ncells <= tile_cells;
     auto advance = [&](void *c, void *n, void *st, int64_t left, int *took) -> int {
+        if (tile_ok) {
+            int k = tile2d_max_steps(rhs->kind == PDEHIP_RHS_DIFFUSION ? 0 : 1);
+            if (k > tile_k) k = tile_k;
+            if (k > left) k = (int)left;
+            bool done = false;
+            PDEHIP_TRY(euler_multi_2d(g, rhs, c, n, dt, k, st, &done));
+            if (done) { *took = k; return 0; }
+            tile_ok = false;
+        }
         if (two_ok && left >= 2) {
             bool done = false;
             PDEHIP_TRY(euler2_with_input_bcs(g, c, n, rhs->param, dt, rhs->bc_c, st, &done));

@@ -208,6 +208,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "rk4_run": [_pg, _pr, _vp, _pvp, _d, _i64, _vp],
     # two Euler steps per sweep (device only: the oracle takes two single steps)
     "diffusion_euler2": [_pg, _pf, _vp, _vp, _d, _d, C.POINTER(_i), _vp],
+    "euler_multi_2d": [_pg, _pr, _vp, _vp, _d, _i, C.POINTER(_i), _vp],
     "diffusion_euler2_slab": [_pg, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],
     "cahn_hilliard_fused": [_pg, _pf, _pf, _vp, _vp, _d, _d, _i, C.POINTER(_i), _vp],
     # run-time specialised expression kernels (pdehip_jit.hip)

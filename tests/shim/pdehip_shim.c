@@ -247,6 +247,32 @@ int pdehip_diffusion_euler2(const pdehip_grid_t *g, const pdehip_bc_face_t *face
     *done = 1;
     return 0;
 }
+int pdehip_euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in_full, void *out_full, double dt, int nsteps,
+                          int *done, void *stream)
+{
+    (void)stream; GRID(g);
+    *done = 0;
+    if (!fused_enabled() || g->ndim != 2 || nsteps < 1 || nsteps > (rhs->kind == PDEHIP_RHS_DIFFUSION ? 8 : 4)) return 0;
+    if (!faces_simple(rhs->bc_c, 2) || (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD && !faces_simple(rhs->bc_mu, 2))) return 0;
+    size_t nb = full_bytes(g, 1);
+    void *a = malloc(nb), *b = calloc(1, nb), *res = NULL;
+    memcpy(a, in_full, nb);
+    pdehip_rhs_t r = *rhs;
+    void *mu = NULL;
+    if (rhs->kind == PDEHIP_RHS_CAHN_HILLIARD) r.scratch_mu = mu = calloc(1, nb);
+    int rc = oracle_euler_run(g, &r, a, b, dt, nsteps, &res);
+    if (!rc) {   /* interior only: the ghost cells of `out` are not part of the contract */
+        int64_t lay[8];
+        pdehip_layout(g, lay);
+        const int esz = g->dtype == PDEHIP_F64 ? 8 : 4;
+        for (int64_t i = 0; i < g->shape[0]; i++)
+            memcpy((char *)out_full + (lay[3] + i * lay[1]) * esz, (char *)res + (lay[3] + i * lay[1]) * esz, (size_t)g->shape[1] * esz);
+    }
+    free(a); free(b); free(mu);
+    TRY(rc);
+    *done = 1;
+    return 0;
+}
 int pdehip_diffusion_euler2_slab(const pdehip_grid_t *g_sub, const pdehip_bc_face_t *faces, const void *in_full, void *out_full,
                                  double diffusivity, double dt, int halo_sides, int *done, void *stream)
 {

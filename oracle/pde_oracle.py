@@ -49,6 +49,25 @@ def lib():
             fn.restype = C.c_int
         handle.oracle_set_corner_points_2d.argtypes = [C.POINTER(_abi.Grid), C.POINTER(C.c_int), C.c_void_p]
         handle.oracle_set_corner_points_2d.restype = C.c_int
+        # OpenMP threads: what this process may really use (affinity mask and cgroup CPU quota) — the GPU boxes show 256
+        # logical CPUs but grant 16: 256 threads on 16 CPUs run the loops tens of times slower
+        import os
+
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            quota, period = (_ROOT / ".." / ".." / "sys" / "fs" / "cgroup" / "cpu.max").resolve().read_text().split()
+        except (OSError, ValueError):
+            try:
+                quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+            except (OSError, ValueError):
+                quota, period = "max", "1"
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+            except OSError:
+                pass
         _LIB = handle
     return _LIB
 

@@ -489,6 +489,7 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
 {
     *done = false;
     if (n.ndim != 2 || in == out || nsteps < 1 || nsteps > tile2d_max_steps(mode) || tune().force_generic) return 0;
+    if (n.n[1] >= (1L << 30) || n.n[2] >= (1L << 30)) return 0;   // 32-bit window arithmetic
     if (mode == 1 && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: Cahn-Hilliard tile sweep without the faces of mu");
     Tile2Args a;
     memset(&a, 0, sizeof(a));
@@ -509,7 +510,7 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
     constexpr int TR = 32, TC = 64;
     a.tiles1 = (int)((n.n[2] + TC - 1) / TC);
     const long tiles = a.tiles1 * ((n.n[1] + TR - 1) / TR);
-    const dim3 grid((unsigned)tiles), block(256);
+    const dim3 grid((unsigned)tiles), block(1024);
     if (n.dtype == PDEHIP_F64) {
         if (mode == 0) hipLaunchKernelGGL((tile2d_kernel<double, 0, TR, TC, kTile2Halo>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((tile2d_kernel<double, 1, TR, TC, kTile2Halo>), grid, block, 0, st, a);

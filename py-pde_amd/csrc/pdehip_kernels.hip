@@ -169,6 +169,9 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // 0.74 vs 0.91 ms (no earlier slope) and 1.11 vs 1.17 ms (one) at 512^3; from two slopes on one wave wins
         // (profiles/r01_time_rk.md)
         if (MODE == LAP_STAGE && (a.st_kind == 1 || !a.st_k[1])) blocks = 2048;
+        // narrow tiles over a long row (e.g. 5 x 1 chunk for 513 cells): a wave carries 1/4 or 1/2 of the bytes of a whole-row
+        // tile per plane, so keep the bytes in flight by marching shorter x-chunks with more waves
+        if (chunks > cz && cz < 4) blocks *= 4 / cz;
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
 #define PDEHIP_CFG3(RY_, CZ_, WY_, PF_) \
     if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st);
@@ -507,17 +510,24 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
     a.n0 = n.n[1]; a.n1 = n.n[2]; a.p1 = n.p[1]; a.off = n.off;
     a.sx = n.lap_scale[1]; a.sy = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2; a.gamma = gamma; a.nsteps = nsteps;
-    constexpr int TR = 32, TC = 64;
-    a.tiles1 = (int)((n.n[2] + TC - 1) / TC);
-    const long tiles = a.tiles1 * ((n.n[1] + TR - 1) / TR);
+    // tile 32 x 64 (halo redundancy 1.9 x at H = 8); grids that would give fewer than one workgroup per CU take 32 x 32 tiles
+    // (2.25 x): a workgroup's K levels run one after the other on ONE CU, so spreading wins over redundancy there
+    const long tiles64 = ((n.n[2] + 63) / 64) * ((n.n[1] + 31) / 32);
+    const int tcw = tiles64 >= 256 ? 64 : 32;
+    a.tiles1 = (int)((n.n[2] + tcw - 1) / tcw);
+    const long tiles = a.tiles1 * ((n.n[1] + 31) / 32);
     const dim3 grid((unsigned)tiles), block(1024);
+#define PDEHIP_T2(T, M)                                                                                            \
+    do {                                                                                                           \
+        if (tcw == 64) hipLaunchKernelGGL((tile2d_kernel<T, M, 32, 64, kTile2Halo>), grid, block, 0, st, a);       \
+        else hipLaunchKernelGGL((tile2d_kernel<T, M, 32, 32, kTile2Halo>), grid, block, 0, st, a);                 \
+    } while (0)
     if (n.dtype == PDEHIP_F64) {
-        if (mode == 0) hipLaunchKernelGGL((tile2d_kernel<double, 0, TR, TC, kTile2Halo>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((tile2d_kernel<double, 1, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+        if (mode == 0) PDEHIP_T2(double, 0); else PDEHIP_T2(double, 1);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((tile2d_kernel<float, 0, TR, TC, kTile2Halo>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((tile2d_kernel<float, 1, TR, TC, kTile2Halo>), grid, block, 0, st, a);
+        if (mode == 0) PDEHIP_T2(float, 0); else PDEHIP_T2(float, 1);
     }
+#undef PDEHIP_T2
     PDEHIP_HIP(hipGetLastError());
     *done = true;
     return 0;

@@ -166,9 +166,9 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION;
     // 2-D grids of a few MB: K steps per launch with the time levels in LDS (pdehip_tile2d.inc) — such grids are bound by
     // launch / cache latency per step, not by HBM.  PDEHIP_TILE2D=off disables it, PDEHIP_TILE2D=<k> caps K,
-    // PDEHIP_TILE2D_CELLS=<n> moves the size limit (default 2^22 cells).
+    // PDEHIP_TILE2D_CELLS=<n> moves the size limit (default 2^21 cells).
     static int tile_k = -1;
-    static long tile_cells = 1L << 22;
+    static long tile_cells = 1L << 21;   // measured (profiles/r02_time_sizes.md): wins up to 1024^2, loses at 2048^2 (HBM-bound there: the register kernel moves fewer bytes)
     if (tile_k < 0) {
         const char *e = getenv("PDEHIP_TILE2D");
         tile_k = (e && !strcmp(e, "off")) ? 0 : (e && atoi(e) > 0 ? atoi(e) : 64);

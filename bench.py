@@ -216,7 +216,7 @@ def bench_distributed(args) -> dict:
     # synthetic data: every rank fills its own slab (no global array is ever materialised)
     rng = np.random.default_rng(1000 + rank)
     a, b = stepper.buf("state_a"), stepper.buf("state_b")
-    stepper.set_local(a, rng.random(stepper.mesh.subgrid.shape))
+    stepper.set_local(a, rng.random(stepper.mesh.local_shape))
     dt = 0.1
     cur = stepper.euler_steps(a, b, dt, args.warmup)
     nxt = b if cur is a else a

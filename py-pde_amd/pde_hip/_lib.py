@@ -132,6 +132,15 @@ def device_count() -> int:
     return n.value
 
 
+def default_device() -> int:
+    """Device of a process that did not name one: its ``LOCAL_RANK`` under a one-process-per-GPU launcher
+    (``torch.distributed.run`` / ``torchrun`` export it), else device 0."""
+    try:
+        return max(0, int(os.environ.get("LOCAL_RANK", "0")))
+    except ValueError:
+        return 0
+
+
 def current_device() -> int | None:
     """Index of the device selected by the first `require_device` call (None before it)."""
     return _DEVICE
@@ -151,7 +160,7 @@ def require_device(device: int | None = None) -> _Lib:
         if device_count() < 1:
             msg = "hip backend: no HIP device visible (MI355X required; there is no CPU fallback)"
             raise RuntimeError(msg)
-        dev = 0 if device is None else int(device)
+        dev = default_device() if device is None else int(device)
         lib.set_device(dev)
         _DEVICE = dev
         _threads_ready.add(threading.get_ident())

@@ -113,6 +113,12 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
             # per (component, face cell) arrays.  Homogeneous tensor values have shape (dim,)*rank
             # (local.py:1341-1352) and broadcast over the face; inhomogeneous ones carry the face.
             face_shape = tuple(n for a, n in enumerate(grid.shape) if a != ax)
+            # normal conditions act on the component along the axis; the ghost kernel indexes their arrays per face cell only,
+            # which covers vector fields.  On tensor fields their values carry the remaining tensor axes (`_shape_tensor`,
+            # pde/grids/boundaries/local.py:190-197): refused instead of being broadcast against the face
+            if normal and len(comp_shape) > 1:
+                msg = "hip backend: array-valued normal boundary conditions on tensor fields are not supported"
+                raise NotImplementedError(msg)
             lead = () if normal else tuple(comp_shape)
             target = lead + face_shape
 
@@ -321,7 +327,12 @@ class HipBackendMixin:
 
     @property
     def device(self) -> int:
-        return 0 if self._device_request is None else self._device_request
+        from ._lib import current_device, default_device
+
+        if self._device_request is not None:
+            return self._device_request
+        cur = current_device()
+        return default_device() if cur is None else cur
 
     @property
     def device_name(self) -> str:

@@ -27,7 +27,6 @@ from typing import Any
 import numpy as np
 
 from . import _abi
-from .backend import convert_bcs
 from .device import DeviceBuffer
 from .mesh import SlabMesh
 
@@ -152,9 +151,8 @@ class SlabStepper:
         self.lib = require_device(device)
         self.eq, self.grid, self.dtype = eq, grid, np.dtype(dtype)
         self.mesh = SlabMesh(grid, self.size, self.rank)
-        sub = self.mesh.subgrid
         self.n = self.mesh.n_local
-        self.g = _abi.make_grid(sub.shape, sub.discretization, self.dtype)
+        self.g = _abi.make_grid(self.mesh.local_shape, grid.discretization, self.dtype)
         lay = (C.c_int64 * 8)()
         self.lib.layout(C.byref(self.g), lay)
         self.comp_elems, self.layer_pitch = int(lay[2]), int(lay[7])
@@ -164,17 +162,15 @@ class SlabStepper:
         self.lib.stream_create(C.byref(self.stream))
         # neighbours; world size 1 + periodic axis 0 can be forced through the exchange path (exchange with itself)
         self.lower, self.upper = self.mesh.lower, self.mesh.upper
-        skip = set(self.mesh.exchanged_faces)
         if force_exchange and self.size == 1 and grid.periodic[0]:
             self.lower = self.upper = 0
-            skip = {(0, False), (0, True)}
         self.exchanging = self.lower is not None or self.upper is not None
         self._lo = -1 if self.lower is None else int(self.lower)
         self._up = -1 if self.upper is None else int(self.upper)
         # right-hand side description
         self.kind, self.param, bc_c, bc_mu = self._describe(eq, grid)
-        self.faces_c = convert_bcs(self.mesh.sub_boundaries(bc_c), skip=skip)
-        self.faces_mu = convert_bcs(self.mesh.sub_boundaries(bc_mu), skip=skip)
+        self.faces_c = self.mesh.slab_faces(bc_c, force_exchange=force_exchange)
+        self.faces_mu = self.mesh.slab_faces(bc_mu, force_exchange=force_exchange)
         self._bufs: dict[str, SlabArray] = {}
         self.rhs = _abi.RHS()
         self.rhs.kind, self.rhs.param = self.kind, self.param
@@ -314,7 +310,7 @@ class SlabStepper:
         return buf
 
     def gather_local(self, buf: SlabArray) -> np.ndarray:
-        shape = self.mesh.subgrid.shape
+        shape = self.mesh.local_shape
         host = np.empty(shape, dtype=self.dtype)
         stage = DeviceBuffer(host.nbytes)
         self.lib.full_to_valid(C.byref(self.g), 1, buf.ptr, stage.ptr, self.stream)
@@ -324,7 +320,7 @@ class SlabStepper:
 
     def get_hostfull(self, buf: SlabArray) -> np.ndarray:
         """The slab incl. its ghost layers in the reference's compact full layout (tests)."""
-        shape = tuple(s + 2 for s in self.mesh.subgrid.shape)
+        shape = tuple(s + 2 for s in self.mesh.local_shape)
         host = np.empty(shape, dtype=self.dtype)
         stage = DeviceBuffer(host.nbytes)
         self.lib.full_to_hostfull(C.byref(self.g), 1, buf.ptr, stage.ptr, self.stream)

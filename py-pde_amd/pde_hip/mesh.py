@@ -12,9 +12,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from .grids import CartesianGrid
-
-
 def subdivide(num: int, chunks: int) -> np.ndarray:
     """Cells per chunk, identical to ``_subdivide`` in pde/grids/_mesh.py:96-111."""
     if chunks > num:
@@ -43,12 +40,80 @@ class SlabMesh:
         else:
             self.lower = rank - 1 if rank > 0 else (size - 1 if periodic0 else None)
             self.upper = rank + 1 if rank < size - 1 else (0 if periodic0 else None)
-        (lo_b, _), dx0 = grid.axes_bounds[0], grid.discretization[0]
-        bounds = [(lo_b + self.lo * dx0, lo_b + self.hi * dx0), *grid.axes_bounds[1:]]
-        periodic = [periodic0 and size == 1, *grid.periodic[1:]]
-        self.subgrid = CartesianGrid(bounds, (self.n_local, *grid.shape[1:]), periodic)
-        # keep the discretization bit-identical to the parent grid (bounds arithmetic may round)
-        self.subgrid._discretization = grid.discretization.copy()
+        self.local_shape = (self.n_local, *[int(n) for n in grid.shape[1:]])
+        self._subgrid = None
+
+    @property
+    def subgrid(self):
+        """The slab as a grid object of the mirror classes (tests / mirror API only; the stepper itself needs just
+        ``local_shape`` and the parent's discretization, so it also takes the real py-pde's grids)."""
+        if self._subgrid is None:
+            from .grids import CartesianGrid
+
+            grid = self.grid
+            bounds_all = getattr(grid, "axes_bounds", None)
+            (lo_b, _), dx0 = bounds_all[0], grid.discretization[0]
+            bounds = [(lo_b + self.lo * dx0, lo_b + self.hi * dx0), *bounds_all[1:]]
+            periodic = [bool(grid.periodic[0]) and self.size == 1, *[bool(p) for p in grid.periodic[1:]]]
+            self._subgrid = CartesianGrid(bounds, self.local_shape, periodic)
+            # keep the discretization bit-identical to the parent grid (bounds arithmetic may round)
+            self._subgrid._discretization = np.array(grid.discretization, dtype=float)
+        return self._subgrid
+
+    def slab_faces(self, bcs, *, force_exchange: bool = False, upload=None):
+        """Face table of THIS slab from the boundary conditions of the WHOLE grid (any ``BoundariesList``: the mirror's or
+        py-pde's own).  Replaces ``GridMesh.extract_boundary_conditions`` + ``_MPIBC`` (pde/grids/_mesh.py:535-569,
+        pde/grids/boundaries/local.py:561-662): faces towards a neighbour are marked SKIP (their ghost layer is filled by the
+        halo exchange), physical faces of axis 0 keep their condition with the index translated into the slab, per-face arrays
+        of the other axes are sliced along axis 0 (the reference refuses those: ``Cannot transfer complicated BC to subgrid``,
+        local.py:1515-1540)."""
+        from . import _abi
+        from .backend import FaceTable, _upload_f64, convert_bcs
+
+        if upload is None:
+            upload = _upload_f64
+
+        class _Host:
+            def __init__(self, arr):
+                self.arr = np.ascontiguousarray(arr, dtype=np.float64)
+                self.ptr = self.arr.ctypes.data
+
+        glob = convert_bcs(bcs, upload=_Host)
+        by_ptr = {h.ptr: h.arr for h in glob.keepalive}
+        exchanged = {(0, False): self.lower is not None, (0, True): self.upper is not None}
+        if force_exchange and self.size == 1 and bool(self.grid.periodic[0]):
+            exchanged = {(0, False): True, (0, True): True}
+        out = FaceTable()
+        nd = len(self.grid.shape)
+        for ax in range(nd):
+            for upper in (False, True):
+                src, dst = glob.c[2 * ax + int(upper)], out.c[2 * ax + int(upper)]
+                if ax == 0 and exchanged[(0, upper)]:
+                    dst.kind = _abi.BC_SKIP
+                    continue
+                if ax == 0 and self.size > 1 and src.kind != _abi.BC_SKIP:
+                    # a physical face of the decomposed axis: the virtual point reads a cell of THIS slab
+                    for idx in ([src.index1] if src.kind == _abi.BC_ORDER1 else [src.index1, src.index2]):
+                        if not self.lo <= idx < self.hi:
+                            msg = "boundary condition of the decomposed axis reads a cell of another slab"
+                            raise NotImplementedError(msg)
+                dst.kind, dst.flags = src.kind, src.flags
+                shift = self.lo if ax == 0 else 0
+                dst.index1, dst.index2 = src.index1 - shift, (src.index2 - shift if src.kind == _abi.BC_ORDER2 else src.index2)
+                dst.const_v, dst.factor1, dst.factor2 = src.const_v, src.factor1, src.factor2
+                if src.flags & _abi.BCF_ARRAYS:
+                    for name in ("const_arr", "factor1_arr", "factor2_arr"):
+                        ptr = getattr(src, name)
+                        if not ptr:
+                            continue
+                        arr = by_ptr[ptr]
+                        if ax > 0:   # face arrays of axes >= 1 have axis 0 as their first face axis (after the tensor axes)
+                            lead = arr.ndim - (nd - 1)
+                            arr = arr[(slice(None),) * lead + (slice(self.lo, self.hi),)]
+                        buf = upload(np.ascontiguousarray(arr))
+                        out.keepalive.append(buf)
+                        setattr(dst, name, buf.ptr)
+        return out
 
     @property
     def exchanged_faces(self) -> set[tuple[int, bool]]:
@@ -101,11 +166,13 @@ class SlabMesh:
 
         new = copy.copy(bc)
         new.grid = self.subgrid
-        if slice_axis0 and not bc.homogeneous:
-            # face arrays of axes >= 1 have axis 0 as their first face axis
+        if slice_axis0:
+            # face arrays of axes >= 1 have axis 0 as their first face axis; value and const are sliced independently,
+            # each only when it really is a per-face array (a MixedBC may carry a scalar value and an array const)
             lead = len(bc._shape_tensor)
             idx = (slice(None),) * lead + (slice(self.lo, self.hi),)
-            new._value = np.ascontiguousarray(bc.value[idx])
+            if np.ndim(bc.value) > lead:
+                new._value = np.ascontiguousarray(bc.value[idx])
             if hasattr(bc, "const") and np.ndim(bc.const) > lead:
                 new.const = np.ascontiguousarray(bc.const[idx])
         return new

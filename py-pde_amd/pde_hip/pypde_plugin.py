@@ -28,6 +28,7 @@ try:
     from pde.backends import backend_registry
     from pde.backends.base import BackendBase
     from pde.grids.cartesian import CartesianGrid
+    from pde.solvers.base import AdaptiveSolverBase
     from pde.tools.config import Parameter
 except ImportError as err:  # pragma: no cover - exercised only without py-pde
     msg = "pde_hip.pypde_plugin needs py-pde (`import pde` failed)"
@@ -40,7 +41,8 @@ from .backend import HipBackendMixin
 from .device import DeviceArray
 
 DEFAULT_CONFIG = {
-    "device": Parameter(value=0, cls=int, description="Index of the HIP device (MI355X) the backend runs on; `hip:<n>` overrides it."),
+    "device": Parameter(value=-1, cls=int, description="Index of the HIP device (MI355X) the backend runs on; `hip:<n>` overrides it. "
+                        "-1: the process default (LOCAL_RANK under a one-process-per-GPU launcher, else 0)."),
     "resident_state": Parameter(
         value=True,
         cls=bool,
@@ -55,7 +57,7 @@ class HipBackend(HipBackendMixin, BackendBase):
 
     def __init__(self, config=None, *, name: str = "hip", device: int | None = None):
         BackendBase.__init__(self, config, name=name)
-        if device is None and "device" in self.config:
+        if device is None and "device" in self.config and int(self.config["device"]) >= 0:
             device = int(self.config["device"])
         self._hip_init(device)
 
@@ -84,6 +86,89 @@ class HipBackend(HipBackendMixin, BackendBase):
 
 
 _operators.register_all(HipBackend, CartesianGrid)
+
+
+class _Statistics(dict):
+    """Step-size statistics gathered by the C loop, with the one method py-pde's controller uses
+    (``OnlineStatistics.to_dict``, pde/solvers/controller.py:285-287)."""
+
+    def to_dict(self) -> dict:
+        return dict(self)
+
+
+class HipSlabSolver(AdaptiveSolverBase):
+    """Explicit solver for runs with ONE PROCESS PER GPU (``python -m torch.distributed.run --nproc-per-node N script.py``):
+    the counterpart of the reference's ``ExplicitMPISolver`` (``pde/solvers/explicit_mpi.py:24-226``, registered name
+    ``"explicit_mpi"``) on the slab-parallel path of this backend (``pde_hip/distributed.py``).
+
+    Every rank runs the same script with the same (replicated) initial state — there is no main / client split as with MPI:
+    each stepper call cuts the state into axis-0 slabs, advances its own slab on its GPU with RCCL halo exchanges (one C call
+    per call of the stepper), and all-gathers the result, so trackers on every rank see the full field.
+
+        eq.solve(state, t_range=10, dt=0.1, solver="hip_slab", backend="hip")                       # Euler
+        eq.solve(state, t_range=10, solver="hip_slab", scheme="runge-kutta", adaptive=True, backend="hip")
+    """
+
+    name = "hip_slab"
+
+    def __init__(self, pde, scheme: str = "euler", *, backend="hip", adaptive: bool = False, tolerance: float = 1e-4):
+        super().__init__(pde, backend=backend, adaptive=adaptive, tolerance=tolerance)
+        if scheme in {"rk", "rk45", "runge-kutta"}:
+            scheme = "runge-kutta"
+        if scheme not in {"euler", "runge-kutta"}:
+            msg = f"Unknown scheme `{scheme}` (euler, runge-kutta)"
+            raise ValueError(msg)
+        if adaptive and scheme != "runge-kutta":
+            msg = "adaptive slab-parallel stepping uses the Runge-Kutta-Fehlberg scheme (scheme='runge-kutta')"
+            raise NotImplementedError(msg)
+        self.scheme = scheme
+
+    def make_stepper(self, state, dt: float | None = None):
+        from . import _abi
+        from .distributed import SlabStepper
+
+        if dt is None:
+            dt = self.dt_default
+        self.info.update(dt=float(dt), steps=0, dt_adaptive=bool(self.adaptive), stochastic=False, scheme=self.scheme, post_step_data=None)
+        if getattr(self.pde, "is_sde", False):
+            msg = "slab-parallel stepping does not support stochastic equations"
+            raise NotImplementedError(msg)
+        self._select_backend(state)
+        if state.__class__.__name__ != "ScalarField":
+            msg = "slab-parallel stepping supports a single ScalarField state"
+            raise NotImplementedError(msg)
+        stepper = SlabStepper(self.pde, state.grid, state.dtype, device=getattr(self.backend, "_device_request", None))
+        self.info["world_size"] = stepper.size
+        cur, nxt = stepper.buf("state_a"), stepper.buf("state_b")
+        ctl = _abi.Adaptive()
+        ctl.tolerance, ctl.dt_min, ctl.dt_max, ctl.dt = float(self.tolerance), float(self.dt_min), float(self.dt_max), float(dt)
+        dt_fixed = float(dt)
+
+        def slab_stepper(state_field, t_start: float, t_end: float) -> float:
+            a, b = cur, nxt
+            stepper.set_local(a, stepper.mesh.extract(state_field.data))
+            if self.adaptive:
+                ctl.t_start, ctl.t_end = float(t_start), float(t_end)
+                before = int(ctl.steps)
+                res = stepper.rkf45_run(a, b, ctl)
+                self.info["steps"] += int(ctl.steps) - before
+                self.info["dt"] = float(ctl.dt)
+                self.info["dt_statistics"] = _Statistics(_abi.adaptive_statistics(ctl))   # the controller calls .to_dict()
+                t_last = float(ctl.t_last)
+            else:
+                steps = max(1, round((t_end - t_start) / dt_fixed))
+                if self.scheme == "euler":
+                    res = stepper.euler_steps(a, b, dt_fixed, steps)
+                else:
+                    stepper.rk4_steps(a, dt_fixed, steps)
+                    res = a
+                self.info["steps"] += steps
+                t_last = t_start + (steps - 1) * dt_fixed + dt_fixed
+            state_field.data[...] = stepper.gather(res)
+            return t_last
+
+        slab_stepper.slab = stepper  # type: ignore[attr-defined]
+        return slab_stepper
 
 
 def register() -> None:

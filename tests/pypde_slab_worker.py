@@ -1,0 +1,67 @@
+"""One rank of a slab-parallel run driven by the REAL py-pde (launched by torch.distributed.run; CPU: host shim via PDEHIP_LIB).
+
+`eq.solve(state, ..., solver="hip_slab", backend="hip")` — pde_hip.pypde_plugin.HipSlabSolver, the counterpart of the
+reference's ExplicitMPISolver — on every rank; rank 0 compares with the reference's own serial numpy + scipy run.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "py-pde_amd", ROOT / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+sys.path.append("/root/reference")
+
+
+def main() -> int:
+    import torch.distributed as dist
+
+    import pde
+
+    import pde_hip.pypde_plugin  # noqa: F401
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    failures, report = [], {}
+    cases = {
+        "diffusion_euler": (pde.DiffusionPDE(0.7, bc={"x": {"value": 0.2}, "y": "periodic", "z": {"derivative": 0.1}}),
+                            pde.UnitGrid([12, 4, 6], periodic=[False, True, False]), dict(t_range=0.5, dt=0.05)),
+        "cahn_hilliard_rk4": (pde.CahnHilliardPDE(0.9), pde.UnitGrid([8, 4, 6], periodic=True), dict(t_range=0.004, dt=1e-3, scheme="runge-kutta")),
+        "expression_rkf45": (pde.PDE({"c": "laplace(c**3 - c - laplace(c))"}), pde.UnitGrid([8, 6, 6], periodic=True),
+                             dict(t_range=0.1, dt=1e-3, scheme="runge-kutta", adaptive=True)),
+    }
+    pde.config["default_backend"] = "scipy"
+    for name, (eq, grid, kw) in cases.items():
+        state = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
+        seen = []
+        tracker = pde.CallbackTracker(lambda s, t: seen.append((t, float(s.data.sum()))), interrupts=kw["t_range"] / 2)
+        res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True, **kw)
+        report[name] = {"steps": info["solver"]["steps"], "world": info["solver"]["world_size"], "interrupts": len(seen)}
+        if rank == 0:
+            ref_kw = {k: v for k, v in kw.items() if k != "scheme"}
+            ref_eq = pde.CahnHilliardPDE() if name == "expression_rkf45" else eq   # the expression class needs numba on numpy
+            ref, rinfo = ref_eq.solve(state, solver="runge-kutta" if kw.get("scheme") else "euler", backend="numpy",
+                                      tracker=pde.CallbackTracker(lambda s, t: None, interrupts=kw["t_range"] / 2), ret_info=True, **ref_kw)
+            err = np.abs(res.data - ref.data).max() / np.abs(ref.data).max()
+            if info["solver"]["steps"] != rinfo["solver"]["steps"]:
+                failures.append(f"{name}: {info['solver']['steps']} steps, reference {rinfo['solver']['steps']}")
+            if not err < 1e-10:
+                failures.append(f"{name}: relative difference {err:.3e}")
+            if len(seen) != 3:
+                failures.append(f"{name}: {len(seen)} tracker interrupts")
+    if rank == 0:
+        print("PYPDESLAB " + json.dumps({"world": world, "cases": report, "failures": failures}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

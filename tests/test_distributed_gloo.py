@@ -289,3 +289,27 @@ def test_multirank_worker_and_bench_under_torchrun(world):
     assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["finite"] and out["slab"]["two_steps_per_sweep"] and sum(out["slab"]["layers_per_rank"]) == 32
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_real_pypde_drives_the_slab_path(world):
+    """`eq.solve(state, solver="hip_slab", backend="hip")` of the REAL py-pde (pde_hip.pypde_plugin.HipSlabSolver, the
+    counterpart of the reference's ExplicitMPISolver) on N ranks under torch.distributed.run: Euler, RK4 and adaptive RKF45
+    with tracker interrupts equal the reference's own serial numpy + scipy run (<= 1e-10, equal step counts)."""
+    import json
+    import subprocess
+    from pathlib import Path
+
+    import shimlib
+
+    if not Path("/root/reference/pde").exists():
+        pytest.skip("py-pde (reference) not available")
+    so = shimlib.build()
+    env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "tests" / "pypde_slab_worker.py")]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
+    assert proc.returncode == 0 and lines, proc.stderr[-3000:]
+    report = json.loads(lines[-1][len("PYPDESLAB "):])
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 3

@@ -37,7 +37,8 @@ def test_registration_and_class_attributes():
     cls = plugin.HipBackend
     assert issubclass(cls, pde.backends.base.BackendBase)
     assert cls.implementation == "hip" and cls.copy_data is True and cls.supports_mpi is False
-    assert pde.config["backend"]["hip"]["device"] == 0
+    assert pde.config["backend"]["hip"]["device"] == -1 and pde.config["backend"]["hip"]["resident_state"] is True   # -1: process default (LOCAL_RANK or 0)
+    assert "hip_slab" in pde.solvers.registered_solvers()
     ops = cls._operators[pde.CartesianGrid]
     assert {"laplace", "gradient", "divergence", "gradient_squared", "vector_laplace"} <= set(ops)
     plugin.register()  # idempotent

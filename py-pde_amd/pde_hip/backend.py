@@ -622,11 +622,12 @@ class HipBackendMixin:
         called without a grid, e.g. by ``ScipySolver``) is uploaded here, where the grid is known."""
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
+        comp_shape = tuple(np.shape(state.data))[: np.ndim(state.data) - len(info.shape)]   # (n,) for a FieldCollection
 
         def to_device(state_data):
             if isinstance(state_data, DeviceArray):
                 return state_data
-            return DeviceArray(info).set_valid(np.asarray(state_data, dtype=info.dtype), self.stream)
+            return DeviceArray(info, comp_shape).set_valid(np.asarray(state_data, dtype=info.dtype), self.stream)
 
         try:
             spec = self.make_rhs_spec(eq, state)
@@ -662,34 +663,49 @@ class HipBackendMixin:
         if pde_kind(eq) != "PDE":
             msg = f"hip backend has no right-hand side for {eq.__class__.__name__}"
             raise NotImplementedError(msg)
-        if state.__class__.__name__ != "ScalarField":
-            msg = "hip backend expression kernels support a single ScalarField state"
-            raise NotImplementedError(msg)
         rhs = dict(eq.rhs)
-        if len(rhs) != 1:
-            msg = "hip backend supports expression PDEs of a single scalar variable"
-            raise NotImplementedError(msg)
-        (var,) = rhs
-        plan = ExpressionPlan(pde_expression(eq, var), var, dict(getattr(eq, "consts", {}) or {}))
+        variables = list(rhs)
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
-        # one face table per operator NAME, like the reference (pde/pdes/pde.py:329-343)
-        tables: dict[str, FaceTable] = {}
-        specs: list[tuple[Any, FaceTable]] = []
-        for op in plan.operators_used:
-            bc = pde_bc_for(eq, var, op)
-            for other, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
-                try:
-                    same = other is bc or bool(other == bc)
-                except (ValueError, TypeError):   # array-valued entries do not compare to a bool
-                    same = False
-                if same:
-                    tables[op] = table
-                    break
-            else:
-                tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
-                specs.append((bc, tables[op]))
-        return ExpressionRhs(self, plan, info, tables)
+        consts = dict(getattr(eq, "consts", {}) or {})
+        kind = state.__class__.__name__
+        if kind == "FieldCollection":
+            fields = list(state)
+            if len(fields) != len(variables) or any(f.__class__.__name__ != "ScalarField" for f in fields):
+                msg = "hip backend expression kernels support collections of scalar fields, one per equation"
+                raise NotImplementedError(msg)
+        elif kind != "ScalarField" or len(variables) != 1:
+            msg = "hip backend expression kernels support a ScalarField or a FieldCollection of scalar fields"
+            raise NotImplementedError(msg)
+
+        def tables_for(var, plan):
+            # one face table per operator NAME in the equation of `var`, like the reference (pde/pdes/pde.py:329-343)
+            tables: dict[str, Any] = {}
+            specs: list[tuple[Any, Any]] = []
+            for op in plan.operators_used:
+                bc = pde_bc_for(eq, var, op)
+                for other, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
+                    try:
+                        same = other is bc or bool(other == bc)
+                    except (ValueError, TypeError):   # array-valued entries do not compare to a bool
+                        same = False
+                    if same:
+                        tables[op] = table
+                        break
+                else:
+                    tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
+                    specs.append((bc, tables[op]))
+            return tables
+
+        parts = []
+        for var in variables:
+            plan = ExpressionPlan(pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var))
+            parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan)))
+        if len(parts) == 1:
+            return parts[0]
+        from .expr import SystemRhs
+
+        return SystemRhs(variables, parts, info)
 
     def _make_expression_stepper(self, solver, state, erhs=None, post_step=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
@@ -705,17 +721,19 @@ class HipBackendMixin:
         if erhs is None:
             erhs = self.make_expression_rhs(solver.pde, state)
         info, lib, stream = erhs.info, self._lib, self.stream
+        ncomp = int(getattr(erhs, "ncomp", 1))                      # > 1: multi-field PDE (SystemRhs)
+        comp_shape = (ncomp,) if ncomp > 1 else ()
         is_rk = solver.__class__.__name__ == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
         nwork = (7 if adaptive else 5) if is_rk else (2 if adaptive else 1)
-        work = [DeviceArray(info) for _ in range(nwork)]
+        work = [DeviceArray(info, comp_shape) for _ in range(nwork)]
         B = [[1 / 4], [3 / 32, 9 / 32], [1932 / 2197, -7200 / 2197, 7296 / 2197], [439 / 216, -8.0, 3680 / 513, -845 / 4104],
              [-8 / 27, 2.0, -3544 / 2565, 1859 / 4104, -11 / 40]]
         A = [0.0, 1 / 4, 3 / 8, 12 / 13, 1.0, 1 / 2]
 
         def lincomb(out, y, coefs, ks):
             cf = (C.c_double * len(coefs))(*coefs)
-            lib.lincomb(info.ref, 1, out.ptr, y.ptr, len(ks), cf, ptr_array(ks), stream)
+            lib.lincomb(info.ref, ncomp, out.ptr, y.ptr, len(ks), cf, ptr_array(ks), stream)
 
         def rk4_step(y, t, dt):
             # every stage in one sweep where the kernels cover it (slope + the combination that follows, like
@@ -728,7 +746,7 @@ class HipBackendMixin:
             if not erhs.apply_stage(k4, k3, dt, t + 0.5 * dt, 0, y, [], [], 1.0, tmp):
                 lincomb(tmp, y, [1.0], [k3])
             if not erhs.apply_stage(tmp, k4, dt, t + dt, 1, y, [k1, k2, k3], [], 0.0, y):
-                lib.rk4_combine(info.ref, 1, y.ptr, k1.ptr, k2.ptr, k3.ptr, k4.ptr, stream)
+                lib.rk4_combine(info.ref, ncomp, y.ptr, k1.ptr, k2.ptr, k3.ptr, k4.ptr, stream)
 
         if not adaptive:
             dt = float(solver.info["dt"])
@@ -764,7 +782,7 @@ class HipBackendMixin:
         solver.info.setdefault("dt_statistics", OnlineStatistics())
         adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
         tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
-        err_dev, ynew0 = DeviceScalar(), DeviceArray(info)
+        err_dev, ynew0 = DeviceScalar(), DeviceArray(info, comp_shape)
 
         def attempt(y, ynew, t, dt_step) -> float:
             if is_rk:
@@ -777,14 +795,14 @@ class HipBackendMixin:
                         lincomb(dst, y, b, ks[: s_ + 1])
                     src, dst = dst, (ynew if dst is tmp else tmp)
                 if not erhs.apply_stage(src, ks[5], dt_step, t + A[5] * dt_step, 2, y, [ks[0], ks[2], ks[3], ks[4]], [], 0.0, ynew, err_dev):
-                    lib.rkf45_combine(info.ref, 1, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
+                    lib.rkf45_combine(info.ref, ncomp, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
             else:
                 k1, k2a = work[0], work[1]
                 erhs.apply(y, k1, "euler", dt_step, t)
                 if not erhs.euler2(y, ynew, 0.5 * dt_step):   # the two half steps in one sweep where covered
                     erhs.apply(y, k2a, "euler", 0.5 * dt_step, t)
                     erhs.apply(k2a, ynew, "euler", 0.5 * dt_step, t + 0.5 * dt_step)
-                lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
+                lib.max_abs_diff(info.ref, ncomp, k1.ptr, ynew.ptr, err_dev.ptr, stream)
             return err_dev.value(stream)
 
         def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
@@ -1075,8 +1093,11 @@ class HipBackendMixin:
         """
         inner = self.make_inner_stepper(solver, state)
         info = self.grid_info(state.grid, state.dtype)
-        resident = bool(_config_get(getattr(self, "config", None), "resident_state", True))
-        dev_state = DeviceArray(info)
+        comp_shape = tuple(np.shape(state.data))[: np.ndim(state.data) - len(info.shape)]
+        # a FieldCollection hands out its sub-fields as separate objects viewing the same memory: reads of `state[0].data`
+        # cannot be intercepted, so collections take the plain upload / download per call
+        resident = bool(_config_get(getattr(self, "config", None), "resident_state", True)) and state.__class__.__name__ != "FieldCollection"
+        dev_state = DeviceArray(info, comp_shape)
         if not resident:
 
             def stepper(state_field, t_start: float, t_end: float) -> float:

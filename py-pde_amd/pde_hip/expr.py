@@ -44,11 +44,13 @@ def _sympy():
 
 
 class ExpressionPlan:
-    """Lower ``expr`` (string, variable ``var``) into passes.  Array names: ``"state"``, ``"tmp<k>"``."""
+    """Lower ``expr`` (string, variable ``var``) into passes.  Array names: ``"state"`` (the equation's own variable),
+    ``"var:<name>"`` (the other scalar fields of a multi-field PDE, ``others``), ``"tmp<k>"``."""
 
-    def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None):
+    def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = ()):
         sp = _sympy()
         self.var = var
+        self.others = tuple(others)
         expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
         self._ops = {name: sp.Function(name) for name in OPERATORS}
         local: dict[str, Any] = dict(self._ops)
@@ -56,6 +58,8 @@ class ExpressionPlan:
         self._t = sp.Symbol("__t", real=True)
         local[var] = self._state
         local["t"] = self._t
+        other_syms = {name: sp.Symbol(f"__v_{name}", real=True) for name in self.others}
+        local.update(other_syms)
         for k, v in (consts or {}).items():
             if not np.isscalar(v):
                 msg = "hip backend: array-valued constants in expressions are not supported"
@@ -70,7 +74,7 @@ class ExpressionPlan:
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
             raise NotImplementedError(msg)
-        free = {str(s) for s in expr.free_symbols} - {"__state", "__t"}
+        free = {str(s) for s in expr.free_symbols} - {"__state", "__t"} - {str(v) for v in other_syms.values()}
         if free:
             msg = f"unknown symbol(s) {sorted(free)} in `{expr_str}` (pass them in `consts`)"
             raise ValueError(msg)
@@ -80,6 +84,8 @@ class ExpressionPlan:
         self._ntmp = 0
         self._memo: dict[Any, str] = {}
         self._arrays = {"state": self._state}  # array name -> sympy symbol standing for its centre value
+        for name, sym in other_syms.items():
+            self._arrays[f"var:{name}"] = sym
         self._lower_top(expr)
 
     # --- lowering --------------------------------------------------------------------------------
@@ -268,9 +274,12 @@ class ExpressionRhs:
             if h is not None:
                 self.lib.jit_check(h, _abi.dtype_code(dtype), ndim)
 
-    def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
-        """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler)."""
+    def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0, others: dict | None = None) -> None:
+        """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler); ``others``: the other
+        fields of a multi-field PDE by variable name."""
         arrays = {"state": state, "out": out, **self.tmps}
+        for name, arr in (others or {}).items():
+            arrays[f"var:{name}"] = arr
         params = (C.c_double * 2)(dt, t)
         self._update_faces(t)
         if self._fused2(state, out, wrap, params):
@@ -377,3 +386,29 @@ class ExpressionRhs:
                 self.lib.jit_destroy(h)
             except Exception:  # noqa: BLE001 - interpreter shutdown
                 pass
+
+
+class SystemRhs:
+    """Right-hand side of a multi-field ``PDE({"u": ..., "v": ...})`` whose fields are all scalar (reference:
+    ``pde/pdes/pde.py:401-499`` compiles one function per variable over a ``FieldCollection``): one
+    :class:`ExpressionRhs` per equation, each seeing the other fields as centre-only inputs (or, where an operator is applied
+    to another field, as the stencil array of a pass).  The state is ONE device array with a leading component axis, like
+    ``FieldCollection.data``.  Same evaluator interface as :class:`ExpressionRhs`; the fused sweeps of single-field
+    expressions (two steps per sweep, stage epilogues) do not apply — stages combine with the pointwise kernels."""
+
+    def __init__(self, variables: list[str], parts: list["ExpressionRhs"], info):
+        self.variables, self.parts, self.info = list(variables), list(parts), info
+        self.ncomp = len(self.variables)
+
+    def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
+        comps = {name: state.component(k) for k, name in enumerate(self.variables)}
+        for k, (name, part) in enumerate(zip(self.variables, self.parts)):
+            others = {n: a for n, a in comps.items() if n != name}
+            part.apply(comps[name], out.component(k), wrap, dt, t, others=others)
+
+    def apply_stage(self, state, k_out, dt, t, kind, y, ks, coefs, c_new, out2, err=None) -> bool:
+        self.apply(state, k_out, "scaled", dt, t)
+        return False
+
+    def euler2(self, state, out, dt: float) -> bool:
+        return False

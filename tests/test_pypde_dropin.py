@@ -357,8 +357,10 @@ def test_unsupported_requests_raise_not_implemented(hip1):
     state = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(7))
     with pytest.raises(NotImplementedError):
         pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, solver="implicit", backend="hip", tracker=None)
-    with pytest.raises(NotImplementedError):
-        pde.PDE({"c": "laplace(c)", "d": "c"}).solve(pde.FieldCollection([state, state]), t_range=0.1, dt=0.01, backend="hip", tracker=None)
+    with pytest.raises(NotImplementedError):    # vector-valued expression PDEs are a "next" item
+        pde.PDE({"u": "vector_laplace(u)"}).solve(pde.VectorField.random_uniform(grid), t_range=0.1, dt=0.01, backend="hip", tracker=None)
+    with pytest.raises(NotImplementedError, match="no kernel for operator"):
+        pde.PDE({"c": "laplace(c) + divergence(gradient(c))"}).solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
 
 
 def test_state_stays_resident_between_tracker_interrupts(hip1):
@@ -475,3 +477,48 @@ def test_integrator_on_the_device(hip1):
     np.testing.assert_allclose(integrate(v.data), v.integral, rtol=1e-13)
     native = hip1.numpy_to_native(f.data, grid=grid)
     assert integrate(native) == pytest.approx(f.integral, rel=1e-13)
+
+
+def _torch_reference(eq, state, **kw):
+    """The reference's eager torch-CPU backend: the only reference path that runs expression PDEs here (Euler only)."""
+    old = pde.config["backend.torch.compile"]
+    pde.config["backend.torch.compile"] = False
+    try:
+        return eq.solve(state, backend="torch", solver="euler", tracker=None, **kw)
+    finally:
+        pde.config["backend.torch.compile"] = old
+
+
+@pytest.mark.parametrize("case", ["two_scalars_1d", "brusselator_2d", "cross_diffusion_2d"])
+def test_multi_field_expression_pdes(hip, case):
+    """`PDE({"u": ..., "v": ...})` on a FieldCollection of scalar fields (pde/pdes/pde.py:299-499; the reference's
+    tests/pdes/test_pde_class.py:145-159 and the Brusselator of its documentation): Euler vs the reference's torch-CPU run,
+    Runge-Kutta vs Euler with a small step, per-variable boundary conditions."""
+    rng = np.random.default_rng(12)
+    if case == "two_scalars_1d":
+        eq = pde.PDE({"u": "laplace(u) - u", "v": "- u * v"})
+        grid = pde.UnitGrid([8])
+    elif case == "brusselator_2d":
+        eq = pde.PDE({"u": "d0 * laplace(u) + a - (1 + b) * u + v * u**2", "v": "d1 * laplace(v) + b * u - v * u**2"},
+                     consts={"a": 1.0, "b": 3.0, "d0": 1.0, "d1": 0.1})
+        grid = pde.UnitGrid([16, 12], periodic=[True, False])
+    else:
+        eq = pde.PDE({"u": "laplace(u + 0.5 * v)", "v": "laplace(v) + 0.1 * laplace(u) - v**3"},
+                     bc_ops={"u:laplace": {"value": 0.2}, "v:laplace": {"derivative": 0.1}})
+        grid = pde.UnitGrid([12, 10])
+    state = pde.FieldCollection.scalar_random_uniform(2, grid, 0.1, 0.9, rng=rng)
+    res, info = eq.solve(state, t_range=0.1, dt=1e-3, backend="hip", solver="euler", tracker=None, ret_info=True)
+    ref = _torch_reference(eq, state, t_range=0.1, dt=1e-3)
+    assert info["solver"]["steps"] == 100 and isinstance(res, pde.FieldCollection)
+    assert max_rel(res.data, ref.data) < 1e-10
+    # right-hand side alone, and the other explicit schemes on the same system
+    rate = hip.native_to_numpy(eq.make_pde_rhs(state, backend="hip")(state.data, 0.0))
+    assert rate.shape == state.data.shape
+    rk = eq.solve(state, t_range=0.1, dt=5e-3, backend="hip", solver="runge-kutta", tracker=None)
+    assert max_rel(rk.data, ref.data) < 2e-3
+    ad, ainfo = eq.solve(state, t_range=0.1, backend="hip", solver="runge-kutta", adaptive=True, tracker=None, ret_info=True)
+    assert max_rel(ad.data, rk.data) < 1e-3 and ainfo["solver"]["dt_statistics"]["count"] == ainfo["solver"]["steps"]
+    # trackers see the collection and its sub-fields
+    seen = []
+    eq.solve(state, t_range=0.02, dt=1e-3, backend="hip", solver="euler", tracker=pde.CallbackTracker(lambda s, t: seen.append(s[1].data.copy()), interrupts=0.01))
+    assert len(seen) == 3 and not np.array_equal(seen[0], seen[-1])

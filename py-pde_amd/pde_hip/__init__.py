@@ -17,7 +17,7 @@ library or a device is missing (there is no CPU fallback).
 from . import operators as _operators
 from .backend import HipBackend, get_backend
 from .boundaries import BoundariesList
-from .fields import ScalarField, Tensor2Field, VectorField
+from .fields import FieldCollection, ScalarField, Tensor2Field, VectorField
 from .grids import CartesianGrid, UnitGrid
 from .pdes import PDE, CahnHilliardPDE, DiffusionPDE
 from .solvers import Controller, EulerSolver, ExplicitSolver, RungeKuttaSolver
@@ -32,6 +32,7 @@ __all__ = [
     "Controller",
     "DiffusionPDE",
     "EulerSolver",
+    "FieldCollection",
     "ExplicitSolver",
     "HipBackend",
     "RungeKuttaSolver",

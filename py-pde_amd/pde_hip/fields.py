@@ -147,3 +147,48 @@ class Tensor2Field(DataFieldBase):
 
     def divergence(self, bc, out=None, **kwargs) -> VectorField:
         return self.apply_operator("tensor_divergence", bc=bc, out=out, **kwargs)
+
+
+class FieldCollection:
+    """Several scalar fields on one grid stored as ONE array with a leading field axis (``pde/fields/collection.py``):
+    ``data`` has shape ``(n, *grid.shape)``, ``collection[i]`` is a :class:`ScalarField` viewing the same memory.  Just enough
+    of the reference class for multi-field expression PDEs on the GPU box (which has no py-pde)."""
+
+    def __init__(self, fields, *, copy_fields: bool = True, dtype=None):
+        fields = list(fields)
+        if not fields or any(not isinstance(f, ScalarField) for f in fields):
+            msg = "FieldCollection (mirror) holds scalar fields"
+            raise NotImplementedError(msg)
+        self.grid = fields[0].grid
+        dt = np.dtype(dtype or np.result_type(*[f.dtype for f in fields]))
+        self._data_full = np.zeros((len(fields),) + self.grid._shape_full, dt)
+        self._fields = []
+        for k, f in enumerate(fields):
+            self._data_full[k] = f._data_full
+            view = ScalarField.__new__(ScalarField)
+            view.grid, view.label, view._data_full = self.grid, f.label, self._data_full[k]
+            self._fields.append(view)
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._data_full[(slice(None),) + (slice(1, -1),) * self.grid.num_axes]
+
+    @data.setter
+    def data(self, value) -> None:
+        self.data[...] = value
+
+    @property
+    def dtype(self):
+        return self._data_full.dtype
+
+    def __iter__(self):
+        return iter(self._fields)
+
+    def __len__(self) -> int:
+        return len(self._fields)
+
+    def __getitem__(self, index):
+        return self._fields[index]
+
+    def copy(self, *, label=None, dtype=None):
+        return FieldCollection([f.copy() for f in self._fields], dtype=dtype or self.dtype)

@@ -248,3 +248,41 @@ def test_runge_kutta_stage_sweeps_of_expressions(monkeypatch, shape, periodic, d
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[2], b[2])
     assert np.isfinite(a[2]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_multi_field_system_brusselator(dtype):
+    """Two coupled scalar fields (`PDE({"u": ..., "v": ...})` on a FieldCollection): one compiled pass per equation with the
+    other field as a centre-only input; Euler steps against the same update written in numpy on the oracle's Laplacians."""
+    from helpers import host_faces, oracle_grid, to_full
+
+    from oracle import pde_oracle as O
+
+    a_, b_, d0, d1, dt, steps = 1.0, 3.0, 1.0, 0.1, 1e-3, 20
+    grid = pde_hip.UnitGrid([24, 130], periodic=[True, False])
+    rng = np.random.default_rng(5)
+    u0, v0 = rng.uniform(0.5, 1.5, grid.shape).astype(dtype), rng.uniform(2.5, 3.5, grid.shape).astype(dtype)
+    state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, u0, dtype=dtype), pde_hip.ScalarField(grid, v0, dtype=dtype)])
+    eq = pde_hip.PDE({"u": "d0 * laplace(u) + a - (1 + b) * u + v * u**2", "v": "d1 * laplace(v) + b * u - v * u**2"},
+                     consts={"a": a_, "b": b_, "d0": d0, "d1": d1})
+    res, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == steps and res.data.shape == (2, *grid.shape) and res.data.dtype == dtype
+    g = oracle_grid(grid, dtype)
+    faces = host_faces(grid.get_boundary_conditions("auto_periodic_neumann")).c
+
+    def lap(x):
+        full = to_full(grid, x)
+        O.set_ghost_cells(g, 1, faces, full)
+        return O.laplace(g, full).astype(np.float64)
+
+    u, v = u0.copy(), v0.copy()
+    for _ in range(steps):
+        ud, vd = u.astype(np.float64), v.astype(np.float64)
+        fu = d0 * lap(u) + a_ - (1 + b_) * ud + vd * ud**2
+        fv = d1 * lap(v) + b_ * ud - vd * ud**2
+        u, v = (ud + dt * fu).astype(dtype), (vd + dt * fv).astype(dtype)
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    assert max_rel(res.data[0].astype(np.float64), u.astype(np.float64)) < tol and max_rel(res.data[1].astype(np.float64), v.astype(np.float64)) < tol
+    rk = eq.solve(state, t_range=steps * dt, dt=4 * dt, solver="runge-kutta", backend="hip")
+    assert max_rel(rk.data.astype(np.float64), res.data.astype(np.float64)) < 1e-3

@@ -133,8 +133,8 @@ def test_expression_pde_solvers_and_functions():
     assert max_rel(r1, O.laplace(oracle_grid(g1), f1) - s1.data**3) < 1e-13
     with pytest.raises(NotImplementedError):
         pde_hip.PDE({"c": "divergence(c)"}).evolution_rate(state)
-    with pytest.raises(NotImplementedError, match="single scalar variable"):
-        pde_hip.PDE({"a": "laplace(a)", "b": "laplace(b)"}).evolution_rate(state)
+    with pytest.raises(NotImplementedError, match="FieldCollection of scalar fields"):
+        pde_hip.PDE({"a": "laplace(a)", "b": "laplace(b)"}).evolution_rate(state)   # two variables need a collection
 
 
 @pytest.mark.gpu

@@ -107,7 +107,7 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
 const char *kMarchWrapper = R"SRC(
 extern "C" __global__ void __launch_bounds__(64 * PDE_WY) pde_kernel(pdehip::LapArgs a)
 {
-    pdehip::lap_march_body<PDE_T, PDE_VEC, PDE_RY, PDE_CZ, PDE_WY, 1, pdehip::LAP_CUSTOM, PDE_HASX, true, PDE_IBC>(a);
+    pdehip::lap_march_body<PDE_T, PDE_VEC, PDE_RY, PDE_CZ, PDE_WY, 1, pdehip::LAP_CUSTOM, PDE_HASX, true, PDE_IBC, PDE_TAILS>(a);
 }
 )SRC";
 
@@ -122,7 +122,8 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
                     int two_level = 0,    // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
                     bool stage = false,   // one-level kernel followed by the Runge-Kutta stage epilogue (LapArgs::st_*)
-                    int wy = 1)           // waves per workgroup (stacked along the rows), one-level kernel
+                    int wy = 1,           // waves per workgroup (stacked along the rows), one-level kernel
+                    bool tails = true)    // rows that end inside a vector / leave idle chunks in a tile (pdehip_march.inc)
 {
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
@@ -147,7 +148,8 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
                                      "-DPDE_CZ=" + std::to_string(cz), std::string("-DPDE_HASX=") + (hasx ? "true" : "false"),
                                      std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level),
-                                     std::string("-DPDE_STAGE=") + (stage ? "1" : "0"), "-DPDE_WY=" + std::to_string(wy)};
+                                     std::string("-DPDE_STAGE=") + (stage ? "1" : "0"), "-DPDE_WY=" + std::to_string(wy),
+                                     std::string("-DPDE_TAILS=") + (tails ? "true" : "false")};
     std::vector<const char *> copts;
     for (auto &o : opts) copts.push_back(o.c_str());
     const int rc = g_rtc.CompileProgram(prog, (int)copts.size(), copts.data());
@@ -332,11 +334,12 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         static int wy_env = -1;   // PDEHIP_JIT_WY: waves per workgroup of the stage sweeps (tuning aid)
         if (wy_env < 0) { const char *e = getenv("PDEHIP_JIT_WY"); wy_env = e ? atoi(e) : 0; }
         const int wy = (stage && wy_env > 0) ? wy_env : 1;
+        const bool tails = (n.n[2] % vec != 0) || (chunks % cz != 0);
         const std::string key = std::string(tname) + "," + std::to_string(ry) + "," + std::to_string(cz) + "," + (hasx ? "x" : "-") + (ibc ? "b" : "-") +
-                                (stage ? "s" : "-") + std::to_string(wy);
+                                (stage ? "s" : "-") + std::to_string(wy) + (tails ? "t" : "-");
         auto it = j->cache.find(key);
         if (it != j->cache.end()) v = it->second;
-        else PDEHIP_TRY(compile_variant(j, key, false, tname, vec, ry, cz, hasx, ibc, &v, 0, stage != nullptr, wy));
+        else PDEHIP_TRY(compile_variant(j, key, false, tname, vec, ry, cz, hasx, ibc, &v, 0, stage != nullptr, wy, tails));
         a.ntz = (a.n2 + 64L * vec * cz - 1) / (64L * vec * cz);
         a.nty = (a.n1 + wy * ry - 1) / (wy * ry);
         const long tiles = a.ntz * a.nty;

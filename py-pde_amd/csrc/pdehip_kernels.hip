@@ -107,13 +107,21 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     constexpr bool kIbc = (MODE <= LAP_CH_MU) || MODE == LAP_STAGE;
     const dim3 grid((unsigned)a.nblocks), block(64 * WY);
     if (a.any_ibc && !kIbc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs are not built for the derivative epilogues");
+    // rows that end inside a lane's vector, or tiles with whole chunks beyond the row, take the TAILS instance
+    const bool tails = (a.n2 % VEC != 0) || (((a.n2 + 64L * VEC - 1) / (64L * VEC)) % CZ != 0);
+#define PDEHIP_MARCH(YIN_, IBC_)                                                                                                       \
+    do {                                                                                                                               \
+        if (tails) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, false>), grid, block, 0, st, a);       \
+    } while (0)
     if (a.any_ibc) {
-        if (y_is_in || !kHasY) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, kIbc>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, !kHasY, kIbc>), grid, block, 0, st, a);
+        if (y_is_in || !kHasY) PDEHIP_MARCH(true, kIbc);
+        else PDEHIP_MARCH(!kHasY, kIbc);
     } else {
-        if (y_is_in || !kHasY) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, !kHasY, false>), grid, block, 0, st, a);
+        if (y_is_in || !kHasY) PDEHIP_MARCH(true, false);
+        else PDEHIP_MARCH(!kHasY, false);
     }
+#undef PDEHIP_MARCH
     PDEHIP_HIP(hipGetLastError());
     return 0;
 }

@@ -135,6 +135,18 @@ int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, v
                          void *stream);
 int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *valid,
                          void *stream);
+/* The same between HOST memory and a device full array, complete on return: the valid data of a field as the
+ * reference holds it — `field.data` is a strided view of the ghost-padded host array (pde/fields/base.py:116-160,
+ * pde/grids/base.py:329-337) — uploaded from / downloaded into that view without a contiguous host copy.
+ * host_strides[4] (bytes): { between components, along the grid's axes right-aligned to three (entries of axes the
+ * grid does not have are ignored) }; the fastest axis must be contiguous (host_strides[3] == element size, else
+ * PDEHIP_E_VALUE).  Transfers run through pinned chunks, large ones on several threads (PDEHIP_PIPELINED_COPY=0:
+ * pdehip_memcpy_* keep to plain hipMemcpy).  Replaces the host side of TorchBackend.numpy_to_native /
+ * native_to_numpy (pde/backends/torch/backend.py:217-260). */
+int pdehip_upload_valid(const pdehip_grid_t *g, int ncomp, const void *host, const int64_t *host_strides,
+                        void *full, void *stream);
+int pdehip_download_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *host,
+                          const int64_t *host_strides, void *stream);
 /* `hostfull` = a device copy of the reference's compact host full array (shape + 2 per axis,
  * `field._data_full`, pde/fields/datafield_base.py:93-126), ghost cells included */
 int pdehip_hostfull_to_full(const pdehip_grid_t *g, int ncomp, const void *hostfull_dev,

@@ -1,5 +1,8 @@
 // pdehip_runtime.hip — device/stream/memory plumbing of the C ABI (include/pdehip.h).
 #include "pdehip_common.h"
+#include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace pdehip {
 static thread_local std::string g_last_error;
@@ -7,6 +10,169 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 }  // namespace pdehip
 
 using namespace pdehip;
+
+// ---------------------------------------------------------------------------------------------
+// Large host <-> device transfers of PAGEABLE memory (numpy arrays: the reference's fields live in host memory,
+// pde/fields/base.py:116-160, so every eq.solve starts with an upload and ends with a download of the state).
+// hipMemcpy stages pageable memory through one pinned buffer with one CPU thread (measured on the MI355X boxes: see
+// profiles/r02_time_transfers.md); here kCopyThreads threads each own two pinned chunks and a stream: while the DMA engine
+// moves one chunk, the thread copies the next one between the user's pages and pinned memory.  The call returns when the
+// whole transfer is complete (the same contract as the small-transfer path).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kPipelinedMin = 32u << 20;   // below this the plain path wins (thread start + first-touch of the pool)
+constexpr size_t kChunk = 4u << 20;
+constexpr int kCopyThreads = 4;
+
+struct CopyLane {
+    void *pinned[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+struct CopyPool {
+    std::mutex m;   // one pipelined transfer at a time
+    int device = -1;
+    CopyLane lane[kCopyThreads];
+};
+CopyPool g_pool;
+
+bool pipelined_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("PDEHIP_PIPELINED_COPY"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+
+int pool_prepare(int dev)
+{
+    if (g_pool.device == dev) return 0;
+    if (g_pool.device >= 0) PDEHIP_FAIL(E_RUNTIME, "pinned transfer pool belongs to device %d (one device per process)", g_pool.device);
+    for (auto &l : g_pool.lane) {
+        for (int b = 0; b < 2; b++) {
+            PDEHIP_HIP(hipHostMalloc(&l.pinned[b], kChunk, hipHostMallocDefault));
+            PDEHIP_HIP(hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming));
+        }
+        PDEHIP_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+    }
+    g_pool.device = dev;
+    return 0;
+}
+
+// the host side of a transfer: a byte stream of `rows` rows of `row` bytes, each contiguous in host memory
+struct HostView {
+    char *base;
+    long n[3];          // components, axis 0, axis 1 (rows = n[0] * n[1] * n[2])
+    int64_t s[3];       // byte strides of the three
+    size_t row;         // bytes of one row (fastest axis)
+    bool contiguous;
+};
+void host_copy(const HostView &h, size_t off, size_t len, char *pinned, bool to_host)
+{
+    if (h.contiguous) {
+        if (to_host) memcpy(h.base + off, pinned, len); else memcpy(pinned, h.base + off, len);
+        return;
+    }
+    while (len) {
+        const size_t r = off / h.row, in = off % h.row, take = (len < h.row - in) ? len : h.row - in;
+        const size_t j = r % h.n[2], t = r / h.n[2], i = t % h.n[1], c = t / h.n[1];
+        char *p = h.base + (int64_t)c * h.s[0] + (int64_t)i * h.s[1] + (int64_t)j * h.s[2] + in;
+        if (to_host) memcpy(p, pinned, take); else memcpy(pinned, p, take);
+        off += take; len -= take; pinned += take;
+    }
+}
+
+// chunks c = lane, lane + nlanes, ... of the transfer; returns a HIP error code (0 = fine)
+hipError_t lane_run(int dev, CopyLane &l, int lane, int nlanes, char *devp, const HostView &host, size_t bytes, bool h2d)
+{
+    hipError_t rc = hipSetDevice(dev);   // a new thread starts on device 0
+    if (rc != hipSuccess) return rc;
+    const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+    int b = 0;
+    size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};   // d2h: chunk whose DMA is in flight in buffer b
+    for (size_t c = lane; c < nchunks; c += nlanes, b ^= 1) {
+        const size_t off = c * kChunk, len = (off + kChunk <= bytes) ? kChunk : bytes - off;
+        // the buffer is free again once the transfer issued two rounds ago is done
+        if ((rc = hipEventSynchronize(l.ev[b])) != hipSuccess) return rc;
+        if (h2d) {
+            host_copy(host, off, len, (char *)l.pinned[b], false);
+            if ((rc = hipMemcpyAsync(devp + off, l.pinned[b], len, hipMemcpyHostToDevice, l.st)) != hipSuccess) return rc;
+        } else {
+            if (pending_len[b]) host_copy(host, pending_off[b], pending_len[b], (char *)l.pinned[b], true);
+            if ((rc = hipMemcpyAsync(l.pinned[b], devp + off, len, hipMemcpyDeviceToHost, l.st)) != hipSuccess) return rc;
+            pending_off[b] = off; pending_len[b] = len;
+        }
+        if ((rc = hipEventRecord(l.ev[b], l.st)) != hipSuccess) return rc;
+    }
+    if ((rc = hipStreamSynchronize(l.st)) != hipSuccess) return rc;
+    if (!h2d) {
+        // the (up to) two chunks still in the pinned buffers
+        for (int k = 0; k < 2; k++, b ^= 1)
+            if (pending_len[b]) { host_copy(host, pending_off[b], pending_len[b], (char *)l.pinned[b], true); pending_len[b] = 0; }
+    }
+    return hipSuccess;
+}
+
+// `devp` <-> host view, complete on return.  Large transfers: kCopyThreads lanes; small ones: one lane on the calling thread.
+int pipelined_copy(void *devp, const HostView &host, size_t bytes, bool h2d, hipStream_t user_stream)
+{
+    int dev = 0;
+    PDEHIP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> guard(g_pool.m);
+    PDEHIP_TRY(pool_prepare(dev));
+    // everything queued on the caller's stream (producers of the source, readers of the destination) first
+    PDEHIP_HIP(hipStreamSynchronize(user_stream));
+    if (bytes < kPipelinedMin) {
+        PDEHIP_HIP(lane_run(dev, g_pool.lane[0], 0, 1, (char *)devp, host, bytes, h2d));
+        return 0;
+    }
+    hipError_t rcs[kCopyThreads];
+    std::thread th[kCopyThreads];
+    for (int t = 0; t < kCopyThreads; t++)
+        th[t] = std::thread([&, t] { rcs[t] = lane_run(dev, g_pool.lane[t], t, kCopyThreads, (char *)devp, host, bytes, h2d); });
+    for (auto &t : th) t.join();
+    for (int t = 0; t < kCopyThreads; t++) PDEHIP_HIP(rcs[t]);
+    return 0;
+}
+int pipelined_copy(void *devp, void *host, size_t bytes, bool h2d, hipStream_t user_stream)
+{
+    HostView h = {(char *)host, {1, 1, 1}, {0, 0, 0}, bytes, true};
+    return pipelined_copy(devp, h, bytes, h2d, user_stream);
+}
+
+// valid cells of a field in host memory (any strides with a contiguous fastest axis) <-> the device's full layout
+int transfer_valid(const pdehip_grid_t *g, int ncomp, void *host, const int64_t *hs, void *full, bool upload, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!host || !hs || !full) PDEHIP_FAIL(E_VALUE, "transfer of valid data: NULL pointer");
+    if (ncomp < 1) PDEHIP_FAIL(E_VALUE, "number of components must be positive (%d)", ncomp);
+    const long es = elem_size(n.dtype);
+    if (hs[3] != es) PDEHIP_FAIL(E_VALUE, "host array must be contiguous along the fastest axis (stride %ld, element %ld bytes)", (long)hs[3], es);
+    HostView h;
+    h.base = (char *)host;
+    h.row = (size_t)(n.n[2] * es);
+    // rows: (component, axis 0, axis 1) of the normalised 3-D shape; 2-D grids have n[0] == 1, 1-D grids n[0] == n[1] == 1
+    if (n.ndim == 3) { h.n[0] = ncomp; h.n[1] = n.n[0]; h.n[2] = n.n[1]; h.s[0] = hs[0]; h.s[1] = hs[1]; h.s[2] = hs[2]; }
+    else if (n.ndim == 2) { h.n[0] = 1; h.n[1] = ncomp; h.n[2] = n.n[1]; h.s[0] = 0; h.s[1] = hs[0]; h.s[2] = hs[2]; }
+    else { h.n[0] = 1; h.n[1] = 1; h.n[2] = ncomp; h.s[0] = 0; h.s[1] = 0; h.s[2] = hs[0]; }
+    const size_t bytes = (size_t)ncomp * n.n[0] * n.n[1] * h.row;
+    h.contiguous = (h.n[2] == 1 || h.s[2] == (int64_t)h.row) && (h.n[1] == 1 || h.s[1] == (int64_t)(h.n[2] * h.row)) &&
+                   (h.n[0] == 1 || h.s[0] == (int64_t)(h.n[1] * h.n[2] * h.row));
+    void *stage = nullptr;
+    PDEHIP_HIP(hipMalloc(&stage, bytes ? bytes : 16));
+    int rc = 0;
+    if (upload) {
+        rc = pipelined_copy(stage, h, bytes, true, as_stream(stream));
+        if (rc == 0) rc = pdehip_valid_to_full(g, ncomp, stage, full, stream);
+        if (rc == 0 && hipStreamSynchronize(as_stream(stream)) != hipSuccess) { set_error("hipStreamSynchronize failed after upload"); rc = E_RUNTIME; }
+    } else {
+        rc = pdehip_full_to_valid(g, ncomp, full, stage, stream);
+        if (rc == 0) rc = pipelined_copy(stage, h, bytes, false, as_stream(stream));
+    }
+    (void)hipFree(stage);
+    return rc;
+}
+}  // namespace
 
 extern "C" {
 
@@ -62,6 +228,7 @@ int pdehip_memset(void *ptr, int value, size_t bytes, void *stream)
 
 int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream)
 {
+    if (bytes >= kPipelinedMin && pipelined_enabled()) return pipelined_copy(dst, const_cast<void *>(src_host), bytes, true, as_stream(stream));
     PDEHIP_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     PDEHIP_HIP(hipStreamSynchronize(as_stream(stream)));  // pageable host memory: keep it simple & safe
     return 0;
@@ -69,10 +236,16 @@ int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *strea
 
 int pdehip_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream)
 {
+    if (bytes >= kPipelinedMin && pipelined_enabled()) return pipelined_copy(const_cast<void *>(src), dst_host, bytes, false, as_stream(stream));
     PDEHIP_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
     PDEHIP_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
+
+int pdehip_upload_valid(const pdehip_grid_t *g, int ncomp, const void *host, const int64_t *host_strides, void *full, void *stream)
+{ return transfer_valid(g, ncomp, const_cast<void *>(host), host_strides, full, true, stream); }
+int pdehip_download_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *host, const int64_t *host_strides, void *stream)
+{ return transfer_valid(g, ncomp, host, host_strides, const_cast<void *>(full), false, stream); }
 
 int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
 {

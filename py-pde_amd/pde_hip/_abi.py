@@ -172,6 +172,8 @@ RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
     "memcpy_h2d": ([_vp, _vp, C.c_size_t, _vp], _i),
     "memcpy_d2h": ([_vp, _vp, C.c_size_t, _vp], _i),
     "memcpy_d2d": ([_vp, _vp, C.c_size_t, _vp], _i),
+    "upload_valid": ([_pg, _i, _vp, C.POINTER(C.c_int64), _vp, _vp], _i),
+    "download_valid": ([_pg, _i, _vp, _vp, C.POINTER(C.c_int64), _vp], _i),
     "stream_create": ([_pvp], _i),
     "stream_destroy": ([_vp], _i),
     "stream_synchronize": ([_vp], _i),

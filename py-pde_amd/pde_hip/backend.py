@@ -539,7 +539,7 @@ class HipBackendMixin:
         info = natives[0].info
         res = DeviceArray(info, out.shape[: out.ndim - nd])
         func(*natives, res, **kwargs)
-        out[...] = res.get_valid(stream=self.stream)
+        res.get_valid(out=out, stream=self.stream)
 
     def make_operator(self, grid, operator, *, bcs, dtype=None, **kwargs):
         """``op(arr, out=None, args=None) -> out`` with BCs (base.py:523-565, numpy/backend.py:178-255).
@@ -1103,7 +1103,7 @@ class HipBackendMixin:
             def stepper(state_field, t_start: float, t_end: float) -> float:
                 dev_state.set_valid(state_field.data, self.stream)
                 result, t_last = inner(dev_state, t_start, t_end)
-                state_field.data[...] = result.get_valid(stream=self.stream)
+                result.get_valid(out=state_field.data, stream=self.stream)
                 return t_last
 
             return stepper
@@ -1196,7 +1196,7 @@ class ResidentState:
             self.host_stale = False
             field.__dict__["_hip_link"] = None
             try:
-                field.data[...] = self.dev_state.get_valid(stream=self.backend.stream)
+                self.dev_state.get_valid(out=field.data, stream=self.backend.stream)
             finally:
                 field.__dict__["_hip_link"] = self
             self.downloads += 1

@@ -116,18 +116,41 @@ class DeviceArray:
         return self.ptr + (comp * self.info.comp_elems + layer * self.info.layer_pitch) * self.itemsize
 
     # --- host <-> device ------------------------------------------------------------------
+    def _host_strides(self, host: np.ndarray):
+        """``host_strides[4]`` of pdehip_upload_valid / pdehip_download_valid for a host array of this array's shape, or
+        None when its memory cannot be described that way (fastest axis not contiguous, tensor axes not collapsible)."""
+        nd = len(self.info.shape)
+        st = host.strides
+        if host.shape != self.shape or host.dtype != self.dtype or not host.flags.aligned:
+            return None
+        if host.shape[-1] > 1 and st[-1] != self.itemsize:
+            return None
+        comp = 0
+        ncs = len(self.comp_shape)
+        if self.ncomp > 1:
+            # the tensor axes must walk through memory like one axis of `ncomp` entries
+            comp = st[ncs - 1]
+            for a in range(ncs - 1):
+                if self.comp_shape[a] > 1 and st[a] != st[a + 1] * self.comp_shape[a + 1]:
+                    return None
+        out = (C.c_int64 * 4)(comp, 0, 0, self.itemsize)
+        for a in range(nd - 1):
+            out[1 + 3 - nd + a] = st[ncs + a]
+        return out
+
     def set_valid(self, data: np.ndarray, stream=None) -> "DeviceArray":
-        """Upload valid data (host numpy, any strides) into the interior."""
+        """Upload valid data (host numpy, any strides) into the interior.  A view with a contiguous fastest axis - such
+        as ``field.data`` of the reference, a window of the ghost-padded host array - is read in place."""
         lib = require_device()
-        host = np.ascontiguousarray(data, dtype=self.dtype)
+        host = np.asarray(data)
         if host.shape != self.shape:
             msg = f"Incompatible shapes {host.shape} != {self.shape}"
             raise ValueError(msg)
-        stage = DeviceBuffer(host.nbytes)
-        lib.memcpy_h2d(stage.ptr, host.ctypes.data, host.nbytes, stream)
-        lib.valid_to_full(self.info.ref, self.ncomp, stage.ptr, self.ptr, stream)
-        lib.stream_synchronize(stream)
-        stage.free()
+        strides = self._host_strides(host)
+        if strides is None:
+            host = np.ascontiguousarray(host, dtype=self.dtype)
+            strides = self._host_strides(host)
+        lib.upload_valid(self.info.ref, self.ncomp, host.ctypes.data, strides, self.ptr, stream)
         return self
 
     def set_hostfull(self, data_full: np.ndarray, stream=None) -> "DeviceArray":
@@ -146,14 +169,17 @@ class DeviceArray:
         return self
 
     def get_valid(self, out: np.ndarray | None = None, stream=None) -> np.ndarray:
-        """Download the interior as a host numpy array (written into ``out`` if given)."""
+        """Download the interior as a host numpy array (written into ``out`` if given: in place when ``out`` has this
+        array's dtype and a contiguous fastest axis, e.g. ``field.data`` of the reference)."""
         lib = require_device()
-        host = np.empty(self.shape, dtype=self.dtype)
-        stage = DeviceBuffer(host.nbytes)
-        lib.full_to_valid(self.info.ref, self.ncomp, self.ptr, stage.ptr, stream)
-        lib.memcpy_d2h(host.ctypes.data, stage.ptr, host.nbytes, stream)
-        stage.free()
-        if out is not None:
+        strides = None
+        if out is not None and out.flags.writeable:
+            strides = self._host_strides(out)
+        host = out if strides is not None else np.empty(self.shape, dtype=self.dtype)
+        if strides is None:
+            strides = self._host_strides(host)
+        lib.download_valid(self.info.ref, self.ncomp, self.ptr, host.ctypes.data, strides, stream)
+        if out is not None and host is not out:
             out[...] = host
             return out
         return host

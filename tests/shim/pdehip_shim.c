@@ -152,6 +152,36 @@ int pdehip_valid_to_full(const pdehip_grid_t *g, int ncomp, const void *valid, v
 { (void)stream; GRID(g); TRY(oracle_valid_to_full(g, ncomp, valid, full)); return 0; }
 int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *valid, void *stream)
 { (void)stream; GRID(g); TRY(oracle_full_to_valid(g, ncomp, full, valid)); return 0; }
+/* strided host view <-> full layout: gather / scatter the rows into a contiguous valid image, then the oracle's copy */
+static int transfer_valid(const pdehip_grid_t *g, int ncomp, char *host, const int64_t *hs, void *full, int upload)
+{
+    GRID(g);
+    if (!host || !hs || !full) return fail(E_VALUE, "transfer of valid data: NULL pointer");
+    if (ncomp < 1) return fail(E_VALUE, "number of components must be positive (%d)", ncomp);
+    const long es = g->dtype == PDEHIP_F64 ? 8 : 4;
+    if (hs[3] != es) return fail(E_VALUE, "host array must be contiguous along the fastest axis (stride %ld, element %ld bytes)", (long)hs[3], es);
+    long n[3] = {1, 1, 1};
+    int64_t st[3] = {0, 0, 0};
+    for (int a = 0; a < g->ndim; a++) { n[3 - g->ndim + a] = g->shape[a]; st[3 - g->ndim + a] = hs[1 + 3 - g->ndim + a]; }
+    const size_t row = (size_t)(n[2] * es);
+    char *valid = malloc((size_t)ncomp * n[0] * n[1] * row + 16);
+    if (!valid) return fail(E_RUNTIME, "out of memory");
+    if (!upload) TRY(oracle_full_to_valid(g, ncomp, full, valid));
+    char *v = valid;
+    for (long c = 0; c < ncomp; c++)
+        for (long i = 0; i < n[0]; i++)
+            for (long j = 0; j < n[1]; j++, v += row) {
+                char *h = host + c * hs[0] + i * st[0] + j * st[1];
+                if (upload) memcpy(v, h, row); else memcpy(h, v, row);
+            }
+    if (upload) TRY(oracle_valid_to_full(g, ncomp, valid, full));
+    free(valid);
+    return 0;
+}
+int pdehip_upload_valid(const pdehip_grid_t *g, int ncomp, const void *host, const int64_t *host_strides, void *full, void *stream)
+{ (void)stream; return transfer_valid(g, ncomp, (char *)host, host_strides, full, 1); }
+int pdehip_download_valid(const pdehip_grid_t *g, int ncomp, const void *full, void *host, const int64_t *host_strides, void *stream)
+{ (void)stream; return transfer_valid(g, ncomp, (char *)host, host_strides, (void *)full, 0); }
 int pdehip_hostfull_to_full(const pdehip_grid_t *g, int ncomp, const void *hostfull, void *full, void *stream)
 { (void)stream; GRID(g); memmove(full, hostfull, full_bytes(g, ncomp)); return 0; }
 int pdehip_full_to_hostfull(const pdehip_grid_t *g, int ncomp, const void *full, void *hostfull, void *stream)

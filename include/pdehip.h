@@ -140,8 +140,8 @@ int pdehip_full_to_valid(const pdehip_grid_t *g, int ncomp, const void *full, vo
  * pde/grids/base.py:329-337) — uploaded from / downloaded into that view without a contiguous host copy.
  * host_strides[4] (bytes): { between components, along the grid's axes right-aligned to three (entries of axes the
  * grid does not have are ignored) }; the fastest axis must be contiguous (host_strides[3] == element size, else
- * PDEHIP_E_VALUE).  Transfers run through pinned chunks, large ones on several threads (PDEHIP_PIPELINED_COPY=0:
- * pdehip_memcpy_* keep to plain hipMemcpy).  Replaces the host side of TorchBackend.numpy_to_native /
+ * PDEHIP_E_VALUE).  Contiguous host memory: one hipMemcpy; windows: rows gathered / scattered through pinned chunks
+ * while the DMA engine works, large fields on several threads.  Replaces the host side of TorchBackend.numpy_to_native /
  * native_to_numpy (pde/backends/torch/backend.py:217-260). */
 int pdehip_upload_valid(const pdehip_grid_t *g, int ncomp, const void *host, const int64_t *host_strides,
                         void *full, void *stream);

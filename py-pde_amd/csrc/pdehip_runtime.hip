@@ -12,15 +12,16 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 using namespace pdehip;
 
 // ---------------------------------------------------------------------------------------------
-// Large host <-> device transfers of PAGEABLE memory (numpy arrays: the reference's fields live in host memory,
-// pde/fields/base.py:116-160, so every eq.solve starts with an upload and ends with a download of the state).
-// hipMemcpy stages pageable memory through one pinned buffer with one CPU thread (measured on the MI355X boxes: see
-// profiles/r02_time_transfers.md); here kCopyThreads threads each own two pinned chunks and a stream: while the DMA engine
-// moves one chunk, the thread copies the next one between the user's pages and pinned memory.  The call returns when the
-// whole transfer is complete (the same contract as the small-transfer path).
+// Host <-> device transfers of a field's valid data where it lies in host memory: the reference's fields are numpy arrays with
+// ghost cells, `field.data` is a strided window of them (pde/fields/base.py:116-160), and every eq.solve starts with an upload
+// and ends with a download of that window.  hipMemcpy moves CONTIGUOUS pageable memory at 56 GB/s on the MI355X boxes
+// (profiles/r02_time_transfers.md) - nothing to add there - but a window first needs a contiguous host copy (numpy: 105 ms per
+// GB in, 49 ms per GB out).  Here the rows of the window are gathered / scattered straight into pinned chunks while the DMA
+// engine moves the previous chunk: kCopyThreads threads for large fields, each with two pinned chunks and a stream.  The call
+// returns when the whole transfer is complete.
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr size_t kPipelinedMin = 32u << 20;   // below this the plain path wins (thread start + first-touch of the pool)
+constexpr size_t kPipelinedMin = 32u << 20;   // below this one lane on the calling thread
 constexpr size_t kChunk = 4u << 20;
 constexpr int kCopyThreads = 4;
 
@@ -35,13 +36,6 @@ struct CopyPool {
     CopyLane lane[kCopyThreads];
 };
 CopyPool g_pool;
-
-bool pipelined_enabled()
-{
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("PDEHIP_PIPELINED_COPY"); on = (e && e[0] == '0') ? 0 : 1; }
-    return on == 1;
-}
 
 int pool_prepare(int dev)
 {
@@ -133,12 +127,6 @@ int pipelined_copy(void *devp, const HostView &host, size_t bytes, bool h2d, hip
     for (int t = 0; t < kCopyThreads; t++) PDEHIP_HIP(rcs[t]);
     return 0;
 }
-int pipelined_copy(void *devp, void *host, size_t bytes, bool h2d, hipStream_t user_stream)
-{
-    HostView h = {(char *)host, {1, 1, 1}, {0, 0, 0}, bytes, true};
-    return pipelined_copy(devp, h, bytes, h2d, user_stream);
-}
-
 // valid cells of a field in host memory (any strides with a contiguous fastest axis) <-> the device's full layout
 int transfer_valid(const pdehip_grid_t *g, int ncomp, void *host, const int64_t *hs, void *full, bool upload, void *stream)
 {
@@ -162,12 +150,12 @@ int transfer_valid(const pdehip_grid_t *g, int ncomp, void *host, const int64_t 
     PDEHIP_HIP(hipMalloc(&stage, bytes ? bytes : 16));
     int rc = 0;
     if (upload) {
-        rc = pipelined_copy(stage, h, bytes, true, as_stream(stream));
+        rc = h.contiguous ? pdehip_memcpy_h2d(stage, host, bytes, stream) : pipelined_copy(stage, h, bytes, true, as_stream(stream));
         if (rc == 0) rc = pdehip_valid_to_full(g, ncomp, stage, full, stream);
         if (rc == 0 && hipStreamSynchronize(as_stream(stream)) != hipSuccess) { set_error("hipStreamSynchronize failed after upload"); rc = E_RUNTIME; }
     } else {
         rc = pdehip_full_to_valid(g, ncomp, full, stage, stream);
-        if (rc == 0) rc = pipelined_copy(stage, h, bytes, false, as_stream(stream));
+        if (rc == 0) rc = h.contiguous ? pdehip_memcpy_d2h(host, stage, bytes, stream) : pipelined_copy(stage, h, bytes, false, as_stream(stream));
     }
     (void)hipFree(stage);
     return rc;
@@ -228,7 +216,6 @@ int pdehip_memset(void *ptr, int value, size_t bytes, void *stream)
 
 int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream)
 {
-    if (bytes >= kPipelinedMin && pipelined_enabled()) return pipelined_copy(dst, const_cast<void *>(src_host), bytes, true, as_stream(stream));
     PDEHIP_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     PDEHIP_HIP(hipStreamSynchronize(as_stream(stream)));  // pageable host memory: keep it simple & safe
     return 0;
@@ -236,7 +223,6 @@ int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *strea
 
 int pdehip_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream)
 {
-    if (bytes >= kPipelinedMin && pipelined_enabled()) return pipelined_copy(const_cast<void *>(src), dst_host, bytes, false, as_stream(stream));
     PDEHIP_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
     PDEHIP_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;

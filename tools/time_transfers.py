@@ -1,7 +1,6 @@
 """Host <-> device transfer rates of a field's valid data (pageable numpy memory, contiguous array and `field.data`-like window).
-usage: python tools/time_transfers.py [n0xn1xn2 ...]      PDEHIP_PIPELINED_COPY=0: plain hipMemcpy for comparison (contiguous only)
+usage: python tools/time_transfers.py [n0xn1xn2 ...]
 """
-import os
 import sys
 import time
 from pathlib import Path
@@ -16,8 +15,6 @@ from pde_hip.device import DeviceArray, DeviceBuffer, GridInfo
 b = pde_hip.get_backend("hip")
 lib = b._lib
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(512, 512, 512), (256, 256, 256), (1024, 1024)]
-mode = "plain hipMemcpy" if os.environ.get("PDEHIP_PIPELINED_COPY") == "0" else "pinned pipeline"
-print(f"# {mode}")
 print("| grid (fp64) | MB | what | ms | GB/s |")
 print("|---|---:|---|---:|---:|")
 

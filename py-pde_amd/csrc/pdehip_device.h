@@ -119,16 +119,22 @@ struct LapArgs {
     const void *st_k[5];   // earlier slopes, NULL-terminated
     double st_c[6];
     void *st_out;
+    // LAP_CUSTOM: per-axis derivative scales of the generated epilogue: d1 = (r - l) / dd1 with dd1 = 2 dx (operators/common.py:60-110),
+    // d2 = (r - 2c + l) * dd2 with dd2 = 1 / dx^2 (:150-190).  (At the end: the kernarg offsets of everything else stay.)
+    double dd1[3], dd2[3];
 };
+
+// per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)
+struct PdeDer { double d1[3], d2[3]; };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the
 // offline build never instantiates that mode and only needs the declaration to parse.
 #ifdef PDEHIP_JIT
-__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p);
-__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p);
+__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d);
+__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d);
 #else
-__device__ __forceinline__ double pde_epilogue(double, double, double, double, double, double, const double *) { return 0.0; }
-__device__ __forceinline__ double pde_epilogue2(double, double, double, double, double, double, const double *) { return 0.0; }
+__device__ __forceinline__ double pde_epilogue(double, double, double, double, double, double, const double *, const PdeDer &) { return 0.0; }
+__device__ __forceinline__ double pde_epilogue2(double, double, double, double, double, double, const double *, const PdeDer &) { return 0.0; }
 #endif
 
 }  // namespace pdehip

@@ -3,7 +3,7 @@
 //
 // The reference turns a sympy expression into numba code (pde/tools/expressions.py:361-388,
 // pde/pdes/pde.py:401-499).  Here the host (pde_hip/expr.py) turns it into the body of
-//     double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)
+//     double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)
 // and this file compiles lap_march_body<..., LAP_CUSTOM, ...> around it with hiprtc: one pass reads
 // the stencil array once, evaluates laplace / gradient_squared in registers and applies the generated
 // pointwise function (plus up to three more arrays at the same cell) — no temporaries, the same HBM
@@ -66,6 +66,8 @@ struct Jit {
     std::string body2;                      // statements of pde_epilogue2 (level 2 of a fused two-pass expression)
     std::map<std::string, Variant> cache;   // key: "T,VEC,RY,CZ,HASX,IBC" or "generic,T"
 };
+// the generated code reads PdeDer (`d.d1[..]`, `d.d2[..]`): only the one-level kernels supply it
+bool uses_axis_derivatives(const Jit *j) { return j->body.find("d.d") != std::string::npos || j->body2.find("d.d") != std::string::npos; }
 
 const char *kGenericKernel = R"SRC(
 // one cell per thread: any shape / 1-D / odd row lengths (ghost cells must be set)
@@ -82,7 +84,11 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
         const T *c = in + e;
         const double mid = (double)c[0];
         double lap, gsq;
+        PdeDer d = {{0, 0, 0}, {0, 0, 0}};
+        const double vm = 2 * mid;
         const double dz = (double)c[1] - (double)c[-1];
+        d.d1[2] = dz / a.dd1[2];
+        d.d2[2] = ((double)c[1] - vm + (double)c[-1]) * a.dd2[2];
         if (a.ndim == 1) {
             lap = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
             gsq = dz * dz * a.gs[2];
@@ -90,16 +96,21 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
             const double dy = (double)c[a.p1] - (double)c[-a.p1];
             lap = ((double)c[-a.p1] - 2 * mid + (double)c[a.p1]) * a.sy + ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
             gsq = dy * dy * a.gs[1] + dz * dz * a.gs[2];
+            d.d1[1] = dy / a.dd1[1];
+            d.d2[1] = ((double)c[a.p1] - vm + (double)c[-a.p1]) * a.dd2[1];
         } else {
-            const double vm = 2 * mid;
             const double dx = (double)c[a.p0] - (double)c[-a.p0], dy = (double)c[a.p1] - (double)c[-a.p1];
             lap = ((double)c[-a.p0] - vm + (double)c[a.p0]) * a.sx + ((double)c[-a.p1] - vm + (double)c[a.p1]) * a.sy +
                   ((double)c[-1] - vm + (double)c[1]) * a.sz;
             gsq = dx * dx * a.gs[0] + dy * dy * a.gs[1] + dz * dz * a.gs[2];
+            d.d1[0] = dx / a.dd1[0];
+            d.d2[0] = ((double)c[a.p0] - vm + (double)c[-a.p0]) * a.dd2[0];
+            d.d1[1] = dy / a.dd1[1];
+            d.d2[1] = ((double)c[a.p1] - vm + (double)c[-a.p1]) * a.dd2[1];
         }
         double ex[3];
         for (int m = 0; m < 3; m++) ex[m] = a.ex[m] ? (double)((const T *)a.ex[m])[e] : 0.0;
-        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)pde_epilogue(mid, lap, gsq, ex[0], ex[1], ex[2], a.par);
+        out[a.o_off + i * a.o_s0 + j * a.o_s1 + k] = (T)pde_epilogue(mid, lap, gsq, ex[0], ex[1], ex[2], a.par, d);
     }
 }
 )SRC";
@@ -127,11 +138,11 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
 {
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
-                      "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n";
+                      "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)\n{\n";
     src += j->body;
     src += "\n}\n";
     if (two_level == E2_CUSTOM2) {
-        src += "__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p)\n{\n";
+        src += "__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)\n{\n";
         src += j->body2;
         src += "\n}\n";
     }
@@ -255,6 +266,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
     a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1; a.o_sc = o.sc;
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     for (int q = 0; q < 3; q++) a.gs[q] = 0.25 / (n.dx[q] * n.dx[q]);   // gradient_squared, central (cartesian.py:661)
+    for (int q = 0; q < 3; q++) { a.dd1[q] = 2 * n.dx[q]; a.dd2[q] = 1 / (n.dx[q] * n.dx[q]); }   // operators/common.py:60-110, :150-190
     a.ndim = n.ndim; a.lx = 1;
     for (int m = 0; m < 3; m++) a.ex[m] = extra3_host ? extra3_host[m] : nullptr;
     for (int q = 0; q < nparams; q++) a.par[q] = params_host[q];
@@ -425,6 +437,7 @@ int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full,
     if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_euler2: at most 12 scalar parameters");
     *done = 0;
     Jit *j = static_cast<Jit *>(handle);
+    if (uses_axis_derivatives(j)) return 0;   // the two-level kernel evaluates laplace / gradient_squared only
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
     if (n.ndim < 2) return 0;
@@ -466,6 +479,7 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
     *done = 0;
     Jit *j = static_cast<Jit *>(handle);
     if (j->body2.empty()) PDEHIP_FAIL(E_VALUE, "jit_fused2: handle was not created with pdehip_jit_create2");
+    if (uses_axis_derivatives(j)) return 0;
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
     if (n.ndim < 2) return 0;

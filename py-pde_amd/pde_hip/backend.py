@@ -699,7 +699,7 @@ class HipBackendMixin:
 
         parts = []
         for var in variables:
-            plan = ExpressionPlan(pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var))
+            plan = ExpressionPlan(pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var), axes=tuple(grid.axes))
             parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan)))
         if len(parts) == 1:
             return parts[0]

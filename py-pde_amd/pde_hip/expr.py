@@ -10,9 +10,10 @@ kernel compiled (hiprtc, ``csrc/pdehip_jit.hip``) around a generated pointwise e
 
 so e.g. ``c - c**3 + laplace(c)`` (Allen–Cahn) or ``nu*laplace(h) + lam*gradient_squared(h)`` (KPZ) are a
 single pass with 1 read + 1 write per cell, ``laplace(c**3 - c - laplace(c))`` is two passes, and the
-Euler update / RK stage scaling is folded into the last pass.  Supported: ``laplace`` and
-``gradient_squared`` (central) of the field or of any pointwise sub-expression, elementary functions,
-constants, explicit time ``t``.  Anything else raises ``NotImplementedError`` like the reference does
+Euler update / RK stage scaling is folded into the last pass.  Supported: ``laplace``,
+``gradient_squared`` (central) and the per-axis derivatives ``d_dx`` / ``d2_dx2`` ... (central; Burgers
+``-u*d_dx(u) + nu*d2_dx2(u)``, KdV ``-6*u*d_dx(u) - d_dx(d2_dx2(u))``) of the field or of any pointwise
+sub-expression, elementary functions, constants, explicit time ``t``.  Anything else raises ``NotImplementedError`` like the reference does
 for unknown backends (``pde/pdes/pde.py:469-496``).
 """
 
@@ -47,12 +48,20 @@ class ExpressionPlan:
     """Lower ``expr`` (string, variable ``var``) into passes.  Array names: ``"state"`` (the equation's own variable),
     ``"var:<name>"`` (the other scalar fields of a multi-field PDE, ``others``), ``"tmp<k>"``."""
 
-    def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = ()):
+    def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
+                 axes: tuple[str, ...] = ()):
+        """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
+        (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS."""
         sp = _sympy()
         self.var = var
         self.others = tuple(others)
         expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
-        self._ops = {name: sp.Function(name) for name in OPERATORS}
+        # operator name -> ("d1" | "d2", normalised axis) for the per-axis derivatives; the kernels number axes right-aligned to 3
+        self.axis_ops: dict[str, tuple[str, int]] = {}
+        for k, ax in enumerate(axes):
+            self.axis_ops[f"d_d{ax}"] = ("d1", 3 - len(axes) + k)
+            self.axis_ops[f"d2_d{ax}2"] = ("d2", 3 - len(axes) + k)
+        self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops)}
         local: dict[str, Any] = dict(self._ops)
         self._state = sp.Symbol("__state", real=True)  # internal name: must not clash with the code symbols
         self._t = sp.Symbol("__t", real=True)
@@ -70,7 +79,7 @@ class ExpressionPlan:
         except (sp.SympifyError, SyntaxError, TypeError) as err:
             msg = f"cannot parse expression `{expr_str}`: {err}"
             raise ValueError(msg) from err
-        unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(OPERATORS)
+        unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(self._ops)
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
             raise NotImplementedError(msg)
@@ -181,7 +190,12 @@ class ExpressionPlan:
         sub: dict[Any, Any] = {}
         src_sym = self._arrays[p.src]
         for a in p.expr.atoms(sp.core.function.AppliedUndef):
-            sub[a] = lap if a.func.__name__ == "laplace" else gsq
+            name = a.func.__name__
+            if name in self.axis_ops:
+                which, axis = self.axis_ops[name]
+                sub[a] = sp.Symbol(f"d.{which}[{axis}]", real=True)   # PdeDer of the kernels (csrc/pdehip_device.h)
+            else:
+                sub[a] = lap if name == "laplace" else gsq
         sub2 = dict(sub)
         sub2[src_sym] = c
         sub2[self._t] = sp.Symbol("t", real=True)

@@ -286,3 +286,105 @@ def test_multi_field_system_brusselator(dtype):
     assert max_rel(res.data[0].astype(np.float64), u.astype(np.float64)) < tol and max_rel(res.data[1].astype(np.float64), v.astype(np.float64)) < tol
     rk = eq.solve(state, t_range=steps * dt, dt=4 * dt, solver="runge-kutta", backend="hip")
     assert max_rel(rk.data.astype(np.float64), res.data.astype(np.float64)) < 1e-3
+
+
+# ---- per-axis derivatives inside expressions (d_dx, d2_dx2, ...: numba/backend.py:105-173, operators/common.py:19-193) ----------
+# Only the reference's numba backend has these operators (torch / numpy backends: none), so there is no golden to record here:
+# the expectation is composed from the oracle's axis derivatives (restated from operators/common.py, compared with the HIP
+# operator kernels in test_hip_derivatives.py) with numpy arithmetic.
+AXIS_CASES = [
+    # id, shape, periodic, bc, dtype, expression, numpy composition
+    ("burgers1d", (64,), [True], "periodic", np.float64, "-u*d_dx(u) + 0.1*d2_dx2(u)",
+     lambda u, d1, d2, lap: -u * d1[0] + 0.1 * d2[0]),
+    ("burgers1d_odd_dirichlet", (37,), [False], {"value": 0.2}, np.float64, "-u*d_dx(u) + 0.1*d2_dx2(u)",
+     lambda u, d1, d2, lap: -u * d1[0] + 0.1 * d2[0]),
+    ("advect2d", (24, 128), [True, False], "auto_periodic_neumann", np.float64, "-0.5*d_dx(u) + 0.25*d_dy(u) + 0.1*laplace(u) - u*d2_dy2(u)",
+     lambda u, d1, d2, lap: -0.5 * d1[0] + 0.25 * d1[1] + 0.1 * lap - u * d2[1]),
+    ("aniso3d", (6, 10, 128), [True, True, False], "auto_periodic_neumann", np.float64, "d2_dx2(u) + 2*d2_dy2(u) + 3*d2_dz2(u) - u*d_dz(u) + d_dx(u)*d_dy(u)",
+     lambda u, d1, d2, lap: d2[0] + 2 * d2[1] + 3 * d2[2] - u * d1[2] + d1[0] * d1[1]),
+    ("aniso3d_f32_ragged", (5, 6, 72), [False, True, True], "auto_periodic_dirichlet", np.float32, "d2_dx2(u) - u*d_dz(u) + d_dy(u)",
+     lambda u, d1, d2, lap: d2[0] - u * d1[2] + d1[1]),
+]
+
+
+def _axis_expectation(grid, data, bc, fn, dtype):
+    from oracle import pde_oracle as O
+
+    g = oracle_grid(grid, dtype)
+    full = to_full(grid, data.astype(dtype))
+    O.set_ghost_cells(g, 1, host_faces(grid.get_boundary_conditions(bc)).c, full)
+    nd = grid.num_axes
+    d1 = [O.axis_derivative(g, full, a, 1).astype(np.float64) for a in range(nd)]
+    d2 = [O.axis_derivative(g, full, a, 2).astype(np.float64) for a in range(nd)]
+    return fn(data.astype(dtype).astype(np.float64), d1, d2, O.laplace(g, full).astype(np.float64))
+
+
+def test_axis_derivative_lowering_and_compile():
+    plan = ExpressionPlan("-u*d_dx(u) + 0.1*d2_dx2(u)", "u", axes=("x",))
+    assert len(plan.passes) == 1 and plan.operators_used == ["d2_dx2", "d_dx"]
+    body, _ = plan.epilogue(plan.passes[0], "euler")
+    assert "d.d1[2]" in body and "d.d2[2]" in body          # the only axis of a 1-D grid is the kernels' fastest axis
+    kdv = ExpressionPlan("-6*u*d_dx(u) - d_dx(d2_dx2(u))", "u", axes=("x",))
+    assert len(kdv.passes) == 3                              # d2_dx2(u) and d_dx(u) materialised, the last pass takes its stencil from the former
+    p3 = ExpressionPlan("d_dx(u)*d_dy(u) + d2_dz2(u)", "u", axes=("x", "y", "z"))
+    body3, _ = p3.epilogue(p3.passes[0], "rate")
+    assert "d.d1[0]" in body3 and "d.d1[1]" in body3 and "d.d2[2]" in body3
+    p2 = ExpressionPlan("d_dx(u) + d2_dy2(u)", "u", axes=("x", "y"))
+    body2, _ = p2.epilogue(p2.passes[0], "rate")
+    assert "d.d1[1]" in body2 and "d.d2[2]" in body2        # 2-D grids: normalised axes 1 and 2
+    with pytest.raises(NotImplementedError, match="no kernel for operator"):
+        ExpressionPlan("d_dz(u)", "u", axes=("x", "y"))      # the grid has no z axis
+    lib = _lib.get_lib()
+    for plan_, nd in ((plan, 1), (p2, 2), (p3, 3), (kdv, 1)):
+        for p in plan_.passes:
+            for wrap in ("rate", "scaled", "euler"):
+                body, _ = plan_.epilogue(p, wrap)
+                h = C.c_void_p()
+                lib.jit_create(body.encode(), C.byref(h))
+                for dt_ in (_abi.F64, _abi.F32):
+                    lib.jit_check(h, dt_, nd)
+                lib.jit_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", AXIS_CASES, ids=[c[0] for c in AXIS_CASES])
+def test_axis_derivative_expressions(case):
+    _, shape, periodic, bc, dtype, expr, fn = case
+    grid = pde_hip.CartesianGrid([[0, 0.5 * n] for n in shape], shape, periodic=periodic)   # dx = 0.5: the scales matter
+    rng = np.random.default_rng(11)
+    data = rng.uniform(-0.5, 0.5, shape)
+    state = pde_hip.ScalarField(grid, data, dtype=dtype)
+    eq = pde_hip.PDE({"u": expr}, bc=bc)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    expect = _axis_expectation(grid, data, bc, fn, dtype)
+    assert max_rel(eq.evolution_rate(state).data, expect) < tol
+    # explicit Euler through the stepper (state + dt*F in the sweep; the two-level kernels decline these epilogues)
+    dt, steps = 1e-3, 4
+    ref = data.astype(dtype)
+    for _ in range(steps):
+        ref = (ref.astype(np.float64) + dt * _axis_expectation(grid, ref, bc, fn, dtype)).astype(dtype)
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert max_rel(out.data, ref) < (1e-12 if dtype == np.float64 else 1e-5)
+    # Runge-Kutta (stage sweeps) and the adaptive controller run on the same kernels
+    rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
+    assert np.isfinite(rk.data).all() and max_rel(rk.data, ref) < 5e-2   # Euler vs RK4 on rough data: truncation error, not parity
+
+
+@pytest.mark.gpu
+def test_kdv_two_pass_chain():
+    """d_dx(d2_dx2(u)): the inner derivative is materialised, the outer pass takes its stencil from the temporary."""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 16]], [128], periodic=True)
+    x = grid.axes_coords[0]
+    data = 0.5 / np.cosh(0.5 * (x - 8)) ** 2
+    state = pde_hip.ScalarField(grid, data)
+    eq = pde_hip.PDE({"u": "-6*u*d_dx(u) - d_dx(d2_dx2(u))"})
+    g = oracle_grid(grid)
+    faces = host_faces(grid.get_boundary_conditions("periodic")).c
+    full = to_full(grid, data)
+    O.set_ghost_cells(g, 1, faces, full)
+    uxx = to_full(grid, O.axis_derivative(g, full, 0, 2))
+    O.set_ghost_cells(g, 1, faces, uxx)
+    expect = -6 * data * O.axis_derivative(g, full, 0, 1) - O.axis_derivative(g, uxx, 0, 1)
+    assert max_rel(eq.evolution_rate(state).data, expect) < 1e-13

@@ -522,3 +522,31 @@ def test_multi_field_expression_pdes(hip, case):
     seen = []
     eq.solve(state, t_range=0.02, dt=1e-3, backend="hip", solver="euler", tracker=pde.CallbackTracker(lambda s, t: seen.append(s[1].data.copy()), interrupts=0.01))
     assert len(seen) == 3 and not np.array_equal(seen[0], seen[-1])
+
+
+def test_axis_derivatives_in_expressions_through_pypde(hip1):
+    """`d_dx` / `d2_dx2` ... inside `pde.PDE` expressions exist only in the reference's numba backend (numba/backend.py:105-173).
+    Cross-check with the reference's OWN operators of another backend: the central `gradient` components and, in 1-D, `laplace`."""
+    bc = {"x-": {"value": 0.3}, "x+": {"derivative": -0.2}}
+    grid = pde.CartesianGrid([[0, 8]], [32])
+    u = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=np.random.default_rng(12))
+    eq = pde.PDE({"u": "-u*d_dx(u) + 0.1*d2_dx2(u)"}, bc=bc)
+    rate = hip1.native_to_numpy(eq.make_pde_rhs(u, backend="hip")(hip1.numpy_to_native(u.data), 0.0))
+    expect = -u.data * u.gradient(bc, backend="scipy").data[0] + 0.1 * u.laplace(bc, backend="scipy").data
+    assert max_rel(rate, expect) < 1e-12
+    res = eq.solve(u, t_range=0.05, dt=0.01, solver="euler", backend="hip", tracker=None)
+    ref = u.copy()
+    for _ in range(5):
+        ref.data = ref.data + 0.01 * (-ref.data * ref.gradient(bc, backend="scipy").data[0] + 0.1 * ref.laplace(bc, backend="scipy").data)
+    assert max_rel(res.data, ref.data) < 1e-12
+    # 2-D, mixed periodicity: d_dx is the FIRST grid axis, d_dy the second
+    grid = pde.CartesianGrid([[0, 4], [0, 12]], [8, 24], periodic=[True, False])   # (the scipy backend wants one dx)
+    v = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=np.random.default_rng(13))
+    bc2 = "auto_periodic_neumann"
+    eq = pde.PDE({"v": "-v*d_dx(v) - 2*v*d_dy(v) + 0.1*laplace(v)"}, bc=bc2)
+    rate = hip1.native_to_numpy(eq.make_pde_rhs(v, backend="hip")(hip1.numpy_to_native(v.data), 0.0))
+    grad = v.gradient(bc2, backend="scipy").data
+    expect = -v.data * grad[0] - 2 * v.data * grad[1] + 0.1 * v.laplace(bc2, backend="scipy").data
+    assert max_rel(rate, expect) < 1e-12
+    with pytest.raises(NotImplementedError, match="no kernel for operator"):
+        pde.PDE({"v": "d_dz(v)"}).make_pde_rhs(v, backend="hip")

@@ -668,6 +668,19 @@ __global__ void __launch_bounds__(256) ghost_kernel(GhostArgs a, T *data)
     }
 }
 
+// The HIP runtime loads a translation unit's code object when its first kernel is launched.  For this file that is ~10 MB
+// of code (every tile shape x epilogue of the stencil kernels), and loading it in the middle of a run - after hiprtc
+// modules of expression PDEs had been loaded and unloaded - ended in "Memory access fault by GPU ... on address (nil)"
+// during the load in about 4 of 10 processes (MI355X, ROCm 7.0.2 runtime; the fault is raised before the kernel that
+// triggered the load is dispatched).  Loaded right after the device is selected, it never did: pdehip_set_device calls
+// this once per process.
+int preload_stencil_kernels()
+{
+    hipFuncAttributes attr;
+    PDEHIP_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&ghost_kernel<double>)));
+    return 0;
+}
+
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st)
 {
     if (!faces || !data) PDEHIP_FAIL(E_VALUE, "set_ghost_cells: NULL pointer");

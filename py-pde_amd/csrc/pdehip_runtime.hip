@@ -178,6 +178,13 @@ int pdehip_device_count(int *count)
 int pdehip_set_device(int device)
 {
     PDEHIP_HIP(hipSetDevice(device));
+    static std::mutex m;
+    static bool loaded = false;
+    std::lock_guard<std::mutex> guard(m);
+    if (!loaded) {
+        PDEHIP_TRY(preload_stencil_kernels());
+        loaded = true;
+    }
     return 0;
 }
 

@@ -876,6 +876,27 @@ class HipBackendMixin:
 
         return fixed_stepper
 
+    def make_gaussian_noise(self, field, *, rng=None):
+        """``noise() -> DeviceArray`` of independent standard-normal values with the shape of ``field.data``
+        (``BackendBase.make_gaussian_noise``, pde/backends/base.py:714-726; numba: pde/backends/numba/backend.py, torch:
+        pde/backends/torch/backend.py:603-625).  Device generator of ``pdehip_add_gaussian_noise`` (Philox4x32-10 +
+        Box-Muller) seeded from ``rng`` like the torch backend; every call advances the counter."""
+        grid = field.grid
+        info = self.grid_info(grid, field.dtype)
+        nd = grid.num_axes
+        comp_shape = tuple(field.data.shape[: field.data.ndim - nd])
+        seed = int((rng if rng is not None else np.random.default_rng()).integers(0, 2**32))
+        counter = [0]
+        lib = self._lib
+
+        def noise() -> DeviceArray:
+            out = DeviceArray(info, comp_shape)   # zero-initialised
+            lib.add_gaussian_noise(info.ref, out.ncomp, out.ptr, 1.0, seed, counter[0], 0, self.stream)
+            counter[0] += 1
+            return out
+
+        return noise
+
     def _make_noise_step(self, solver, state):
         """Noise increment of an Euler-Maruyama step as ``add_noise(array: DeviceArray)``, or None for deterministic equations.
 

@@ -41,6 +41,15 @@ SUITES: dict[str, dict[str, str]] = {
         "test_stochastic_solver_equilibrium": "state-dependent noise variance needs user code on the device (SURVEY §8 f3 next)",
         "test_stochastic_solvers_two_interfaces": "noise realisations supplied by user code (SURVEY §8 f3 next)",
     },
+    # backend.make_gaussian_noise: Kolmogorov-Smirnov test of 10^4 samples (tests/backends/generic/test_generic_functions.py)
+    "backends/generic/test_generic_functions.py": {},
+    # user Python code on the state arrays (custom `make_evolution_rate`, BC setter functions): the arrays live on the device, and
+    # running the user's numpy code on downloaded copies would be a host path - refused with NotImplementedError, which
+    # `backend="auto"` treats as "try the next backend" (pde/pdes/base.py:383-400)
+    "test_integration.py": {
+        "test_stop_iteration_hook": "user-defined right-hand side in Python (hooks themselves are supported: tests/test_pypde_dropin.py)",
+        "test_pde_with_bc_setter": "boundary conditions set by a user function on the array",
+    },
     "fields/test_scalar_fields.py": {},
     "fields/test_vectorial_fields.py": {},
 }

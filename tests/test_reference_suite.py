@@ -80,4 +80,5 @@ def test_reference_generic_tests_with_hip(rel, fused):
     assert not unexpected, f"{rel}: {unexpected}"
     stale = [k for k in expected_fail if any(k in n and r == "PASSED" for n, r in results.items())]
     assert not stale, f"{rel}: listed as 'next' but passing now: {stale}"
-    assert sum(r == "PASSED" for r in results.values()) >= 1
+    if not all(any(k in n for k in expected_fail) for n in results):   # (a file may consist of refused features only)
+        assert sum(r == "PASSED" for r in results.values()) >= 1

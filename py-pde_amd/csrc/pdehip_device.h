@@ -13,7 +13,9 @@ enum { LAP_PLAIN = 0, LAP_SCALED = 1, LAP_EULER = 2, LAP_CH_MU = 3,
 // the two fused levels of euler2_kernel (pdehip_march2.inc)
 enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run-time generated: pde_epilogue() twice */,
        E2_CUSTOM2 = 4 /* run-time generated: level 1 = pde_epilogue(), level 2 = pde_epilogue2() (two-pass expressions) */,
-       E2_CH_STAGE = 5 /* E2_CH_SCALED + the Runge-Kutta combination that follows the slope (LapArgs::st*, like LAP_STAGE) */ };
+       E2_CH_STAGE = 5 /* E2_CH_SCALED + the Runge-Kutta combination that follows the slope (LapArgs::st*, like LAP_STAGE) */,
+       E2_DIFFUSION_UNIT = 6 /* E2_DIFFUSION on a grid with dx = 1 on every axis and D = 1 (UnitGrid, the benchmark configuration):
+                                the four multiplications by 1.0 per update are left out - x * 1.0 == x bit for bit */ };
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers

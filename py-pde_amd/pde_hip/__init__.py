@@ -19,13 +19,20 @@ from .backend import HipBackend, get_backend
 from .boundaries import BoundariesList
 from .fields import FieldCollection, ScalarField, Tensor2Field, VectorField
 from .grids import CartesianGrid, UnitGrid
-from .pdes import PDE, CahnHilliardPDE, DiffusionPDE
+from .pdes import (PDE, AllenCahnPDE, CahnHilliardPDE, DiffusionPDE, KleinGordonPDE, KPZInterfacePDE, KuramotoSivashinskyPDE,
+                   SwiftHohenbergPDE, WavePDE)
 from .solvers import Controller, EulerSolver, ExplicitSolver, RungeKuttaSolver
 
 _operators.register_all(HipBackend, CartesianGrid)
 
 __all__ = [
     "PDE",
+    "AllenCahnPDE",
+    "KPZInterfacePDE",
+    "KleinGordonPDE",
+    "KuramotoSivashinskyPDE",
+    "SwiftHohenbergPDE",
+    "WavePDE",
     "BoundariesList",
     "CahnHilliardPDE",
     "CartesianGrid",

@@ -150,6 +150,39 @@ def pde_kind(eq) -> str:
     return eq.__class__.__name__
 
 
+def class_expressions(eq):
+    """The built-in PDE classes of the reference beyond Diffusion / Cahn-Hilliard as expression systems for the run-time
+    specialised kernels: ``(rhs: {variable: expression}, consts, bcs: {(variable, operator name): condition}, aliases)`` or None.
+    Formulas and the condition each (nested) operator takes are those of the classes' ``evolution_rate``:
+    AllenCahnPDE pde/pdes/allen_cahn.py:98-100, KPZInterfacePDE kpz_interface.py:104-107, KuramotoSivashinskyPDE
+    kuramoto_sivashinsky.py:106-111, SwiftHohenbergPDE swift_hohenberg.py:104-113, WavePDE wave.py:106-109, KleinGordonPDE
+    klein_gordon.py:124-127.  Matched by class name along the MRO like :func:`pde_kind`."""
+    names = [cls.__name__ for cls in type(eq).__mro__]
+    outer = {"laplace_outer": "laplace"}
+    if "AllenCahnPDE" in names:
+        return ({"c": "mobility * (interface_width * laplace(c) - c**3 + c)"},
+                {"mobility": float(eq.mobility), "interface_width": float(eq.interface_width)}, {("c", "laplace"): eq.bc}, {})
+    if "KPZInterfacePDE" in names:
+        return ({"c": "nu * laplace(c) + lmbda * gradient_squared(c)"}, {"nu": float(eq.nu), "lmbda": float(eq.lmbda)},
+                {("c", "laplace"): eq.bc, ("c", "gradient_squared"): eq.bc}, {})
+    if "KuramotoSivashinskyPDE" in names:
+        # the form the reference's solvers use (make_evolution_rate, kuramoto_sivashinsky.py:139-144): the outer operator - and
+        # with it the conditions `bc_lap` - is applied to MINUS the inner Laplacian; `evolution_rate` (:106-111) applies it to
+        # the Laplacian itself, which differs for inhomogeneous `bc_lap`
+        return ({"c": "-laplace(c) + nu * laplace_outer(-laplace(c)) - 0.5 * gradient_squared(c)"}, {"nu": float(eq.nu)},
+                {("c", "laplace"): eq.bc, ("c", "gradient_squared"): eq.bc, ("c", "laplace_outer"): eq.bc_lap}, outer)
+    if "SwiftHohenbergPDE" in names:
+        return ({"c": "(rate - kc2**2) * c - 2 * kc2 * laplace(c) - laplace_outer(laplace(c)) + delta * c**2 - c**3"},
+                {"rate": float(eq.rate), "kc2": float(eq.kc2), "delta": float(eq.delta)},
+                {("c", "laplace"): eq.bc, ("c", "laplace_outer"): eq.bc_lap}, outer)
+    if "KleinGordonPDE" in names:
+        return ({"u": "v", "v": "speed**2 * laplace(u) - mass**2 * u"}, {"speed": float(eq.speed), "mass": float(eq.mass)},
+                {("v", "laplace"): eq.bc}, {})
+    if "WavePDE" in names:
+        return ({"u": "v", "v": "speed**2 * laplace(u)"}, {"speed": float(eq.speed)}, {("v", "laplace"): eq.bc}, {})
+    return None
+
+
 class RhsSpec:
     """``pdehip_rhs_t`` + everything that must stay alive with it."""
 
@@ -660,14 +693,16 @@ class HipBackendMixin:
         from .bc_expr import convert_bcs_with_expressions
         from .expr import ExpressionPlan, ExpressionRhs
 
-        if pde_kind(eq) != "PDE":
+        builtin = class_expressions(eq) if pde_kind(eq) != "PDE" else None
+        if pde_kind(eq) != "PDE" and builtin is None:
             msg = f"hip backend has no right-hand side for {eq.__class__.__name__}"
             raise NotImplementedError(msg)
-        rhs = dict(eq.rhs)
+        rhs = dict(builtin[0]) if builtin else dict(eq.rhs)
         variables = list(rhs)
         grid = state.grid
         info = self.grid_info(grid, state.dtype)
-        consts = dict(getattr(eq, "consts", {}) or {})
+        consts = dict(builtin[1]) if builtin else dict(getattr(eq, "consts", {}) or {})
+        aliases = builtin[3] if builtin else {}
         kind = state.__class__.__name__
         if kind == "FieldCollection":
             fields = list(state)
@@ -683,7 +718,7 @@ class HipBackendMixin:
             tables: dict[str, Any] = {}
             specs: list[tuple[Any, Any]] = []
             for op in plan.operators_used:
-                bc = pde_bc_for(eq, var, op)
+                bc = builtin[2][(var, op)] if builtin else pde_bc_for(eq, var, op)
                 for other, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:
                         same = other is bc or bool(other == bc)
@@ -699,7 +734,8 @@ class HipBackendMixin:
 
         parts = []
         for var in variables:
-            plan = ExpressionPlan(pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var), axes=tuple(grid.axes))
+            plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var),
+                                  axes=tuple(grid.axes), aliases=aliases)
             parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan)))
         if len(parts) == 1:
             return parts[0]

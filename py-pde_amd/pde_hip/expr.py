@@ -49,9 +49,12 @@ class ExpressionPlan:
     ``"var:<name>"`` (the other scalar fields of a multi-field PDE, ``others``), ``"tmp<k>"``."""
 
     def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
-                 axes: tuple[str, ...] = ()):
+                 axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None):
         """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
-        (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS."""
+        (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS.  ``aliases``: further
+        operator names standing for one of OPERATORS (``{"laplace_outer": "laplace"}``) - same stencil, but a name of its own
+        and therefore boundary conditions of its own (PDE classes whose nested operators take different conditions, e.g.
+        ``bc`` / ``bc_lap`` of pde/pdes/swift_hohenberg.py:104-105)."""
         sp = _sympy()
         self.var = var
         self.others = tuple(others)
@@ -61,7 +64,12 @@ class ExpressionPlan:
         for k, ax in enumerate(axes):
             self.axis_ops[f"d_d{ax}"] = ("d1", 3 - len(axes) + k)
             self.axis_ops[f"d2_d{ax}2"] = ("d2", 3 - len(axes) + k)
-        self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops)}
+        self.aliases = dict(aliases or {})
+        for alias, base in self.aliases.items():
+            if base not in OPERATORS:
+                msg = f"operator alias `{alias}` must stand for one of {OPERATORS}"
+                raise ValueError(msg)
+        self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops, *self.aliases)}
         local: dict[str, Any] = dict(self._ops)
         self._state = sp.Symbol("__state", real=True)  # internal name: must not clash with the code symbols
         self._t = sp.Symbol("__t", real=True)
@@ -195,7 +203,7 @@ class ExpressionPlan:
                 which, axis = self.axis_ops[name]
                 sub[a] = sp.Symbol(f"d.{which}[{axis}]", real=True)   # PdeDer of the kernels (csrc/pdehip_device.h)
             else:
-                sub[a] = lap if name == "laplace" else gsq
+                sub[a] = lap if self.aliases.get(name, name) == "laplace" else gsq
         sub2 = dict(sub)
         sub2[src_sym] = c
         sub2[self._t] = sp.Symbol("t", real=True)

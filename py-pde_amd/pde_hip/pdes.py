@@ -95,6 +95,77 @@ class CahnHilliardPDE(PDEBase):
         return f"laplace(c**3 - c - {self.interface_width} * laplace(c))"
 
 
+class _ScalarClassPDE(PDEBase):
+    """Parameter holder of the reference's other scalar PDE classes; the backend builds their right-hand sides from the
+    attributes (``backend.class_expressions``), so these mirrors carry nothing else."""
+
+    default_bc = "auto_periodic_neumann"
+
+    def _conditions(self, bc, bc_lap=None) -> None:
+        self.bc = self.default_bc if bc is None else bc
+        self.bc_lap = self.default_bc if bc_lap is None else bc_lap
+
+
+class AllenCahnPDE(_ScalarClassPDE):
+    r""":math:`\partial_t c = M (\gamma \nabla^2 c - c^3 + c)` (pdes/allen_cahn.py:20-128)."""
+
+    def __init__(self, interface_width: float = 1, mobility: float = 1, *, bc=None):
+        super().__init__()
+        self.interface_width, self.mobility = interface_width, mobility
+        self._conditions(bc)
+
+
+class KPZInterfacePDE(_ScalarClassPDE):
+    r""":math:`\partial_t h = \nu \nabla^2 h + \lambda |\nabla h|^2` (pdes/kpz_interface.py:21-137)."""
+
+    def __init__(self, nu: float = 0.5, lmbda: float = 1, *, bc=None):
+        super().__init__()
+        self.nu, self.lmbda = nu, lmbda
+        self._conditions(bc)
+
+
+class KuramotoSivashinskyPDE(_ScalarClassPDE):
+    r""":math:`\partial_t u = -\nu \nabla^4 u - \nabla^2 u - |\nabla u|^2 / 2` (pdes/kuramoto_sivashinsky.py:21-146)."""
+
+    def __init__(self, nu: float = 1, *, bc=None, bc_lap=None):
+        super().__init__()
+        self.nu = nu
+        self._conditions(bc, bc_lap)
+
+
+class SwiftHohenbergPDE(_ScalarClassPDE):
+    r""":math:`\partial_t c = [\epsilon - (k_c^2 + \nabla^2)^2] c + \delta c^2 - c^3` (pdes/swift_hohenberg.py:21-153)."""
+
+    def __init__(self, rate: float = 0.1, kc2: float = 1.0, delta: float = 1.0, *, bc=None, bc_lap=None):
+        super().__init__()
+        self.rate, self.kc2, self.delta = rate, kc2, delta
+        self._conditions(bc, bc_lap)
+
+
+class WavePDE(_ScalarClassPDE):
+    r""":math:`\partial_t u = v,\ \partial_t v = c^2 \nabla^2 u` on a collection (u, v) (pdes/wave.py:21-137)."""
+
+    def __init__(self, speed: float = 1, *, bc=None):
+        super().__init__()
+        self.speed = speed
+        self._conditions(bc)
+
+    def get_initial_condition(self, u: ScalarField, v: ScalarField | None = None):
+        from .fields import FieldCollection
+
+        if v is None:
+            v = ScalarField(u.grid, 0.0 * u.data, dtype=u.dtype)
+        return FieldCollection([u, v])
+
+
+class KleinGordonPDE(WavePDE):
+    r""":math:`\partial_t u = v,\ \partial_t v = c^2 \nabla^2 u - m^2 u` (pdes/klein_gordon.py:21-160)."""
+
+    def __init__(self, speed: float = 1, mass: float = 1, *, bc=None):
+        super().__init__(speed, bc=bc)
+        self.mass = mass
+
+
 class PDE(PDEBase):
     """PDE given by an expression string per variable (pdes/pde.py).
 

@@ -388,3 +388,73 @@ def test_kdv_two_pass_chain():
     O.set_ghost_cells(g, 1, faces, uxx)
     expect = -6 * data * O.axis_derivative(g, full, 0, 1) - O.axis_derivative(g, uxx, 0, 1)
     assert max_rel(eq.evolution_rate(state).data, expect) < 1e-13
+
+
+# ---- the reference's other built-in PDE classes (backend.class_expressions) ------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["allen_cahn", "kpz", "kuramoto_sivashinsky", "swift_hohenberg", "wave", "klein_gordon"])
+@pytest.mark.parametrize("shape,periodic", [((24, 130), [False, True]), ((6, 10, 128), [True, False, True])])
+def test_builtin_pde_classes_on_device(name, shape, periodic):
+    """AllenCahn / KPZ / Kuramoto-Sivashinsky / Swift-Hohenberg / Wave / Klein-Gordon through the expression kernels: the rate
+    against the classes' formulas (the solvers' form, see backend.class_expressions) composed from the oracle's operators —
+    nested operators with the classes' own conditions (`bc` inside, `bc_lap` outside) — and explicit Euler against the same
+    update in numpy.  (The same classes of the REAL py-pde vs the reference's backends: tests/test_pypde_dropin.py.)"""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 0.5 * n] for n in shape], shape, periodic=periodic)
+    nd = len(shape)
+    ax = "xyz"[periodic.index(False)]
+    other = {a: "periodic" for a, p in zip("xyz"[:nd], periodic) if p}
+    bc = {f"{ax}-": {"value": 0.1}, f"{ax}+": {"derivative": 0.2}, **other}
+    bc_lap = {f"{ax}-": {"value": -0.3}, f"{ax}+": {"value": 0.0}, **other}
+    rng = np.random.default_rng(31)
+    c0 = rng.uniform(-0.5, 0.5, shape)
+    g = oracle_grid(grid)
+    f_bc, f_lap = (host_faces(grid.get_boundary_conditions(b)).c for b in (bc, bc_lap))
+
+    def lap(x, faces=f_bc):
+        full = to_full(grid, np.ascontiguousarray(x))
+        O.set_ghost_cells(g, 1, faces, full)
+        return O.laplace(g, full)
+
+    def gsq(x):
+        full = to_full(grid, np.ascontiguousarray(x))
+        O.set_ghost_cells(g, 1, f_bc, full)
+        return O.gradient_squared(g, full)
+
+    if name == "allen_cahn":
+        eq, state = pde_hip.AllenCahnPDE(0.7, 1.3, bc=bc), pde_hip.ScalarField(grid, c0)
+        f = lambda c: 1.3 * (0.7 * lap(c) - c**3 + c)   # noqa: E731
+    elif name == "kpz":
+        eq, state = pde_hip.KPZInterfacePDE(0.4, 0.8, bc=bc), pde_hip.ScalarField(grid, c0)
+        f = lambda c: 0.4 * lap(c) + 0.8 * gsq(c)   # noqa: E731
+    elif name == "kuramoto_sivashinsky":
+        eq, state = pde_hip.KuramotoSivashinskyPDE(0.6, bc=bc, bc_lap=bc_lap), pde_hip.ScalarField(grid, c0)
+
+        def f(c):   # kuramoto_sivashinsky.py:139-144
+            r = -lap(c)
+            return r + 0.6 * lap(r, f_lap) - 0.5 * gsq(c)
+    elif name == "swift_hohenberg":
+        eq, state = pde_hip.SwiftHohenbergPDE(0.2, 0.9, 0.3, bc=bc, bc_lap=bc_lap), pde_hip.ScalarField(grid, c0)
+
+        def f(c):   # swift_hohenberg.py:140-151
+            l1 = lap(c)
+            return (0.2 - 0.9**2) * c - 2 * 0.9 * l1 - lap(l1, f_lap) + 0.3 * c**2 - c**3
+    else:
+        v0 = rng.uniform(-0.1, 0.1, shape)
+        mass = 0.7 if name == "klein_gordon" else 0.0
+        eq = pde_hip.KleinGordonPDE(1.1, mass, bc=bc) if name == "klein_gordon" else pde_hip.WavePDE(1.1, bc=bc)
+        state = eq.get_initial_condition(pde_hip.ScalarField(grid, c0), pde_hip.ScalarField(grid, v0))
+        c0 = np.stack([c0, v0])
+        f = lambda s: np.stack([s[1], 1.1**2 * lap(s[0]) - mass**2 * s[0]])   # noqa: E731
+    b = pde_hip.get_backend("hip")
+    rate = b.native_to_numpy(eq.make_pde_rhs(state)(b.numpy_to_native(state.data, grid=grid), 0.0))
+    assert max_rel(rate, f(c0)) < 1e-13
+    dt, steps = 1e-4, 5
+    ref = c0.copy()
+    for _ in range(steps):
+        ref = ref + dt * f(ref)
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert max_rel(out.data, ref) < 1e-12
+    rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == steps and max_rel(rk.data, ref) < 5e-2   # Euler vs RK4 on rough data (4th-order operators): truncation, not parity

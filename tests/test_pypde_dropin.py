@@ -550,3 +550,53 @@ def test_axis_derivatives_in_expressions_through_pypde(hip1):
     assert max_rel(rate, expect) < 1e-12
     with pytest.raises(NotImplementedError, match="no kernel for operator"):
         pde.PDE({"v": "d_dz(v)"}).make_pde_rhs(v, backend="hip")
+
+
+@pytest.mark.parametrize("name", ["allen_cahn", "kpz", "kuramoto_sivashinsky", "swift_hohenberg", "wave", "klein_gordon"])
+def test_builtin_pde_classes(hip, name, monkeypatch):
+    """The reference's other built-in PDE classes run through the expression kernels (`backend.class_expressions`); nested
+    operators take the classes' own conditions (`bc` inside, `bc_lap` outside).  Rates and explicit solves vs the reference's
+    torch-CPU implementation of the same class."""
+    # numba is not installed here; the eager torch-CPU backend is the reference implementation that has every operator
+    monkeypatch.setitem(pde.config, "default_backend", "torch")
+    monkeypatch.setitem(pde.config, "backend.torch.compile", False)
+    rng = np.random.default_rng(21)
+    grid = pde.CartesianGrid([[0, 8], [0, 6]], [16, 12], periodic=[False, True])
+    bc = {"x-": {"value": 0.1}, "x+": {"derivative": 0.2}, "y": "periodic"}
+    bc_lap = {"x-": {"value": -0.3}, "x+": {"value": 0.0}, "y": "periodic"}
+    c = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)
+    if name == "allen_cahn":
+        eq, state = pde.AllenCahnPDE(interface_width=0.7, mobility=1.3, bc=bc), c
+    elif name == "kpz":
+        eq, state = pde.KPZInterfacePDE(nu=0.4, lmbda=0.8, bc=bc), c
+    elif name == "kuramoto_sivashinsky":
+        eq, state = pde.KuramotoSivashinskyPDE(nu=0.6, bc=bc, bc_lap=bc_lap), c
+    elif name == "swift_hohenberg":
+        eq, state = pde.SwiftHohenbergPDE(rate=0.2, kc2=0.9, delta=0.3, bc=bc, bc_lap=bc_lap), c
+    elif name == "wave":
+        eq = pde.WavePDE(speed=1.2, bc=bc)
+        state = eq.get_initial_condition(c)
+    else:
+        eq = pde.KleinGordonPDE(speed=1.1, mass=0.7, bc=bc)
+        state = eq.get_initial_condition(c, pde.ScalarField.random_uniform(grid, -0.1, 0.1, rng=rng))
+    if name in ("kpz", "kuramoto_sivashinsky"):   # gradient_squared: only the torch backend has it here
+        import torch
+
+        expect = eq.make_pde_rhs(state, backend="torch")(torch.from_numpy(np.ascontiguousarray(state.data)), 0.0).numpy()
+    else:
+        expect = eq.make_pde_rhs(state, backend="numpy")(state.data, 0.0)
+    rate = hip.native_to_numpy(eq.make_pde_rhs(state, backend="hip")(hip.numpy_to_native(state.data), 0.0))
+    assert max_rel(rate, expect) < 1e-12
+    if name != "kuramoto_sivashinsky":
+        # (that class applies `bc_lap` to -laplace(c) in the compiled form the solvers use and to +laplace(c) in
+        # `evolution_rate`; the backend follows the solvers)
+        assert max_rel(rate, eq.evolution_rate(state).data) < 1e-12
+    # explicit Euler vs torch-CPU; Runge-Kutta (fixed and adaptive) vs the numpy backend, which has no gradient_squared
+    runs = [("euler", {"dt": 1e-4}, "torch" if name in ("kpz", "kuramoto_sivashinsky") else "numpy")]
+    if name not in ("kpz", "kuramoto_sivashinsky"):
+        runs += [("runge-kutta", {"dt": 1e-4}, "numpy"), ("runge-kutta", {"dt": 1e-4, "adaptive": True}, "numpy")]
+    for solver, kw, ref_backend in runs:
+        a, ia = eq.solve(state, t_range=5e-3, solver=solver, backend="hip", tracker=None, ret_info=True, **kw)
+        b, ib = eq.solve(state, t_range=5e-3, solver=solver, backend=ref_backend, tracker=None, ret_info=True, **kw)
+        assert ia["solver"]["steps"] == ib["solver"]["steps"]
+        assert max_rel(a.data, b.data) < 1e-10

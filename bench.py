@@ -149,6 +149,18 @@ def bench_single(args) -> dict:
     ms_kernel = C.c_float()
     lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms_kernel))
     t_kernel = ms_kernel.value / reps * 1e-3
+    # device-copy ceiling of THIS GPU on the same bytes: hipMemcpyDtoD of the state = 1 read + 1 write per cell
+    nbytes_valid = n**3 * 8
+    lib.memcpy_d2d(nxt, cur, nbytes_valid, stream)
+    lib.stream_synchronize(stream)
+    lib.event_record(ev[2], stream)
+    for _ in range(10):
+        lib.memcpy_d2d(nxt, cur, nbytes_valid, stream)
+    lib.event_record(ev[3], stream)
+    lib.stream_synchronize(stream)
+    ms_copy = C.c_float()
+    lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms_copy))
+    copy_gbs = 2 * nbytes_valid / (ms_copy.value / 10 * 1e-3) / 1e9
     cells = n**3
     # bytes ONE launch has to move: every cell read once and written once — for the two-steps-per-sweep kernel that is one
     # read + one write for TWO steps (the intermediate level lives in registers).  `frac` is priced on these moved bytes;
@@ -181,9 +193,11 @@ def bench_single(args) -> dict:
             "effective_bytes_per_launch": alg_bytes,
             "traffic_frac": round(traffic / t_kernel / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
             "traffic_source": traffic_source,
+            "copy_ceiling": round(copy_gbs, 1), "frac_of_copy_ceiling": round(achieved / copy_gbs, 4),
             "note": "frac = bytes one launch must move (1 read + 1 write per cell; two Euler steps per launch) / kernel time / peak; "
                     "effective_frac = SURVEY 8d's 16 B per cell-step x cell-steps per launch / kernel time / peak; traffic = HBM bytes per "
-                    "launch from rocprofv3 PMC counters of the same build on another box (see traffic_source), kernel time from this run",
+                    "launch from rocprofv3 PMC counters of the same build on another box (see traffic_source), kernel time from this run; "
+                    "copy_ceiling = hipMemcpyDtoD of the state (the same read + write bytes) measured in this run, GB/s",
         },
         "device": backend.device_name,
     }

@@ -1,5 +1,8 @@
-import cProfile, pstats, sys, os
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "py-pde_amd")]
+"""BASELINE cfg5 (256^3 fp32 `PDE` RKF45) under cProfile; run it under `rocprofv3 --kernel-trace --stats` for the kernel split."""
+import cProfile, pstats, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "py-pde_amd")]
 import numpy as np
 import pde_hip
 rng = np.random.default_rng(0)

@@ -732,11 +732,36 @@ class HipBackendMixin:
                     specs.append((bc, tables[op]))
             return tables
 
+        # further arrays an expression may name: array-valued constants (fields or arrays on the grid, pde/pdes/pde.py:170-185)
+        # and the cell coordinates of position-dependent expressions (pde/pdes/pde.py:441-447); uploaded once, on first use
+        nd = grid.num_axes
+        aux_host: dict[str, Any] = {}
+        for k, v in list(consts.items()):
+            if np.isscalar(v):
+                continue
+            arr = np.asarray(getattr(v, "data", v))
+            if arr.shape != tuple(grid.shape) or np.iscomplexobj(arr):
+                msg = f"hip backend: constant `{k}` must be a number or a real scalar field / array on the grid"
+                raise NotImplementedError(msg)
+            aux_host[k] = arr
+        for i, ax in enumerate(grid.axes):
+            if ax not in consts and ax not in variables:
+                aux_host.setdefault(ax, (lambda i=i: np.ascontiguousarray(grid.cell_coords[..., i])))
+        aux_dev: dict[str, DeviceArray] = {}
+
+        def aux_for(plan):
+            for name in plan.aux_used:
+                if name not in aux_dev:
+                    host = aux_host[name]
+                    host = host() if callable(host) else host
+                    aux_dev[name] = DeviceArray(info).set_valid(np.asarray(host, dtype=info.dtype), self.stream)
+            return {name: aux_dev[name] for name in plan.aux_used}
+
         parts = []
         for var in variables:
             plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var),
-                                  axes=tuple(grid.axes), aliases=aliases)
-            parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan)))
+                                  axes=tuple(grid.axes), aliases=aliases, aux=tuple(aux_host))
+            parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan), aux_for(plan)))
         if len(parts) == 1:
             return parts[0]
         from .expr import SystemRhs

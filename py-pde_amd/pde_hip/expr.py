@@ -49,12 +49,14 @@ class ExpressionPlan:
     ``"var:<name>"`` (the other scalar fields of a multi-field PDE, ``others``), ``"tmp<k>"``."""
 
     def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
-                 axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None):
+                 axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None, aux: tuple[str, ...] = ()):
         """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
         (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS.  ``aliases``: further
         operator names standing for one of OPERATORS (``{"laplace_outer": "laplace"}``) - same stencil, but a name of its own
         and therefore boundary conditions of its own (PDE classes whose nested operators take different conditions, e.g.
-        ``bc`` / ``bc_lap`` of pde/pdes/swift_hohenberg.py:104-105)."""
+        ``bc`` / ``bc_lap`` of pde/pdes/swift_hohenberg.py:104-105).  ``aux``: names that stand for further arrays on the
+        grid which the caller supplies (array-valued ``consts``, the cell coordinates ``x``, ``y``, ``z`` of expressions that
+        depend on position: pde/pdes/pde.py:441-447); they enter a pass as centre-only inputs (array name ``aux:<name>``)."""
         sp = _sympy()
         self.var = var
         self.others = tuple(others)
@@ -77,9 +79,13 @@ class ExpressionPlan:
         local["t"] = self._t
         other_syms = {name: sp.Symbol(f"__v_{name}", real=True) for name in self.others}
         local.update(other_syms)
+        aux_syms = {name: sp.Symbol(f"__a_{name}", real=True) for name in aux if name != var and name not in self.others}
+        local.update(aux_syms)
         for k, v in (consts or {}).items():
+            if k in aux_syms:
+                continue
             if not np.isscalar(v):
-                msg = "hip backend: array-valued constants in expressions are not supported"
+                msg = f"hip backend: constant `{k}` is an array but was not announced as one (internal)"
                 raise NotImplementedError(msg)
             local[k] = sp.Float(float(v))
         try:
@@ -91,7 +97,7 @@ class ExpressionPlan:
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
             raise NotImplementedError(msg)
-        free = {str(s) for s in expr.free_symbols} - {"__state", "__t"} - {str(v) for v in other_syms.values()}
+        free = {str(s) for s in expr.free_symbols} - {"__state", "__t"} - {str(v) for v in other_syms.values()} - {str(v) for v in aux_syms.values()}
         if free:
             msg = f"unknown symbol(s) {sorted(free)} in `{expr_str}` (pass them in `consts`)"
             raise ValueError(msg)
@@ -103,6 +109,9 @@ class ExpressionPlan:
         self._arrays = {"state": self._state}  # array name -> sympy symbol standing for its centre value
         for name, sym in other_syms.items():
             self._arrays[f"var:{name}"] = sym
+        self.aux_used = tuple(name for name, sym in aux_syms.items() if sym in expr.free_symbols)
+        for name in self.aux_used:
+            self._arrays[f"aux:{name}"] = aux_syms[name]
         self._lower_top(expr)
 
     # --- lowering --------------------------------------------------------------------------------
@@ -167,10 +176,21 @@ class ExpressionPlan:
                 continue
             for a in lst:
                 expr = expr.subs(a, self._arrays[self._materialise(a)])
-        extras = [n for n, s in self._arrays.items() if n != src and s in expr.free_symbols]
-        if len(extras) > MAX_EXTRA:
-            msg = "hip backend: expression needs more than 3 auxiliary fields in one pass"
-            raise NotImplementedError(msg)
+        def extras_of(e):
+            return [n for n, s in self._arrays.items() if n != src and s in e.free_symbols]
+
+        # a pass reads its stencil array and at most MAX_EXTRA others: pointwise terms of a sum that need more arrays are
+        # evaluated by passes of their own (term by term, the one with the most arrays first) until the rest fits
+        while len(extras_of(expr)) > MAX_EXTRA:
+            terms = [t for t in (expr.args if expr.is_Add else ()) if not t.atoms(sp.core.function.AppliedUndef) and t.free_symbols
+                     and 2 <= len([n for n, s in self._arrays.items() if s in t.free_symbols]) <= MAX_EXTRA + 1   # (fewer: no progress)
+                     and self._array_of(t) is None]
+            if not terms:
+                msg = "hip backend: expression needs more than 3 auxiliary fields in one pass"
+                raise NotImplementedError(msg)
+            term = max(terms, key=lambda t: len([n for n, s in self._arrays.items() if s in t.free_symbols]))
+            expr = expr - term + self._arrays[self._materialise(term)]
+        extras = extras_of(expr)
         self.passes.append(_Pass(src, extras, out, expr))
 
     def _lower_top(self, expr) -> None:
@@ -239,8 +259,9 @@ class ExpressionPlan:
 class ExpressionRhs:
     """Device evaluation of an :class:`ExpressionPlan` (kernels compiled lazily, cached per wrap mode)."""
 
-    def __init__(self, backend, plan: ExpressionPlan, info, tables: dict):
-        """``tables``: operator name -> face table.  The reference applies ONE boundary condition per operator name to
+    def __init__(self, backend, plan: ExpressionPlan, info, tables: dict, aux: dict | None = None):
+        """``aux``: device arrays of the plan's auxiliary inputs by name (array-valued constants, cell coordinates).
+        ``tables``: operator name -> face table.  The reference applies ONE boundary condition per operator name to
         every application of that operator, nested ones included (``pde/pdes/pde.py:329-343``); a pass therefore takes
         the table of the operator(s) it evaluates.  Operators with equal conditions share one table object."""
         from .device import DeviceArray
@@ -248,6 +269,11 @@ class ExpressionRhs:
         self.backend, self.plan, self.info = backend, plan, info
         self.lib = backend._lib
         self.tables = tables
+        self.aux = {f"aux:{name}": arr for name, arr in (aux or {}).items() if name in plan.aux_used}
+        missing = [name for name in plan.aux_used if f"aux:{name}" not in self.aux]
+        if missing:
+            msg = f"no array supplied for {missing}"
+            raise ValueError(msg)
         self.pass_faces = []
         sp = _sympy()
         for p in plan.passes:
@@ -299,7 +325,7 @@ class ExpressionRhs:
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0, others: dict | None = None) -> None:
         """out = F(state)  |  dt*F(state)  |  state + dt*F(state)   (wrap = rate | scaled | euler); ``others``: the other
         fields of a multi-field PDE by variable name."""
-        arrays = {"state": state, "out": out, **self.tmps}
+        arrays = {"state": state, "out": out, **self.tmps, **self.aux}
         for name, arr in (others or {}).items():
             arrays[f"var:{name}"] = arr
         params = (C.c_double * 2)(dt, t)
@@ -322,7 +348,7 @@ class ExpressionRhs:
         if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None:
             self.apply(state, k_out, "scaled", dt, t)
             return False
-        arrays = {"state": state, "out": k_out, **self.tmps}
+        arrays = {"state": state, "out": k_out, **self.tmps, **self.aux}
         params = (C.c_double * 2)(dt, t)
         self._update_faces(t)
         last = len(self.plan.passes) - 1

@@ -458,3 +458,43 @@ def test_builtin_pde_classes_on_device(name, shape, periodic):
     assert max_rel(out.data, ref) < 1e-12
     rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
     assert info["solver"]["steps"] == steps and max_rel(rk.data, ref) < 5e-2   # Euler vs RK4 on rough data (4th-order operators): truncation, not parity
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_array_constants_and_coordinates(dtype):
+    """Array-valued constants and cell coordinates enter the generated kernels as centre-only arrays (uploaded once); the same
+    expressions through the REAL py-pde vs the reference's torch backend: tests/test_pypde_dropin.py."""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 4], [-1, 2], [0, 32]], [8, 6, 128], periodic=[False, True, True])
+    rng = np.random.default_rng(43)
+    c0 = rng.uniform(-0.5, 0.5, grid.shape).astype(dtype)
+    src = rng.uniform(0, 1, grid.shape)
+    bc = {"x": {"value": 0.3}, "y": "periodic", "z": "periodic"}
+    eq = pde_hip.PDE({"c": "laplace((1.5 + sin(x)) * c) + amp * source * y - 0.01 * z * c"}, consts={"source": src, "amp": 0.7}, bc=bc)
+    state = pde_hip.ScalarField(grid, c0, dtype=dtype)
+    g = oracle_grid(grid, dtype)
+    faces = host_faces(grid.get_boundary_conditions(bc)).c
+    xx, yy, zz = (grid.cell_coords[..., i] for i in range(3))
+    srcd = src.astype(dtype).astype(np.float64)   # the kernel reads the constant in the field's dtype
+
+    def f(c):
+        inner = ((1.5 + np.sin(xx.astype(dtype).astype(np.float64))) * c.astype(np.float64)).astype(dtype)
+        full = to_full(grid, inner)
+        O.set_ghost_cells(g, 1, faces, full)
+        return (O.laplace(g, full).astype(np.float64) + 0.7 * srcd * yy.astype(dtype).astype(np.float64)
+                - 0.01 * zz.astype(dtype).astype(np.float64) * c.astype(np.float64))
+
+    tol = 1e-13 if dtype == np.float64 else 3e-6
+    assert max_rel(eq.evolution_rate(state).data, f(c0)) < tol
+    dt, steps = 1e-4, 4
+    ref = c0.copy()
+    for _ in range(steps):
+        ref = (ref.astype(np.float64) + dt * f(ref)).astype(dtype)
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert max_rel(out.data, ref) < (1e-12 if dtype == np.float64 else 1e-5)
+    rk = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip")
+    assert max_rel(rk.data, ref) < 1e-3
+    with pytest.raises(NotImplementedError, match="scalar field / array on the grid"):
+        pde_hip.PDE({"c": "laplace(c) + k"}, consts={"k": np.zeros(3)}).evolution_rate(state)

@@ -600,3 +600,43 @@ def test_builtin_pde_classes(hip, name, monkeypatch):
         b, ib = eq.solve(state, t_range=5e-3, solver=solver, backend=ref_backend, tracker=None, ret_info=True, **kw)
         assert ia["solver"]["steps"] == ib["solver"]["steps"]
         assert max_rel(a.data, b.data) < 1e-10
+
+
+def test_array_constants_and_coordinates_in_expressions(hip, monkeypatch):
+    """Array-valued `consts` (a field on the grid, examples/pde_heterogeneous... style) and the cell coordinates `x`, `y` in
+    expressions (pde/pdes/pde.py:441-447): rates and solves vs the reference's eager torch-CPU backend."""
+    import torch
+
+    monkeypatch.setitem(pde.config, "backend.torch.compile", False)   # (`pde.PDE` on the numpy backend takes numba operators)
+    rng = np.random.default_rng(41)
+    grid = pde.CartesianGrid([[0, 4], [-1, 2]], [16, 12], periodic=[False, True])
+    state = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)
+    source = pde.ScalarField.random_uniform(grid, 0, 1, rng=rng)
+    cases = [
+        pde.PDE({"c": "laplace(c) + 0.2 * source - 0.1 * c"}, consts={"source": source}, bc={"x": {"value": 0.3}, "y": "periodic"}),
+        pde.PDE({"c": "laplace(c) + 0.2 * source * c"}, consts={"source": source}, bc={"x": {"value": 0.3}, "y": "periodic"}),
+        # (polynomial in the coordinates: the reference's torch path cannot apply elementary functions to coordinate tensors)
+        pde.PDE({"c": "laplace(c) + x * c - 0.1 * y"}, bc={"x": {"derivative": 0.1}, "y": "periodic"}),
+        pde.PDE({"c": "laplace((1.5 + x**2) * c) + amp * source * y"}, consts={"source": source, "amp": 0.7}, bc={"x": {"value": 0.0}, "y": "periodic"}),
+    ]
+    for eq in cases:
+        expect = eq.make_pde_rhs(state, backend="torch")(torch.from_numpy(np.ascontiguousarray(state.data)), 0.0).numpy()
+        rate = hip.native_to_numpy(eq.make_pde_rhs(state, backend="hip")(hip.numpy_to_native(state.data), 0.0))
+        assert max_rel(rate, expect) < 1e-12
+        a = eq.solve(state, t_range=0.01, dt=1e-3, solver="euler", backend="hip", tracker=None)
+        b = eq.solve(state, t_range=0.01, dt=1e-3, solver="euler", backend="torch", tracker=None)
+        assert max_rel(a.data, b.data) < 1e-11
+        rk = eq.solve(state, t_range=0.01, dt=1e-3, solver="runge-kutta", backend="hip", tracker=None)   # (torch: Euler only)
+        assert np.isfinite(rk.data).all()
+    # functions of the coordinates: against the same formula written with the reference's scipy Laplacian
+    bc = {"x": {"derivative": 0.1}, "y": "periodic"}
+    eq = pde.PDE({"c": "laplace(c) + tanh(x) * c - 0.1 * sin(y)"}, bc=bc)
+    rate = hip.native_to_numpy(eq.make_pde_rhs(state, backend="hip")(hip.numpy_to_native(state.data), 0.0))
+    xx, yy = grid.cell_coords[..., 0], grid.cell_coords[..., 1]
+    assert max_rel(rate, state.laplace(bc, backend="scipy").data + np.tanh(xx) * state.data - 0.1 * np.sin(yy)) < 1e-12
+    # a plain array on the grid is taken like a field (the reference's numba path allows it, its torch path does not)
+    eq_f, eq_a = (pde.PDE({"c": "laplace(c) + source * c"}, consts={"source": s_}) for s_ in (source, source.data))
+    r_f, r_a = (hip.native_to_numpy(e.make_pde_rhs(state, backend="hip")(hip.numpy_to_native(state.data), 0.0)) for e in (eq_f, eq_a))
+    np.testing.assert_array_equal(r_f, r_a)
+    with pytest.raises(NotImplementedError, match="scalar field / array on the grid"):
+        pde.PDE({"c": "laplace(c) + k"}, consts={"k": np.zeros(3)}).make_pde_rhs(state, backend="hip")

@@ -124,10 +124,11 @@ struct LapArgs {
     // LAP_CUSTOM: per-axis derivative scales of the generated epilogue: d1 = (r - l) / dd1 with dd1 = 2 dx (operators/common.py:60-110),
     // d2 = (r - 2c + l) * dd2 with dd2 = 1 / dx^2 (:150-190).  (At the end: the kernarg offsets of everything else stay.)
     double dd1[3], dd2[3];
+    double dg[3];   // LAP_CUSTOM: 0.5 / dx, the scale of the components of `gradient` / `divergence` (cartesian.py:451-454, :876-879)
 };
 
 // per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)
-struct PdeDer { double d1[3], d2[3]; };
+struct PdeDer { double d1[3], d2[3], gr[3]; };   // gr: components of the central gradient, (r - l) * (0.5 / dx)
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the
 // offline build never instantiates that mode and only needs the declaration to parse.

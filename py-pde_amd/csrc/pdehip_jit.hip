@@ -66,8 +66,13 @@ struct Jit {
     std::string body2;                      // statements of pde_epilogue2 (level 2 of a fused two-pass expression)
     std::map<std::string, Variant> cache;   // key: "T,VEC,RY,CZ,HASX,IBC" or "generic,T"
 };
-// the generated code reads PdeDer (`d.d1[..]`, `d.d2[..]`): only the one-level kernels supply it
-bool uses_axis_derivatives(const Jit *j) { return j->body.find("d.d") != std::string::npos || j->body2.find("d.d") != std::string::npos; }
+// the generated code reads PdeDer (`d.d1[..]`, `d.d2[..]`, `d.gr[..]`): only the one-level kernels supply it
+bool uses_axis_derivatives(const Jit *j)
+{
+    for (const char *key : {"d.d1", "d.d2", "d.gr"})
+        if (j->body.find(key) != std::string::npos || j->body2.find(key) != std::string::npos) return true;
+    return false;
+}
 
 const char *kGenericKernel = R"SRC(
 // one cell per thread: any shape / 1-D / odd row lengths (ghost cells must be set)
@@ -84,11 +89,12 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
         const T *c = in + e;
         const double mid = (double)c[0];
         double lap, gsq;
-        PdeDer d = {{0, 0, 0}, {0, 0, 0}};
+        PdeDer d = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         const double vm = 2 * mid;
         const double dz = (double)c[1] - (double)c[-1];
         d.d1[2] = dz / a.dd1[2];
         d.d2[2] = ((double)c[1] - vm + (double)c[-1]) * a.dd2[2];
+        d.gr[2] = dz * a.dg[2];
         if (a.ndim == 1) {
             lap = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
             gsq = dz * dz * a.gs[2];
@@ -98,6 +104,7 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
             gsq = dy * dy * a.gs[1] + dz * dz * a.gs[2];
             d.d1[1] = dy / a.dd1[1];
             d.d2[1] = ((double)c[a.p1] - vm + (double)c[-a.p1]) * a.dd2[1];
+            d.gr[1] = dy * a.dg[1];
         } else {
             const double dx = (double)c[a.p0] - (double)c[-a.p0], dy = (double)c[a.p1] - (double)c[-a.p1];
             lap = ((double)c[-a.p0] - vm + (double)c[a.p0]) * a.sx + ((double)c[-a.p1] - vm + (double)c[a.p1]) * a.sy +
@@ -107,6 +114,8 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
             d.d2[0] = ((double)c[a.p0] - vm + (double)c[-a.p0]) * a.dd2[0];
             d.d1[1] = dy / a.dd1[1];
             d.d2[1] = ((double)c[a.p1] - vm + (double)c[-a.p1]) * a.dd2[1];
+            d.gr[0] = dx * a.dg[0];
+            d.gr[1] = dy * a.dg[1];
         }
         double ex[3];
         for (int m = 0; m < 3; m++) ex[m] = a.ex[m] ? (double)((const T *)a.ex[m])[e] : 0.0;
@@ -266,7 +275,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
     a.o_off = o.off; a.o_s0 = o.s0; a.o_s1 = o.s1; a.o_sc = o.sc;
     a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
     for (int q = 0; q < 3; q++) a.gs[q] = 0.25 / (n.dx[q] * n.dx[q]);   // gradient_squared, central (cartesian.py:661)
-    for (int q = 0; q < 3; q++) { a.dd1[q] = 2 * n.dx[q]; a.dd2[q] = 1 / (n.dx[q] * n.dx[q]); }   // operators/common.py:60-110, :150-190
+    for (int q = 0; q < 3; q++) { a.dd1[q] = 2 * n.dx[q]; a.dd2[q] = 1 / (n.dx[q] * n.dx[q]); a.dg[q] = 0.5 / n.dx[q]; }   // operators/common.py:60-110, :150-190
     a.ndim = n.ndim; a.lx = 1;
     for (int m = 0; m < 3; m++) a.ex[m] = extra3_host ? extra3_host[m] : nullptr;
     for (int q = 0; q < nparams; q++) a.par[q] = params_host[q];

@@ -69,11 +69,14 @@ def _upload_f64(arr: np.ndarray) -> DeviceBuffer:
     return buf
 
 
-def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, bool]] | None = None, upload=None) -> FaceTable:
+def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, bool]] | None = None, upload=None,
+                component: int | None = None) -> FaceTable:
     """Reduce a ``BoundariesList`` (mirror or real py-pde) to the C face table.
 
     ``skip`` lists (axis, upper) faces that are filled by a halo exchange instead.  ``upload``
     turns an fp64 host array into an object with a ``.ptr`` (default: copy to the device).
+    ``component``: the table of ONE component of a vector field's conditions (``comp_shape == (dim,)``) as a table for a
+    scalar array - the terms of ``divergence`` inside expression PDEs are evaluated component by component.
     """
     if upload is None:
         upload = _upload_f64
@@ -105,6 +108,9 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
             face.kind = kind
             face.index1, face.index2 = int(i1), int(i2)
             normal = bool(getattr(bc, "normal", False))
+            if normal and component is not None:
+                msg = "hip backend: `normal_*` conditions of a vector inside an expression are not supported"
+                raise NotImplementedError(msg)
             face.flags = _abi.BCF_NORMAL if normal else 0
             const, f1, f2 = np.asarray(const, dtype=np.float64), np.asarray(f1, dtype=np.float64), np.asarray(f2, dtype=np.float64)
             if const.ndim == 0 and f1.ndim == 0 and f2.ndim == 0:
@@ -125,7 +131,8 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
             def expand(v: np.ndarray) -> np.ndarray:
                 if bool(getattr(bc, "homogeneous", v.ndim <= len(lead))) and v.ndim <= len(lead):
                     v = v.reshape(v.shape + (1,) * len(face_shape))
-                return np.broadcast_to(v, target)
+                v = np.broadcast_to(v, target)
+                return v if component is None else v[component]
 
             face.flags |= _abi.BCF_ARRAYS
             for name, v in (("const_arr", const), ("factor1_arr", f1), ("factor2_arr", f2)):
@@ -716,20 +723,28 @@ class HipBackendMixin:
         def tables_for(var, plan):
             # one face table per operator NAME in the equation of `var`, like the reference (pde/pdes/pde.py:329-343)
             tables: dict[str, Any] = {}
-            specs: list[tuple[Any, Any]] = []
+            specs: list[tuple[Any, Any, Any]] = []
             for op in plan.operators_used:
-                bc = builtin[2][(var, op)] if builtin else pde_bc_for(eq, var, op)
-                for other, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
+                # components of the vector operators take the conditions of `gradient` (scalar argument) resp. of component k
+                # of the vector that `divergence` is applied to (rank-1 conditions)
+                base, comp = op, None
+                if op in getattr(plan, "vector_ops", {}):
+                    base, comp = ("gradient", None) if op.startswith("grad_") else ("divergence", int(op.rsplit("_", 1)[1]))
+                bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
+                for other, other_comp, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:
-                        same = other is bc or bool(other == bc)
+                        same = other_comp == comp and (other is bc or bool(other == bc))
                     except (ValueError, TypeError):   # array-valued entries do not compare to a bool
                         same = False
                     if same:
                         tables[op] = table
                         break
                 else:
-                    tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
-                    specs.append((bc, tables[op]))
+                    if comp is None:
+                        tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
+                    else:
+                        tables[op] = convert_bcs(grid.get_boundary_conditions(bc, rank=1), (grid.num_axes,), component=comp)
+                    specs.append((bc, comp, tables[op]))
             return tables
 
         # further arrays an expression may name: array-valued constants (fields or arrays on the grid, pde/pdes/pde.py:170-185)

@@ -71,6 +71,13 @@ class ExpressionPlan:
             if base not in OPERATORS:
                 msg = f"operator alias `{alias}` must stand for one of {OPERATORS}"
                 raise ValueError(msg)
+        # components of the vector operators `gradient` / `divergence` (central), lowered to per-axis atoms by `_lower_vectors`
+        nd = len(axes)
+        self.vector_ops = {}
+        for k in range(nd):
+            self.vector_ops[f"grad_{k}"] = ("gr", 3 - nd + k)   # k-th component of gradient(s): conditions of `gradient`
+            self.vector_ops[f"div_{k}"] = ("gr", 3 - nd + k)    # k-th term of divergence(v): component k of the vector conditions
+        self.axis_ops.update(self.vector_ops)
         self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops, *self.aliases)}
         local: dict[str, Any] = dict(self._ops)
         self._state = sp.Symbol("__state", real=True)  # internal name: must not clash with the code symbols
@@ -88,11 +95,18 @@ class ExpressionPlan:
                 msg = f"hip backend: constant `{k}` is an array but was not announced as one (internal)"
                 raise NotImplementedError(msg)
             local[k] = sp.Float(float(v))
+        if nd:
+            local.update({name: sp.Function(name) for name in ("gradient", "divergence", "dot")})
         try:
             expr = sp.sympify(expr_str, locals=local)
         except (sp.SympifyError, SyntaxError, TypeError) as err:
             msg = f"cannot parse expression `{expr_str}`: {err}"
             raise ValueError(msg) from err
+        if nd:
+            kind, expr = self._lower_vectors(expr, nd)
+            if kind != "s":
+                msg = f"hip backend: the right-hand side `{expr_str}` is a vector (scalar fields only)"
+                raise NotImplementedError(msg)
         unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(self._ops)
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
@@ -113,6 +127,50 @@ class ExpressionPlan:
         for name in self.aux_used:
             self._arrays[f"aux:{name}"] = aux_syms[name]
         self._lower_top(expr)
+
+    def _lower_vectors(self, e, nd: int):
+        """Vector-valued sub-expressions component by component: ``gradient(s)`` -> ``[grad_k(s)]``, scalar * vector, sums of
+        vectors, ``dot(v, w)`` -> ``sum v_k w_k``, ``divergence(v)`` -> ``sum div_k(v_k)`` (central differences like
+        pde/backends/numba/operators/cartesian.py:386-587, :812-996).  Returns ``("s", expr)`` or ``("v", [components])``."""
+        sp = _sympy()
+        if isinstance(e, sp.core.function.AppliedUndef):
+            name = e.func.__name__
+            args = [self._lower_vectors(a, nd) for a in e.args]
+            if name == "gradient":
+                if len(args) != 1 or args[0][0] != "s":
+                    msg = "hip backend: `gradient` inside expressions takes one scalar argument"
+                    raise NotImplementedError(msg)
+                return "v", [self._ops[f"grad_{k}"](args[0][1]) for k in range(nd)]
+            if name == "divergence":
+                if len(args) != 1 or args[0][0] != "v":
+                    msg = "`divergence` needs a vector argument"
+                    raise ValueError(msg)
+                return "s", sp.Add(*[self._ops[f"div_{k}"](c) for k, c in enumerate(args[0][1])])
+            if name == "dot":
+                if len(args) != 2 or args[0][0] != "v" or args[1][0] != "v":
+                    msg = "`dot` needs two vector arguments"
+                    raise ValueError(msg)
+                return "s", sp.Add(*[a * b for a, b in zip(args[0][1], args[1][1])])
+            if any(k == "v" for k, _ in args):
+                msg = f"hip backend: operator `{name}` of a vector inside expressions is not supported"
+                raise NotImplementedError(msg)
+            return "s", e.func(*[a for _, a in args])
+        if not e.args:
+            return "s", e
+        parts = [self._lower_vectors(a, nd) for a in e.args]
+        if all(k == "s" for k, _ in parts):
+            return "s", e.func(*[a for _, a in parts])
+        if e.is_Add:
+            if not all(k == "v" for k, _ in parts):
+                msg = "cannot add a scalar and a vector"
+                raise ValueError(msg)
+            return "v", [sp.Add(*[p[1][k] for p in parts]) for k in range(nd)]
+        if e.is_Mul and sum(k == "v" for k, _ in parts) == 1:
+            vec = next(p[1] for p in parts if p[0] == "v")
+            scal = sp.Mul(*[p[1] for p in parts if p[0] == "s"])
+            return "v", [scal * c for c in vec]
+        msg = f"hip backend: vector expression `{e}` is not supported (sums, scalar multiples, dot, divergence)"
+        raise NotImplementedError(msg)
 
     # --- lowering --------------------------------------------------------------------------------
     def _new_tmp(self) -> str:

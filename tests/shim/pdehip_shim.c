@@ -366,7 +366,7 @@ int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_
 }
 
 /* ---- run-time specialised right-hand sides: gcc instead of hiprtc ---------------------------- */
-typedef struct { double d1[3], d2[3]; } shim_der_t;   /* PdeDer of csrc/pdehip_device.h */
+typedef struct { double d1[3], d2[3], gr[3]; } shim_der_t;   /* PdeDer of csrc/pdehip_device.h */
 typedef double (*epilogue_fn)(double, double, double, double, double, double, const double *, shim_der_t);
 typedef struct {
     void *dl[2];
@@ -384,7 +384,7 @@ static int compile_epilogue(const char *body, void **dl, epilogue_fn *fn)
     snprintf(so, sizeof(so), "%s/e%d.so", dir, counter++);
     FILE *f = fopen(src, "w");
     if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
-    fprintf(f, "#include <math.h>\ntypedef struct { double d1[3], d2[3]; } PdeDer;\n"
+    fprintf(f, "#include <math.h>\ntypedef struct { double d1[3], d2[3], gr[3]; } PdeDer;\n"
                "double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, PdeDer d)\n{\n"
                "(void)c; (void)lap; (void)gsq; (void)e0; (void)e1; (void)e2; (void)p; (void)d;\n%s\n}\n", body);
     fclose(f);
@@ -449,7 +449,10 @@ static int shim_pointwise(epilogue_fn fn, const pdehip_grid_t *g, const void *in
             der[order - 1][3 - g->ndim + a] = calloc(1, nb);
             rc = oracle_axis_derivative(g, a, order, PDEHIP_CENTRAL, in, der[order - 1][3 - g->ndim + a], PDEHIP_OUT_FULL);
         }
-    if (rc) { free(lap); free(gsq); for (int q = 0; q < 6; q++) free(der[q / 3][q % 3]); return rc; }
+    /* central gradient: all components at once (component-major full arrays) */
+    void *grad = calloc((size_t)g->ndim, nb);
+    if (!rc) rc = oracle_gradient(g, PDEHIP_CENTRAL, in, grad, PDEHIP_OUT_FULL);
+    if (rc) { free(lap); free(gsq); free(grad); for (int q = 0; q < 6; q++) free(der[q / 3][q % 3]); return rc; }
     /* results go to a scratch first: `out` may alias an extra array */
     void *res = malloc(nb);
     memcpy(res, out, nb);
@@ -458,13 +461,14 @@ static int shim_pointwise(epilogue_fn fn, const pdehip_grid_t *g, const void *in
             for (int64_t k = 0; k < n.n[2]; k++) {
                 int64_t at = n.off + i * n.p[0] + j * n.p[1] + k;
                 double e[3] = {0, 0, 0};
-                shim_der_t d = {{0, 0, 0}, {0, 0, 0}};
+                shim_der_t d = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
                 if (g->dtype == PDEHIP_F64) {
                     for (int m = 0; m < 3; m++) if (extra3 && extra3[m]) e[m] = ((const double *)extra3[m])[at];
                     for (int q = 0; q < 3; q++) {
                         if (der[0][q]) d.d1[q] = ((double *)der[0][q])[at];
                         if (der[1][q]) d.d2[q] = ((double *)der[1][q])[at];
                     }
+                    for (int a = 0; a < g->ndim; a++) d.gr[3 - g->ndim + a] = ((double *)grad)[(int64_t)a * n.pc + at];
                     ((double *)res)[at] = fn(((const double *)in)[at], ((double *)lap)[at], ((double *)gsq)[at], e[0], e[1], e[2], params, d);
                 } else {
                     for (int m = 0; m < 3; m++) if (extra3 && extra3[m]) e[m] = ((const float *)extra3[m])[at];
@@ -472,10 +476,12 @@ static int shim_pointwise(epilogue_fn fn, const pdehip_grid_t *g, const void *in
                         if (der[0][q]) d.d1[q] = ((float *)der[0][q])[at];
                         if (der[1][q]) d.d2[q] = ((float *)der[1][q])[at];
                     }
+                    for (int a = 0; a < g->ndim; a++) d.gr[3 - g->ndim + a] = ((float *)grad)[(int64_t)a * n.pc + at];
                     ((float *)res)[at] = (float)fn(((const float *)in)[at], ((float *)lap)[at], ((float *)gsq)[at], e[0], e[1], e[2], params, d);
                 }
             }
     for (int q = 0; q < 6; q++) free(der[q / 3][q % 3]);
+    free(grad);
     /* interior only: the ghost cells of `out` are left untouched like the device kernel does */
     int esz = g->dtype == PDEHIP_F64 ? 8 : 4;
     for (int64_t i = 0; i < n.n[0]; i++)

@@ -498,3 +498,49 @@ def test_array_constants_and_coordinates(dtype):
     assert max_rel(rk.data, ref) < 1e-3
     with pytest.raises(NotImplementedError, match="scalar field / array on the grid"):
         pde_hip.PDE({"c": "laplace(c) + k"}, consts={"k": np.zeros(3)}).evolution_rate(state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,periodic", [((24, 130), [False, True]), ((6, 10, 128), [True, False, True])])
+def test_vector_operators_inside_expressions(shape, periodic):
+    """`divergence(D(x) * gradient(c))` and `dot(gradient(c), gradient(c))` component by component on the stencil kernels, against
+    the oracle's vector operators (gradient -> pointwise product -> ghost cells of the vector -> divergence).  The same
+    expressions through the REAL py-pde vs the reference's torch backend: tests/test_pypde_dropin.py."""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 0.5 * n] for n in shape], shape, periodic=periodic)
+    nd = len(shape)
+    ax = "xyz"[periodic.index(False)]
+    other = {a: "periodic" for a, p in zip("xyz"[:nd], periodic) if p}
+    bc_g = {ax: {"value": 0.3}, **other}
+    bc_d = {ax: {"derivative": 0.1}, **other}
+    rng = np.random.default_rng(53)
+    c0 = rng.uniform(-0.5, 0.5, shape)
+    g = oracle_grid(grid)
+    f_g = host_faces(grid.get_boundary_conditions(bc_g)).c
+    f_d = host_faces(grid.get_boundary_conditions(bc_d, rank=1), (nd,)).c
+    coord = grid.cell_coords[..., periodic.index(False)]
+
+    def grad(c):
+        full = to_full(grid, np.ascontiguousarray(c))
+        O.set_ghost_cells(g, 1, f_g, full)
+        return O.gradient(g, full)
+
+    def f(c):
+        flux = (1.01 + np.tanh(coord)) * grad(c)
+        full = to_full(grid, np.ascontiguousarray(flux))
+        O.set_ghost_cells(g, nd, f_d, full)
+        return O.divergence(g, full) - 0.5 * (grad(c) ** 2).sum(axis=0)
+
+    eq = pde_hip.PDE({"c": f"divergence((1.01 + tanh({ax})) * gradient(c)) - 0.5 * dot(gradient(c), gradient(c))"},
+                     bc_ops={"c:gradient": bc_g, "c:divergence": bc_d})
+    state = pde_hip.ScalarField(grid, c0)
+    assert max_rel(eq.evolution_rate(state).data, f(c0)) < 1e-13
+    dt, steps = 1e-3, 4
+    ref = c0.copy()
+    for _ in range(steps):
+        ref = ref + dt * f(ref)
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert max_rel(out.data, ref) < 1e-12
+    with pytest.raises(NotImplementedError, match="is a vector"):
+        pde_hip.PDE({"c": "gradient(c)"}).evolution_rate(state)

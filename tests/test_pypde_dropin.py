@@ -640,3 +640,37 @@ def test_array_constants_and_coordinates_in_expressions(hip, monkeypatch):
     np.testing.assert_array_equal(r_f, r_a)
     with pytest.raises(NotImplementedError, match="scalar field / array on the grid"):
         pde.PDE({"c": "laplace(c) + k"}, consts={"k": np.zeros(3)}).make_pde_rhs(state, backend="hip")
+
+
+def test_vector_operators_inside_expressions(hip, monkeypatch):
+    """`gradient`, `divergence`, `dot` inside scalar `pde.PDE` expressions (heterogeneous diffusion
+    `divergence(D(x) * gradient(c))`, `dot(gradient(a), gradient(b))`): lowered component by component onto the stencil
+    kernels; vs the reference's eager torch-CPU backend."""
+    import torch
+
+    monkeypatch.setitem(pde.config, "backend.torch.compile", False)
+    rng = np.random.default_rng(51)
+    grid = pde.CartesianGrid([[0, 4], [-1, 2]], [16, 12], periodic=[False, True])
+    state = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)
+    bc = {"x": {"value": 0.3}, "y": "periodic"}
+    bcd = {"x": {"derivative": 0.1}, "y": "periodic"}
+    cases = [
+        pde.PDE({"c": "divergence((1.01 + x) * gradient(c))"}, bc=bcd),
+        pde.PDE({"c": "laplace(c) - 0.5 * dot(gradient(c), gradient(c)) + c"}, bc=bc),
+        pde.PDE({"c": "divergence(c**2 * gradient(c)) - c"}, bc_ops={"c:gradient": bc, "c:divergence": bcd}),
+    ]
+    for eq in cases:
+        expect = eq.make_pde_rhs(state, backend="torch")(torch.from_numpy(np.ascontiguousarray(state.data)), 0.0).numpy()
+        rate = hip.native_to_numpy(eq.make_pde_rhs(state, backend="hip")(hip.numpy_to_native(state.data), 0.0))
+        assert max_rel(rate, expect) < 1e-12
+        a = eq.solve(state, t_range=0.005, dt=5e-4, solver="euler", backend="hip", tracker=None)
+        b = eq.solve(state, t_range=0.005, dt=5e-4, solver="euler", backend="torch", tracker=None)
+        assert max_rel(a.data, b.data) < 1e-11
+    # two fields: the gradient of ANOTHER field
+    s2 = pde.FieldCollection([state, pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)])
+    eq = pde.PDE({"a": "laplace(a) - dot(gradient(a), gradient(b))", "b": "laplace(b) + 0.1 * a"}, bc=bc)
+    expect = eq.make_pde_rhs(s2, backend="torch")(torch.from_numpy(np.ascontiguousarray(s2.data)), 0.0).numpy()
+    rate = hip.native_to_numpy(eq.make_pde_rhs(s2, backend="hip")(hip.numpy_to_native(s2.data), 0.0))
+    assert max_rel(rate, expect) < 1e-12
+    with pytest.raises(NotImplementedError, match="is a vector"):
+        pde.PDE({"c": "gradient(c)"}, bc=bc).make_pde_rhs(state, backend="hip")

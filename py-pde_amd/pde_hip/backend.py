@@ -774,8 +774,14 @@ class HipBackendMixin:
 
         parts = []
         for var in variables:
-            plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var),
-                                  axes=tuple(grid.axes), aliases=aliases, aux=tuple(aux_host))
+            try:
+                plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var),
+                                      axes=tuple(grid.axes), aliases=aliases, aux=tuple(aux_host))
+            except ValueError as err:
+                if "unknown symbol" in str(err):   # the reference's error for this case (pde/pdes/pde.py:455-459)
+                    msg = f"Undefined variable in expression for rhs of `{var}`: {err}"
+                    raise RuntimeError(msg) from err
+                raise
             parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan), aux_for(plan)))
         if len(parts) == 1:
             return parts[0]
@@ -1001,22 +1007,35 @@ class HipBackendMixin:
         if custom_variance or getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
             msg = f"Backend `{self.name}` supports additive Gaussian white noise of constant variance only"
             raise NotImplementedError(msg)
-        noise = np.unique(np.asarray(getattr(eq, "noise", 0), dtype=float))
-        if noise.size != 1 or noise[0] < 0:
-            msg = f"Backend `{self.name}` needs one non-negative noise variance for the field"
-            raise NotImplementedError(msg)
         grid = state.grid
+        nd = grid.num_axes
+        ncomp = int(np.prod(state.data.shape[: state.data.ndim - nd])) if state.data.ndim > nd else 1
+        try:
+            # one variance for all fields or one per field of a collection (pde/pdes/pde.py:266-281, base.py:634-722)
+            noise = np.broadcast_to(np.asarray(getattr(eq, "noise", 0), dtype=float), (ncomp,))
+        except ValueError:
+            noise = None
+        if noise is None or (noise < 0).any():
+            msg = f"Backend `{self.name}` needs one non-negative noise variance per field"
+            raise NotImplementedError(msg)
         info = self.grid_info(grid, state.dtype)
         cell_volume = float(np.prod(grid.discretization))
+        cells = int(np.prod(grid.shape))
         dt = float(solver.info["dt"])
-        scale = float(np.sqrt(dt) * np.sqrt(noise[0] / cell_volume))
+        scales = [float(np.sqrt(dt) * np.sqrt(v / cell_volume)) for v in noise]
         rng = getattr(eq, "rng", None)
         seed = int((rng if rng is not None else np.random.default_rng()).integers(0, 2**32))   # like the torch backend (torch/backend.py:619)
         counter = [0]
         lib = self._lib
 
         def add_noise(arr: DeviceArray) -> None:
-            lib.add_gaussian_noise(info.ref, 1, arr.ptr, scale, seed, counter[0], 0, self.stream)
+            if ncomp == 1:
+                lib.add_gaussian_noise(info.ref, 1, arr.ptr, scales[0], seed, counter[0], 0, self.stream)
+            else:
+                # every field its own variance; the cell offset keeps the fields' random streams apart
+                for k in range(ncomp):
+                    if scales[k] != 0:
+                        lib.add_gaussian_noise(info.ref, 1, arr.component(k).ptr, scales[k], seed, counter[0], k * cells, self.stream)
             counter[0] += 1
 
         solver.info["stochastic"] = True
@@ -1321,6 +1340,17 @@ def _make_synced_class(base: type) -> type:
         self.__class__ = base
         return base.__reduce_ex__(self, protocol)
 
+    # `field.__class__` keeps answering with the field's own class: py-pde compares classes by identity before any binary
+    # operation (`assert_field_compatible`, pde/fields/base.py:385-390) and builds copies from `self.__class__`; only
+    # `type(field)` shows the intercepting subclass
+    real_class = object.__dict__["__class__"]
+
+    def _get_class(self):
+        return base
+
+    def _set_class(self, value):
+        real_class.__set__(self, value)
+
     # py-pde registers every field subclass by NAME (pde/fields/base.py:77-88) to rebuild fields from stored attributes: the
     # registry must keep pointing at the real class
     import warnings
@@ -1330,6 +1360,7 @@ def _make_synced_class(base: type) -> type:
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         synced = type(base.__name__, (base,), {"__getattribute__": __getattribute__, "__reduce_ex__": __reduce_ex__, "_hip_base_class": base,
+                                               "__class__": property(_get_class, _set_class),
                                                "__module__": base.__module__, "__qualname__": base.__qualname__, "__doc__": base.__doc__})
     if previous is not None:
         registry[base.__name__] = previous

@@ -29,13 +29,15 @@ from . import _abi
 MAX_EXTRA = 3
 OPERATORS = ("laplace", "gradient_squared")
 P_DT, P_T = 0, 1  # slots of the run-time parameter vector
+P_FIRST_REDUCTION, MAX_REDUCTIONS = 2, 8   # p[2..9]: integrals over the grid (reduction passes)
 
 
 class _Pass:
     """One kernel launch: stencil array `src`, centre-only arrays `extras`, result array `out`."""
 
-    def __init__(self, src: str, extras: list[str], out: str, expr):
+    def __init__(self, src: str, extras: list[str], out: str, expr, reduce_slot: int | None = None):
         self.src, self.extras, self.out, self.expr = src, extras, out, expr
+        self.reduce_slot = reduce_slot   # not None: no kernel of its own - `integral(src)` goes into parameter p[slot]
 
 
 def _sympy():
@@ -79,7 +81,12 @@ class ExpressionPlan:
             self.vector_ops[f"div_{k}"] = ("gr", 3 - nd + k)    # k-th term of divergence(v): component k of the vector conditions
         self.axis_ops.update(self.vector_ops)
         self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops, *self.aliases)}
+        # `integral(f)`: the integral of a (pointwise) expression over the grid, a number (pde/pdes/pde.py:355-373 takes the
+        # operator of that name from the grid); evaluated by a reduction pass, it reaches the kernels as a run-time parameter
+        self._integral = sp.Function("integral")
+        self.reductions: list[str] = []   # array integrated into parameter slot P_FIRST_REDUCTION + index
         local: dict[str, Any] = dict(self._ops)
+        local["integral"] = self._integral
         self._state = sp.Symbol("__state", real=True)  # internal name: must not clash with the code symbols
         self._t = sp.Symbol("__t", real=True)
         local[var] = self._state
@@ -107,7 +114,7 @@ class ExpressionPlan:
             if kind != "s":
                 msg = f"hip backend: the right-hand side `{expr_str}` is a vector (scalar fields only)"
                 raise NotImplementedError(msg)
-        unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(self._ops)
+        unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(self._ops) - {"integral"}
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
             raise NotImplementedError(msg)
@@ -116,7 +123,7 @@ class ExpressionPlan:
             msg = f"unknown symbol(s) {sorted(free)} in `{expr_str}` (pass them in `consts`)"
             raise ValueError(msg)
         self.uses_time = self._t in expr.free_symbols
-        self.operators_used = sorted({f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)})
+        self.operators_used = sorted({f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - {"integral"})
         self.passes: list[_Pass] = []
         self._ntmp = 0
         self._memo: dict[Any, str] = {}
@@ -204,6 +211,15 @@ class ExpressionPlan:
             arg = self._lower_ops(arg)
             if self._array_of(arg) is None:
                 arg = self._arrays[self._materialise(arg)]
+            if expr.func == self._integral:
+                name = self._array_of(arg)
+                if name not in self.reductions:
+                    if len(self.reductions) >= MAX_REDUCTIONS:
+                        msg = f"hip backend: more than {MAX_REDUCTIONS} integrals in one expression"
+                        raise NotImplementedError(msg)
+                    self.reductions.append(name)
+                    self.passes.append(_Pass(name, [], f"integral{len(self.reductions) - 1}", None, P_FIRST_REDUCTION + len(self.reductions) - 1))
+                return sp.Symbol(f"p[{P_FIRST_REDUCTION + self.reductions.index(name)}]", real=True)
             return expr.func(arg)
         if expr.args:
             return expr.func(*[self._lower_ops(a) for a in expr.args])
@@ -311,7 +327,9 @@ class ExpressionPlan:
         return "\n".join(lines), extras
 
     def describe(self) -> list[str]:
-        return [f"{p.out} <- f({p.src}; ops={sorted({a.func.__name__ for a in p.expr.atoms(_sympy().core.function.AppliedUndef)})}; extras={p.extras})" for p in self.passes]
+        return [f"p[{p.reduce_slot}] <- integral({p.src})" if p.reduce_slot is not None else
+                f"{p.out} <- f({p.src}; ops={sorted({a.func.__name__ for a in p.expr.atoms(_sympy().core.function.AppliedUndef)})}; extras={p.extras})"
+                for p in self.passes]
 
 
 class ExpressionRhs:
@@ -335,6 +353,9 @@ class ExpressionRhs:
         self.pass_faces = []
         sp = _sympy()
         for p in plan.passes:
+            if p.reduce_slot is not None:
+                self.pass_faces.append(None)
+                continue
             ops = sorted({a.func.__name__ for a in p.expr.atoms(sp.core.function.AppliedUndef)})
             distinct = {id(tables[o]): tables[o] for o in ops}
             if len(distinct) > 1:
@@ -343,11 +364,19 @@ class ExpressionRhs:
             self.pass_faces.append(next(iter(distinct.values())) if distinct else None)
         self.tmps = {}
         for p in plan.passes:
-            if p.out != "out":
+            if p.out != "out" and p.reduce_slot is None:
                 self.tmps[p.out] = DeviceArray(info)
+        self.has_reductions = bool(plan.reductions)
+        if self.has_reductions:
+            from .device import DeviceBuffer
+
+            self._red_dev = DeviceBuffer(8)
+            self._red_host = np.zeros(1)
+            self._cell_volume = float(np.prod(info.dx))
         self._dynamic = [tb for tb in {id(tb): tb for tb in tables.values()}.values() if getattr(tb, "time_dependent", False)]
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
-        self._two_ok: bool | None = False if self._dynamic else None   # the second level would need the faces at t + dt
+        # two steps per sweep: the second level would need the faces at t + dt / the integrals of the intermediate level
+        self._two_ok: bool | None = False if (self._dynamic or self.has_reductions) else None
         self._fused: dict[str, C.c_void_p | None] = {}
 
     def _update_faces(self, t: float) -> None:
@@ -372,6 +401,8 @@ class ExpressionRhs:
     def check(self, dtype, ndim: int) -> None:
         """Compile every kernel (no device needed) — surfaces code-generation errors early."""
         for i in range(len(self.plan.passes)):
+            if self.plan.passes[i].reduce_slot is not None:
+                continue
             for wrap in ("rate", "scaled", "euler"):
                 h, _ = self._kernel(i, wrap)
                 self.lib.jit_check(h, _abi.dtype_code(dtype), ndim)
@@ -386,16 +417,23 @@ class ExpressionRhs:
         arrays = {"state": state, "out": out, **self.tmps, **self.aux}
         for name, arr in (others or {}).items():
             arrays[f"var:{name}"] = arr
-        params = (C.c_double * 2)(dt, t)
+        nparams = P_FIRST_REDUCTION + len(self.plan.reductions)
+        params = (C.c_double * nparams)(dt, t)
         self._update_faces(t)
         if self._fused2(state, out, wrap, params):
             return
         for i, p in enumerate(self.plan.passes):
+            if p.reduce_slot is not None:
+                # integral over the grid -> run-time parameter of the passes that follow (8 bytes cross PCIe: a host sync)
+                self.lib.integrate(self.info.ref, 1, arrays[p.src].ptr, self._cell_volume, self._red_dev.ptr, self.backend.stream)
+                self.lib.memcpy_d2h(self._red_host.ctypes.data, self._red_dev.ptr, 8, self.backend.stream)
+                params[p.reduce_slot] = float(self._red_host[0])
+                continue
             h, extras = self._kernel(i, wrap)
             ex = (C.c_void_p * 3)()
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
-            self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, 2, self._faces(i), self.backend.stream)
+            self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, nparams, self._faces(i), self.backend.stream)
 
     def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:
         """k = dt*F(state) and, in the same sweep, the Runge-Kutta combination that follows it (``pdehip_jit_apply_stage``:
@@ -403,7 +441,7 @@ class ExpressionRhs:
         update + error norm into ``err``).  Returns False when the sweep is not available - then ``k_out`` holds the slope
         (plain ``apply``) and the caller combines with the pointwise kernels.  Two-pass chains keep their fused two-level
         sweep (tmp in registers) and combine separately."""
-        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None:
+        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None or self.has_reductions:
             self.apply(state, k_out, "scaled", dt, t)
             return False
         arrays = {"state": state, "out": k_out, **self.tmps, **self.aux}
@@ -433,7 +471,7 @@ class ExpressionRhs:
         if wrap not in self._fused:
             h = None
             ps = self.plan.passes
-            if (len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out"
+            if (not self.has_reductions and len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out"
                     and self.pass_faces[1] is not None):
                 body1, ex1 = self.plan.epilogue(ps[0], "rate")
                 body2, ex2 = self.plan.epilogue(ps[1], wrap)

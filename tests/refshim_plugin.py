@@ -50,6 +50,21 @@ def pytest_configure(config):
         # the reference's default backend is numba; where a generic test computes its yardstick without naming a
         # backend, the reference's scipy operators take its place in this container
         pde.config["default_backend"] = "scipy"
+        # ... and where it names numba explicitly (`pde.PDE` on the numpy backend takes its operators from there,
+        # pde/pdes/pde.py:349-358), the name resolves to the reference's scipy operators as well
+        from pde.backends import backend_registry, get_backend
+
+        backend_registry._backends["numba"] = get_backend("scipy")
+        # ... and `numba.typed.Dict`, the container of the operators' `bc_args` on that path (pde/pdes/pde.py:469-482), is a dict
+        import importlib.machinery
+        import types
+
+        nb, typed = types.ModuleType("numba"), types.ModuleType("numba.typed")
+        nb.__spec__ = importlib.machinery.ModuleSpec("numba", None)
+        typed.__spec__ = importlib.machinery.ModuleSpec("numba.typed", None)
+        typed.Dict = dict
+        nb.typed = typed
+        sys.modules["numba"], sys.modules["numba.typed"] = nb, typed
 
 
 def pytest_unconfigure(config):
@@ -57,6 +72,25 @@ def pytest_unconfigure(config):
     if _shim_ctx is not None:
         _shim_ctx.__exit__(None, None, None)
         _shim_ctx = None
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_make_collect_report(collector):
+    """`tests/pdes/test_pde_class.py` imports numba at module level for ONE numba-only test; the hip-parametrised tests of
+    that file do not touch it.  While such a module is being imported an empty stand-in lets the import succeed when numba is
+    not installed (removed again right away: py-pde must keep seeing numba as absent)."""
+    import importlib.util
+    import types
+
+    stub = False
+    if isinstance(collector, pytest.Module) and "numba" not in sys.modules and importlib.util.find_spec("numba") is None:
+        sys.modules["numba"] = types.ModuleType("numba")
+        stub = True
+    try:
+        yield
+    finally:
+        if stub:
+            sys.modules.pop("numba", None)
 
 
 @pytest.hookimpl(tryfirst=True)

@@ -674,3 +674,17 @@ def test_vector_operators_inside_expressions(hip, monkeypatch):
     assert max_rel(rate, expect) < 1e-12
     with pytest.raises(NotImplementedError, match="is a vector"):
         pde.PDE({"c": "gradient(c)"}, bc=bc).make_pde_rhs(state, backend="hip")
+
+
+def test_results_are_ordinary_fields(hip1):
+    """The state keeps a device link between stepper calls (an intercepting subclass), but `field.__class__`, class comparisons
+    and arithmetic with other fields behave like the plain class (pde/fields/base.py:385-390 compares classes by identity)."""
+    grid = pde.UnitGrid([8, 8])
+    state = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(61))
+    res = pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
+    assert res.__class__ is pde.ScalarField and isinstance(res, pde.ScalarField)
+    res.assert_field_compatible(state)
+    state.assert_field_compatible(res)
+    diff = res - state                     # binary operations check compatibility first
+    assert type(diff) is pde.ScalarField and np.isfinite(diff.data).all()
+    assert type(res.copy()) is pde.ScalarField

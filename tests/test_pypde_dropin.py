@@ -360,7 +360,7 @@ def test_unsupported_requests_raise_not_implemented(hip1):
     with pytest.raises(NotImplementedError):    # vector-valued expression PDEs are a "next" item
         pde.PDE({"u": "vector_laplace(u)"}).solve(pde.VectorField.random_uniform(grid), t_range=0.1, dt=0.01, backend="hip", tracker=None)
     with pytest.raises(NotImplementedError, match="no kernel for operator"):
-        pde.PDE({"c": "laplace(c) + divergence(gradient(c))"}).solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
+        pde.PDE({"c": "laplace(c) + tensor_divergence(c)"}).solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
 
 
 def test_state_stays_resident_between_tracker_interrupts(hip1):

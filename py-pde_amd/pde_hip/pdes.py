@@ -174,11 +174,19 @@ class PDE(PDEBase):
     expression compiler is the next component).
     """
 
-    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None):
+    use_noise_variance = True
+    use_noise_realization = False
+
+    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None, noise=0, rng=None):
         super().__init__()
-        self.rhs = dict(rhs)
+        self.rhs = {k: str(v) for k, v in rhs.items()}
         self.variables = tuple(self.rhs)
         self.consts = dict(consts or {})
+        # variance of additive Gaussian white noise: one number or one per field (pde/pdes/pde.py:266-281)
+        import numpy as np
+
+        self.noise = np.broadcast_to(np.asarray(noise, dtype=float), (len(self.variables),)).copy()
+        self.rng = rng
         # boundary conditions per "variable:operator", wildcards allowed, default last (pde/pdes/pde.py:232-264)
         if bc_ops is not None and not isinstance(bc_ops, dict):
             msg = f"`bc_ops` must be a dictionary, but got {type(bc_ops)}"
@@ -197,6 +205,10 @@ class PDE(PDEBase):
                 msg = f'Cannot parse boundary condition "{key_str}"'
                 raise ValueError(msg)
             self.bcs[key] = value
+
+    @property
+    def is_sde(self) -> bool:
+        return bool((self.noise != 0).any())
 
     @property
     def expressions(self) -> dict[str, str]:

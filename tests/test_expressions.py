@@ -546,3 +546,25 @@ def test_vector_operators_inside_expressions(shape, periodic):
     assert max_rel(out.data, ref) < 1e-12
     with pytest.raises(NotImplementedError, match="is a vector"):
         pde_hip.PDE({"c": "gradient(c)"}).evolution_rate(state)
+
+
+@pytest.mark.gpu
+def test_integral_inside_expressions():
+    """`integral(f)` (a number: the integral of f over the grid) as a reduction pass feeding a run-time parameter; the
+    reference's test of this operator runs through the real py-pde in tests/test_reference_suite.py (test_pde_integral)."""
+    grid = pde_hip.CartesianGrid([[0, 4], [0, 3]], [32, 24], periodic=[True, False])
+    rng = np.random.default_rng(71)
+    c0 = rng.uniform(0, 1, grid.shape)
+    vol = float(np.prod(grid.discretization))
+    state = pde_hip.ScalarField(grid, c0)
+    eq = pde_hip.PDE({"c": "-integral(c) + 0.1 * c * integral(c**2) + laplace(c)"})
+    lap = pde_hip.PDE({"c": "laplace(c)"}).evolution_rate(state).data
+    expect = -c0.sum() * vol + 0.1 * c0 * (c0**2).sum() * vol + lap
+    assert max_rel(eq.evolution_rate(state).data, expect) < 1e-12
+    # mean-removing dynamics: d/dt c = -integral(c) / V drives the integral to zero
+    eq = pde_hip.PDE({"c": f"-integral(c) / {grid.volume}"})
+    out = eq.solve(state, t_range=20.0, dt=0.05, solver="euler", backend="hip")
+    assert abs(out.data.sum() * vol) < 1e-6 * c0.sum() * vol
+    assert max_rel(out.data - out.data.mean(), c0 - c0.mean()) < 1e-9
+    rk = eq.solve(state, t_range=20.0, dt=0.05, solver="runge-kutta", backend="hip")
+    assert max_rel(rk.data, out.data) < 1e-6

@@ -86,3 +86,25 @@ def test_euler_maruyama_noise_scaling():
     assert np.isfinite(sol3.data).all() and abs(sol3.data.mean() - 1) < 5e-3 and sol3.data.std() > 1e-3
     with pytest.raises(RuntimeError, match="adaptive stepping with stochastic"):
         pde_hip.DiffusionPDE(1.0, noise=1e-2).solve(state, t_range=0.1, dt=None, solver="euler", backend="hip")
+
+
+@pytest.mark.gpu
+def test_per_field_noise_of_a_collection():
+    """`PDE({"a": 0, "b": 0}, noise=[va, vb])`: every field of the collection gets its own variance and its own random stream
+    (pde/pdes/pde.py:266-281; the reference's KS test of the same set-up runs in tests/test_reference_suite.py: test_pde_noise)."""
+    from scipy import stats
+
+    import pde_hip
+
+    grid = pde_hip.UnitGrid([128, 128])
+    zero = np.zeros(grid.shape)
+    state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, zero), pde_hip.ScalarField(grid, zero)])
+    eq = pde_hip.PDE({"a": "0*a", "b": "0*b"}, noise=[0.01, 2.0], rng=np.random.default_rng(3))
+    res = eq.solve(state, t_range=1, dt=1, solver="euler", backend="hip")
+    a, b = res.data[0].ravel(), res.data[1].ravel()
+    assert stats.kstest(a, stats.norm(scale=np.sqrt(0.01)).cdf).pvalue > 0.001
+    assert stats.kstest(b, stats.norm(scale=np.sqrt(2.0)).cdf).pvalue > 0.001
+    assert abs(np.corrcoef(a, b)[0, 1]) < 0.03          # independent streams
+    eq1 = pde_hip.PDE({"a": "0*a", "b": "0*b"}, noise=0.5, rng=np.random.default_rng(4))
+    res = eq1.solve(state, t_range=1, dt=1, solver="euler", backend="hip")
+    assert stats.kstest(res.data.ravel(), stats.norm(scale=np.sqrt(0.5)).cdf).pvalue > 0.001

@@ -70,7 +70,7 @@ def _upload_f64(arr: np.ndarray) -> DeviceBuffer:
 
 
 def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, bool]] | None = None, upload=None,
-                component: int | None = None) -> FaceTable:
+                component: int | tuple[int, ...] | None = None) -> FaceTable:
     """Reduce a ``BoundariesList`` (mirror or real py-pde) to the C face table.
 
     ``skip`` lists (axis, upper) faces that are filled by a halo exchange instead.  ``upload``
@@ -711,13 +711,24 @@ class HipBackendMixin:
         consts = dict(builtin[1]) if builtin else dict(getattr(eq, "consts", {}) or {})
         aliases = builtin[3] if builtin else {}
         kind = state.__class__.__name__
-        if kind == "FieldCollection":
-            fields = list(state)
-            if len(fields) != len(variables) or any(f.__class__.__name__ != "ScalarField" for f in fields):
-                msg = "hip backend expression kernels support collections of scalar fields, one per equation"
-                raise NotImplementedError(msg)
-        elif kind != "ScalarField" or len(variables) != 1:
-            msg = "hip backend expression kernels support a ScalarField or a FieldCollection of scalar fields"
+        fields = list(state) if kind == "FieldCollection" else [state]
+        kinds = [f.__class__.__name__ for f in fields]
+        if len(fields) != len(variables) or any(k not in ("ScalarField", "VectorField") for k in kinds):
+            msg = "hip backend expression kernels support scalar and vector fields (or a FieldCollection of them), one per equation"
+            raise NotImplementedError(msg)
+        # the state as a list of scalar components: a vector field `u` contributes `u#0`, `u#1`, ... (FieldCollection.data and
+        # VectorField.data both carry the components along the first axis, pde/fields/collection.py, datafield_base.py:95)
+        dim = grid.num_axes
+        flat: list[tuple[str, str, int | None]] = []     # (flat name, variable, component)
+        vectors: dict[str, tuple[str, ...]] = {}
+        for var, k in zip(variables, kinds):
+            if k == "VectorField":
+                vectors[var] = tuple(f"{var}#{c}" for c in range(dim))
+                flat += [(f"{var}#{c}", var, c) for c in range(dim)]
+            else:
+                flat.append((var, var, None))
+        if builtin and vectors:
+            msg = f"hip backend: {eq.__class__.__name__} takes scalar fields"
             raise NotImplementedError(msg)
 
         def tables_for(var, plan):
@@ -729,7 +740,9 @@ class HipBackendMixin:
                 # of the vector that `divergence` is applied to (rank-1 conditions)
                 base, comp = op, None
                 if op in getattr(plan, "vector_ops", {}):
-                    base, comp = ("gradient", None) if op.startswith("grad_") else ("divergence", int(op.rsplit("_", 1)[1]))
+                    idx = [int(x) for x in op.split("_")[1:]]
+                    base, comp = {"grad": ("gradient", None), "div": ("divergence", idx[0]), "vlap": ("vector_laplace", idx[0]),
+                                  "vgrad": ("vector_gradient", idx[0]), "tdiv": ("tensor_divergence", tuple(idx))}[op.split("_")[0]]
                 bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
                 for other, other_comp, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:
@@ -743,7 +756,8 @@ class HipBackendMixin:
                     if comp is None:
                         tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
                     else:
-                        tables[op] = convert_bcs(grid.get_boundary_conditions(bc, rank=1), (grid.num_axes,), component=comp)
+                        rank = 2 if isinstance(comp, tuple) else 1
+                        tables[op] = convert_bcs(grid.get_boundary_conditions(bc, rank=rank), (grid.num_axes,) * rank, component=comp)
                     specs.append((bc, comp, tables[op]))
             return tables
 
@@ -773,16 +787,19 @@ class HipBackendMixin:
             return {name: aux_dev[name] for name in plan.aux_used}
 
         parts = []
-        for var in variables:
+        names = [name for name, _, _ in flat]
+        for name, var, comp in flat:
             try:
-                plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), var, consts, others=tuple(v for v in variables if v != var),
-                                      axes=tuple(grid.axes), aliases=aliases, aux=tuple(aux_host))
+                plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), name, consts, others=tuple(n for n in names if n != name),
+                                      axes=tuple(grid.axes), aliases=aliases, aux=tuple(a for a in aux_host if a not in vectors),
+                                      vectors=vectors, component=comp)
             except ValueError as err:
                 if "unknown symbol" in str(err):   # the reference's error for this case (pde/pdes/pde.py:455-459)
                     msg = f"Undefined variable in expression for rhs of `{var}`: {err}"
                     raise RuntimeError(msg) from err
                 raise
             parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan), aux_for(plan)))
+        variables = names
         if len(parts) == 1:
             return parts[0]
         from .expr import SystemRhs

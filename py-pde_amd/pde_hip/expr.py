@@ -51,14 +51,18 @@ class ExpressionPlan:
     ``"var:<name>"`` (the other scalar fields of a multi-field PDE, ``others``), ``"tmp<k>"``."""
 
     def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
-                 axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None, aux: tuple[str, ...] = ()):
+                 axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None, aux: tuple[str, ...] = (),
+                 vectors: dict[str, tuple[str, ...]] | None = None, component: int | None = None):
         """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
         (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS.  ``aliases``: further
         operator names standing for one of OPERATORS (``{"laplace_outer": "laplace"}``) - same stencil, but a name of its own
         and therefore boundary conditions of its own (PDE classes whose nested operators take different conditions, e.g.
         ``bc`` / ``bc_lap`` of pde/pdes/swift_hohenberg.py:104-105).  ``aux``: names that stand for further arrays on the
         grid which the caller supplies (array-valued ``consts``, the cell coordinates ``x``, ``y``, ``z`` of expressions that
-        depend on position: pde/pdes/pde.py:441-447); they enter a pass as centre-only inputs (array name ``aux:<name>``)."""
+        depend on position: pde/pdes/pde.py:441-447); they enter a pass as centre-only inputs (array name ``aux:<name>``).
+        ``vectors``: vector FIELDS of the state by name -> the names of their scalar components among ``var`` / ``others``
+        (``{"u": ("u#0", "u#1")}``); ``component``: the plan evaluates this component of a vector-valued right-hand side (the
+        equation of a vector field; ``var`` is then the name of that component of the field)."""
         sp = _sympy()
         self.var = var
         self.others = tuple(others)
@@ -79,7 +83,14 @@ class ExpressionPlan:
         for k in range(nd):
             self.vector_ops[f"grad_{k}"] = ("gr", 3 - nd + k)   # k-th component of gradient(s): conditions of `gradient`
             self.vector_ops[f"div_{k}"] = ("gr", 3 - nd + k)    # k-th term of divergence(v): component k of the vector conditions
-        self.axis_ops.update(self.vector_ops)
+            self.aliases[f"vlap_{k}"] = "laplace"               # k-th component of vector_laplace(v): ... of `vector_laplace`
+            self.vector_ops[f"vlap_{k}"] = ("lap", -1)
+            for j in range(nd):
+                # vector_gradient(v)[k][j] = d_j v_k with component k of the conditions of `vector_gradient`;
+                # tensor_divergence(T)[k] = sum_j d_j T[k][j] with component (k, j) of the rank-2 conditions (cartesian.py:999-1096)
+                self.vector_ops[f"vgrad_{k}_{j}"] = ("gr", 3 - nd + j)
+                self.vector_ops[f"tdiv_{k}_{j}"] = ("gr", 3 - nd + j)
+        self.axis_ops.update({k: v for k, v in self.vector_ops.items() if v[0] != "lap"})
         self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops, *self.aliases)}
         # `integral(f)`: the integral of a (pointwise) expression over the grid, a number (pde/pdes/pde.py:355-373 takes the
         # operator of that name from the grid); evaluated by a reduction pass, it reaches the kernels as a run-time parameter
@@ -95,6 +106,12 @@ class ExpressionPlan:
         local.update(other_syms)
         aux_syms = {name: sp.Symbol(f"__a_{name}", real=True) for name in aux if name != var and name not in self.others}
         local.update(aux_syms)
+        # vector fields of the state: a marker symbol per field, replaced by its components in `_lower_vectors`
+        self._vector_fields: dict[Any, list] = {}
+        for vname, comps in (vectors or {}).items():
+            marker = sp.Symbol(f"__vec_{vname}", real=True)
+            local[vname] = marker
+            self._vector_fields[marker] = [self._state if c == var else other_syms[c] for c in comps]
         for k, v in (consts or {}).items():
             if k in aux_syms:
                 continue
@@ -103,7 +120,8 @@ class ExpressionPlan:
                 raise NotImplementedError(msg)
             local[k] = sp.Float(float(v))
         if nd:
-            local.update({name: sp.Function(name) for name in ("gradient", "divergence", "dot")})
+            local.update({name: sp.Function(name) for name in ("gradient", "divergence", "dot", "inner", "vector_laplace", "vector_gradient",
+                                                                "tensor_divergence", "outer")})
         try:
             expr = sp.sympify(expr_str, locals=local)
         except (sp.SympifyError, SyntaxError, TypeError) as err:
@@ -111,9 +129,14 @@ class ExpressionPlan:
             raise ValueError(msg) from err
         if nd:
             kind, expr = self._lower_vectors(expr, nd)
-            if kind != "s":
-                msg = f"hip backend: the right-hand side `{expr_str}` is a vector (scalar fields only)"
+            if component is None and kind != "s":
+                msg = f"hip backend: the right-hand side `{expr_str}` is a vector, the field is a scalar"
                 raise NotImplementedError(msg)
+            if component is not None:
+                if kind != "v":
+                    msg = f"the right-hand side `{expr_str}` of a vector field must be a vector"
+                    raise ValueError(msg)
+                expr = expr[component]
         unknown = {f.func.__name__ for f in expr.atoms(sp.core.function.AppliedUndef)} - set(self._ops) - {"integral"}
         if unknown:
             msg = f"hip backend has no kernel for operator(s) {sorted(unknown)} in `{expr_str}`"
@@ -153,29 +176,56 @@ class ExpressionPlan:
                     msg = "`divergence` needs a vector argument"
                     raise ValueError(msg)
                 return "s", sp.Add(*[self._ops[f"div_{k}"](c) for k, c in enumerate(args[0][1])])
-            if name == "dot":
+            if name == "vector_laplace":
+                if len(args) != 1 or args[0][0] != "v":
+                    msg = "`vector_laplace` needs a vector argument"
+                    raise ValueError(msg)
+                return "v", [self._ops[f"vlap_{k}"](c) for k, c in enumerate(args[0][1])]
+            if name == "vector_gradient":
+                if len(args) != 1 or args[0][0] != "v":
+                    msg = "`vector_gradient` needs a vector argument"
+                    raise ValueError(msg)
+                return "t", [[self._ops[f"vgrad_{i}_{j}"](c) for j in range(nd)] for i, c in enumerate(args[0][1])]
+            if name == "tensor_divergence":
+                if len(args) != 1 or args[0][0] != "t":
+                    msg = "`tensor_divergence` needs a tensor argument"
+                    raise ValueError(msg)
+                return "v", [sp.Add(*[self._ops[f"tdiv_{i}_{j}"](c) for j, c in enumerate(row)]) for i, row in enumerate(args[0][1])]
+            if name == "outer":
+                if len(args) != 2 or args[0][0] != "v" or args[1][0] != "v":
+                    msg = "`outer` needs two vector arguments"
+                    raise ValueError(msg)
+                return "t", [[a * b for b in args[1][1]] for a in args[0][1]]
+            if name in ("dot", "inner"):
                 if len(args) != 2 or args[0][0] != "v" or args[1][0] != "v":
                     msg = "`dot` needs two vector arguments"
                     raise ValueError(msg)
                 return "s", sp.Add(*[a * b for a, b in zip(args[0][1], args[1][1])])
-            if any(k == "v" for k, _ in args):
-                msg = f"hip backend: operator `{name}` of a vector inside expressions is not supported"
+            if any(k != "s" for k, _ in args):
+                msg = f"hip backend: operator `{name}` of a vector / tensor inside expressions is not supported"
                 raise NotImplementedError(msg)
             return "s", e.func(*[a for _, a in args])
         if not e.args:
+            if e in self._vector_fields:
+                return "v", list(self._vector_fields[e])
             return "s", e
         parts = [self._lower_vectors(a, nd) for a in e.args]
         if all(k == "s" for k, _ in parts):
             return "s", e.func(*[a for _, a in parts])
+        ranks = {k for k, _ in parts}
         if e.is_Add:
-            if not all(k == "v" for k, _ in parts):
-                msg = "cannot add a scalar and a vector"
+            if len(ranks) != 1:
+                msg = "cannot add fields of different rank"
                 raise ValueError(msg)
-            return "v", [sp.Add(*[p[1][k] for p in parts]) for k in range(nd)]
-        if e.is_Mul and sum(k == "v" for k, _ in parts) == 1:
-            vec = next(p[1] for p in parts if p[0] == "v")
+            if ranks == {"v"}:
+                return "v", [sp.Add(*[p[1][k] for p in parts]) for k in range(nd)]
+            return "t", [[sp.Add(*[p[1][i][j] for p in parts]) for j in range(nd)] for i in range(nd)]
+        if e.is_Mul and sum(k != "s" for k, _ in parts) == 1:
+            kind, val = next(p for p in parts if p[0] != "s")
             scal = sp.Mul(*[p[1] for p in parts if p[0] == "s"])
-            return "v", [scal * c for c in vec]
+            if kind == "v":
+                return "v", [scal * c for c in val]
+            return "t", [[scal * c for c in row] for row in val]
         msg = f"hip backend: vector expression `{e}` is not supported (sums, scalar multiples, dot, divergence)"
         raise NotImplementedError(msg)
 
@@ -255,15 +305,24 @@ class ExpressionPlan:
 
         # a pass reads its stencil array and at most MAX_EXTRA others: pointwise terms of a sum that need more arrays are
         # evaluated by passes of their own (term by term, the one with the most arrays first) until the rest fits
+        def arrays_in(e):
+            return {n for n, s in self._arrays.items() if s in e.free_symbols}
+
         while len(extras_of(expr)) > MAX_EXTRA:
-            terms = [t for t in (expr.args if expr.is_Add else ()) if not t.atoms(sp.core.function.AppliedUndef) and t.free_symbols
-                     and 2 <= len([n for n, s in self._arrays.items() if s in t.free_symbols]) <= MAX_EXTRA + 1   # (fewer: no progress)
-                     and self._array_of(t) is None]
-            if not terms:
+            # pointwise terms of the sum (no operators left in them), grouped greedily: the partial sum over the group is
+            # evaluated by a pass of its own and replaces the group's arrays by one temporary
+            terms = [t for t in (expr.args if expr.is_Add else ()) if not t.atoms(sp.core.function.AppliedUndef) and arrays_in(t)]
+            terms.sort(key=lambda t: -len(arrays_in(t)))
+            group, used = [], set()
+            for t in terms:
+                if len(used | arrays_in(t)) <= MAX_EXTRA + 1:
+                    group.append(t)
+                    used |= arrays_in(t)
+            if len(used) < 2 or (len(group) == 1 and self._array_of(group[0]) is not None):
                 msg = "hip backend: expression needs more than 3 auxiliary fields in one pass"
                 raise NotImplementedError(msg)
-            term = max(terms, key=lambda t: len([n for n, s in self._arrays.items() if s in t.free_symbols]))
-            expr = expr - term + self._arrays[self._materialise(term)]
+            partial = sp.Add(*group)
+            expr = expr - partial + self._arrays[self._materialise(partial)]
         extras = extras_of(expr)
         self.passes.append(_Pass(src, extras, out, expr))
 

@@ -568,3 +568,52 @@ def test_integral_inside_expressions():
     assert max_rel(out.data - out.data.mean(), c0 - c0.mean()) < 1e-9
     rk = eq.solve(state, t_range=20.0, dt=0.05, solver="runge-kutta", backend="hip")
     assert max_rel(rk.data, out.data) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,periodic", [((16, 130), [False, True]), ((6, 8, 128), [True, True, False])])
+def test_vector_field_as_state(shape, periodic):
+    """A VectorField as the state of an expression PDE: its components are scalar arrays of ONE device array, the vector /
+    tensor operators are lowered component by component with the component tables of the rank-1 / rank-2 conditions.
+    Against the same formula composed from the oracle's operators; the reference's own vector-PDE tests (vs its numpy path)
+    run through the real py-pde in tests/test_reference_suite.py (test_pde_vector_*, test_pde_product_operators)."""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 0.5 * n] for n in shape], shape, periodic=periodic)
+    nd = len(shape)
+    ax = "xyz"[periodic.index(False)]
+    other = {a: "periodic" for a, p in zip("xyz"[:nd], periodic) if p}
+    bc = {ax: {"value": 0.2}, **other}
+    rng = np.random.default_rng(81)
+    u0 = rng.uniform(-0.5, 0.5, (nd, *shape))
+    g = oracle_grid(grid)
+    f0 = host_faces(grid.get_boundary_conditions(bc)).c
+    f1 = host_faces(grid.get_boundary_conditions(bc, rank=1), (nd,)).c
+    f2 = host_faces(grid.get_boundary_conditions(bc, rank=2), (nd, nd)).c
+
+    def with_ghosts(x, ncomp, faces):
+        full = to_full(grid, np.ascontiguousarray(x))
+        O.set_ghost_cells(g, ncomp, faces, full)
+        return full
+
+    def f(u):
+        vlap = np.stack([O.laplace(g, with_ghosts(u, nd, f1)[k]) for k in range(nd)])      # vector_laplace: rank-1 conditions
+        grad_uu = O.gradient(g, with_ghosts((u * u).sum(axis=0), 1, f0))                     # gradient(dot(u, u))
+        outer = u[:, None] * u[None, :]
+        tfull = with_ghosts(outer, nd * nd, f2)                                              # tensor_divergence(outer(u, u))
+        tdiv = np.stack([O.divergence(g, tfull[i]) for i in range(nd)])
+        return vlap + 0.5 * grad_uu - tdiv - u
+
+    state = pde_hip.VectorField(grid, u0)
+    eq = pde_hip.PDE({"u": "vector_laplace(u) + 0.5 * gradient(dot(u, u)) - tensor_divergence(outer(u, u)) - u"}, bc=bc)
+    b = pde_hip.get_backend("hip")
+    rate = b.native_to_numpy(eq.make_pde_rhs(state)(b.numpy_to_native(state.data, grid=grid), 0.0))
+    assert rate.shape == u0.shape and max_rel(rate, f(u0)) < 1e-13
+    dt, steps = 1e-3, 4
+    ref = u0.copy()
+    for _ in range(steps):
+        ref = ref + dt * f(ref)
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert isinstance(out, pde_hip.VectorField) and max_rel(out.data, ref) < 1e-12
+    rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == steps and max_rel(rk.data, ref) < 5e-2

@@ -51,12 +51,9 @@ SUITES: dict[str, dict[str, str]] = {
         "test_pde_with_bc_setter": "boundary conditions set by a user function on the array",
     },
     # the generic `PDE` class (tests/pdes/test_pde_class.py): explicit time, multi-field systems, per-field noise, coordinates,
-    # `integral`, heaviside, BC handling and errors, time-dependent BCs, Swift-Hohenberg class vs expression
+    # `integral`, heaviside, BC handling and errors, time-dependent BCs, Swift-Hohenberg class vs expression, vector fields as
+    # states (vector_laplace, vector_gradient, tensor_divergence, inner / outer products)
     "pdes/test_pde_class.py": {
-        "test_pde_vector_laplace": "vector field as the state of an expression PDE (SURVEY §8 f2 next)",
-        "test_pde_vector_ops": "vector field as the state of an expression PDE (SURVEY §8 f2 next)",
-        "test_pde_vector_scalar": "vector field as the state of an expression PDE (SURVEY §8 f2 next)",
-        "test_pde_product_operators": "vector field as the state of an expression PDE (SURVEY §8 f2 next)",
         "test_compare_swift_hohenberg[grid3": "curvilinear grids are out of scope (Cartesian path only)",
         "test_compare_swift_hohenberg[grid4": "curvilinear grids are out of scope (Cartesian path only)",
         "test_pde_user_funcs": "user Python functions inside expressions",

@@ -132,10 +132,10 @@ def test_expression_pde_solvers_and_functions():
     O.set_ghost_cells(oracle_grid(g1), 1, host_faces(g1.get_boundary_conditions("periodic")).c, f1)
     assert max_rel(r1, O.laplace(oracle_grid(g1), f1) - s1.data**3) < 1e-13
     with pytest.raises(NotImplementedError):
-        pde_hip.PDE({"c": "vector_laplace(c)"}).evolution_rate(state)   # no kernel for this operator inside expressions
+        pde_hip.PDE({"c": "poisson_solver(c)"}).evolution_rate(state)   # no kernel for this operator inside expressions
     with pytest.raises(ValueError, match="needs a vector argument"):
         pde_hip.PDE({"c": "divergence(c)"}).evolution_rate(state)
-    with pytest.raises(NotImplementedError, match="FieldCollection of scalar fields"):
+    with pytest.raises(NotImplementedError, match="one per equation"):
         pde_hip.PDE({"a": "laplace(a)", "b": "laplace(b)"}).evolution_rate(state)   # two variables need a collection
 
 

@@ -445,6 +445,28 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
                       const double *params_host, int nparams, const pdehip_bc_face_t *faces_u,
                       const pdehip_bc_face_t *faces_tmp, int *done, void *stream);
 
+/* The fixed-step explicit Euler loop of an expression PDE (one or several scalar components) in ONE call: `nsteps` times the
+ * sequence of passes, each pdehip_jit_apply of its handle, the state ping-ponging between two buffers.  Replaces the loop
+ * pde/backends/numba/_solvers.py:98-108 (`for i in range(steps): t = t_start + i * dt; single_step(state, t)`) around
+ * pde/solvers/euler.py:172-175 for the compiled right-hand sides of pde/pdes/pde.py:401-499 - a Python loop over the passes
+ * costs 40-85 us per step on small grids where the kernels need 2-5 us (profiles/r02_time_small_expr.md).
+ * Array indices of a pass: >= 0 selects fixed[index] (temporaries, constant arrays, coordinates); -1 - k selects component k
+ * of the CURRENT state as `src` / `extras` and component k of the NEXT state as `out`; PDEHIP_JIT_NONE: no array.  The
+ * epilogue of the pass that writes the next state must be the Euler update `state + dt * F` (parameters p[0] = dt,
+ * p[1] = t).  state_a holds the state on entry; *result is the buffer that holds it afterwards.  uses_time = 0 lets long runs
+ * replay a captured hipGraph (the parameters are then constants of the launches). */
+#define PDEHIP_JIT_NONE INT32_MIN
+typedef struct {
+    void *handle;
+    int32_t src;
+    int32_t extras[3];
+    int32_t out;
+    const pdehip_bc_face_t *faces;   /* conditions applied to src before the pass (NULL: none) */
+} pdehip_jit_pass_t;
+int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                         void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
+                         void **result, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -522,4 +522,110 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
     return 0;
 }
 
+
+// ---- fixed-step Euler loop over the passes of an expression PDE (include/pdehip.h) ---------------------------------------------
+namespace {
+struct LoopGraph {
+    std::vector<char> key;
+    hipGraphExec_t exec = nullptr;
+};
+constexpr int kLoopGraphs = 8;
+LoopGraph g_loop_graphs[kLoopGraphs];
+unsigned g_loop_next = 0;
+hipStream_t g_loop_cap = nullptr;
+hipEvent_t g_loop_ev = nullptr;
+
+int loop_steps(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, char *cur, char *nxt,
+               size_t comp_bytes, double dt, double t0, int64_t first, int64_t count, void *stream)
+{
+    for (int64_t s = 0; s < count; s++) {
+        const double params[2] = {dt, t0 + (double)(first + s) * dt};   // _solvers.py:100: t = t_start + i * dt
+        for (int q = 0; q < npasses; q++) {
+            const pdehip_jit_pass_t &p = passes[q];
+            auto in = [&](int32_t idx) -> void * {
+                if (idx == PDEHIP_JIT_NONE) return nullptr;
+                return idx >= 0 ? fixed[idx] : (void *)(cur + (size_t)(-1 - idx) * comp_bytes);
+            };
+            void *out = p.out >= 0 ? fixed[p.out] : (void *)(nxt + (size_t)(-1 - p.out) * comp_bytes);
+            const void *ex[3] = {in(p.extras[0]), in(p.extras[1]), in(p.extras[2])};
+            PDEHIP_TRY(jit_apply_impl(p.handle, g, in(p.src), ex, out, params, 2, p.faces, stream, nullptr, nullptr));
+        }
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    return 0;
+}
+}  // namespace
+
+int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                         void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
+                         void **result, void *stream)
+{
+    if (!g || !passes || !state_a || !state_b || !result || (nfixed > 0 && !fixed)) PDEHIP_FAIL(E_VALUE, "jit_euler_run: NULL pointer");
+    if (npasses < 1 || ncomp < 1 || nsteps < 0) PDEHIP_FAIL(E_VALUE, "jit_euler_run: bad pass / component / step count");
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    const size_t comp_bytes = (size_t)n.pc * elem_size(n.dtype);
+    for (int q = 0; q < npasses; q++) {
+        const pdehip_jit_pass_t &p = passes[q];
+        if (!p.handle) PDEHIP_FAIL(E_VALUE, "jit_euler_run: pass %d has no handle", q);
+        const int32_t idx[5] = {p.src, p.extras[0], p.extras[1], p.extras[2], p.out};
+        for (int m = 0; m < 5; m++) {
+            if (idx[m] == PDEHIP_JIT_NONE && m != 0 && m != 4) continue;
+            if (idx[m] == PDEHIP_JIT_NONE || idx[m] >= nfixed || idx[m] < -ncomp)
+                PDEHIP_FAIL(E_VALUE, "jit_euler_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
+        }
+    }
+    char *cur = (char *)state_a, *nxt = (char *)state_b;
+    int64_t s = 0;
+    // the first two steps always run as plain launches: they build whatever kernel is not built yet (no hiprtc inside a capture)
+    const int64_t head = nsteps < 2 ? nsteps : 2;
+    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, 0, head, stream));
+    s = head;
+    if (head % 2) { char *t = cur; cur = nxt; nxt = t; }
+    constexpr int64_t kBlock = 16;   // even: the buffers are back in place after a block
+    static int graphs = -1;
+    if (graphs < 0) { const char *e = getenv("PDEHIP_GRAPH"); graphs = (e && e[0] == '0') ? 0 : 1; }
+    if (graphs && !uses_time && nsteps - s >= 4 * kBlock) {
+        // launch-bound regime: replay a captured block (cached per passes / arrays / dt)
+        std::vector<char> key;
+        auto put = [&](const void *ptr, size_t len) { key.insert(key.end(), (const char *)ptr, (const char *)ptr + len); };
+        put(g, sizeof(*g)); put(passes, sizeof(*passes) * npasses);
+        if (nfixed) put(fixed, sizeof(void *) * nfixed);
+        put(&cur, sizeof(cur)); put(&nxt, sizeof(nxt)); put(&ncomp, sizeof(ncomp)); put(&dt, sizeof(dt));
+        LoopGraph *entry = nullptr;
+        for (auto &e : g_loop_graphs)
+            if (e.exec && e.key == key) { entry = &e; break; }
+        if (!g_loop_cap) PDEHIP_HIP(hipStreamCreateWithFlags(&g_loop_cap, hipStreamNonBlocking));
+        if (!g_loop_ev) PDEHIP_HIP(hipEventCreateWithFlags(&g_loop_ev, hipEventDisableTiming));
+        if (!entry) {
+            LoopGraph &e = g_loop_graphs[g_loop_next++ % kLoopGraphs];
+            if (e.exec) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            PDEHIP_HIP(hipStreamBeginCapture(g_loop_cap, hipStreamCaptureModeThreadLocal));
+            const int rc = loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, 0, kBlock, (void *)g_loop_cap);
+            const hipError_t ce = hipStreamEndCapture(g_loop_cap, &graph);
+            if (rc == 0 && ce == hipSuccess && hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                e.key = key;
+                entry = &e;
+            } else {
+                e.exec = nullptr;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
+        }
+        if (entry) {
+            hipStream_t user = as_stream(stream);
+            PDEHIP_HIP(hipEventRecord(g_loop_ev, user));
+            PDEHIP_HIP(hipStreamWaitEvent(g_loop_cap, g_loop_ev, 0));
+            for (; s + kBlock <= nsteps; s += kBlock) PDEHIP_HIP(hipGraphLaunch(entry->exec, g_loop_cap));
+            PDEHIP_HIP(hipEventRecord(g_loop_ev, g_loop_cap));
+            PDEHIP_HIP(hipStreamWaitEvent(user, g_loop_ev, 0));
+        }
+    }
+    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, s, nsteps - s, stream));
+    if ((nsteps - s) % 2) { char *t = cur; cur = nxt; nxt = t; }
+    *result = cur;
+    return 0;
+}
+
 }  // extern "C"

@@ -74,6 +74,15 @@ class RHS(C.Structure):
     ]
 
 
+JIT_NONE = -(2**31)   # PDEHIP_JIT_NONE
+
+
+class JitPass(C.Structure):
+    """``pdehip_jit_pass_t``: one pass of the Euler loop of an expression PDE (``pdehip_jit_euler_run``)."""
+
+    _fields_ = [("handle", C.c_void_p), ("src", C.c_int32), ("extras", C.c_int32 * 3), ("out", C.c_int32), ("faces", C.c_void_p)]
+
+
 class Adaptive(C.Structure):
     """``pdehip_adaptive_t``: controller state of the adaptive loop (``pdehip_slab_rkf45_run``)."""
 
@@ -222,6 +231,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_euler2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, C.POINTER(_i), _vp],
     "jit_create2": [C.c_char_p, C.c_char_p, _pvp],
     "jit_fused2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, _pf, C.POINTER(_i), _vp],
+    "jit_euler_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _vp, _vp, _i, _d, _d, _i, _i64, _pvp, _vp],
 }
 
 

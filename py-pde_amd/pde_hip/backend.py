@@ -19,6 +19,7 @@ There is no CPU path: everything below ends in a libpdehip call or raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import inspect
 import logging
 from collections import defaultdict
@@ -849,12 +850,28 @@ class HipBackendMixin:
 
         if not adaptive:
             dt = float(solver.info["dt"])
+            cells = int(np.prod(info.shape))
+            can_two = ncomp == 1 and getattr(erhs, "_two_ok", False) is not False
+
+            def use_loop(steps: int) -> bool:
+                # large grids whose expression runs two steps per sweep keep that (Python overhead is noise there)
+                if is_rk or post_step is not None or not hasattr(erhs, "euler_loop") or os.environ.get("PDEHIP_EXPR_LOOP") == "0":
+                    return False
+                return not (can_two and cells > (1 << 21))
 
             def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
                 steps = max(1, round((t_end - t_start) / dt))
                 cur, nxt = state_data, work[0]
                 i = 0
                 try:
+                    if use_loop(steps):
+                        # the whole loop in ONE C call (captured as a hipGraph for long runs): a Python iteration per step
+                        # costs 40-85 us where the kernels of a small grid need 2-5 us
+                        done = erhs.euler_loop(cur, nxt, dt, t_start, steps)
+                        if done is not None:
+                            if done is not cur:
+                                cur, nxt = nxt, cur
+                            i = steps
                     while i < steps:
                         t = t_start + i * dt
                         if is_rk:
@@ -1140,7 +1157,6 @@ class HipBackendMixin:
         work_ptrs = ptr_array(work)
         if not adaptive:
             dt = float(solver.info["dt"])
-
             def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
                 steps = max(1, round((t_end - t_start) / dt))
                 if is_rk:

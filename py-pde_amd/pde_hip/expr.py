@@ -391,6 +391,14 @@ class ExpressionPlan:
                 for p in self.passes]
 
 
+def _run_loop(lib, info, loop, state, other, ncomp: int, dt: float, t0: float, nsteps: int, uses_time: bool, stream):
+    passes, fixed, nfixed, _keep = loop
+    result = C.c_void_p()
+    lib.jit_euler_run(info.ref, passes, len(passes), fixed, nfixed, state.ptr, other.ptr, ncomp, dt, t0, int(bool(uses_time)), int(nsteps),
+                      C.byref(result), stream)
+    return state if result.value == state.ptr else other
+
+
 class ExpressionRhs:
     """Device evaluation of an :class:`ExpressionPlan` (kernels compiled lazily, cached per wrap mode)."""
 
@@ -526,6 +534,60 @@ class ExpressionRhs:
                 return False
         return True
 
+    # --- the whole fixed-step Euler loop in one C call (pdehip_jit_euler_run) ------------------------------------------------
+    def loop_ok(self) -> bool:
+        """The passes of this expression can run inside ``pdehip_jit_euler_run``: no conditions that change with time, no
+        integrals (their values travel through the host)."""
+        return not self._dynamic and not self.has_reductions
+
+    def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list) -> list:
+        """``pdehip_jit_pass_t`` entries of one Euler step of this equation; ``own``: component of the state it advances,
+        ``components``: the other variables' components by name, ``fixed``: list of device pointers that the entries index
+        (extended here), ``keep``: objects that must outlive the descriptor."""
+        index: dict[str, int] = {}
+
+        def resolve(name: str, is_out: bool = False) -> int:
+            if name == "state":
+                return -1 - own
+            if name == "out":
+                assert is_out
+                return -1 - own
+            if name.startswith("var:"):
+                return -1 - components[name[4:]]
+            if name not in index:
+                arr = self.tmps.get(name) or self.aux.get(name)
+                index[name] = len(fixed)
+                fixed.append(arr.ptr)
+                keep.append(arr)
+            return index[name]
+
+        entries = []
+        for i, p in enumerate(self.plan.passes):
+            h, extras = self._kernel(i, "euler")
+            e = _abi.JitPass()
+            e.handle = h.value
+            e.src = resolve(p.src)
+            for m in range(3):
+                e.extras[m] = resolve(extras[m]) if m < len(extras) else _abi.JIT_NONE
+            e.out = resolve(p.out, True)
+            faces = self._faces(i)
+            e.faces = C.cast(faces, C.c_void_p).value if faces is not None else None
+            keep.append(faces)
+            entries.append(e)
+        return entries
+
+    def euler_loop(self, state, other, dt: float, t0: float, nsteps: int):
+        """``nsteps`` explicit Euler steps starting from ``state`` with ``other`` as the second buffer; returns the array that
+        holds the result, or None when the loop is not available (then nothing was done)."""
+        if not self.loop_ok():
+            return None
+        if getattr(self, "_loop", None) is None:
+            fixed: list = []
+            keep: list = []
+            entries = self.loop_passes(0, {}, fixed, keep)
+            self._loop = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
+        return _run_loop(self.lib, self.info, self._loop, state, other, 1, dt, t0, nsteps, self.plan.uses_time, self.backend.stream)
+
     def _fused_handle(self, wrap: str):
         if wrap not in self._fused:
             h = None
@@ -615,3 +677,20 @@ class SystemRhs:
 
     def euler2(self, state, out, dt: float) -> bool:
         return False
+
+    def euler_loop(self, state, other, dt: float, t0: float, nsteps: int):
+        """The fixed-step Euler loop of the whole system in one C call (every equation reads the current state of all
+        fields and writes its component of the next one); None when an equation cannot take part."""
+        if not all(p.loop_ok() for p in self.parts):
+            return None
+        if getattr(self, "_loop", None) is None:
+            fixed: list = []
+            keep: list = []
+            components = {name: k for k, name in enumerate(self.variables)}
+            entries = []
+            for k, part in enumerate(self.parts):
+                entries += part.loop_passes(k, components, fixed, keep)
+            self._loop = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
+        part0 = self.parts[0]
+        uses_time = any(p.plan.uses_time for p in self.parts)
+        return _run_loop(part0.lib, self.info, self._loop, state, other, self.ncomp, dt, t0, nsteps, uses_time, part0.backend.stream)

@@ -573,6 +573,41 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
     return 0;
 }
 
+/* the Euler loop over the passes of an expression PDE: the same sequence of pdehip_jit_apply calls */
+int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                         void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
+                         void **result, void *stream)
+{
+    (void)uses_time; GRID(g);
+    if (!passes || !state_a || !state_b || !result || (nfixed > 0 && !fixed)) return fail(E_VALUE, "jit_euler_run: NULL pointer");
+    if (npasses < 1 || ncomp < 1 || nsteps < 0) return fail(E_VALUE, "jit_euler_run: bad pass / component / step count");
+    const size_t comp_bytes = full_bytes(g, 1);
+    char *cur = state_a, *nxt = state_b;
+    for (int q = 0; q < npasses; q++) {
+        const int32_t idx[5] = {passes[q].src, passes[q].extras[0], passes[q].extras[1], passes[q].extras[2], passes[q].out};
+        for (int m = 0; m < 5; m++) {
+            if (idx[m] == PDEHIP_JIT_NONE && m != 0 && m != 4) continue;
+            if (idx[m] == PDEHIP_JIT_NONE || idx[m] >= nfixed || idx[m] < -ncomp)
+                return fail(E_VALUE, "jit_euler_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
+        }
+    }
+    for (int64_t s = 0; s < nsteps; s++) {
+        const double params[2] = {dt, t0 + (double)s * dt};
+        for (int q = 0; q < npasses; q++) {
+            const pdehip_jit_pass_t *p = &passes[q];
+            const void *ex[3];
+            for (int m = 0; m < 3; m++)
+                ex[m] = p->extras[m] == PDEHIP_JIT_NONE ? NULL : (p->extras[m] >= 0 ? fixed[p->extras[m]] : (void *)(cur + (size_t)(-1 - p->extras[m]) * comp_bytes));
+            void *src = p->src >= 0 ? fixed[p->src] : (void *)(cur + (size_t)(-1 - p->src) * comp_bytes);
+            void *out = p->out >= 0 ? fixed[p->out] : (void *)(nxt + (size_t)(-1 - p->out) * comp_bytes);
+            TRY(pdehip_jit_apply(p->handle, g, src, ex, out, params, 2, p->faces, stream));
+        }
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    *result = cur;
+    return 0;
+}
+
 #ifndef SHIM_WITH_COMM
 /* slab-parallel layer: provided by pdehip_shim_comm.cpp when it is linked in */
 #define NOCOMM(name, ...) int pdehip_##name(__VA_ARGS__) { return fail(E_NOTIMPL, "shim: pdehip_" #name " needs the comm part of the shim"); }

@@ -617,3 +617,33 @@ def test_vector_field_as_state(shape, periodic):
     assert isinstance(out, pde_hip.VectorField) and max_rel(out.data, ref) < 1e-12
     rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
     assert info["solver"]["steps"] == steps and max_rel(rk.data, ref) < 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps", [1, 2, 7, 150])
+def test_euler_loop_in_one_call_equals_the_python_loop(steps, monkeypatch):
+    """`pdehip_jit_euler_run` (all steps of a fixed-step Euler run in one C call, long runs as a replayed hipGraph) against the
+    step-by-step Python loop over the same passes: bit-identical, for one- and multi-pass expressions, explicit time, systems
+    of fields, vector states and auxiliary arrays."""
+    rng = np.random.default_rng(91)
+    grid = pde_hip.CartesianGrid([[0, 8], [0, 16]], [24, 130], periodic=[False, True])
+    bc = {"x": {"value": 0.1}, "y": "periodic"}
+    c = pde_hip.ScalarField(grid, rng.uniform(-0.3, 0.3, grid.shape))
+    uv = pde_hip.FieldCollection([pde_hip.ScalarField(grid, rng.uniform(0.5, 1.5, grid.shape)), pde_hip.ScalarField(grid, rng.uniform(2.5, 3.5, grid.shape))])
+    vec = pde_hip.VectorField(grid, rng.uniform(-0.3, 0.3, (2, *grid.shape)))
+    cases = [
+        (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0*x"}, bc=bc), c),                                   # one pass (+ a coordinate array)
+        (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0.01 * sin(t)"}, bc=bc), c),                         # explicit time: no graph
+        (pde_hip.PDE({"c": "-0.1 * laplace(laplace(c)) - laplace(c) - c**3 + 0.2 * x"}, bc=bc), c),      # passes with a temporary
+        (pde_hip.PDE({"u": "laplace(u) + 1 - 4 * u + v * u**2", "v": "0.1 * laplace(v) + 3 * u - v * u**2"}, bc=bc), uv),
+        (pde_hip.PDE({"u": "vector_laplace(u) - u + 0.1 * gradient(dot(u, u))"}, bc=bc), vec),
+    ]
+    for eq, state in cases:
+        dt = 1e-4   # (stable for the fourth-order case as well)
+        monkeypatch.setenv("PDEHIP_EXPR_LOOP", "0")
+        ref, iref = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip", ret_info=True)
+        monkeypatch.delenv("PDEHIP_EXPR_LOOP")
+        out, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip", ret_info=True)
+        assert info["solver"]["steps"] == iref["solver"]["steps"] == steps
+        np.testing.assert_array_equal(out.data, ref.data)
+        assert np.isfinite(out.data).all() and not np.array_equal(out.data, state.data)

@@ -453,8 +453,8 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
  * Array indices of a pass: >= 0 selects fixed[index] (temporaries, constant arrays, coordinates); -1 - k selects component k
  * of the CURRENT state as `src` / `extras` and component k of the NEXT state as `out`; PDEHIP_JIT_NONE: no array.  The
  * epilogue of the pass that writes the next state must be the Euler update `state + dt * F` (parameters p[0] = dt,
- * p[1] = t).  state_a holds the state on entry; *result is the buffer that holds it afterwards.  uses_time = 0 lets long runs
- * replay a captured hipGraph (the parameters are then constants of the launches). */
+ * p[1] = t).  state_a holds the state on entry; *result is the buffer that holds it afterwards.  uses_time = 0 allows replaying a
+ * captured hipGraph for long runs (PDEHIP_JIT_GRAPH=1; measured slower than the plain launches of this loop, so off by default). */
 #define PDEHIP_JIT_NONE INT32_MIN
 typedef struct {
     void *handle;

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "pdehip_common.h"
@@ -66,6 +67,9 @@ struct Jit {
     std::string body2;                      // statements of pde_epilogue2 (level 2 of a fused two-pass expression)
     std::map<std::string, Variant> cache;   // key: "T,VEC,RY,CZ,HASX,IBC" or "generic,T"
 };
+std::map<std::string, Variant> g_shared;   // epilogue source(s) + variant key -> loaded kernel, for the life of the process
+std::mutex g_shared_mutex;
+
 // the generated code reads PdeDer (`d.d1[..]`, `d.d2[..]`, `d.gr[..]`): only the one-level kernels supply it
 bool uses_axis_derivatives(const Jit *j)
 {
@@ -146,6 +150,18 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
                     bool tails = true)    // rows that end inside a vector / leave idle chunks in a tile (pdehip_march.inc)
 {
     PDEHIP_TRY(load_rtc());
+    // kernels already built in this process for the same epilogue(s) and variant: every eq.solve creates new handles for the
+    // same expressions, and a hiprtc build costs 50-150 ms (a 4000-step run of a 256^2 grid spent 9/10 of its wall time there)
+    const std::string shared_key = j->body + '\x01' + j->body2 + '\x01' + key;
+    if (out && !key.empty()) {
+        std::lock_guard<std::mutex> guard(g_shared_mutex);
+        auto it = g_shared.find(shared_key);
+        if (it != g_shared.end()) {
+            *out = it->second;
+            j->cache[key] = *out;
+            return 0;
+        }
+    }
     std::string src = "#define PDEHIP_JIT 1\n#include \"pdehip_device.h\"\nnamespace pdehip {\n"
                       "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)\n{\n";
     src += j->body;
@@ -190,6 +206,10 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
     PDEHIP_HIP(hipModuleLoadData(&out->module, code.data()));
     PDEHIP_HIP(hipModuleGetFunction(&out->fn, out->module, "pde_kernel"));
     j->cache[key] = *out;
+    if (!key.empty()) {
+        std::lock_guard<std::mutex> guard(g_shared_mutex);
+        g_shared[shared_key] = *out;
+    }
     return 0;
 }
 
@@ -238,10 +258,8 @@ int pdehip_jit_create2(const char *body1, const char *body2, void **handle)
 int pdehip_jit_destroy(void *handle)
 {
     if (!handle) return 0;
-    Jit *j = static_cast<Jit *>(handle);
-    for (auto &kv : j->cache)
-        if (kv.second.module) (void)hipModuleUnload(kv.second.module);
-    delete j;
+    // (the modules stay loaded: they are shared through g_shared by every handle with the same epilogue)
+    delete static_cast<Jit *>(handle);
     return 0;
 }
 
@@ -583,8 +601,10 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     s = head;
     if (head % 2) { char *t = cur; cur = nxt; nxt = t; }
     constexpr int64_t kBlock = 16;   // even: the buffers are back in place after a block
+    // measured (256^2 Allen-Cahn, one pass per step): replaying the captured block 4.36 us per step, plain launches from this
+    // loop 3.68 us - the run-time built kernels carry 1.3 KB of arguments per node; the graph stays an option (PDEHIP_JIT_GRAPH=1)
     static int graphs = -1;
-    if (graphs < 0) { const char *e = getenv("PDEHIP_GRAPH"); graphs = (e && e[0] == '0') ? 0 : 1; }
+    if (graphs < 0) { const char *e = getenv("PDEHIP_JIT_GRAPH"); graphs = (e && e[0] == '1') ? 1 : 0; }
     if (graphs && !uses_time && nsteps - s >= 4 * kBlock) {
         // launch-bound regime: replay a captured block (cached per passes / arrays / dt)
         std::vector<char> key;

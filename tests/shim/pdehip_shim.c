@@ -450,7 +450,7 @@ static int shim_pointwise(epilogue_fn fn, const pdehip_grid_t *g, const void *in
             rc = oracle_axis_derivative(g, a, order, PDEHIP_CENTRAL, in, der[order - 1][3 - g->ndim + a], PDEHIP_OUT_FULL);
         }
     /* central gradient: all components at once (component-major full arrays) */
-    void *grad = calloc((size_t)g->ndim, nb);
+    void *grad = calloc((size_t)(g->ndim > 0 ? g->ndim : 1), nb);
     if (!rc) rc = oracle_gradient(g, PDEHIP_CENTRAL, in, grad, PDEHIP_OUT_FULL);
     if (rc) { free(lap); free(gsq); free(grad); for (int q = 0; q < 6; q++) free(der[q / 3][q % 3]); return rc; }
     /* results go to a scratch first: `out` may alias an extra array */

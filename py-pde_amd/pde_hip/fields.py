@@ -58,7 +58,11 @@ class DataFieldBase:
         return self._data_full.dtype
 
     def copy(self, *, label=None, dtype=None):
-        return self.__class__(self.grid, np.array(self._data_full, dtype=dtype or self.dtype), label=label or self.label, with_ghost_cells=True)
+        # ONE pass over the data (a 1 GB field: the second copy of `np.array` inside the constructor cost as much as the upload)
+        new = self.__class__.__new__(self.__class__)
+        new.grid, new.label = self.grid, label or self.label
+        new._data_full = np.array(self._data_full, dtype=dtype or self.dtype, copy=True, order="C")
+        return new
 
     @classmethod
     def random_uniform(cls, grid, vmin: float = 0, vmax: float = 1, *, label=None, dtype=None, rng=None):

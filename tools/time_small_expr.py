@@ -11,6 +11,7 @@ import numpy as np
 import pde_hip
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+solver = sys.argv[2] if len(sys.argv) > 2 else "euler"          # euler | runge-kutta | adaptive (Euler with error control)
 grid = pde_hip.UnitGrid([n, n], periodic=True)
 rng = np.random.default_rng(0)
 c = pde_hip.ScalarField(grid, rng.uniform(-0.1, 0.1, grid.shape))
@@ -24,13 +25,15 @@ cases = [
     ("Burgers-type, d_dx", pde_hip.PDE({"c": "-c * d_dx(c) + 0.1 * laplace(c)"}), c, 1e-3),
 ]
 steps = 4000
-print(f"| {n}^2 fp64, {steps} Euler steps through eq.solve | us per step |")
-print("|---|---:|")
+print(f"| {n}^2 fp64, {solver}, t_range = {steps} dt through eq.solve | us per step | steps |")
+print("|---|---:|---:|")
 for name, eq, state, dt in cases:
-    eq.solve(state, t_range=20 * dt, dt=dt, solver="euler", backend="hip")   # builds / compiles
+    kw = {"solver": "euler", "dt": None, "adaptive": True} if solver == "adaptive" else {"solver": solver, "dt": dt}
+    eq.solve(state, t_range=20 * dt, backend="hip", **kw)   # builds / compiles
     pde_hip.get_backend("hip").synchronize()
     t0 = time.perf_counter()
-    res = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    res, info = eq.solve(state, t_range=steps * dt, backend="hip", ret_info=True, **kw)
     _ = res.data.sum()
     t = time.perf_counter() - t0
-    print(f"| {name} | {t / steps * 1e6:.1f} |", flush=True)
+    done = info["solver"]["steps"]
+    print(f"| {name} | {t / done * 1e6:.1f} | {done} |", flush=True)

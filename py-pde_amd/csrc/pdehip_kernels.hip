@@ -424,7 +424,14 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
         long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
         if (nxc < 1) nxc = 1;
-        if (nxc > a.n0 / 16) nxc = a.n0 / 16 > 0 ? a.n0 / 16 : 1;
+        // chunks of at least 16 planes (two recomputed planes per chunk: <= 12.5 % extra work) - but a small grid must not
+        // leave the chip idle for that: down to 2 planes per chunk while fewer than one round of wave tiles exists (100^3: 150
+        // tiles of 17 planes took 19.7 us per step, 8.1 now; 64^3 18.4 -> 5.7, 128^3 13.1 -> 7.0, 200^3 28.8 -> 21.7)
+        static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
+        long minlx = 16;
+        while (minlx > 2 && tiles * (a.n0 / minlx) < want) minlx /= 2;
+        if (floor_env > 0) minlx = floor_env;
+        if (nxc > a.n0 / minlx) nxc = a.n0 / minlx > 0 ? a.n0 / minlx : 1;
         const long lx = (a.n0 + nxc - 1) / nxc;
         a.lx = (int)lx;
         a.nxc = (a.n0 + lx - 1) / lx;

@@ -474,7 +474,7 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
 #define PDEHIP_E2(RY_, HY_, RG_, XS_, NT_)                                                                                               \
     if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                                          \
         if (m2 == E2_DIFFUSION) {                                                                                                       \
-            if constexpr (HY_ && !XS_) {   /* every 3-D instance except the one-sided slab ends */                                        \
+            if constexpr (!XS_) {   /* every instance except the one-sided slab ends */                                                       \
                 if (unit) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION_UNIT, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);  \
                 else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);            \
             } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);             \

@@ -136,7 +136,7 @@ class SlabMesh:
         (they are listed in :attr:`exchanged_faces` and never evaluated).  Per-face arrays of the
         other axes are sliced along axis 0; the reference refuses those
         (``Cannot transfer complicated BC to subgrid``, local.py:1515-1540)."""
-        from .boundaries import BCBase, BoundariesList, BoundaryPair, BoundaryPeriodic, _PeriodicBC
+        from .boundaries import BoundariesList, BoundaryPair, BoundaryPeriodic, _PeriodicBC
 
         out = []
         for ax, pair in enumerate(bcs):

@@ -95,12 +95,17 @@ extern "C" __global__ void __launch_bounds__(256) pde_kernel(pdehip::LapArgs a)
         double lap, gsq;
         PdeDer d = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
         const double vm = 2 * mid;
-        const double dz = (double)c[1] - (double)c[-1];
+        double zl = (double)c[-1], zr = (double)c[1];
+        if (a.ndim == 1 && a.any_ibc) {   // 1-D: the two virtual points on the fly (as in lap_generic_kernel)
+            if (k == 0 && a.ibc[2][0].on) zl = (double)(T)(a.ibc[2][0].c + a.ibc[2][0].f * (double)in[a.off + a.ibc[2][0].idx]);
+            if (k == a.n2 - 1 && a.ibc[2][1].on) zr = (double)(T)(a.ibc[2][1].c + a.ibc[2][1].f * (double)in[a.off + a.ibc[2][1].idx]);
+        }
+        const double dz = zr - zl;
         d.d1[2] = dz / a.dd1[2];
-        d.d2[2] = ((double)c[1] - vm + (double)c[-1]) * a.dd2[2];
+        d.d2[2] = (zr - vm + zl) * a.dd2[2];
         d.gr[2] = dz * a.dg[2];
         if (a.ndim == 1) {
-            lap = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
+            lap = (zl - 2 * mid + zr) * a.sz;
             gsq = dz * dz * a.gs[2];
         } else if (a.ndim == 2) {
             const double dy = (double)c[a.p1] - (double)c[-a.p1];
@@ -329,7 +334,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
                 r = in_faces[2 * ar + side];
                 if (r.kind == PDEHIP_BC_SKIP) continue;
                 const int ax = 3 - n.ndim + ar;
-                if (fast && r.kind == PDEHIP_BC_ORDER1 && r.flags == 0 && r.index1 >= 0 && r.index1 < n.n[ax]) {
+                if ((fast || n.ndim == 1) && r.kind == PDEHIP_BC_ORDER1 && r.flags == 0 && r.index1 >= 0 && r.index1 < n.n[ax]) {   // 1-D: the generic kernel does it too
                     fg.on[ax][side] = 1; fg.idx[ax][side] = r.index1; fg.c[ax][side] = r.const_v; fg.f[ax][side] = r.factor1;
                     r.kind = PDEHIP_BC_SKIP;
                     n_fused++;

@@ -44,7 +44,14 @@ __global__ void __launch_bounds__(256) lap_generic_kernel(LapArgs a)
         const double mid = (double)c[0];
         double lap;
         if (a.ndim == 1) {
-            lap = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
+            double l = (double)c[-1], r = (double)c[1];
+            if (a.any_ibc) {
+                // 1-D: the two virtual points on the fly (`const + factor * in[idx]`, rounded like a stored ghost cell): a step of a
+                // small 1-D grid is ONE launch instead of ghost kernel + stencil kernel
+                if (k == 0 && a.ibc[2][0].on) l = (double)(T)(a.ibc[2][0].c + a.ibc[2][0].f * (double)in[a.off + a.ibc[2][0].idx]);
+                if (k == a.n2 - 1 && a.ibc[2][1].on) r = (double)(T)(a.ibc[2][1].c + a.ibc[2][1].f * (double)in[a.off + a.ibc[2][1].idx]);
+            }
+            lap = (l - 2 * mid + r) * a.sz;
         } else if (a.ndim == 2) {
             const double lx = ((double)c[-a.p1] - 2 * mid + (double)c[a.p1]) * a.sy;
             const double ly = ((double)c[-1] - 2 * mid + (double)c[1]) * a.sz;
@@ -197,7 +204,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
 #undef PDEHIP_CFG2
         PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
     }
-    if (a.any_ibc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");
+    if (a.any_ibc && n.ndim != 1) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs requested for the generic kernel");
     if (MODE > LAP_CH_MU) PDEHIP_FAIL(E_RUNTIME, "internal: derivative and stage epilogues need the vectorised kernel");
     const long total = n.n[0] * n.n[1] * n.n[2];
     long blocks = (total + 255) / 256;

@@ -596,7 +596,8 @@ int laplace_with_input_bcs(const pdehip_grid_t *g, void *in, const void *y, void
     int n_rest = 0, n_fused = 0;
     static int fuse_axes = -1;   // PDEHIP_FUSE_AXES: bit per normalised axis (tuning / testing aid)
     if (fuse_axes < 0) { const char *e = getenv("PDEHIP_FUSE_AXES"); fuse_axes = e ? atoi(e) : 7; }
-    const bool can_fuse = laplace_can_fuse_bcs(n, in, out, mode == LAP_EULER ? y : nullptr);
+    // (1-D grids: the one-cell-per-thread kernel evaluates its two virtual points itself for the plain epilogues)
+    const bool can_fuse = laplace_can_fuse_bcs(n, in, out, mode == LAP_EULER ? y : nullptr) || (n.ndim == 1 && mode <= LAP_CH_MU && !stage);
     for (int a = 0; a < PDEHIP_MAX_DIM; a++)
         for (int side = 0; side < 2; side++) {
             pdehip_bc_face_t &r = rest[2 * a + side];

@@ -308,21 +308,38 @@ class ExpressionPlan:
         def arrays_in(e):
             return {n for n, s in self._arrays.items() if s in e.free_symbols}
 
-        while len(extras_of(expr)) > MAX_EXTRA:
-            # pointwise terms of the sum (no operators left in them), grouped greedily: the partial sum over the group is
-            # evaluated by a pass of its own and replaces the group's arrays by one temporary
-            terms = [t for t in (expr.args if expr.is_Add else ()) if not t.atoms(sp.core.function.AppliedUndef) and arrays_in(t)]
-            terms.sort(key=lambda t: -len(arrays_in(t)))
-            group, used = [], set()
-            for t in terms:
-                if len(used | arrays_in(t)) <= MAX_EXTRA + 1:
-                    group.append(t)
-                    used |= arrays_in(t)
-            if len(used) < 2 or (len(group) == 1 and self._array_of(group[0]) is not None):
+        def limit():
+            # the pass that writes the result also carries the Euler update `state + dt * F`: when the state is neither its
+            # stencil array nor one of its inputs, one slot stays free for it
+            need_state = out == "out" and src != "state" and "state" not in extras_of(expr)
+            return MAX_EXTRA - (1 if need_state else 0)
+
+        while len(extras_of(expr)) > limit():
+            # Somewhere in the tree a sum or a product has pointwise arguments (no operators left in them) that can be
+            # evaluated by a pass of their own: the partial sum / product over a greedily chosen group of them replaces the
+            # group's arrays by one temporary.  The node whose group covers the most arrays goes first.
+            best = None
+            for node in sp.preorder_traversal(expr):
+                if not (node.is_Add or node.is_Mul):
+                    continue
+                terms = [t for t in node.args if not t.atoms(sp.core.function.AppliedUndef) and arrays_in(t)]
+                terms.sort(key=lambda t: -len(arrays_in(t)))
+                group, used = [], set()
+                for t in terms:
+                    if len(used | arrays_in(t)) <= MAX_EXTRA:   # (its own pass: stencil array + extras, a slot to spare)
+                        group.append(t)
+                        used |= arrays_in(t)
+                if len(used) < 2 or (len(group) == 1 and self._array_of(group[0]) is not None):
+                    continue
+                if best is None or len(used) > best[0]:
+                    best = (len(used), node, group)
+            if best is None:
                 msg = "hip backend: expression needs more than 3 auxiliary fields in one pass"
                 raise NotImplementedError(msg)
-            partial = sp.Add(*group)
-            expr = expr - partial + self._arrays[self._materialise(partial)]
+            _, node, group = best
+            partial = node.func(*group)
+            rest = [t for t in node.args if not any(t is g for g in group)]
+            expr = expr.xreplace({node: node.func(*rest, self._arrays[self._materialise(partial)])})
         extras = extras_of(expr)
         self.passes.append(_Pass(src, extras, out, expr))
 

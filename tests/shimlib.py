@@ -46,6 +46,26 @@ def build(force: bool = False) -> Path:
     return SHIM_SO
 
 
+def _forget_layouts() -> None:
+    """Backend objects cache the array layout of a grid (pitches, component stride) as the library reports it; the shim's
+    compact host layout differs from the device's padded one, so the caches are dropped whenever the library is swapped
+    (a test that evaluates the same grid with both libraries in one process would otherwise mix them)."""
+    import sys
+
+    mod = sys.modules.get("pde_hip.backend")
+    if mod is not None:
+        for backend in list(getattr(mod, "_BACKENDS", {}).values()):
+            backend._info_cache.clear()
+    pde_mod = sys.modules.get("pde.backends")
+    if pde_mod is not None:
+        try:
+            hip = pde_mod.backend_registry._backends.get("hip")
+        except AttributeError:
+            hip = None
+        if hip is not None and hasattr(hip, "_info_cache"):
+            hip._info_cache.clear()
+
+
 @contextlib.contextmanager
 def use_shim(fused: bool = False, devices: int = 1):
     """Install the shim as ``pde_hip._lib``'s library; restores the previous state on exit."""
@@ -58,9 +78,11 @@ def use_shim(fused: bool = False, devices: int = 1):
     os.environ["PDEHIP_SHIM_DEVICES"] = str(devices)
     _lib._LIB, _lib._DEVICE = _lib._Lib(so), None
     _lib._threads_ready.clear()
+    _forget_layouts()
     try:
         yield _lib._LIB
     finally:
+        _forget_layouts()
         _lib._LIB, _lib._DEVICE = saved[0], saved[1]
         _lib._threads_ready.clear()
         _lib._threads_ready.update(saved[2])

@@ -45,8 +45,8 @@ GRIDS = [((37,), [False]), ((64,), [True]), ((12, 130), [False, True]), ((24, 72
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(36))
-def test_random_expressions_device_vs_oracle_shim(seed):
+@pytest.mark.parametrize("seed,dtype", [(s, np.float64) for s in range(36)] + [(s, np.float32) for s in range(100, 112)])
+def test_random_expressions_device_vs_oracle_shim(seed, dtype):
     import shimlib
 
     rng = np.random.default_rng(2000 + seed)
@@ -63,9 +63,9 @@ def test_random_expressions_device_vs_oracle_shim(seed):
     def evaluate():
         b = pde_hip.get_backend("hip")
         if two:
-            state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d) for d in data])
+            state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d, dtype=dtype) for d in data])
         else:
-            state = pde_hip.ScalarField(grid, data[0])
+            state = pde_hip.ScalarField(grid, data[0], dtype=dtype)
         eq = pde_hip.PDE(rhs, bc=bc)
         rate = b.native_to_numpy(eq.make_pde_rhs(state)(b.numpy_to_native(state.data, grid=grid), 0.0))
         out = eq.solve(state, t_range=3e-4, dt=1e-4, solver="euler", backend="hip")
@@ -75,5 +75,13 @@ def test_random_expressions_device_vs_oracle_shim(seed):
     with shimlib.use_shim(fused=False):
         rate_ref, out_ref = evaluate()
     assert np.isfinite(rate_ref).all(), rhs
-    np.testing.assert_array_equal(rate_dev, rate_ref, err_msg=str(rhs))
-    np.testing.assert_array_equal(out_dev, out_ref, err_msg=str(rhs))
+    if dtype == np.float64:
+        np.testing.assert_array_equal(rate_dev, rate_ref, err_msg=str(rhs))
+        np.testing.assert_array_equal(out_dev, out_ref, err_msg=str(rhs))
+    else:
+        # fp32 storage: the kernels keep the stencil values in fp64 registers, the shim rounds them to fp32 between the
+        # oracle's operator and the epilogue - agreement to fp32 rounding of the intermediate terms
+        from helpers import max_rel
+
+        assert rate_dev.dtype == np.float32 and max_rel(rate_dev.astype(np.float64), rate_ref.astype(np.float64)) < 2e-5, rhs
+        assert max_rel(out_dev.astype(np.float64), out_ref.astype(np.float64)) < 2e-5, rhs

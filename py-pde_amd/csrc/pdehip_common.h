@@ -130,6 +130,8 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
                   const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr);
 // K Euler steps of a 2-D grid per launch, time levels in LDS (pdehip_tile2d.inc): diffusion (rhs->kind 0) or Cahn-Hilliard
 int tile2d_max_steps(int mode);
+int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
+                const InputBCs *fm, int nsteps, Tile2Args *args, unsigned *nblocks, int *tile_columns, bool *done);
 int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
                   const InputBCs *fm, int nsteps, hipStream_t st, bool *done);
 int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,

@@ -130,6 +130,23 @@ struct LapArgs {
 // per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)
 struct PdeDer { double d1[3], d2[3], gr[3]; };   // gr: components of the central gradient, (r - l) * (0.5 / dx)
 
+// arguments of tile2d_kernel (pdehip_tile2d.inc): K Euler steps of a 2-D grid per launch, time levels in LDS
+struct Tile2Args {
+    const void *in;
+    void *out;
+    long n0, n1;           // rows (first grid axis), columns (fastest axis)
+    long p1, off;          // row pitch, offset of cell (0, 0)
+    double sx, sy;         // dx^-2 of the row axis / the column axis
+    double s1, s2, gamma;  // diffusion: s1 = D, s2 = dt;  Cahn-Hilliard: gamma, s2 = dt
+    int nsteps;            // K
+    int per[2];            // periodic axes
+    double c[2][2][2], f[2][2][2];   // [field: 0 = state, 1 = mu][axis][side]: ghost = c + f * adjacent cell (local faces)
+    int tiles1;            // tiles along the columns
+    // MODE 2 (run-time generated update): parameters and derivative scales of the generated epilogue, [row axis, column axis]
+    double par[12];
+    double gs[2], dd1[2], dd2[2], dg[2];
+};
+
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the
 // offline build never instantiates that mode and only needs the declaration to parse.
 #ifdef PDEHIP_JIT

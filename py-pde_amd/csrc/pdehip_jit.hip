@@ -148,6 +148,15 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 }
 )SRC";
 
+// the multi-step 2-D kernel (time levels in LDS, pdehip_tile2d.inc) around the generated update; PDE_CZ = tile columns
+constexpr int kTileVariant = 100;
+const char *kTileWrapper = R"SRC(
+extern "C" __global__ void __launch_bounds__(1024) pde_kernel(pdehip::Tile2Args a)
+{
+    pdehip::tile2d_body<PDE_T, 2, 32, PDE_CZ, 8>(a);
+}
+)SRC";
+
 int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
                     int two_level = 0,    // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
                     bool stage = false,   // one-level kernel followed by the Runge-Kutta stage epilogue (LapArgs::st_*)
@@ -176,19 +185,20 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
         src += j->body2;
         src += "\n}\n";
     }
-    if (two_level) src += "#include \"pdehip_march2.inc\"\n";   // PDE_HASX carries HAS_Y there
+    if (two_level == kTileVariant) src += "#include \"pdehip_tile2d.inc\"\n";
+    else if (two_level) src += "#include \"pdehip_march2.inc\"\n";   // PDE_HASX carries HAS_Y there
     else if (!generic) src += "#include \"pdehip_march.inc\"\n";
     src += "}  // namespace pdehip\n";
-    src += two_level ? kMarch2Wrapper : (generic ? kGenericKernel : kMarchWrapper);
-    const char *hdr_src[] = {kDeviceH, kMarchInc, kMarch2Inc};
-    const char *hdr_name[] = {"pdehip_device.h", "pdehip_march.inc", "pdehip_march2.inc"};
+    src += two_level == kTileVariant ? kTileWrapper : (two_level ? kMarch2Wrapper : (generic ? kGenericKernel : kMarchWrapper));
+    const char *hdr_src[] = {kDeviceH, kMarchInc, kMarch2Inc, kTile2dInc};
+    const char *hdr_name[] = {"pdehip_device.h", "pdehip_march.inc", "pdehip_march2.inc", "pdehip_tile2d.inc"};
     hiprtcProgram prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src.c_str(), "pde_kernel.hip", 3, hdr_src, hdr_name) != 0)
+    if (g_rtc.CreateProgram(&prog, src.c_str(), "pde_kernel.hip", 4, hdr_src, hdr_name) != 0)
         PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
     std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
                                      "-DPDE_CZ=" + std::to_string(cz), std::string("-DPDE_HASX=") + (hasx ? "true" : "false"),
-                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level),
+                                     std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level == kTileVariant ? 0 : two_level),
                                      std::string("-DPDE_STAGE=") + (stage ? "1" : "0"), "-DPDE_WY=" + std::to_string(wy),
                                      std::string("-DPDE_TAILS=") + (tails ? "true" : "false")};
     std::vector<const char *> copts;
@@ -245,6 +255,7 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 1, 4, ndim == 3, true, nullptr, 0, true));   // stage sweeps: 1-row tiles
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr,
                                               j->body2.empty() ? E2_CUSTOM : E2_CUSTOM2));
+    if (ndim == 2 && j->body2.empty()) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 1, 64, false, true, nullptr, kTileVariant));
     return 0;
 }
 
@@ -600,6 +611,56 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     }
     char *cur = (char *)state_a, *nxt = (char *)state_b;
     int64_t s = 0;
+    // 2-D grids of a few MB and a ONE-pass expression of the state alone: K = 8 steps per launch with the time levels in LDS
+    // (pdehip_tile2d.inc around the generated update) - such grids are bound by launch / dependency latency, not by bytes
+    {
+        static int tile_on = -1;
+        static long tile_cells = 1L << 21;
+        if (tile_on < 0) {
+            const char *e = getenv("PDEHIP_TILE2D");
+            tile_on = (e && (e[0] == '0' || !strcmp(e, "off"))) ? 0 : 1;
+            if ((e = getenv("PDEHIP_TILE2D_CELLS")) != nullptr) tile_cells = atol(e);
+        }
+        const pdehip_jit_pass_t &p = passes[0];
+        Jit *j = static_cast<Jit *>(p.handle);
+        const bool plain = npasses == 1 && ncomp == 1 && p.src == -1 && p.out == -1 && p.extras[0] == PDEHIP_JIT_NONE &&
+                           p.extras[1] == PDEHIP_JIT_NONE && p.extras[2] == PDEHIP_JIT_NONE && p.faces && !uses_time && j->body2.empty();
+        if (tile_on && plain && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
+            InputBCs fc;
+            memset(&fc, 0, sizeof(fc));
+            bool ok = true;
+            for (int a = 0; a < 2 && ok; a++)
+                for (int side = 0; side < 2; side++) {
+                    const pdehip_bc_face_t &r = p.faces[2 * a + side];
+                    const int ax = 1 + a;
+                    if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) { ok = false; break; }
+                    fc.on[ax][side] = 1; fc.idx[ax][side] = r.index1; fc.c[ax][side] = r.const_v; fc.f[ax][side] = r.factor1;
+                }
+            const int kmax = tile2d_max_steps(2);
+            while (ok && s < nsteps) {
+                const int k = (int)((nsteps - s) < kmax ? (nsteps - s) : kmax);
+                Tile2Args ta;
+                unsigned nblocks = 0;
+                int tcw = 0;
+                bool done = false;
+                PDEHIP_TRY(plan_tile2d(n, cur, nxt, 2, 0.0, 0.0, 0.0, fc, nullptr, k, &ta, &nblocks, &tcw, &done));
+                if (!done) { ok = false; break; }
+                ta.par[0] = dt; ta.par[1] = t0;
+                const char *tname = n.dtype == PDEHIP_F64 ? "double" : "float";
+                const std::string key = std::string("tile,") + tname + "," + std::to_string(tcw);
+                Variant v;
+                auto it = j->cache.find(key);
+                if (it != j->cache.end()) v = it->second;
+                else PDEHIP_TRY(compile_variant(j, key, false, tname, n.dtype == PDEHIP_F64 ? 2 : 4, 1, tcw, false, true, &v, kTileVariant));
+                void *kargs[] = {&ta};
+                PDEHIP_HIP(hipModuleLaunchKernel(v.fn, nblocks, 1, 1, 1024, 1, 1, 0, as_stream(stream), kargs, nullptr));
+                s += k;
+                char *t = cur; cur = nxt; nxt = t;
+            }
+            if (ok) { *result = cur; return 0; }
+            // (not covered: nothing was launched - `ok` can only turn false before the first launch)
+        }
+    }
     // the first two steps always run as plain launches: they build whatever kernel is not built yet (no hiprtc inside a capture)
     const int64_t head = nsteps < 2 ? nsteps : 2;
     PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, 0, head, stream));

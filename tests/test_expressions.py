@@ -632,6 +632,8 @@ def test_euler_loop_in_one_call_equals_the_python_loop(steps, monkeypatch):
     uv = pde_hip.FieldCollection([pde_hip.ScalarField(grid, rng.uniform(0.5, 1.5, grid.shape)), pde_hip.ScalarField(grid, rng.uniform(2.5, 3.5, grid.shape))])
     vec = pde_hip.VectorField(grid, rng.uniform(-0.3, 0.3, (2, *grid.shape)))
     cases = [
+        (pde_hip.PDE({"c": "c - c**3 + laplace(c)"}, bc=bc), c),                                         # one pass of the state alone: 8 steps per launch (LDS kernel)
+        (pde_hip.PDE({"c": "0.3 * laplace(c) + 0.5 * gradient_squared(c) - c * d_dx(c) + 0.1 * d2_dy2(c)"}, bc=bc), c),   # ... with every stencil input
         (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0*x"}, bc=bc), c),                                   # one pass (+ a coordinate array)
         (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0.01 * sin(t)"}, bc=bc), c),                         # explicit time: no graph
         (pde_hip.PDE({"c": "-0.1 * laplace(laplace(c)) - laplace(c) - c**3 + 0.2 * x"}, bc=bc), c),      # passes with a temporary

@@ -145,6 +145,7 @@ struct Tile2Args {
     // MODE 2 (run-time generated update): parameters and derivative scales of the generated epilogue, [row axis, column axis]
     double par[12];
     double gs[2], dd1[2], dd2[2], dg[2];
+    long pc;               // MODE 3 (two fields): elements between the two component arrays
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

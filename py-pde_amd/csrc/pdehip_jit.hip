@@ -153,7 +153,7 @@ constexpr int kTileVariant = 100;
 const char *kTileWrapper = R"SRC(
 extern "C" __global__ void __launch_bounds__(1024) pde_kernel(pdehip::Tile2Args a)
 {
-    pdehip::tile2d_body<PDE_T, 2, 32, PDE_CZ, 8>(a);
+    pdehip::tile2d_body<PDE_T, PDE_RY, 32, PDE_CZ, 8>(a);   // PDE_RY carries the mode: 2 one field, 3 two coupled fields
 }
 )SRC";
 
@@ -180,7 +180,7 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
                       "__device__ __forceinline__ double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)\n{\n";
     src += j->body;
     src += "\n}\n";
-    if (two_level == E2_CUSTOM2) {
+    if (two_level == E2_CUSTOM2 || (two_level == kTileVariant && !j->body2.empty())) {
         src += "__device__ __forceinline__ double pde_epilogue2(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, const PdeDer &d)\n{\n";
         src += j->body2;
         src += "\n}\n";
@@ -255,7 +255,7 @@ int pdehip_jit_check(void *handle, int dtype, int ndim)
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 1, 4, ndim == 3, true, nullptr, 0, true));   // stage sweeps: 1-row tiles
     if (ndim >= 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, ndim == 3 ? 2 : 1, 1, ndim == 3, true, nullptr,
                                               j->body2.empty() ? E2_CUSTOM : E2_CUSTOM2));
-    if (ndim == 2 && j->body2.empty()) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, 1, 64, false, true, nullptr, kTileVariant));
+    if (ndim == 2) PDEHIP_TRY(compile_variant(j, "", false, tname, vec, j->body2.empty() ? 2 : 3, 64, false, true, nullptr, kTileVariant));
     return 0;
 }
 
@@ -621,37 +621,66 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
             tile_on = (e && (e[0] == '0' || !strcmp(e, "off"))) ? 0 : 1;
             if ((e = getenv("PDEHIP_TILE2D_CELLS")) != nullptr) tile_cells = atol(e);
         }
+        // one field: ONE pass of the state alone.  Two fields (reaction-diffusion systems): one pass per field, each reading its
+        // own component through the stencil and at most the OTHER component's centre value (slot e0): both fields advance in
+        // lockstep inside the kernel (pde_epilogue for the first, pde_epilogue2 for the second)
         const pdehip_jit_pass_t &p = passes[0];
-        Jit *j = static_cast<Jit *>(p.handle);
-        const bool plain = npasses == 1 && ncomp == 1 && p.src == -1 && p.out == -1 && p.extras[0] == PDEHIP_JIT_NONE &&
-                           p.extras[1] == PDEHIP_JIT_NONE && p.extras[2] == PDEHIP_JIT_NONE && p.faces && !uses_time && j->body2.empty();
-        if (tile_on && plain && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
-            InputBCs fc;
-            memset(&fc, 0, sizeof(fc));
-            bool ok = true;
-            for (int a = 0; a < 2 && ok; a++)
-                for (int side = 0; side < 2; side++) {
-                    const pdehip_bc_face_t &r = p.faces[2 * a + side];
-                    const int ax = 1 + a;
-                    if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) { ok = false; break; }
-                    fc.on[ax][side] = 1; fc.idx[ax][side] = r.index1; fc.c[ax][side] = r.const_v; fc.f[ax][side] = r.factor1;
+        auto none = [](int32_t v) { return v == PDEHIP_JIT_NONE; };
+        auto own_pass = [&](const pdehip_jit_pass_t &q, int comp, int other) {
+            return q.src == -1 - comp && q.out == -1 - comp && (none(q.extras[0]) || q.extras[0] == -1 - other) && none(q.extras[1]) &&
+                   none(q.extras[2]) && q.faces && static_cast<Jit *>(q.handle)->body2.empty();
+        };
+        const bool one = npasses == 1 && ncomp == 1 && own_pass(p, 0, 0) && none(p.extras[0]);
+        const bool two = npasses == 2 && ncomp == 2 && own_pass(passes[0], 0, 1) && own_pass(passes[1], 1, 0);
+        if (tile_on && (one || two) && !uses_time && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
+            Jit *j = static_cast<Jit *>(p.handle);
+            if (two) {
+                // the second field reads the first one as e0 and vice versa: when a pass does not use the other field its slot
+                // is simply ignored by its epilogue.  One combined handle per pair of epilogues, for the life of the process.
+                static std::map<std::string, Jit *> pairs;
+                static std::mutex pairs_mutex;
+                Jit *j1 = static_cast<Jit *>(passes[1].handle);
+                const std::string pk = j->body + '\x02' + j1->body;
+                std::lock_guard<std::mutex> guard(pairs_mutex);
+                auto it = pairs.find(pk);
+                if (it == pairs.end()) {
+                    Jit *jc = new Jit();
+                    jc->body = j->body;
+                    jc->body2 = j1->body;
+                    it = pairs.emplace(pk, jc).first;
                 }
-            const int kmax = tile2d_max_steps(2);
+                j = it->second;
+            }
+            InputBCs fc, fm;
+            memset(&fc, 0, sizeof(fc));
+            memset(&fm, 0, sizeof(fm));
+            bool ok = true;
+            for (int f = 0; f < (two ? 2 : 1) && ok; f++)
+                for (int a = 0; a < 2 && ok; a++)
+                    for (int side = 0; side < 2; side++) {
+                        const pdehip_bc_face_t &r = passes[f].faces[2 * a + side];
+                        const int ax = 1 + a;
+                        if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 < 0 || r.index1 >= n.n[ax]) { ok = false; break; }
+                        InputBCs &t = f ? fm : fc;
+                        t.on[ax][side] = 1; t.idx[ax][side] = r.index1; t.c[ax][side] = r.const_v; t.f[ax][side] = r.factor1;
+                    }
+            const int mode = two ? 3 : 2;
+            const int kmax = tile2d_max_steps(mode);
             while (ok && s < nsteps) {
                 const int k = (int)((nsteps - s) < kmax ? (nsteps - s) : kmax);
                 Tile2Args ta;
                 unsigned nblocks = 0;
                 int tcw = 0;
                 bool done = false;
-                PDEHIP_TRY(plan_tile2d(n, cur, nxt, 2, 0.0, 0.0, 0.0, fc, nullptr, k, &ta, &nblocks, &tcw, &done));
+                PDEHIP_TRY(plan_tile2d(n, cur, nxt, mode, 0.0, 0.0, 0.0, fc, two ? &fm : nullptr, k, &ta, &nblocks, &tcw, &done));
                 if (!done) { ok = false; break; }
                 ta.par[0] = dt; ta.par[1] = t0;
                 const char *tname = n.dtype == PDEHIP_F64 ? "double" : "float";
-                const std::string key = std::string("tile,") + tname + "," + std::to_string(tcw);
+                const std::string key = std::string(two ? "tile2," : "tile,") + tname + "," + std::to_string(tcw);
                 Variant v;
                 auto it = j->cache.find(key);
                 if (it != j->cache.end()) v = it->second;
-                else PDEHIP_TRY(compile_variant(j, key, false, tname, n.dtype == PDEHIP_F64 ? 2 : 4, 1, tcw, false, true, &v, kTileVariant));
+                else PDEHIP_TRY(compile_variant(j, key, false, tname, n.dtype == PDEHIP_F64 ? 2 : 4, mode, tcw, false, true, &v, kTileVariant));
                 void *kargs[] = {&ta};
                 PDEHIP_HIP(hipModuleLaunchKernel(v.fn, nblocks, 1, 1, 1024, 1, 1, 0, as_stream(stream), kargs, nullptr));
                 s += k;

@@ -526,21 +526,22 @@ int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, 
     *done = false;
     if (n.ndim != 2 || in == out || nsteps < 1 || nsteps > tile2d_max_steps(mode) || tune().force_generic) return 0;
     if (n.n[1] >= (1L << 30) || n.n[2] >= (1L << 30)) return 0;   // 32-bit window arithmetic
-    if (mode == 1 && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: Cahn-Hilliard tile sweep without the faces of mu");
+    const bool two = mode == 1 || mode == 3;   // a second table of conditions: mu (Cahn-Hilliard) / the second field (mode 3)
+    if (two && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: tile sweep of two fields without the second table of conditions");
     Tile2Args &a = *pa;
     memset(&a, 0, sizeof(a));
     for (int k = 0; k < 2; k++) {
         const int ax = 1 + k;
         const int cls = classify_axis(fc, ax, n.n[ax]);
-        if (cls < 0 || (mode == 1 && classify_axis(*fm, ax, n.n[ax]) != cls)) return 0;
+        if (cls < 0 || (two && classify_axis(*fm, ax, n.n[ax]) != cls)) return 0;
         a.per[k] = cls;
         for (int side = 0; side < 2; side++) {
             a.c[0][k][side] = fc.c[ax][side]; a.f[0][k][side] = fc.f[ax][side];
-            if (mode == 1) { a.c[1][k][side] = fm->c[ax][side]; a.f[1][k][side] = fm->f[ax][side]; }
+            if (two) { a.c[1][k][side] = fm->c[ax][side]; a.f[1][k][side] = fm->f[ax][side]; }
         }
     }
     a.in = in; a.out = out;
-    a.n0 = n.n[1]; a.n1 = n.n[2]; a.p1 = n.p[1]; a.off = n.off;
+    a.n0 = n.n[1]; a.n1 = n.n[2]; a.p1 = n.p[1]; a.off = n.off; a.pc = n.pc;
     a.sx = n.lap_scale[1]; a.sy = n.lap_scale[2];
     a.s1 = s1; a.s2 = s2; a.gamma = gamma; a.nsteps = nsteps;
     for (int k = 0; k < 2; k++) {   // scales of the generated epilogue's inputs (as in jit_apply_impl)

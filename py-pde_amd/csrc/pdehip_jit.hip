@@ -632,15 +632,20 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
         };
         const bool one = npasses == 1 && ncomp == 1 && own_pass(p, 0, 0) && none(p.extras[0]);
         const bool two = npasses == 2 && ncomp == 2 && own_pass(passes[0], 0, 1) && own_pass(passes[1], 1, 0);
-        if (tile_on && (one || two) && !uses_time && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
+        // two-pass chain of ONE field: tmp = f1(state), state' = f2(tmp; e0 = state) (mode 4, like the Cahn-Hilliard pair)
+        const bool chain = npasses == 2 && ncomp == 1 && p.src == -1 && p.out >= 0 && none(p.extras[0]) && none(p.extras[1]) && none(p.extras[2]) &&
+                           p.faces && passes[1].src == p.out && passes[1].out == -1 && (none(passes[1].extras[0]) || passes[1].extras[0] == -1) &&
+                           none(passes[1].extras[1]) && none(passes[1].extras[2]) && passes[1].faces &&
+                           static_cast<Jit *>(p.handle)->body2.empty() && static_cast<Jit *>(passes[1].handle)->body2.empty();
+        if (tile_on && (one || two || chain) && !uses_time && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
             Jit *j = static_cast<Jit *>(p.handle);
-            if (two) {
+            if (two || chain) {
                 // the second field reads the first one as e0 and vice versa: when a pass does not use the other field its slot
                 // is simply ignored by its epilogue.  One combined handle per pair of epilogues, for the life of the process.
                 static std::map<std::string, Jit *> pairs;
                 static std::mutex pairs_mutex;
                 Jit *j1 = static_cast<Jit *>(passes[1].handle);
-                const std::string pk = j->body + '\x02' + j1->body;
+                const std::string pk = j->body + (two ? '\x02' : '\x03') + j1->body;
                 std::lock_guard<std::mutex> guard(pairs_mutex);
                 auto it = pairs.find(pk);
                 if (it == pairs.end()) {
@@ -655,7 +660,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
             memset(&fc, 0, sizeof(fc));
             memset(&fm, 0, sizeof(fm));
             bool ok = true;
-            for (int f = 0; f < (two ? 2 : 1) && ok; f++)
+            for (int f = 0; f < ((two || chain) ? 2 : 1) && ok; f++)
                 for (int a = 0; a < 2 && ok; a++)
                     for (int side = 0; side < 2; side++) {
                         const pdehip_bc_face_t &r = passes[f].faces[2 * a + side];
@@ -664,7 +669,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                         InputBCs &t = f ? fm : fc;
                         t.on[ax][side] = 1; t.idx[ax][side] = r.index1; t.c[ax][side] = r.const_v; t.f[ax][side] = r.factor1;
                     }
-            const int mode = two ? 3 : 2;
+            const int mode = two ? 3 : (chain ? 4 : 2);
             const int kmax = tile2d_max_steps(mode);
             while (ok && s < nsteps) {
                 const int k = (int)((nsteps - s) < kmax ? (nsteps - s) : kmax);
@@ -672,11 +677,11 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                 unsigned nblocks = 0;
                 int tcw = 0;
                 bool done = false;
-                PDEHIP_TRY(plan_tile2d(n, cur, nxt, mode, 0.0, 0.0, 0.0, fc, two ? &fm : nullptr, k, &ta, &nblocks, &tcw, &done));
+                PDEHIP_TRY(plan_tile2d(n, cur, nxt, mode, 0.0, 0.0, 0.0, fc, (two || chain) ? &fm : nullptr, k, &ta, &nblocks, &tcw, &done));
                 if (!done) { ok = false; break; }
                 ta.par[0] = dt; ta.par[1] = t0;
                 const char *tname = n.dtype == PDEHIP_F64 ? "double" : "float";
-                const std::string key = std::string(two ? "tile2," : "tile,") + tname + "," + std::to_string(tcw);
+                const std::string key = std::string(two ? "tile2," : (chain ? "tile4," : "tile,")) + tname + "," + std::to_string(tcw);
                 Variant v;
                 auto it = j->cache.find(key);
                 if (it != j->cache.end()) v = it->second;

@@ -517,7 +517,7 @@ static int classify_axis(const InputBCs &fg, int ax, long n)
 // K Euler steps of a 2-D grid per launch with the time levels in LDS (pdehip_tile2d.inc).  mode 0: diffusion (s1 = D), 1:
 // Cahn-Hilliard (gamma; fm = faces of mu).  *done = false when grid / faces / step count are not covered.
 constexpr int kTile2Halo = 8;
-int tile2d_max_steps(int mode) { return mode == 1 ? kTile2Halo / 2 : kTile2Halo; }
+int tile2d_max_steps(int mode) { return (mode == 1 || mode == 4) ? kTile2Halo / 2 : kTile2Halo; }
 
 // arguments and launch geometry of tile2d_kernel; mode 2 = the run-time built instance (pdehip_jit.hip fills par / scales)
 int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
@@ -526,7 +526,7 @@ int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, 
     *done = false;
     if (n.ndim != 2 || in == out || nsteps < 1 || nsteps > tile2d_max_steps(mode) || tune().force_generic) return 0;
     if (n.n[1] >= (1L << 30) || n.n[2] >= (1L << 30)) return 0;   // 32-bit window arithmetic
-    const bool two = mode == 1 || mode == 3;   // a second table of conditions: mu (Cahn-Hilliard) / the second field (mode 3)
+    const bool two = mode == 1 || mode == 3 || mode == 4;   // a second table of conditions: mu (Cahn-Hilliard) / the second field (mode 3) / the temporary (mode 4)
     if (two && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: tile sweep of two fields without the second table of conditions");
     Tile2Args &a = *pa;
     memset(&a, 0, sizeof(a));

@@ -637,6 +637,8 @@ def test_euler_loop_in_one_call_equals_the_python_loop(steps, monkeypatch):
         (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0*x"}, bc=bc), c),                                   # one pass (+ a coordinate array)
         (pde_hip.PDE({"c": "c - c**3 + laplace(c) + 0.01 * sin(t)"}, bc=bc), c),                         # explicit time: no graph
         (pde_hip.PDE({"c": "-0.1 * laplace(laplace(c)) - laplace(c) - c**3 + 0.2 * x"}, bc=bc), c),      # passes with a temporary
+        (pde_hip.PDE({"c": "(0.1 - 1) * c - 0.2 * laplace(c) - 0.01 * laplace(laplace(c)) - c**3"}, bc=bc), c),   # two-pass chain: LDS kernel, mode 4
+        (pde_hip.PDE({"c": "laplace(c**3 - c - 0.01 * laplace(c)) + 0*c"}, bc_ops={"c:laplace": {"x": {"derivative": 0.1}, "y": "periodic"}}), c),
         (pde_hip.PDE({"u": "laplace(u) + 1 - 4 * u + v * u**2", "v": "0.1 * laplace(v) + 3 * u - v * u**2"}, bc=bc), uv),   # two fields in lockstep (LDS kernel)
         (pde_hip.PDE({"u": "laplace(u) - u * d_dx(u)", "v": "0.1 * laplace(v) + gradient_squared(v) - u"},
                      bc_ops={"u:*": bc, "v:*": {"x": {"derivative": 0.3}, "y": "periodic"}}), uv),                     # ... one of them ignores the other; own conditions per field

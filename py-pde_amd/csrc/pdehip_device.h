@@ -146,6 +146,8 @@ struct Tile2Args {
     double par[12];
     double gs[2], dd1[2], dd2[2], dg[2];
     long pc;               // MODE 3 (two fields): elements between the two component arrays
+    double t0;             // MODE 2-4: time of step 0 of the run and index of this launch's first step: level l is evaluated at
+    long step0;            //   t0 + (step0 + l) * dt, the expression of the step loop (numba/_solvers.py:100), in p[1]
 };
 
 // LAP_CUSTOM: the pointwise epilogue is generated at run time (pde_hip/expr.py -> pdehip_jit.hip); the

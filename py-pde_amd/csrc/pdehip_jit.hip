@@ -637,7 +637,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                            p.faces && passes[1].src == p.out && passes[1].out == -1 && (none(passes[1].extras[0]) || passes[1].extras[0] == -1) &&
                            none(passes[1].extras[1]) && none(passes[1].extras[2]) && passes[1].faces &&
                            static_cast<Jit *>(p.handle)->body2.empty() && static_cast<Jit *>(passes[1].handle)->body2.empty();
-        if (tile_on && (one || two || chain) && !uses_time && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {
+        if (tile_on && (one || two || chain) && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {   // (explicit time: evaluated per level)
             Jit *j = static_cast<Jit *>(p.handle);
             if (two || chain) {
                 // the second field reads the first one as e0 and vice versa: when a pass does not use the other field its slot
@@ -679,7 +679,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                 bool done = false;
                 PDEHIP_TRY(plan_tile2d(n, cur, nxt, mode, 0.0, 0.0, 0.0, fc, (two || chain) ? &fm : nullptr, k, &ta, &nblocks, &tcw, &done));
                 if (!done) { ok = false; break; }
-                ta.par[0] = dt; ta.par[1] = t0;
+                ta.par[0] = dt; ta.par[1] = t0; ta.t0 = t0; ta.step0 = (long)s;
                 const char *tname = n.dtype == PDEHIP_F64 ? "double" : "float";
                 const std::string key = std::string(two ? "tile2," : (chain ? "tile4," : "tile,")) + tname + "," + std::to_string(tcw);
                 Variant v;

@@ -98,6 +98,12 @@ def pytest_generate_tests(metafunc):
     """Runs before pytest resolves the ``parametrize`` marks: the marks hold the module's list OBJECTS, so editing
     them in place re-parametrises every generic test with the hip backend."""
     mod = metafunc.module
+    # tests the reference parametrises over an explicit ["numpy", "numba"] list: the hip backend takes their place too
+    for mark in metafunc.definition.iter_markers("parametrize"):
+        if len(mark.args) >= 2 and mark.args[0] == "backend" and isinstance(mark.args[1], list):
+            values = mark.args[1]
+            if values and all(isinstance(v, str) for v in values) and "numpy" in values:
+                values[:] = ["hip"]
     for name in BACKEND_LIST_NAMES:
         lst = getattr(mod, name, None)
         if isinstance(lst, list) and lst != ["hip"]:

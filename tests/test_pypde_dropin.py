@@ -688,3 +688,19 @@ def test_results_are_ordinary_fields(hip1):
     diff = res - state                     # binary operations check compatibility first
     assert type(diff) is pde.ScalarField and np.isfinite(diff.data).all()
     assert type(res.copy()) is pde.ScalarField
+
+
+def test_hook_changes_before_stop_iteration_are_kept(hip1):
+    """A hook that modifies the state in place and THEN raises StopIteration: the modification is part of the final state
+    (the reference's arrays are the state itself; tests/pdes/test_pde_class.py:546-566 checks exactly this)."""
+    def post_step_hook(state_data, t):
+        state_data[:3, :] = 1
+        if t > 0.25:
+            raise StopIteration
+        return state_data
+
+    eq = pde.PDE({"c": "laplace(c)"}, post_step_hook=post_step_hook)
+    state = pde.ScalarField(pde.UnitGrid([8, 8]))
+    result = eq.solve(state, dt=0.1, t_range=10, backend="hip", tracker=None)
+    np.testing.assert_allclose(result.data[:3, :], 1)
+    assert (result.data[3:, :] > 0).all() and (result.data[3:, :] < 1).all()

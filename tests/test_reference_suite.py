@@ -2,7 +2,7 @@
 
 A child pytest collects test files straight from ``/root/reference/tests`` (nothing is copied; skipped where the
 reference is absent, e.g. on the GPU box) with ``tests/refshim_plugin.py`` standing in for the reference's conftest:
-it puts ``"hip"`` into ``ALL_BACKENDS`` & co., registers the plugin class with the real py-pde and installs the
+it puts ``"hip"`` into ``ALL_BACKENDS`` & co. and into explicit ``["numpy", "numba"]`` backend lists, registers the plugin class with the real py-pde and installs the
 tests-only host shim behind the C ABI.  Every hip-parametrised test of the listed files must pass, except the ids in
 ``NEXT`` — features SURVEY.md §8f lists as "next" that the backend refuses with ``NotImplementedError`` today; the
 list is checked both ways (a test that starts passing must be removed from it).
@@ -32,7 +32,9 @@ SUITES: dict[str, dict[str, str]] = {
     "backends/generic/test_boundaries.py": {},
     # solver x backend matrix, erf known answer (tests/solvers/test_generic_solvers.py:123-230)
     # ... incl. Euler-Maruyama with the device generator (additive noise; Milstein / implicit solvers are refused)
-    "solvers/test_generic_solvers.py": {},
+    "solvers/test_generic_solvers.py": {
+        "test_solvers_complex": "complex-valued fields (real fp64 / fp32 only)",
+    },
     # noise scaling: Kolmogorov-Smirnov test of the final field against the analytical normal distribution
     "pdes/test_diffusion_pdes.py": {},
     "solvers/test_explicit_solvers.py": {
@@ -48,6 +50,9 @@ SUITES: dict[str, dict[str, str]] = {
     # `backend="auto"` treats as "try the next backend" (pde/pdes/base.py:383-400)
     "test_integration.py": {
         "test_stop_iteration_hook": "user-defined right-hand side in Python (hooks themselves are supported: tests/test_pypde_dropin.py)",
+        "test_custom_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
+        "test_array_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
+        "test_inhomogeneous_bcs_func": "boundary condition given as a Python function of the array (use an expression string)",
         "test_pde_with_bc_setter": "boundary conditions set by a user function on the array",
     },
     # the generic `PDE` class (tests/pdes/test_pde_class.py): explicit time, multi-field systems, per-field noise, coordinates,

@@ -14,8 +14,8 @@ not read the field — is exactly the constant-coefficient form the ghost kernel
 
 with per-face-cell coefficient arrays (``PDEHIP_BCF_ARRAYS``, ``include/pdehip.h``).  ``A`` and ``B`` are split off
 symbolically (``B = dF/dvalue``, ``A = F(value=0)``) and evaluated on the wall points once (time independent: the face
-then costs nothing extra in the time loop) or whenever the time changes (``ExprFaceTable.update``).  Conditions that are
-non-linear in ``value`` or given as Python callables raise ``NotImplementedError``.
+then costs nothing extra in the time loop) or whenever the time changes (``ExprFaceTable.update``).  Conditions given as Python FUNCTIONS are probed on the host (coefficient arrays before every
+right-hand side); conditions that are non-linear in ``value`` raise ``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -39,13 +39,27 @@ class _AffineFace:
     def __init__(self, bc):
         import sympy as sp
 
-        if getattr(bc, "_is_func", False):
-            msg = "hip backend: boundary conditions given as Python functions cannot run on the device (use an expression string)"
-            raise NotImplementedError(msg)
         if getattr(bc, "rank", 0) != 0:
             msg = "Expression boundary conditions only work for scalar conditions"
             raise NotImplementedError(msg)
         grid = bc.grid
+        self._callable = None
+        if getattr(bc, "_is_func", False):
+            # the condition is a Python function F(adjacent_value, dx, *coords, t) (pde/grids/boundaries/local.py:921-963): it
+            # cannot run on the device, but its coefficient arrays can be taken on the host - before every right-hand side,
+            # because nothing is known about its dependence on t - as long as it is affine in `adjacent_value`
+            self._callable = bc._make_function()
+            self._target = bc._input["target"]
+            self._value_func = bc._prepare_function(bc._input["value_expr"])
+            self.time_dependent = True
+            self.dx = float(grid.discretization[bc.axis])
+            coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
+            self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
+            self.face_shape = self.coords[0].shape if self.coords else ()
+            index = int(bc._get_value_cell_index(with_ghost_cells=False))
+            self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
+            self.evaluate(0.0)   # raises for functions that are not affine in the adjacent value
+            return
         expr = sp.sympify(bc._func_expression._sympy_expr)
         names = ["value", "dx", *grid.axes, "t"]
         by_name = {s.name: s for s in expr.free_symbols}
@@ -70,7 +84,30 @@ class _AffineFace:
         index = int(bc._get_value_cell_index(with_ghost_cells=False))
         self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
 
+    def _evaluate_callable(self, t: float) -> tuple[np.ndarray, np.ndarray]:
+        shape = self.face_shape
+        probe = [np.full(shape, v, dtype=np.float64) for v in (0.0, 1.0, 2.0)]
+
+        def call(func, v):
+            return np.array(np.broadcast_to(np.asarray(func(v, self.dx, *self.coords, t), dtype=np.float64), shape), dtype=np.float64, order="C")
+
+        with np.errstate(all="ignore"):
+            if self._target in ("value", "derivative"):
+                f0, f1 = call(self._value_func, probe[0]), call(self._value_func, probe[1])
+                if np.array_equal(f0, f1, equal_nan=True):
+                    # the usual case - a function of position and time only: exactly the reference's `2 f - value` / `dx f + value`
+                    return (2 * f0, np.full(shape, -1.0)) if self._target == "value" else (self.dx * f0, np.full(shape, 1.0))
+            a = call(self._callable, probe[0])
+            b = call(self._callable, probe[1]) - a
+            check = call(self._callable, probe[2])
+        if not np.allclose(check, a + 2 * b, rtol=1e-12, atol=1e-12, equal_nan=True):
+            msg = "hip backend: boundary condition function is not affine in the adjacent value (needs run-time code generation)"
+            raise NotImplementedError(msg)
+        return a, b
+
     def evaluate(self, t: float) -> tuple[np.ndarray, np.ndarray]:
+        if self._callable is not None:
+            return self._evaluate_callable(t)
         with np.errstate(all="ignore"):
             a = np.asarray(self._offset(self.dx, *self.coords, t), dtype=np.float64)
             b = np.asarray(self._slope(self.dx, *self.coords, t), dtype=np.float64)

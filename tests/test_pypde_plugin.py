@@ -12,6 +12,8 @@ from __future__ import annotations
 import sys
 from pathlib import Path
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -90,11 +92,29 @@ def test_unsupported_boundaries_raise_not_implemented():
     with pytest.raises(NotImplementedError, match="not linear"):
         convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": "value**2"}, rank=0), upload=HostBuf)
 
+    # conditions given as Python functions are probed on the host (before every right-hand side): affine ones work ...
     def user_bc(value, dx, x, y, t):
-        return value
+        return 0.5 * value + np.sign(x) * t
 
-    with pytest.raises(NotImplementedError, match="Python functions"):
-        convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": user_bc}, rank=0), upload=HostBuf)
+    table = convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": user_bc}, rank=0), upload=HostBuf)
+    assert table.time_dependent
+
+    def user_value(value, dx, x, y, t):
+        return np.sin(y)
+
+    ref = convert_bcs_with_expressions(grid.get_boundary_conditions({"value_expression": "sin(y)"}, rank=0), upload=HostBuf)
+    fun = convert_bcs_with_expressions(grid.get_boundary_conditions({"type": "value_expression", "value": user_value}, rank=0), upload=HostBuf)
+    fun.update({"t": 0.3})
+    for k in range(4):   # exactly the coefficient arrays of the expression form (2 f, -1)
+        n = grid.shape[1 - k // 2]
+        for name in ("const_arr", "factor1_arr"):
+            a = np.ctypeslib.as_array((C.c_double * n).from_address(getattr(ref.c[k], name)))
+            b = np.ctypeslib.as_array((C.c_double * n).from_address(getattr(fun.c[k], name)))
+            np.testing.assert_array_equal(a, b)
+
+    # ... functions that are not affine in the adjacent value do not
+    with pytest.raises(NotImplementedError, match="not affine"):
+        convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": lambda value, dx, x, y, t: value**2}, rank=0), upload=HostBuf)
 
 
 @pytest.mark.parametrize("bc", [

@@ -52,7 +52,6 @@ SUITES: dict[str, dict[str, str]] = {
         "test_stop_iteration_hook": "user-defined right-hand side in Python (hooks themselves are supported: tests/test_pypde_dropin.py)",
         "test_custom_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
         "test_array_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
-        "test_inhomogeneous_bcs_func": "boundary condition given as a Python function of the array (use an expression string)",
         "test_pde_with_bc_setter": "boundary conditions set by a user function on the array",
     },
     # the generic `PDE` class (tests/pdes/test_pde_class.py): explicit time, multi-field systems, per-field noise, coordinates,

@@ -1,0 +1,84 @@
+"""Differential fuzz of the class PDEs through the REAL py-pde: random grids (1-3 axes, mixed periodicity, non-unit spacing),
+random boundary conditions per face (Dirichlet / Neumann / mixed / curvature / position- and time-dependent expressions), random solver — hip (tests-only host shim: the
+product's BC conversion, right-hand-side selection, stepper loops) against the reference's numpy backend on the same objects."""
+
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REF = Path("/root/reference")
+if not (REF / "pde").exists():
+    pytest.skip("py-pde (reference) not available", allow_module_level=True)
+if str(REF) not in sys.path:
+    sys.path.append(str(REF))
+
+import pde  # noqa: E402
+import shimlib  # noqa: E402
+from helpers import max_rel  # noqa: E402
+
+
+def _random_face(rng, axes=""):
+    kind = rng.integers(6 if axes else 4)
+    if kind == 4:   # expression conditions: position and time dependent
+        return {"value_expression": f"0.1 * sin(3 * t) + 0.05 * {axes[rng.integers(len(axes))]}"}
+    if kind == 5:
+        return {"derivative_expression": f"0.1 * cos(t) * {axes[rng.integers(len(axes))]}"}
+    if kind == 0:
+        return {"value": float(rng.uniform(-0.5, 0.5))}
+    if kind == 1:
+        return {"derivative": float(rng.uniform(-0.3, 0.3))}
+    if kind == 2:
+        return {"type": "mixed", "value": float(rng.uniform(0.1, 1.0)), "const": float(rng.uniform(-0.3, 0.3))}
+    return {"curvature": float(rng.uniform(-0.2, 0.2))}
+
+
+def _random_bc(rng, grid):
+    bc = {}
+    for ax, per in zip(grid.axes, grid.periodic):
+        if per:
+            bc[ax] = "periodic"
+        else:
+            others = "".join(a for a in grid.axes if a != ax)
+            bc[f"{ax}-"], bc[f"{ax}+"] = _random_face(rng, others), _random_face(rng, others)
+    return bc
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_class_pde_runs_match_the_reference(seed, monkeypatch):
+    monkeypatch.setitem(pde.config, "default_backend", "scipy")   # operators of the numpy path (numba is not installed here)
+    rng = np.random.default_rng(3000 + seed)
+    nd = 1 + seed % 3
+    shape = [int(rng.integers(5, 14)) for _ in range(nd)]
+    periodic = [bool(rng.integers(2)) for _ in range(nd)]
+    dx = float(rng.choice([0.5, 1.0, 2.0]))                        # (the scipy operators want one spacing for all axes)
+    grid = pde.CartesianGrid([[0, dx * n] for n in shape], shape, periodic=periodic)
+    state = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)
+    which = seed % 4
+    if which == 0:
+        eq = pde.DiffusionPDE(diffusivity=float(rng.uniform(0.2, 1.5)), bc=_random_bc(rng, grid))
+    elif which == 1:
+        eq = pde.CahnHilliardPDE(interface_width=float(rng.uniform(0.5, 1.5)), bc_c=_random_bc(rng, grid), bc_mu=_random_bc(rng, grid))
+    elif which == 2:
+        eq = pde.AllenCahnPDE(interface_width=float(rng.uniform(0.5, 1.5)), mobility=float(rng.uniform(0.5, 1.5)), bc=_random_bc(rng, grid))
+    else:
+        eq = pde.SwiftHohenbergPDE(rate=0.1, kc2=float(rng.uniform(0.2, 1.0)), delta=float(rng.uniform(0, 1)), bc=_random_bc(rng, grid),
+                                   bc_lap=_random_bc(rng, grid))
+    solver = ["euler", "runge-kutta"][int(rng.integers(2))]
+    adaptive = bool(seed % 5 == 0) and solver == "runge-kutta"
+    dt = 1e-3 * dx**4
+    kw = dict(t_range=12 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
+    if adaptive:
+        kw["adaptive"] = True
+    ref, iref = eq.solve(state, backend="numpy", **kw)
+    with shimlib.use_shim(fused=bool(seed % 2)):
+        import pde_hip.pypde_plugin  # noqa: F401
+
+        out, info = eq.solve(state, backend="hip", **kw)
+        got = np.array(out.data)   # (the result is linked to its device copy: read it while that library is in place)
+    assert info["solver"]["steps"] == iref["solver"]["steps"]
+    assert np.isfinite(ref.data).all()
+    assert max_rel(got, ref.data) < 1e-9, (type(eq).__name__, shape, periodic, solver)

@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the slab/RCCL path even on one rank (periodic halo sent to self) - overhead probe")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-extra", action="store_true", help="skip the operator roofline, the cfg2/cfg3/cfg5 timings and the parity bit")
     return ap.parse_args()
 
 
@@ -201,6 +202,92 @@ def bench_single(args) -> dict:
         },
         "device": backend.device_name,
     }
+    if not args.no_extra:
+        out["roofline_operator"] = operator_roofline(backend, lib, spec, cur, nxt, stream, ev, cells)
+        del a, b
+        try:
+            out["parity"] = parity_bit(backend, n)
+            out["extra"] = extra_configs(backend)
+        except Exception as err:   # the metric line must survive a failure of the side measurements; it says so
+            out.setdefault("parity", None)
+            out["extra_error"] = f"{type(err).__name__}: {err}"
+    return out
+
+
+def operator_roofline(backend, lib, spec, a, out, stream, ev, cells: int) -> dict:
+    """The kernel north_star names: the 3-D fp64 Laplacian on the resident field (`pdehip_laplace`, ghost cells set once),
+    60 applications timed with HIP events on the launch stream; 16 algorithmic bytes per cell."""
+    from pde_hip import _abi
+
+    info = spec.info
+    lib.set_ghost_cells(info.ref, 1, spec.bc_c.c, a, stream)
+    for _ in range(5):
+        lib.laplace(info.ref, a, out, _abi.OUT_FULL, stream)
+    lib.stream_synchronize(stream)
+    reps = 60
+    lib.event_record(ev[2], stream)
+    for _ in range(reps):
+        lib.laplace(info.ref, a, out, _abi.OUT_FULL, stream)
+    lib.event_record(ev[3], stream)
+    lib.stream_synchronize(stream)
+    ms = C.c_float()
+    lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms))
+    t = ms.value / reps * 1e-3
+    gbs = cells * BYTES_PER_CELL_STEP / t / 1e9
+    return {"bound": "hbm", "kernel": "lap_march_kernel<double,3-D> (pdehip_laplace: one read + one write per cell)", "applications": reps,
+            "kernel_ms": round(t * 1e3, 4), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "mcells_per_s": round(cells / t / 1e6, 1), "bytes_per_launch": cells * BYTES_PER_CELL_STEP}
+
+
+def parity_bit(backend, n: int) -> dict | None:
+    """Parity check accompanying the timing: 6 Euler steps from the seeded initial state through the SAME
+    entry point the timed region uses (`pdehip_euler_run`: three two-step sweeps), SHA-256 of the whole final field against
+    the digest of the REFERENCE's own torch-CPU run (tests/golden/configs.npz, written by tests/golden/make_golden_configs.py)."""
+    import hashlib
+
+    import pde_hip
+
+    path = ROOT / "tests" / "golden" / "configs.npz"
+    if n != 512 or not path.exists():
+        return None
+    golden = np.load(path, allow_pickle=False)
+    key = "cfg4_diffusion_512cube_6steps/sha256"
+    if key not in golden.files:
+        return None
+    grid = pde_hip.UnitGrid([n] * 3, periodic=True)
+    state = pde_hip.ScalarField.random_uniform(grid, rng=np.random.default_rng(0))
+    res = pde_hip.DiffusionPDE(1.0).solve(state, t_range=0.6, dt=0.1, solver="euler", backend=backend)
+    digest = hashlib.sha256(np.ascontiguousarray(res.data).tobytes()).hexdigest()
+    return {"check": "sha256 of the whole 512^3 field after 6 Euler steps == the reference's torch-CPU run", "ok": digest == str(golden[key]),
+            "sha256": digest[:16], "golden": "tests/golden/configs.npz:cfg4_diffusion_512cube_6steps"}
+
+
+def extra_configs(backend) -> dict:
+    """One-line timings of the other BASELINE.json configurations through `eq.solve` of the mirror front end (state uploaded
+    once, resident; wall until the device is done).  They are parity-test cases (tests/test_baseline_configs.py), not the
+    metric; quoted here so that the driver's run records them next to it."""
+    import pde_hip
+
+    rng = np.random.default_rng(0)
+    out = {}
+
+    def run(name, eq, grid, dtype, t_range, dt, solver, lo=0.0, hi=1.0, **kw):
+        state = pde_hip.ScalarField(grid, rng.uniform(lo, hi, grid.shape), dtype=dtype)
+        eq.solve(state, t_range=t_range / 50, dt=dt, solver=solver, backend=backend, **kw)   # warm-up: allocations, run-time builds
+        backend.synchronize()
+        t0 = time.perf_counter()
+        _, info = eq.solve(state, t_range=t_range, dt=dt, solver=solver, backend=backend, ret_info=True, **kw)
+        backend.synchronize()
+        wall = time.perf_counter() - t0
+        steps = info["solver"]["steps"]
+        cells = int(np.prod(grid.shape))
+        out[name] = {"steps": steps, "wall_ms": round(wall * 1e3, 2), "us_per_step": round(wall / steps * 1e6, 2),
+                     "mcell_steps_per_s": round(cells * steps / wall / 1e6, 1)}
+
+    run("cfg2_diffusion_1024sq_f64_euler", pde_hip.DiffusionPDE(), pde_hip.CartesianGrid([[0, 1024]] * 2, 1024, periodic=True), np.float64, 100.0, 0.1, "euler")
+    run("cfg3_cahn_hilliard_512sq_f64_euler_1e4_steps", pde_hip.CahnHilliardPDE(), pde_hip.UnitGrid([512, 512]), np.float64, 10.0, 1e-3, "euler")
+    run("cfg5_expression_256cube_f32_rkf45", pde_hip.PDE({"c": "laplace(c**3 - c - laplace(c))"}), pde_hip.UnitGrid([256] * 3, periodic=True),
+        np.float32, 1.0, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, adaptive=True)
     return out
 
 
@@ -270,6 +357,9 @@ def main():
         ngpu = 1
         wall = r["wall"]
         line = {"roofline": r["roofline"]}
+        for key in ("roofline_operator", "parity", "extra", "extra_error"):
+            if key in r:
+                line[key] = r[key]
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, args.cpu_seconds)
         ref_file = ROOT / "profiles" / "reference_cpu.json"
         if ref_file.exists() and not args.no_cpu_baseline:

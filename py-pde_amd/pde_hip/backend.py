@@ -148,14 +148,37 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
 # ---------------------------------------------------------------------------------------------
 # right hand sides the fused steppers know
 # ---------------------------------------------------------------------------------------------
+# methods that define the right-hand side of a PDE class (pde/pdes/base.py:211-449, pde/pdes/pde.py:636-900): a user subclass that
+# overrides ANY of them is a different equation - the reference honours the override through `eq.make_evolution_rate`, this backend
+# maps the class onto a built-in kernel and must therefore refuse it
+_RHS_METHODS = ("evolution_rate", "make_evolution_rate", "make_pde_rhs", "_make_pde_rhs_numba", "_make_pde_rhs_numba_cached",
+                "_make_pde_rhs_collection_numba", "_make_pde_rhs_collection_torch", "_make_pde_rhs_collection_jax",
+                "_compile_rhs_single", "_add_operators_to_expr", "_prepare_cache", "expression", "expressions")
+
+
+def known_pde_class(eq, names) -> type | None:
+    """The class of ``eq`` or the nearest base class whose NAME is in ``names`` (the reference's and the mirror's classes both
+    match) — provided no class between ``type(eq)`` and it redefines a method of the right-hand side.  A subclass that only
+    adds e.g. a post-step hook is accepted; one that changes the equation raises ``NotImplementedError`` (``backend="auto"``
+    treats that as "try the next backend", pde/pdes/base.py:383-400)."""
+    mro = type(eq).__mro__
+    for i, cls in enumerate(mro):
+        if cls.__name__ in names:
+            for sub in mro[:i]:
+                changed = [m for m in _RHS_METHODS if m in vars(sub)]
+                if changed:
+                    msg = (f"hip backend: {sub.__name__} overrides {', '.join(changed)} of {cls.__name__}; user-defined right-hand sides "
+                           "in Python cannot run on the device (the built-in kernel of the base class would silently ignore the override)")
+                    raise NotImplementedError(msg)
+            return cls
+    return None
+
+
 def pde_kind(eq) -> str:
-    """``"DiffusionPDE"`` / ``"CahnHilliardPDE"`` / ``"PDE"`` for objects of these classes OR subclasses of them (user classes
-    that add e.g. a post-step hook), looked up by class name along the MRO so that the reference's and the mirror's classes
-    both match; otherwise the object's own class name."""
-    for cls in type(eq).__mro__:
-        if cls.__name__ in {"DiffusionPDE", "CahnHilliardPDE", "PDE"}:
-            return cls.__name__
-    return eq.__class__.__name__
+    """``"DiffusionPDE"`` / ``"CahnHilliardPDE"`` / ``"PDE"`` for objects of these classes OR subclasses that leave the
+    right-hand side alone (see :func:`known_pde_class`); otherwise the object's own class name."""
+    cls = known_pde_class(eq, {"DiffusionPDE", "CahnHilliardPDE", "PDE"})
+    return cls.__name__ if cls is not None else eq.__class__.__name__
 
 
 def class_expressions(eq):
@@ -164,8 +187,12 @@ def class_expressions(eq):
     Formulas and the condition each (nested) operator takes are those of the classes' ``evolution_rate``:
     AllenCahnPDE pde/pdes/allen_cahn.py:98-100, KPZInterfacePDE kpz_interface.py:104-107, KuramotoSivashinskyPDE
     kuramoto_sivashinsky.py:106-111, SwiftHohenbergPDE swift_hohenberg.py:104-113, WavePDE wave.py:106-109, KleinGordonPDE
-    klein_gordon.py:124-127.  Matched by class name along the MRO like :func:`pde_kind`."""
-    names = [cls.__name__ for cls in type(eq).__mro__]
+    klein_gordon.py:124-127.  Matched by class name along the MRO like :func:`pde_kind` (subclasses that redefine the
+    right-hand side are refused, :func:`known_pde_class`)."""
+    base = known_pde_class(eq, {"AllenCahnPDE", "KPZInterfacePDE", "KuramotoSivashinskyPDE", "SwiftHohenbergPDE", "KleinGordonPDE", "WavePDE"})
+    if base is None:
+        return None
+    names = [cls.__name__ for cls in base.__mro__]
     outer = {"laplace_outer": "laplace"}
     if "AllenCahnPDE" in names:
         return ({"c": "mobility * (interface_width * laplace(c) - c**3 + c)"},
@@ -1299,6 +1326,12 @@ class ResidentState:
     class is swapped for a dynamic subclass whose data attributes (``data``, ``_data_full`` ...) first bring the host
     arrays up to date — one pinned-speed download — and then count as a possible modification, so the next stepper call
     uploads again.  Nothing else about the field changes; copies of it are ordinary fields.
+
+    Limitation: synchronisation happens on ATTRIBUTE ACCESS.  A numpy view obtained earlier (``arr = state.data``
+    kept by a tracker or by the caller) is not refreshed behind the holder's back while the run goes on — it shows the state of
+    its last ``state.data`` access — and writes made through such a held view after that access are not seen.  Code that wants
+    the reference's behaviour (the stepper updates the host array in place at every call) sets ``resident_state=False`` in the
+    backend's configuration, which restores the upload / download per stepper call of ``pde/backends/torch/backend.py:654-662``.
     """
 
     def __init__(self, field, dev_state: DeviceArray, backend):

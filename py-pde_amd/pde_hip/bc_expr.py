@@ -52,6 +52,7 @@ class _AffineFace:
             self._target = bc._input["target"]
             self._value_func = bc._prepare_function(bc._input["value_expr"])
             self.time_dependent = True
+            self.needs_time = False         # a callable is evaluated at t = 0 when no time is given (local.py:1137-1146)
             self.dx = float(grid.discretization[bc.axis])
             coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
             self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
@@ -60,7 +61,8 @@ class _AffineFace:
             self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
             self.evaluate(0.0)   # raises for functions that are not affine in the adjacent value
             return
-        expr = sp.sympify(bc._func_expression._sympy_expr)
+        mirror = hasattr(bc, "virtual_point_sympy")       # pde_hip.boundaries.ExpressionBC (stand-alone mirror)
+        expr = sp.sympify(bc.virtual_point_sympy if mirror else bc._func_expression._sympy_expr)
         names = ["value", "dx", *grid.axes, "t"]
         by_name = {s.name: s for s in expr.free_symbols}
         unknown = set(by_name) - set(names)
@@ -77,11 +79,16 @@ class _AffineFace:
         self._offset = sp.lambdify(args, offset, modules="numpy")
         self._slope = sp.lambdify(args, slope, modules="numpy")
         self.time_dependent = "t" in by_name
+        self.needs_time = self.time_dependent
         self.dx = float(grid.discretization[bc.axis])
-        coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
-        self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
+        if mirror:
+            self.coords = bc.wall_coordinates()
+            index = bc.value_cell_index
+        else:
+            coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
+            self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
+            index = int(bc._get_value_cell_index(with_ghost_cells=False))
         self.face_shape = self.coords[0].shape if self.coords else ()
-        index = int(bc._get_value_cell_index(with_ghost_cells=False))
         self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
 
     def _evaluate_callable(self, t: float) -> tuple[np.ndarray, np.ndarray]:
@@ -94,7 +101,7 @@ class _AffineFace:
         with np.errstate(all="ignore"):
             if self._target in ("value", "derivative"):
                 f0, f1 = call(self._value_func, probe[0]), call(self._value_func, probe[1])
-                if np.array_equal(f0, f1, equal_nan=True):
+                if np.array_equal(f0, f1, equal_nan=True) and np.array_equal(f0, call(self._value_func, probe[2]), equal_nan=True):
                     # the usual case - a function of position and time only: exactly the reference's `2 f - value` / `dx f + value`
                     return (2 * f0, np.full(shape, -1.0)) if self._target == "value" else (self.dx * f0, np.full(shape, 1.0))
             a = call(self._callable, probe[0])
@@ -136,12 +143,16 @@ class ExprFaceTable:
         """Re-evaluate the coefficient arrays of time-dependent faces for ``args["t"]`` (no-op otherwise)."""
         if not self._dynamic:
             return
-        if args is None:
-            # same contract as the reference (pde/grids/boundaries/local.py:1139-1146)
-            msg = ("Require value for `t` for time-dependent BC. The value must be passed explicitly via `args` when "
-                   "calling a differential operator.")
-            raise RuntimeError(msg)
-        t = float(args["t"])
+        if args is None or "t" not in args:
+            # same contract as the reference (pde/grids/boundaries/local.py:1137-1146): expressions that contain `t` need it,
+            # Python functions are evaluated at t = 0
+            if any(face.needs_time for face, _, _ in self._dynamic):
+                msg = ("Require value for `t` for time-dependent BC. The value must be passed explicitly via `args` when "
+                       "calling a differential operator.")
+                raise RuntimeError(msg)
+            t = 0.0
+        else:
+            t = float(args["t"])
         if self._t is not None and t == self._t:
             return
         for face, buf_a, buf_b in self._dynamic:

@@ -5,8 +5,9 @@ Mirror of the part of ``pde.grids.boundaries`` the hot path consumes: every loca
 or ``const + f1 * arr[i1] + f2 * arr[i2]`` (2nd order, ``:2022-2061``).  The classes expose the
 attribute names :class:`pde_hip.backend.HipBackend` reads from real py-pde objects as well
 (``axis``, ``upper``, ``rank``, ``homogeneous``, ``normal``, ``get_virtual_point_data()``), so the
-conversion to ``pdehip_bc_face_t`` is shared.  Expression / user-function BCs need run-time code
-generation and are out of scope: they raise ``NotImplementedError``.
+conversion to ``pdehip_bc_face_t`` is shared.  Expression conditions (``value_expression`` ...,
+``pde/grids/boundaries/local.py:766-1150``) are :class:`ExpressionBC` here: they carry the sympy form of
+their virtual point, which ``pde_hip/bc_expr.py`` lowers for the device.
 """
 
 from __future__ import annotations
@@ -188,6 +189,92 @@ class CurvatureBC(BCBase):
         f2 = np.full_like(value, -1.0)
         i1, i2 = (size - 1, size - 2) if self.upper else (0, 1)
         return (value, f1, i1, f2, i2)
+
+
+class ExpressionBC(BCBase):
+    """Virtual point given by an expression ``F(value, dx, *coords, t)`` of the field value in the adjacent cell (or in
+    ``value_cell``), the spacing normal to the wall, the wall point and the time (``pde/grids/boundaries/local.py:766-866``):
+    ``virtual_point`` = the expression itself, ``value`` -> ``2*(e) - value``, ``derivative`` -> ``dx*(e) + value``,
+    ``mixed`` -> ``(2*dx*(const) + (2 - (e)*dx)*value) / ((e)*dx + 2)``.  Strings only (Python functions cannot travel to
+    the device through this mirror)."""
+
+    names = ["virtual_point"]
+    target = "virtual_point"
+
+    def __init__(self, grid, axis, upper, *, rank=0, value=0, const=0, target=None, value_cell=None):
+        BCBase.__init__(self, grid, axis, upper, rank=rank, value=0)
+        if self.rank != 0:
+            msg = "Expression boundary conditions only work for scalar conditions"
+            raise NotImplementedError(msg)
+        if callable(value) or callable(const):
+            msg = "pde_hip mirror: expression boundary conditions take strings or numbers"
+            raise NotImplementedError(msg)
+        self.target = self.target if target is None else target
+        self.value_cell = value_cell
+        self.homogeneous = False
+        self._input = {"value_expr": value, "const_expr": const, "target": self.target}
+        if self.target == "virtual_point":
+            text = f"{value}"
+        elif self.target == "value":
+            text = f"2 * ({value}) - value"
+        elif self.target == "derivative":
+            text = f"dx * ({value}) + value"
+        elif self.target == "mixed":
+            text = f"(2 * dx * ({const}) + (2 - ({value}) * dx) * value) / (({value}) * dx + 2)"
+        else:
+            msg = f"Unknown target `{self.target}` for expression"
+            raise ValueError(msg)
+        import sympy
+
+        names = ["value", "dx", *grid.axes, "t"]
+        try:
+            self.virtual_point_sympy = sympy.sympify(text.replace("^", "**"), locals={n: sympy.Symbol(n) for n in names})
+        except (sympy.SympifyError, SyntaxError, TypeError) as err:
+            raise BCDataError(f"Could not evaluate BC expression `{text}` with signature {names}.") from err
+
+    @property
+    def value_cell_index(self) -> int:
+        """Index (into the valid array along ``axis``) of the cell whose value enters the expression."""
+        n = int(self.grid.shape[self.axis])
+        if self.value_cell is None:
+            return n - 1 if self.upper else 0
+        return int(self.value_cell) % n
+
+    def wall_coordinates(self) -> list[np.ndarray]:
+        """Coordinates of the wall points of this face, one array of the face's shape per grid axis
+        (``GridBase._boundary_coordinates``, pde/grids/base.py)."""
+        grid = self.grid
+        coords = []
+        for a in range(grid.num_axes):
+            if a == self.axis:
+                coords.append(np.array([grid.axes_bounds[a][1] if self.upper else grid.axes_bounds[a][0]], dtype=np.float64))
+            else:
+                coords.append(np.asarray(grid.axes_coords[a], dtype=np.float64))
+        mesh = np.meshgrid(*coords, indexing="ij")
+        return [np.take(m, 0, axis=self.axis) for m in mesh]
+
+    def get_virtual_point_data(self):
+        msg = "expression boundary conditions have no constant virtual-point data"
+        raise NotImplementedError(msg)
+
+    def __repr__(self) -> str:
+        side = "upper" if self.upper else "lower"
+        return f"{self.__class__.__name__}(axis={self.axis}, {side}, {self.target}={self._input['value_expr']!r})"
+
+
+class ExpressionValueBC(ExpressionBC):
+    names = ["value_expression", "value_expr"]
+    target = "value"
+
+
+class ExpressionDerivativeBC(ExpressionBC):
+    names = ["derivative_expression", "derivative_expr"]
+    target = "derivative"
+
+
+class ExpressionMixedBC(ExpressionBC):
+    names = ["mixed_expression", "mixed_expr", "robin_expression", "robin_expr"]
+    target = "mixed"
 
 
 class NormalDirichletBC(DirichletBC):

@@ -78,6 +78,12 @@ class SlabMesh:
                 self.arr = np.ascontiguousarray(arr, dtype=np.float64)
                 self.ptr = self.arr.ctypes.data
 
+        for pair in bcs:
+            for bc in (pair.low, pair.high):
+                if getattr(bc, "rank", 0) != 0 or getattr(bc, "normal", False):
+                    # the slab loops advance scalar fields (rank-0 conditions); `normal_*` conditions belong to vector fields
+                    msg = "slab-parallel stepping supports conditions of scalar fields only (got a rank-1 / `normal` condition)"
+                    raise NotImplementedError(msg)
         glob = convert_bcs(bcs, upload=_Host)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         exchanged = {(0, False): self.lower is not None, (0, True): self.upper is not None}
@@ -89,6 +95,13 @@ class SlabMesh:
             for upper in (False, True):
                 src, dst = glob.c[2 * ax + int(upper)], out.c[2 * ax + int(upper)]
                 if ax == 0 and exchanged[(0, upper)]:
+                    # the exchange copies the neighbour's layer as it is: only the plain periodic wrap-around may be replaced by
+                    # it.  An anti-periodic axis (flip_sign: factor -1, pde/grids/boundaries/local.py:1728-1731) would silently
+                    # run as periodic; the reference's `_MPIBC` is likewise only installed for periodic=True faces
+                    wraps = self.rank == (self.size - 1 if upper else 0)     # the face of the WHOLE grid (inner faces have no condition)
+                    if wraps and (src.kind != _abi.BC_ORDER1 or (src.flags & _abi.BCF_ARRAYS) or src.factor1 != 1.0 or src.const_v != 0.0):
+                        msg = "anti-periodic axis 0 cannot be slab decomposed (the halo exchange copies the neighbour's layer unchanged)"
+                        raise NotImplementedError(msg)
                     dst.kind = _abi.BC_SKIP
                     continue
                 if ax == 0 and self.size > 1 and src.kind != _abi.BC_SKIP:

@@ -134,6 +134,15 @@ class HipSlabSolver(AdaptiveSolverBase):
             msg = "slab-parallel stepping does not support stochastic equations"
             raise NotImplementedError(msg)
         self._select_backend(state)
+        # a post-step hook would have to run on the gathered state between the steps of the C loops: refused instead of being
+        # dropped silently (the single-GPU steppers run hooks, `solver="euler"`)
+        try:
+            self.pde.make_post_step_hook(state, backend="numpy")
+        except NotImplementedError:
+            pass                                   # no hook defined: the normal case (pde/pdes/base.py:160-208)
+        else:
+            msg = f"slab-parallel stepping does not support the post-step hook of {self.pde.__class__.__name__}"
+            raise NotImplementedError(msg)
         if state.__class__.__name__ != "ScalarField":
             msg = "slab-parallel stepping supports a single ScalarField state"
             raise NotImplementedError(msg)

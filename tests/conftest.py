@@ -32,6 +32,13 @@ def pytest_configure(config):
         _SHIM.__enter__()
 
 
+def pytest_sessionfinish(session, exitstatus):
+    import refpath
+
+    if refpath.REAL:
+        refpath.log_loaded_libraries("pytest")
+
+
 def pytest_unconfigure(config):
     global _SHIM
     if _SHIM is not None:

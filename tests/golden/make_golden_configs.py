@@ -49,6 +49,13 @@ CASES = [
     dict(id="cfg5_expression_256cube_f32_rkf45", pde="expression", rhs={"c": "laplace(c**3 - c - laplace(c))"}, bounds=[[0, 256]] * 3,
          shape=[256, 256, 256], periodic=[True] * 3, bc="auto_periodic_neumann", solver="runge-kutta", dt=1e-3, adaptive=True,
          t_range=0.25, backend="numpy", dtype="float32", vmin=-0.1, vmax=0.1, stride=32),
+    # round 3: cfg3 at the step count of the published benchmark (10^4 Euler steps,
+    # scripts/performance_solvers.py:53-66, :140) and cfg5 over >= 100 accepted steps
+    dict(id="cfg3_cahn_hilliard_512sq_10k", pde="cahn_hilliard", gamma=1.0, bounds=[[0, 512]] * 2, shape=[512, 512], periodic=[False, False],
+         bc="auto_periodic_neumann", solver="euler", dt=1e-3, t_range=10.0, backend="torch", vmin=0.0, vmax=1.0, stride=16),
+    dict(id="cfg5_expression_256cube_f32_rkf45_long", pde="expression", rhs={"c": "laplace(c**3 - c - laplace(c))"}, bounds=[[0, 256]] * 3,
+         shape=[256, 256, 256], periodic=[True] * 3, bc="auto_periodic_neumann", solver="runge-kutta", dt=1e-3, adaptive=True,
+         t_range=1.5, backend="numpy", dtype="float32", vmin=-0.1, vmax=0.1, stride=32),
 ]
 
 

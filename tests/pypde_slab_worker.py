@@ -17,7 +17,9 @@ ROOT = Path(__file__).resolve().parent.parent
 for p in (ROOT, ROOT / "py-pde_amd", ROOT / "tests"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
-sys.path.append("/root/reference")
+from refpath import add_to_path  # noqa: E402
+
+add_to_path()
 
 
 def main() -> int:

@@ -25,8 +25,9 @@ HERE = Path(__file__).resolve().parent
 for p in (HERE, HERE.parent / "py-pde_amd", HERE.parent):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
-if "/root/reference" not in sys.path:
-    sys.path.append("/root/reference")
+from refpath import add_to_path  # noqa: E402
+
+add_to_path()
 
 import shimlib  # noqa: E402
 
@@ -65,6 +66,13 @@ def pytest_configure(config):
         typed.Dict = dict
         nb.typed = typed
         sys.modules["numba"], sys.modules["numba.typed"] = nb, typed
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import refpath
+
+    if refpath.REAL:
+        refpath.log_loaded_libraries("reference-suite child")
 
 
 def pytest_unconfigure(config):

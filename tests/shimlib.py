@@ -71,6 +71,12 @@ def use_shim(fused: bool = False, devices: int = 1):
     """Install the shim as ``pde_hip._lib``'s library; restores the previous state on exit."""
     from pde_hip import _lib
 
+    from refpath import REAL
+
+    if REAL:
+        # PDEHIP_DROPIN_REAL=1 (tools/gpu_dropin_real.sh, GPU box only): the drop-in tests drive the REAL libpdehip.so
+        yield _lib.get_lib()
+        return
     so = build()
     saved = (_lib._LIB, _lib._DEVICE, set(_lib._threads_ready))
     env = {k: os.environ.get(k) for k in ("PDEHIP_SHIM_FUSED", "PDEHIP_SHIM_DEVICES")}

@@ -68,6 +68,29 @@ def test_sub_boundaries_slice_inhomogeneous_values():
     assert t.c[0].kind == _abi.BC_SKIP and t.c[1].kind == _abi.BC_ORDER1
 
 
+def test_slab_faces_refuse_what_the_exchange_cannot_express():
+    """an anti-periodic axis 0 must not silently run as periodic; `normal` conditions belong to vector fields."""
+    from helpers import HostBuf
+
+    grid = pde_hip.UnitGrid([8, 4], periodic=[True, False])
+    anti = grid.get_boundary_conditions({"x": "anti-periodic", "y": {"value": 1.0}})
+    for size, rank in ((2, 0), (2, 1), (3, 2)):
+        with pytest.raises(NotImplementedError, match="anti-periodic"):
+            SlabMesh(grid, size, rank).slab_faces(anti, upload=HostBuf)
+    SlabMesh(grid, 3, 1).slab_faces(anti, upload=HostBuf)          # an inner slab never sees the wrap-around
+    with pytest.raises(NotImplementedError, match="anti-periodic"):
+        SlabMesh(grid, 1, 0).slab_faces(anti, force_exchange=True, upload=HostBuf)
+    plain = grid.get_boundary_conditions({"x": "periodic", "y": {"value": 1.0}})
+    t = SlabMesh(grid, 2, 0).slab_faces(plain, upload=HostBuf)
+    assert t.c[0].kind == t.c[1].kind == _abi.BC_SKIP and t.c[2].kind == _abi.BC_ORDER1
+    g2 = pde_hip.UnitGrid([8, 4], periodic=False)
+    inner = SlabMesh(g2, 2, 1).slab_faces(g2.get_boundary_conditions({"x": {"value": 2.0}, "y": "derivative"}), upload=HostBuf)
+    assert inner.c[0].kind == _abi.BC_SKIP and inner.c[1].kind == _abi.BC_ORDER1      # inner face exchanged, outer face physical
+    vec = g2.get_boundary_conditions({"x": {"normal_value": 1.0}, "y": "derivative"}, rank=1)
+    with pytest.raises(NotImplementedError, match="normal"):
+        SlabMesh(g2, 2, 0).slab_faces(vec, upload=HostBuf)
+
+
 # ---- multi-process runs ----------------------------------------------------------------------------------
 def _free_port() -> int:
     with socket.socket() as s:
@@ -302,7 +325,9 @@ def test_real_pypde_drives_the_slab_path(world):
 
     import shimlib
 
-    if not Path("/root/reference/pde").exists():
+    import refpath
+
+    if not refpath.available():
         pytest.skip("py-pde (reference) not available")
     so = shimlib.build()
     env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120"}

@@ -10,7 +10,7 @@ import pytest
 import sys
 from pathlib import Path
 
-REF = Path("/root/reference")
+from refpath import REF  # noqa: E402
 if not (REF / "pde").exists():
     pytest.skip("py-pde (reference) not available", allow_module_level=True)
 if str(REF) not in sys.path:

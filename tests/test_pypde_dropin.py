@@ -18,7 +18,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-REF = Path("/root/reference")
+from refpath import REAL, REF  # noqa: E402
 if not (REF / "pde").exists():
     pytest.skip("py-pde (reference) not available", allow_module_level=True)
 if str(REF) not in sys.path:
@@ -34,7 +34,10 @@ from pde_hip import _lib  # noqa: E402
 
 @pytest.fixture(params=[False, True], ids=["unfused", "fused"])
 def hip(request):
-    """The shim as the library of the backend; both the 'not covered' and the fused branches of the host code."""
+    """The shim as the library of the backend; both the 'not covered' and the fused branches of the host code.
+    (PDEHIP_DROPIN_REAL=1 on the GPU box: the real libpdehip.so, one variant.)"""
+    if REAL and request.param:
+        pytest.skip("real library: one variant")
     with shimlib.use_shim(fused=request.param):
         yield pde.backends.get_backend("hip")
 
@@ -74,6 +77,8 @@ def test_registration_does_not_touch_the_device():
 
 
 def test_one_device_per_process(hip1):
+    if REAL:
+        pytest.skip("needs the shim's four pretend devices")
     with shimlib.use_shim(devices=4):
         b2 = pde.backends.get_backend("hip:2")
         f = pde.ScalarField(pde.UnitGrid([4, 4]), 1.0)
@@ -361,6 +366,53 @@ def test_unsupported_requests_raise_not_implemented(hip1):
         pde.PDE({"T": "T"}).solve(pde.Tensor2Field.random_uniform(grid), t_range=0.1, dt=0.01, backend="hip", tracker=None)
     with pytest.raises(NotImplementedError, match="no kernel for operator"):
         pde.PDE({"c": "laplace(c) + poisson_solver(c)"}).solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
+
+
+def test_subclasses_that_change_the_equation_are_refused(hip1):
+    """a user subclass that overrides `evolution_rate` / `make_evolution_rate` is another equation (the reference
+    honours the override); mapping it onto the base class's kernel would be silently wrong.  Subclasses that only add a
+    post-step hook keep working."""
+    grid = pde.UnitGrid([8, 8])
+    state = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(7))
+
+    class WithSource(pde.DiffusionPDE):
+        def evolution_rate(self, state, t=0):
+            return super().evolution_rate(state, t) + 1.0
+
+    class WithSourceRate(pde.AllenCahnPDE):
+        def make_evolution_rate(self, state, backend="numpy"):
+            return super().make_evolution_rate(state, backend=backend)
+
+    class OnlyHook(pde.DiffusionPDE):
+        def make_post_step_hook(self, state, backend="numpy"):
+            def hook(state_data, t, data):
+                return state_data, data + 1
+
+            return hook, 0
+
+    for eq in (WithSource(), WithSourceRate()):
+        with pytest.raises(NotImplementedError, match="overrides"):
+            eq.solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
+    res, info = OnlyHook().solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None, ret_info=True)
+    ref = pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
+    np.testing.assert_array_equal(res.data, ref.data)
+    assert info["solver"]["post_step_data"] == 10
+    # the slab-parallel solver has no place to run a hook: refused instead of dropped (ADVICE r2)
+    with pytest.raises(NotImplementedError, match="post-step hook"):
+        OnlyHook().solve(state, t_range=0.1, dt=0.01, solver="hip_slab", backend="hip", tracker=None)
+
+
+def test_function_bcs_without_time_use_t0(hip1):
+    """conditions given as Python functions are evaluated at t = 0 when an operator is called without `args`
+    (pde/grids/boundaries/local.py:1137-1146); only expressions that contain `t` demand it."""
+    grid = pde.UnitGrid([6, 5])
+    field = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(3))
+    bc = {"x-": {"value_expression": lambda v, dx, x, y, t: 0.5 + 0.1 * y + t}, "x+": {"derivative": 0.0}, "y": "derivative"}
+    got = field.laplace(bc, backend="hip")
+    ref = field.laplace(bc, backend="scipy")
+    np.testing.assert_allclose(got.data, ref.data, rtol=1e-12, atol=1e-12)
+    with pytest.raises(RuntimeError, match="Require value for `t`"):
+        field.laplace({"x": {"value_expression": "t"}, "y": "derivative"}, backend="hip")
 
 
 def test_state_stays_resident_between_tracker_interrupts(hip1):

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-REF = Path("/root/reference")
+from refpath import REF  # noqa: E402
 if not (REF / "pde").exists():
     pytest.skip("py-pde (reference) not available", allow_module_level=True)
 if str(REF) not in sys.path:

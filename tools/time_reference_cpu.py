@@ -2,10 +2,11 @@
 
 numba is not installable here, so the reference paths that run are (i) its eager torch-CPU backend and (ii) its numpy
 backend with scipy operators; the CPU oracle (oracle/pde_oracle.c, the C port of the numba formulas) is timed on the
-same cores for an apples-to-apples ratio.  py-pde cannot travel to the GPU box, so this runs in the BUILD CONTAINER and
-writes profiles/reference_cpu.json, which bench.py attaches to its line as `cpu_baseline_reference` (labelled as such).
+same cores for an apples-to-apples ratio.  Runs in the build container (reference at /root/reference) or, once per round, on
+the GPU box's host cores with the reference shipped as untracked scratch (`PDEHIP_REFERENCE=<dir>`, tools/gpu_r3_dropin.sh);
+writes the JSON that bench.py attaches to its line as `cpu_baseline_reference` (labelled with where it was measured).
 
-usage: python tools/time_reference_cpu.py [n=512] [steps=6]
+usage: [PDEHIP_REFERENCE=dir] python tools/time_reference_cpu.py [n=512] [steps=6] [output.json]
 """
 import ctypes as C
 import json
@@ -16,7 +17,8 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "py-pde_amd")]
-sys.path.append("/root/reference")
+REF = os.environ.get("PDEHIP_REFERENCE") or "/root/reference"
+sys.path.append(REF)
 import numpy as np
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
@@ -38,7 +40,7 @@ grid = pde.UnitGrid([n] * 3, periodic=True)
 state = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(0))
 eq = pde.DiffusionPDE()
 out = {"workload": f"DiffusionPDE(D=1) on UnitGrid([{n}]*3, periodic=True) fp64, explicit Euler dt=0.1", "cores": cores,
-       "where": "build container (the reference cannot travel to the GPU box)", "unit": "Mcells/s"}
+       "where": os.environ.get("PDEHIP_WHERE") or "build container (the reference cannot travel to the GPU box)", "unit": "Mcells/s"}
 
 # (i) reference, eager torch-CPU backend: time the stepper alone (Controller profiler), warm
 eq.solve(state, t_range=0.1, dt=0.1, backend="torch", solver="euler", tracker=None)
@@ -80,4 +82,5 @@ lib.oracle_euler_run(C.byref(g), C.byref(rhs), a.ctypes.data, b.ctypes.data, 0.1
 wall = time.perf_counter() - t0
 out["oracle_port_same_cores"] = {"value": round(n**3 * k / wall / 1e6, 1), "steps": k, "seconds": round(wall, 2), "kind": "port"}
 print(out["oracle_port_same_cores"], flush=True)
-(ROOT / "profiles" / "reference_cpu.json").write_text(json.dumps(out, indent=1) + "\n")
+target = Path(sys.argv[3]) if len(sys.argv) > 3 else ROOT / "profiles" / "reference_cpu.json"
+target.write_text(json.dumps(out, indent=1) + "\n")

@@ -383,23 +383,37 @@ static const Tune2 &tune2()
     return t;
 }
 
-template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
-                           Euler2Plan *plan)
+// fp32 tiles (fp32 storage, fp64 registers).  The wide tile - 4 cells per lane (16-byte accesses), 2 rows - is at 252 VGPRs
+// without room for the stage epilogue (256 + 64 B of scratch with it).  The NARROW tile - 2 cells per lane (8-byte accesses),
+// 4 rows, the shape of the fp64 tile - needs 194 VGPRs (204 with the stage epilogue) and recomputes 1.5 x instead of 2 x of
+// the intermediate level.  PDEHIP_F32_TILE="vec,ry[,stage_vec,stage_ry]" overrides the choice (tuning aid).
+struct TuneF32 { int vec, ry, svec, sry; };
+static const TuneF32 &tune_f32()
 {
-    constexpr int VEC = 16 / sizeof(T);
+    static TuneF32 t = {0, 0, 0, 0};
+    static bool set = false;
+    if (!set) {
+        set = true;
+        const char *e = getenv("PDEHIP_F32_TILE");
+        if (e) sscanf(e, "%d,%d,%d,%d", &t.vec, &t.ry, &t.svec, &t.sry);
+    }
+    return t;
+}
+
+template <typename T, int VEC>
+static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
+                            Euler2Plan *plan, int ry_f32)
+{
     constexpr int CW = 64 * VEC;
     const Tune2 &t2 = tune2();
-    // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32 computes in fp64 registers, 4 cells per lane: only the
-    // 2-row tile fits the register file without spilling
+    // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32: see tune_f32()
     const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
     int ry = t2.ry ? t2.ry : 4;
-    if (a.n1 % ry || sizeof(T) == 4) ry = 2;
-    // the stage epilogue (six more streams) does not fit the ragged 4-row tile without spilling: 2-row tiles there
-    if (m2 == E2_CH_STAGE && ry == 4 && a.n2 % CW != 0) ry = 2;
+    if (sizeof(T) == 4) ry = ry_f32;
+    while (ry > 1 && a.n1 % ry) ry /= 2;
+    // the stage epilogue (six more streams) does not fit the ragged 4-row fp64 tile without spilling: 2-row tiles there
+    if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && a.n2 % CW != 0) ry = 2;
     if (!has_y) ry = 1;
-    // ... and not at all the fp32 tile (fp64 registers, 4 cells per lane): fp32 3-D stages stay separate kernels
-    if (m2 == E2_CH_STAGE && sizeof(T) == 4 && has_y) return 0;
     if (a.n2 % VEC || a.n1 % ry || (ry != 1 && ry != 2 && ry != 4)) return 0;
     a.ntz = (a.n2 + CW - 1) / CW;   // the row may end inside the last chunk
     a.nty = a.n1 / ry;
@@ -457,6 +471,7 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     // real halo planes instead of BCs on the slowest axis: both sides (1), upper side only (2), lower side only (3)
     if (xplain) a.per[0] = xplain == 1 ? 2 : (xplain == 2 ? 3 : 4);
     if (plan) {   // the caller launches a run-time compiled instance itself (pdehip_jit.hip)
+        if (has_y ? (ry != 2 && ry != 4) : ry != 1) return 0;
         plan->a = a; plan->grid = (unsigned)a.nblocks; plan->block = 64u * nwz * nwy; plan->ry = ry; plan->has_y = has_y;
         *done = true;
         return 0;
@@ -464,6 +479,19 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     // the stage epilogue exists for real halo layers on BOTH sides (a run-time argument of the plain instances) but not as
     // one-sided (XS) instances: the first / last slab of a non-periodic axis combines with the pointwise kernels
     if (m2 == E2_CH_STAGE && xplain > 1) return 0;
+    {   // is there an offline instance of this tile?  (the list below, PDEHIP_E2; asked before a dry run answers "covered")
+        const bool xs_ = xplain > 1;
+        bool have;
+        if (!has_y) have = ry == 1 && !xs_ && (sizeof(T) == 8 || VEC == 4);
+        else if (sizeof(T) == 8) have = ry == 4 || ry == 2;
+        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_);
+        else have = ry == 4 || ry == 2 || (ry == 1 && !xs_);
+        if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = false;   // (256 VGPRs + scratch)
+        // a 1-row tile of a 3-D grid is its own neighbour's halo: the tile of row 1 reads the virtual row -1, which only the
+        // tile of row 0 transforms (`ylo`) - correct for periodic rows only
+        if (has_y && ry == 1 && !a.per[1]) have = false;
+        if (!have) return 0;
+    }
     if (dry_run) { *done = true; return 0; }
     if (m2 == E2_CUSTOM || m2 == E2_CUSTOM2) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
     // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
@@ -479,7 +507,8 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
     static const bool unit_off = getenv("PDEHIP_NO_UNIT") != nullptr;   // A/B aid
     const bool unit = !unit_off && a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
 #define PDEHIP_E2(RY_, HY_, RG_, XS_, NT_)                                                                                               \
-    if (ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                                          \
+    if (!launched && ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                             \
+        launched = true;                                                                                                                 \
         if (m2 == E2_DIFFUSION) {                                                                                                       \
             if constexpr (!XS_) {   /* every instance except the one-sided slab ends */                                                       \
                 if (unit) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION_UNIT, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);  \
@@ -488,20 +517,54 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         }                                                                                                                                \
         else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
         else if (m2 == E2_CH_STAGE) {                                                                                                    \
-            if constexpr (!XS_ && !NT_ && !(RY_ == 4 && RG_) && !(sizeof(T) == 4 && HY_)) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_STAGE, HY_, RG_, false, false>), grid, block, 0, st, a); \
+            if constexpr (!XS_ && !NT_ && !(sizeof(T) == 8 && RY_ == 4 && RG_) && !(sizeof(T) == 4 && VEC == 4 && HY_ && RY_ > 1)) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_STAGE, HY_, RG_, false, false>), grid, block, 0, st, a); \
+            else return 0;                                                                                                               \
         } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
     }
-    PDEHIP_E2(1, false, true, false, false)
-    PDEHIP_E2(2, true, true, false, false)
-    PDEHIP_E2(2, true, true, true, false)
+    bool launched = false;
+    if constexpr (sizeof(T) == 8 || VEC == 4) {
+        PDEHIP_E2(1, false, true, false, false)
+        PDEHIP_E2(2, true, true, false, false)
+        PDEHIP_E2(2, true, true, true, false)
+    }
     if constexpr (sizeof(T) == 8) {
         PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(4, true, false, false, false) PDEHIP_E2(4, true, false, false, true)
         PDEHIP_E2(4, true, true, true, false)
     }
+    if constexpr (sizeof(T) == 4 && VEC == 4) { PDEHIP_E2(1, true, true, false, false) }   // 1-row wide tile (with the stage epilogue: 220 VGPRs)
+    if constexpr (sizeof(T) == 4 && VEC == 2) {   // narrow fp32 tiles, 3-D only
+        PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(2, true, true, false, false) PDEHIP_E2(1, true, true, false, false)
+        PDEHIP_E2(4, true, true, true, false) PDEHIP_E2(2, true, true, true, false)
+    }
 #undef PDEHIP_E2
+    if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
     PDEHIP_HIP(hipGetLastError());
     *done = true;
     return 0;
+}
+
+template <typename T>
+static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
+                           Euler2Plan *plan)
+{
+    if constexpr (sizeof(T) == 8) {
+        return launch_euler2_tv<double, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 0);
+    } else {
+        const TuneF32 &tf = tune_f32();
+        const bool stage = m2 == E2_CH_STAGE;
+        // Measured at 256^3 / 512^3 (profiles/r03_f32_tiles.md): the sweeps without the stage epilogue are fastest on the wide
+        // 2-row tile (diffusion 0.0233 vs 0.0249 ms per step, Cahn-Hilliard 0.0575 vs 0.0585); the Runge-Kutta stage sweeps
+        // need the narrow 4-row tile to carry their epilogue at all (RKF45 attempt 0.786 -> 0.755 ms).  The run-time built
+        // kernels of pdehip_jit.hip keep the wide tile (`plan`).
+        int vec = 4, ry = 2;
+        if (n.ndim == 3 && !plan) {
+            if (stage) { vec = tf.svec ? tf.svec : 2; ry = tf.svec ? tf.sry : 4; }
+            else if (tf.vec) { vec = tf.vec; ry = tf.ry; }
+        }
+        if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
+        if (vec == 2) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
+        return launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
+    }
 }
 
 // periodic (1) / local (0) / not covered (-1) classification of the two faces of one axis

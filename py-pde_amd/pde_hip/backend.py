@@ -1217,6 +1217,35 @@ class HipBackendMixin:
         ynew = DeviceArray(info)
         sync_errors = getattr(solver, "_sync_errors", None) or (lambda e: e)
 
+        if is_rk and getattr(solver, "_sync_errors", None) is None and os.environ.get("PDEHIP_ADAPTIVE_LOOP", "1") != "0":
+            # The whole adaptive loop of pde/backends/numba/_solvers.py:249-281 in ONE C call (`pdehip_slab_rkf45_run` without a
+            # communicator and without neighbours = the serial use of the slab loop templates): stage sequence, error norm,
+            # accept / reject, controller and step statistics run in C; the host reads 8 bytes per attempt and nothing else.
+            from .solvers import AdaptiveStatistics
+
+            flags = C.c_int(0)
+            lib.slab_flags_supported(info.ref, spec.ref, -1, -1, C.byref(flags))
+            ctl = _abi.Adaptive()
+            ctl.tolerance, ctl.dt_min, ctl.dt_max = tolerance, dt_min, float(solver.dt_max)
+            solver.info["dt_statistics"] = AdaptiveStatistics(ctl)
+
+            def adaptive_loop(state_data: DeviceArray, t_start: float, t_end: float):
+                ctl.t_start, ctl.t_end, ctl.dt = float(t_start), float(t_end), float(solver.info["dt"])
+                before = int(ctl.steps)
+                res = C.c_void_p()
+                try:
+                    lib.slab_rkf45_run(None, info.ref, spec.ref, -1, -1, flags.value, state_data.ptr, ynew.ptr, work_ptrs, err_dev.ptr,
+                                       C.byref(ctl), C.byref(res), stream)
+                finally:
+                    solver.info["steps"] += int(ctl.steps) - before
+                if res.value != state_data.ptr:
+                    lib.memcpy_d2d(state_data.ptr, res.value, state_data.nbytes, stream)
+                solver.info["dt"] = float(ctl.dt)
+                return state_data, float(ctl.t_last)
+
+            adaptive_loop.keepalive = (work, ynew, err_dev, spec)   # type: ignore[attr-defined]  (work_ptrs holds raw pointers only)
+            return adaptive_loop
+
         two_half_steps = [spec.kind == _abi.RHS_DIFFUSION]
 
         def attempt(state_data: DeviceArray, ynew: DeviceArray, dt_step: float) -> float:

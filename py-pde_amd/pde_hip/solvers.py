@@ -44,6 +44,30 @@ class OnlineStatistics:
         return {"min": self.min, "max": self.max, "mean": self.mean, "std": self.std, "count": self.count}
 
 
+class AdaptiveStatistics:
+    """Statistics of the accepted step sizes kept by the C loops (``pdehip_adaptive_t``: Welford sums like
+    ``pde.tools.math.OnlineStatistics``, pde/tools/math.py:125-174), read through the interface the controller and users
+    see: ``count`` / ``min`` / ``max`` / ``mean`` / ``std`` / ``to_dict()`` (pde/solvers/controller.py:285-287)."""
+
+    def __init__(self, ctl):
+        self._ctl = ctl
+
+    def to_dict(self) -> dict[str, Any]:
+        from ._abi import adaptive_statistics
+
+        return adaptive_statistics(self._ctl)
+
+    def __getattr__(self, name):
+        if name in {"count", "min", "max", "mean", "std"}:
+            return self.to_dict()[name]
+        raise AttributeError(name)
+
+    @property
+    def var(self) -> float:
+        std = self.to_dict()["std"]
+        return std * std
+
+
 def make_dt_adjuster(dt_min: float, dt_max: float) -> Callable[[float, float], float]:
     """``adjust_dt(dt, error_rel)`` keeping ``error_rel`` near 1 (solvers/base.py:559-592)."""
 

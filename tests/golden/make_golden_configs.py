@@ -55,7 +55,7 @@ CASES = [
          bc="auto_periodic_neumann", solver="euler", dt=1e-3, t_range=10.0, backend="torch", vmin=0.0, vmax=1.0, stride=16),
     dict(id="cfg5_expression_256cube_f32_rkf45_long", pde="expression", rhs={"c": "laplace(c**3 - c - laplace(c))"}, bounds=[[0, 256]] * 3,
          shape=[256, 256, 256], periodic=[True] * 3, bc="auto_periodic_neumann", solver="runge-kutta", dt=1e-3, adaptive=True,
-         t_range=1.5, backend="numpy", dtype="float32", vmin=-0.1, vmax=0.1, stride=32),
+         t_range=2.6, backend="numpy", dtype="float32", vmin=-0.1, vmax=0.1, stride=32),
 ]
 
 

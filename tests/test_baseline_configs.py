@@ -179,7 +179,7 @@ def test_cfg5_256cube_f32_expression_rkf45(cid):
     """cfg5: PDE({'c': 'laplace(c**3 - c - laplace(c))'}) on 256^3 fp32, adaptive RKF45 (tolerance 1e-4, dt0 = 1e-3):
     equal step count and <= 1e-5 relative against the oracle's adaptive loop over the whole field, and against the
     reference's numpy+scipy run (sample) — fp32 contract of include/pdehip.h (fp32 storage, fp64 registers).
-    `_long`: t_range = 1.5, i.e. >= 100 accepted steps."""
+    `_long`: t_range = 2.6, i.e. >= 100 accepted steps."""
     if cid not in CASES or f"{cid}/steps" not in CONFIGS.files:
         pytest.skip(f"golden data of {cid} not generated")
     case = CASES[cid]

@@ -320,3 +320,23 @@ def test_sub_slabs_with_one_physical_face(backend, dtype, shape, split):
         assert done.value == 1
     np.testing.assert_array_equal(parts.get_valid(), whole.get_valid())
     np.testing.assert_array_equal(whole.get_valid(), _oracle_steps(grid, bcs, data, 0.6, 2e-3, 2))
+
+
+@pytest.mark.parametrize("tile", ["default", "4,2,4,1", "2,4,2,4", "2,2,2,2", "2,1,2,1", "4,1,4,1"])
+def test_fp32_tile_shapes(tile):
+    """Every fp32 wave tile of the two-level kernel (wide: 4 cells per lane, 2 or 1 rows; narrow: 2 cells per lane, 4 / 2 / 1
+    rows; the stage epilogue of the Runge-Kutta sweeps on each) gives the oracle's bits: Euler runs, RK4 step, RKF45 attempt
+    (tests/f32_tile_worker.py in a process of its own - the tile choice is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = dict(os.environ)
+    env.pop("PDEHIP_F32_TILE", None)
+    if tile != "default":
+        env["PDEHIP_F32_TILE"] = tile
+    worker = Path(__file__).resolve().parent / "f32_tile_worker.py"
+    proc = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("F32TILE ")]
+    assert proc.returncode == 0 and lines and lines[-1] == "F32TILE OK", (proc.stdout[-2000:], proc.stderr[-2000:])

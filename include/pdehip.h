@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 1
+#define PDEHIP_ABI_VERSION 2
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -95,7 +95,37 @@ typedef struct pdehip_rhs {
     pdehip_bc_face_t bc_c[2 * PDEHIP_MAX_DIM];  /* BCs of the state field */
     pdehip_bc_face_t bc_mu[2 * PDEHIP_MAX_DIM]; /* BCs of mu (Cahn-Hilliard only) */
     void *scratch_mu;               /* full array (Cahn-Hilliard only) */
+    /* Faces whose coefficient arrays depend on time (expression conditions that contain `t`): a program from
+     * pdehip_bcprog_create that rewrites the const / factor arrays the face tables above point to, or NULL.  Every entry point
+     * that evaluates the right-hand side runs it for the time of THAT evaluation first, on the same stream (Euler: t + i*dt,
+     * Runge-Kutta: the stage times t + a_s*dt; pde/solvers/euler.py:172-175, pde/solvers/runge_kutta.py:52-59, :135-145 pass
+     * `t` to the right-hand side, which hands it to the conditions as args={"t": t}: pde/pdes/diffusion.py:119-121). */
+    void *bc_program;
+    double t;                       /* time of a single evaluation (rhs_scaled, rk4_step, rkf45_attempt, ab2_step) / of the
+                                       first step of a fixed-step run (euler_run, rk4_run); ignored without bc_program */
 } pdehip_rhs_t;
+
+/* ---- boundary conditions given as expressions of position and time, evaluated ON THE DEVICE ---------------------------------
+ * Replaces the per-call evaluation of ExpressionBC (pde/grids/boundaries/local.py:766-1150; numba twin
+ * pde/backends/numba/_boundaries.py:256-394, torch twin pde/backends/torch/_boundaries.py:258-345).  A condition whose virtual
+ * point F(value, dx, coords, t) is affine in the adjacent value is  ghost = A(dx, coords, t) + B(dx, coords, t) * value, i.e. a
+ * first-order face with per-cell coefficient arrays (PDEHIP_BCF_ARRAYS).  A program is C source (compiled with hiprtc) that
+ * defines
+ *     PDEHIP_BC_FN void bc_face(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)
+ * (c0..c2 = coordinates of the wall point along the grid axes), plus one descriptor per face: where A and B go and how the face
+ * cell (i1, i2) maps to coordinates.  pdehip_bcprog_run evaluates all faces of
+ * the program for time t in ONE launch; the stencil kernels and the ghost kernel then read the arrays as usual. */
+typedef struct pdehip_bcprog_face {
+    double *const_arr, *factor_arr;   /* fp64 device arrays of m1 * m2 face cells (C order), written by the program */
+    int64_t m1, m2;                   /* face extents along the remaining grid axes in grid order (1 where there is none) */
+    double origin[3], step[3];        /* per coordinate k: index[k] == 0: c[k] = origin[k] (the wall, or an unused slot);        */
+    int32_t index[3];                 /*   index[k] == 1 / 2: c[k] = (i1 / i2 + 0.5) * step[k] + origin[k] - the cell centres of */
+    int32_t reserved;                 /*   the reference (discretize_interval, pde/grids/base.py:88-113), operation by operation */
+    double dx;                        /* spacing normal to the wall */
+} pdehip_bcprog_face_t;
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle);
+int pdehip_bcprog_run(void *handle, double t, void *stream);
+int pdehip_bcprog_destroy(void *handle);
 
 /* ---- runtime ------------------------------------------------------------------ */
 const char *pdehip_last_error(void);
@@ -276,6 +306,10 @@ int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, d
  * sums, then one workgroup): the result does not depend on scheduling; it differs from the reference's sequential sum by
  * the usual reordering error (relative 1e-13 at 512^3). */
 int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream);
+/* out_dev[c] = number of cells of component c that are NaN or +-inf (as a double): the check of the reference's
+ * ConsistencyTracker (`np.all(np.isfinite(field.data))`, pde/trackers/trackers.py:974-1003) without moving the field to the host -
+ * 8 bytes per component cross PCIe instead of the whole state at every interrupt. */
+int pdehip_count_nonfinite(const pdehip_grid_t *g, int ncomp, const void *arr_full, double *out_dev, void *stream);
 
 /* ---- fused time steppers ----------------------------------------------------------
  * k_out = dt * rhs(y): applies the BCs of y (and of mu) — on the fly inside the stencil kernel where the
@@ -465,7 +499,21 @@ typedef struct {
 } pdehip_jit_pass_t;
 int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                          void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
-                         void **result, void *stream);
+                         void *bc_program, void **result, void *stream);
+/* Runge-Kutta loops of an expression PDE in ONE call: `nsteps` classical RK4 steps with fixed dt (ctl == NULL;
+ * pde/solvers/runge_kutta.py:29-66 inside the loop pde/backends/numba/_solvers.py:98-108), or the ADAPTIVE Runge-Kutta-Fehlberg
+ * loop from ctl->t_start to ctl->t_end (runge_kutta.py:68-156 inside pde/backends/numba/_solvers.py:249-281 with the controller
+ * pde/solvers/base.py:572-592; the host reads 8 bytes per attempt, nothing per stage).  The passes are those of
+ * pdehip_jit_euler_run with another meaning of the state indices: -1 - k as `src` / `extras` is component k of the STAGE INPUT,
+ * as `out` component k of the SLOPE; the epilogue of the passes that write a slope must compute `dt * F` (p[0] = dt of the
+ * step, p[1] = time of the stage).  work: 5 (RK4: k1..k4, tmp) or 7 (RKF45: k1..k6, tmp) arrays of ncomp components each; y
+ * is advanced in place (RK4) or ping-pongs with ynew (adaptive: *result names the array holding the final state).  A single-
+ * component expression whose last pass runs on the vectorised kernel takes the stage epilogue of pdehip_jit_apply_stage
+ * (stage_fuse != 0); everything else combines with pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine: bit-identical.
+ * bc_program (or NULL): time-dependent faces, refreshed for every stage time. */
+int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream);
 
 #ifdef __cplusplus
 }

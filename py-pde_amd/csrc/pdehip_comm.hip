@@ -126,6 +126,7 @@ struct HipOps {
         return 0;
     }
     int zero(void *p, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(p, 0, bytes, as_stream(st))); return 0; }
+    int refresh(void *bc_program, double t, void *st) { return pdehip_bcprog_run(bc_program, t, st); }
     int fail(const char *msg) { PDEHIP_FAIL(E_NOTIMPL, "%s", msg); }
     int fail_runtime(const char *fmt, double v) { PDEHIP_FAIL(E_RUNTIME, fmt, v); }
     // BCs of `in` (faces not marked SKIP) + stencil into the full array `out`
@@ -286,6 +287,8 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{static_cast<Comm *>(comm)};
+    // (two streams per step: faces that change with time take the single-stream sweeps, pdehip_slab_euler_sweeps)
+    if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler_run(ops, g_local, q, rhs, lower, upper, buf_a, buf_b, dt, nsteps, result, stream);
 }
 
@@ -340,6 +343,7 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
         PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
     }
     HipOps ops{c};
+    if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
@@ -422,7 +426,7 @@ int pdehip_slab_rhs_scaled(void *comm, const pdehip_grid_t *g_local, const pdehi
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{c};
-    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream);
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream, rhs->t);
 }
 
 int pdehip_slab_euler_sweeps(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
@@ -452,7 +456,8 @@ int pdehip_slab_rk4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_r
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{c};
-    for (int64_t s = 0; s < nsteps; s++) PDEHIP_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream));
+    for (int64_t s = 0; s < nsteps; s++)
+        PDEHIP_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream, rhs->t + (double)s * dt));
     return 0;
 }
 

@@ -25,6 +25,15 @@ template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vect
 template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };   // narrow fp32 tiles of euler2_kernel (8 B per lane)
 
+// streaming loads of the plane data of the march kernels.  PDEHIP_NT_LOADS (build-time A/B switch, tools/build_variant.sh):
+// 1 = non-temporal loads, 2 = non-temporal loads and plain stores everywhere.  Measured on copy kernels (profiles/
+// r03_microbench5_infinity_cache_direction.log): nt load + plain store 6.49 TB/s vs plain load + nt store 6.24 at 1 GiB.
+#ifdef PDEHIP_NT_LOADS
+#define PDEHIP_LDV(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define PDEHIP_LDV(ptr) (*(ptr))
+#endif
+
 // wavefront shift by one lane through DPP (gfx9 wave_shr:1 / wave_shl:1).  Lane 0 (resp. lane
 // 63) has no source lane and keeps `old`, which carries the value from outside the chunk.
 __device__ __forceinline__ double wave_shr1(double old, double src)

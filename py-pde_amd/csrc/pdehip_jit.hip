@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "pdehip_common.h"
+#include "pdehip_rk_loops.h"
 #include "pdehip_sources.h"   // generated: kDeviceH, kMarchInc (raw string literals)
 
 using namespace pdehip;
@@ -557,6 +558,127 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
 }
 
 
+// ---- boundary conditions given as expressions, evaluated on the device (include/pdehip.h: pdehip_bcprog_*) ------------------------
+namespace {
+struct BcFaceDev {   // device copy of a face descriptor + the start of its cells in the launch
+    double *A, *B;
+    long m1, m2;
+    double origin[3], step[3];
+    int index[3];
+    int pad;
+    double dx;
+    long start;
+};
+struct BcProg {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    BcFaceDev *faces_dev = nullptr;
+    int nfaces = 0;
+    long total = 0;
+};
+const char *kBcKernel = R"SRC(
+struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; int pad; double dx; long start; };
+extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t)
+{
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        int f = 0;
+        for (int q = 1; q < nfaces; q++)
+            if (i >= faces[q].start) f = q;
+        const BcFaceDev &F = faces[f];
+        const long loc = i - F.start, i2 = loc % F.m2, i1 = loc / F.m2;
+        double c[3];
+        for (int k = 0; k < 3; k++) {
+            const int w = F.index[k];
+            // the cell centres of the reference, operation by operation: (i + 0.5) * dx + x_min  (pde/grids/base.py:112-113)
+            c[k] = w == 0 ? F.origin[k] : ((double)(w == 1 ? i1 : i2) + 0.5) * F.step[k] + F.origin[k];
+        }
+        double a = 0, b = 0;
+        bc_face(f, F.dx, c[0], c[1], c[2], t, &a, &b);
+        F.A[loc] = a;
+        F.B[loc] = b;
+    }
+}
+)SRC";
+}  // namespace
+
+extern "C" {
+
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle)
+{
+    if (!source || !faces || !handle || nfaces < 1 || nfaces > 64) PDEHIP_FAIL(E_VALUE, "bcprog_create: NULL pointer or bad face count");
+    PDEHIP_TRY(load_rtc());
+    std::string src = "#define PDEHIP_BC_FN __device__ __forceinline__\n";
+    src += source;
+    src += kBcKernel;
+    hiprtcProgram prog = nullptr;
+    if (g_rtc.CreateProgram(&prog, src.c_str(), "bc_program.hip", 0, nullptr, nullptr) != 0) PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    if (g_rtc.CompileProgram(prog, 4, opts) != 0) {
+        size_t n = 0;
+        g_rtc.GetProgramLogSize(prog, &n);
+        std::string log(n + 1, '\0');
+        if (n) g_rtc.GetProgramLog(prog, &log[0]);
+        g_rtc.DestroyProgram(&prog);
+        PDEHIP_FAIL(E_VALUE, "boundary-condition program does not compile: %.400s", log.c_str());
+    }
+    size_t n = 0;
+    g_rtc.GetCodeSize(prog, &n);
+    std::vector<char> code(n);
+    g_rtc.GetCode(prog, code.data());
+    g_rtc.DestroyProgram(&prog);
+    BcProg *b = new BcProg();
+    std::vector<BcFaceDev> host((size_t)nfaces);
+    long start = 0;
+    for (int f = 0; f < nfaces; f++) {
+        const pdehip_bcprog_face_t &s = faces[f];
+        if (!s.const_arr || !s.factor_arr || s.m1 < 1 || s.m2 < 1) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d has no arrays / cells", f); }
+        BcFaceDev &d = host[f];
+        d.A = s.const_arr; d.B = s.factor_arr; d.m1 = s.m1; d.m2 = s.m2; d.dx = s.dx; d.start = start; d.pad = 0;
+        for (int k = 0; k < 3; k++) { d.origin[k] = s.origin[k]; d.step[k] = s.step[k]; d.index[k] = s.index[k]; }
+        start += s.m1 * s.m2;
+    }
+    b->nfaces = nfaces;
+    b->total = start;
+    hipError_t e = hipModuleLoadData(&b->module, code.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&b->fn, b->module, "bc_refresh");
+    if (e == hipSuccess) e = hipMalloc(&b->faces_dev, sizeof(BcFaceDev) * host.size());
+    if (e == hipSuccess) e = hipMemcpy(b->faces_dev, host.data(), sizeof(BcFaceDev) * host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (b->faces_dev) (void)hipFree(b->faces_dev);
+        if (b->module) (void)hipModuleUnload(b->module);
+        delete b;
+        PDEHIP_FAIL(E_RUNTIME, "bcprog_create: %s", hipGetErrorString(e));
+    }
+    *handle = b;
+    return 0;
+}
+
+int pdehip_bcprog_run(void *handle, double t, void *stream)
+{
+    BcProg *b = static_cast<BcProg *>(handle);
+    if (!b) PDEHIP_FAIL(E_VALUE, "bcprog_run: NULL handle");
+    const BcFaceDev *faces = b->faces_dev;
+    int nfaces = b->nfaces;
+    long total = b->total;
+    void *kargs[] = {&faces, &nfaces, &total, &t};
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    PDEHIP_HIP(hipModuleLaunchKernel(b->fn, blocks, 1, 1, 256, 1, 1, 0, as_stream(stream), kargs, nullptr));
+    return 0;
+}
+
+int pdehip_bcprog_destroy(void *handle)
+{
+    BcProg *b = static_cast<BcProg *>(handle);
+    if (!b) return 0;
+    // (the module stays loaded: unloading code objects in the middle of a run was the trigger of the lazy-load fault noted in
+    // pdehip_kernels.hip; a program is a few KB)
+    if (b->faces_dev) (void)hipFree(b->faces_dev);
+    delete b;
+    return 0;
+}
+
+}  // extern "C"
+
 // ---- fixed-step Euler loop over the passes of an expression PDE (include/pdehip.h) ---------------------------------------------
 namespace {
 struct LoopGraph {
@@ -569,11 +691,29 @@ unsigned g_loop_next = 0;
 hipStream_t g_loop_cap = nullptr;
 hipEvent_t g_loop_ev = nullptr;
 
+// all passes of one evaluation: `src` / `extras` index -1 - k = component k of `cur`, `out` index -1 - k = component k of `nxt`
+int run_passes(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, char *cur, char *nxt,
+               size_t comp_bytes, const double *params, void *stream, int skip_last = 0)
+{
+    for (int q = 0; q < npasses - skip_last; q++) {
+        const pdehip_jit_pass_t &p = passes[q];
+        auto in = [&](int32_t idx) -> void * {
+            if (idx == PDEHIP_JIT_NONE) return nullptr;
+            return idx >= 0 ? fixed[idx] : (void *)(cur + (size_t)(-1 - idx) * comp_bytes);
+        };
+        void *out = p.out >= 0 ? fixed[p.out] : (void *)(nxt + (size_t)(-1 - p.out) * comp_bytes);
+        const void *ex[3] = {in(p.extras[0]), in(p.extras[1]), in(p.extras[2])};
+        PDEHIP_TRY(jit_apply_impl(p.handle, g, in(p.src), ex, out, params, 2, p.faces, stream, nullptr, nullptr));
+    }
+    return 0;
+}
+
 int loop_steps(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, char *cur, char *nxt,
-               size_t comp_bytes, double dt, double t0, int64_t first, int64_t count, void *stream)
+               size_t comp_bytes, double dt, double t0, int64_t first, int64_t count, void *stream, void *bc_program = nullptr)
 {
     for (int64_t s = 0; s < count; s++) {
         const double params[2] = {dt, t0 + (double)(first + s) * dt};   // _solvers.py:100: t = t_start + i * dt
+        if (bc_program) PDEHIP_TRY(pdehip_bcprog_run(bc_program, params[1], stream));   // the faces of THIS step's time
         for (int q = 0; q < npasses; q++) {
             const pdehip_jit_pass_t &p = passes[q];
             auto in = [&](int32_t idx) -> void * {
@@ -592,8 +732,9 @@ int loop_steps(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npas
 
 int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                          void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
-                         void **result, void *stream)
+                         void *bc_program, void **result, void *stream)
 {
+    if (bc_program) uses_time = 1;
     if (!g || !passes || !state_a || !state_b || !result || (nfixed > 0 && !fixed)) PDEHIP_FAIL(E_VALUE, "jit_euler_run: NULL pointer");
     if (npasses < 1 || ncomp < 1 || nsteps < 0) PDEHIP_FAIL(E_VALUE, "jit_euler_run: bad pass / component / step count");
     NGrid n;
@@ -637,7 +778,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                            p.faces && passes[1].src == p.out && passes[1].out == -1 && (none(passes[1].extras[0]) || passes[1].extras[0] == -1) &&
                            none(passes[1].extras[1]) && none(passes[1].extras[2]) && passes[1].faces &&
                            static_cast<Jit *>(p.handle)->body2.empty() && static_cast<Jit *>(passes[1].handle)->body2.empty();
-        if (tile_on && (one || two || chain) && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {   // (explicit time: evaluated per level)
+        if (tile_on && !bc_program && (one || two || chain) && n.ndim == 2 && n.n[1] * n.n[2] <= tile_cells && nsteps >= 2) {   // (explicit time: evaluated per level)
             Jit *j = static_cast<Jit *>(p.handle);
             if (two || chain) {
                 // the second field reads the first one as e0 and vice versa: when a pass does not use the other field its slot
@@ -697,7 +838,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     }
     // the first two steps always run as plain launches: they build whatever kernel is not built yet (no hiprtc inside a capture)
     const int64_t head = nsteps < 2 ? nsteps : 2;
-    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, 0, head, stream));
+    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, 0, head, stream, bc_program));
     s = head;
     if (head % 2) { char *t = cur; cur = nxt; nxt = t; }
     constexpr int64_t kBlock = 16;   // even: the buffers are back in place after a block
@@ -742,9 +883,86 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
             PDEHIP_HIP(hipStreamWaitEvent(user, g_loop_ev, 0));
         }
     }
-    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, s, nsteps - s, stream));
+    PDEHIP_TRY(loop_steps(g, passes, npasses, fixed, cur, nxt, comp_bytes, dt, t0, s, nsteps - s, stream, bc_program));
     if ((nsteps - s) % 2) { char *t = cur; cur = nxt; nxt = t; }
     *result = cur;
+    return 0;
+}
+
+// ---- Runge-Kutta loops over the passes of an expression PDE: the generic loops of pdehip_rk_loops.h with the passes as evaluator ----
+namespace {
+struct JitEval {
+    const pdehip_grid_t *g;
+    const pdehip_jit_pass_t *passes;
+    int npasses;
+    void *const *fixed;
+    int ncomp;
+    size_t comp_bytes;
+    int stage_fuse;     // 1: try the stage epilogue of the last pass, 0: never, -1: refused once (stays off)
+    void *bc_program;
+
+    int refresh(double t, void *st) { return bc_program ? pdehip_bcprog_run(bc_program, t, st) : 0; }
+    // k_out = dt * F(in; t) and - where the last pass carries it - the combination `sf` in the same sweep (*fused)
+    int slope(void *in, void *k_out, double dt, double t, const StageFuse *sf, bool *fused, void *st)
+    {
+        *fused = false;
+        const double params[2] = {dt, t};
+        PDEHIP_TRY(refresh(t, st));
+        const pdehip_jit_pass_t &last = passes[npasses - 1];
+        const bool try_stage = sf && stage_fuse > 0 && ncomp == 1 && last.out == -1;
+        PDEHIP_TRY(run_passes(g, passes, npasses, fixed, (char *)in, (char *)k_out, comp_bytes, params, st, try_stage ? 1 : 0));
+        if (!try_stage) return 0;
+        auto arr = [&](int32_t idx) -> void * {
+            if (idx == PDEHIP_JIT_NONE) return nullptr;
+            return idx >= 0 ? fixed[idx] : (void *)((char *)in + (size_t)(-1 - idx) * comp_bytes);
+        };
+        const void *ex[3] = {arr(last.extras[0]), arr(last.extras[1]), arr(last.extras[2])};
+        int nk = 0;
+        while (nk < 5 && sf->k[nk]) nk++;
+        int done = 0;
+        PDEHIP_TRY(pdehip_jit_apply_stage(last.handle, g, arr(last.src), ex, k_out, params, 2, last.faces, sf->kind, sf->y, nk, sf->k, sf->c,
+                                          sf->c_new, sf->out2, sf->err, &done, st));
+        if (done) { *fused = true; return 0; }
+        stage_fuse = -1;   // only the generic kernel covers this grid: plain pass + pointwise combination from now on
+        return run_passes(g, passes + npasses - 1, 1, fixed, (char *)in, (char *)k_out, comp_bytes, params, st);
+    }
+    int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *st) { return pdehip_lincomb(g, ncomp, out, y, n, c, k, st); }
+    int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, ncomp, y, k1, k2, k3, k4, st); }
+    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, ncomp, y, ynew, k6, err, st); }
+    int zero(void *ptr, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(st))); return 0; }
+    int read_scalar(double *host, const double *dev, void *st)
+    {
+        PDEHIP_HIP(hipMemcpyAsync(host, dev, sizeof(double), hipMemcpyDeviceToHost, as_stream(st)));
+        PDEHIP_HIP(hipStreamSynchronize(as_stream(st)));
+        return 0;
+    }
+    int fail_runtime(const char *fmt, double v) { PDEHIP_FAIL(E_RUNTIME, fmt, v); }
+};
+}  // namespace
+
+int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    if (!g || !passes || !y || !work_host || !result || (nfixed > 0 && !fixed)) PDEHIP_FAIL(E_VALUE, "jit_rk_run: NULL pointer");
+    if (npasses < 1 || ncomp < 1 || nsteps < 0) PDEHIP_FAIL(E_VALUE, "jit_rk_run: bad pass / component / step count");
+    if (ctl && (!ynew || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "jit_rk_run: the adaptive loop needs ynew, err_dev, tolerance > 0 and dt > 0");
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    for (int q = 0; q < npasses; q++) {
+        const pdehip_jit_pass_t &p = passes[q];
+        if (!p.handle) PDEHIP_FAIL(E_VALUE, "jit_rk_run: pass %d has no handle", q);
+        const int32_t idx[5] = {p.src, p.extras[0], p.extras[1], p.extras[2], p.out};
+        for (int m = 0; m < 5; m++) {
+            if (idx[m] == PDEHIP_JIT_NONE && m != 0 && m != 4) continue;
+            if (idx[m] == PDEHIP_JIT_NONE || idx[m] >= nfixed || idx[m] < -ncomp)
+                PDEHIP_FAIL(E_VALUE, "jit_rk_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
+        }
+    }
+    JitEval ev{g, passes, npasses, fixed, ncomp, (size_t)n.pc * elem_size(n.dtype), stage_fuse ? 1 : 0, bc_program};
+    if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
+    for (int64_t s = 0; s < nsteps; s++) PDEHIP_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));
+    *result = y;
     return 0;
 }
 

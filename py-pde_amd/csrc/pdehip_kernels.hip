@@ -116,9 +116,15 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     if (a.any_ibc && !kIbc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs are not built for the derivative epilogues");
     // rows that end inside a lane's vector, or tiles with whole chunks beyond the row, take the TAILS instance
     const bool tails = (a.n2 % VEC != 0) || (((a.n2 + 64L * VEC - 1) / (64L * VEC)) % CZ != 0);
+    // streaming stores: 3-D outputs that do not fit the 256 MB Infinity Cache (a smaller field is re-read from that cache by the
+    // next sweep); the whole-row tiles of aligned rows only (the hot instances)
+    const int ncomp_out = (MODE == LAP_GRAD_C || MODE == LAP_GRAD_F || MODE == LAP_GRAD_B) ? 3 : (MODE == LAP_STAGE ? 2 : 1);
+    static const bool nt_off = getenv("PDEHIP_NO_NT") != nullptr;   // A/B aid
+    const bool nt = HAS_X && !tails && !nt_off && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) * ncomp_out > 192.0 * 1048576.0);
 #define PDEHIP_MARCH(YIN_, IBC_)                                                                                                       \
     do {                                                                                                                               \
         if (tails) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, true>), grid, block, 0, st, a);  \
+        else if (HAS_X && nt) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, false, HAS_X>), grid, block, 0, st, a); \
         else hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, false>), grid, block, 0, st, a);       \
     } while (0)
     if (a.any_ibc) {
@@ -501,7 +507,11 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const bool xs = xplain > 1;
     const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
     // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
+#if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
+    const bool nt = false;   // A/B variant: non-temporal loads, plain stores
+#else
     const bool nt = !ragged && m2 != E2_CH_STAGE && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
+#endif
     // unit spacing and D = 1 (UnitGrid benchmarks): the 3-D instances exist without the multiplications by 1.0 (fp32 and the
     // cache-resident sizes are VALU-bound: up to 10 %)
     static const bool unit_off = getenv("PDEHIP_NO_UNIT") != nullptr;   // A/B aid

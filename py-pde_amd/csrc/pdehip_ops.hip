@@ -196,6 +196,19 @@ __global__ void __launch_bounds__(256) partial_sum_kernel(SumArgs a)
     const double s = block_sum(acc);
     if (threadIdx.x == 0) a.partial[(long)a.comp * a.nblocks + blockIdx.x] = s;
 }
+// number of non-finite cells (NaN, +-inf) of one component: the partial / final sum skeleton with a predicate
+template <typename T>
+__global__ void __launch_bounds__(256) partial_nonfinite_kernel(SumArgs a)
+{
+    const T *in = (const T *)a.in + (long)a.comp * a.g.pc;
+    double acc = 0;
+    for_each_chunk<1>(a.g, 1, [&](int, long, long, long, long e) {
+        const double v = (double)in[e];
+        acc += (v - v == 0.0) ? 0.0 : 1.0;   // x - x is 0 for finite x, NaN for NaN and +-inf
+    });
+    const double s = block_sum(acc);
+    if (threadIdx.x == 0) a.partial[(long)a.comp * a.nblocks + blockIdx.x] = s;
+}
 __global__ void __launch_bounds__(256) final_sum_kernel(SumArgs a)
 {
     double acc = 0;
@@ -807,6 +820,30 @@ int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, do
         a.comp = c;
         if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((partial_sum_kernel<double>), dim3(a.nblocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((partial_sum_kernel<float>), dim3(a.nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, a);
+    }
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
+int pdehip_count_nonfinite(const pdehip_grid_t *g, int ncomp, const void *arr_full, double *out_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!arr_full || !out_dev) PDEHIP_FAIL(E_VALUE, "count_nonfinite: NULL pointer");
+    if (ncomp < 1 || ncomp > 64) PDEHIP_FAIL(E_VALUE, "count_nonfinite: 1..64 components");
+    static double *partial = nullptr;
+    constexpr int kBlocks = 1024;
+    if (!partial) PDEHIP_HIP(hipMalloc(&partial, sizeof(double) * 64 * kBlocks));
+    SumArgs a;
+    a.g = dev_grid(n); a.in = arr_full; a.partial = partial; a.out = out_dev; a.vol = 1.0;
+    long blocks = (n.n[0] * n.n[1] * n.n[2] + 255) / 256;
+    a.nblocks = (int)(blocks < kBlocks ? (blocks < 1 ? 1 : blocks) : kBlocks);
+    hipStream_t st = as_stream(stream);
+    for (int c = 0; c < ncomp; c++) {
+        a.comp = c;
+        if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((partial_nonfinite_kernel<double>), dim3(a.nblocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((partial_nonfinite_kernel<float>), dim3(a.nblocks), dim3(256), 0, st, a);
         hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, a);
     }
     PDEHIP_HIP(hipGetLastError());

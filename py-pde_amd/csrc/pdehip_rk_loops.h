@@ -1,0 +1,129 @@
+// pdehip_rk_loops.h — Runge-Kutta step sequences and the adaptive loop, written ONCE against an evaluator policy `Eval`.
+//
+// The reference jit-compiles these loops around whatever right-hand side the PDE provides: RK4 pde/solvers/runge_kutta.py:29-66,
+// RKF45 :68-156, the adaptive loop pde/backends/numba/_solvers.py:199-319 with the controller pde/solvers/base.py:533-594.
+// Here the right-hand side of an expression PDE is a list of kernel passes (pdehip_jit.hip); this header holds the control flow
+// around it, so that a whole run is ONE C call: no Python per step or per stage, 8 bytes to the host per adaptive attempt.
+// Two instantiations: csrc/pdehip_jit.hip (JitEval: run-time built HIP kernels — the product) and tests/shim/pdehip_shim_comm.cpp
+// (host memory, gcc-built epilogues, oracle kernels — TESTS ONLY), so the CPU test-suite executes exactly this sequence.
+// (The slab-parallel twins for the built-in right-hand sides, with their halo exchanges, are in pdehip_slab_loops.h.)
+//
+// Eval provides:
+//   int slope(void *in, void *k_out, double dt, double t, const StageFuse *sf, bool *fused, void *st)
+//        k_out = dt * F(in; t); if it can, also the combination `sf` in the same sweep (*fused = true) — then k_out is written
+//        only for sf->kind 0 / 3;   int lincomb / rk4_combine / rkf45_combine(...): the pointwise kernels of include/pdehip.h;
+//   int zero(void *, size_t, void *st);   int read_scalar(double *host, const double *dev, void *st);
+//   int fail_runtime(const char *fmt, double value)   (sets the error message, returns the RuntimeError status)
+#pragma once
+
+#include <cmath>
+#include <cstring>
+
+#include "pdehip_slab_loops.h"   // StageFuse, slab::rkf45_row, slab::adjust_dt, SLAB_TRY
+
+namespace pdehip {
+namespace rk {
+
+// one classical RK4 step in place on y; w = k1..k4, tmp (runge_kutta.py:52-61; same stage sequence as pdehip_rk4_step: the array
+// of k4 doubles as the second stage-input buffer, a fused last sweep never stores k4)
+template <class Eval>
+int rk4_step(Eval &ev, void *y, void *const *w, double dt, double t, void *st)
+{
+    void *k1 = w[0], *k2 = w[1], *k3 = w[2], *k4 = w[3], *tmp = w[4];
+    const double half = 0.5, one = 1.0;
+    const void *kk[1];
+    bool fused = false;
+    StageFuse sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.y = y; sf.c_new = half; sf.out2 = tmp;
+    SLAB_TRY(ev.slope(y, k1, dt, t, &sf, &fused, st));
+    if (!fused) { kk[0] = k1; SLAB_TRY(ev.lincomb(tmp, y, 1, &half, kk, st)); }
+    sf.out2 = k4;
+    SLAB_TRY(ev.slope(tmp, k2, dt, t + 0.5 * dt, &sf, &fused, st));
+    if (!fused) { kk[0] = k2; SLAB_TRY(ev.lincomb(k4, y, 1, &half, kk, st)); }
+    sf.c_new = one; sf.out2 = tmp;
+    SLAB_TRY(ev.slope(k4, k3, dt, t + 0.5 * dt, &sf, &fused, st));
+    if (!fused) { kk[0] = k3; SLAB_TRY(ev.lincomb(tmp, y, 1, &one, kk, st)); }
+    sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.c_new = 0.0; sf.out2 = y;
+    SLAB_TRY(ev.slope(tmp, k4, dt, t + dt, &sf, &fused, st));
+    if (!fused) SLAB_TRY(ev.rk4_combine(y, k1, k2, k3, k4, st));
+    return 0;
+}
+
+// one RKF45 attempt: ynew and *err_dev from y (runge_kutta.py:135-153); w = k1..k6, tmp; stage inputs alternate between tmp and
+// ynew (free until the last sweep), like pdehip_rkf45_attempt
+template <class Eval>
+int rkf45_attempt(Eval &ev, void *y, void *ynew, void *const *w, double dt, double t, double *err_dev, void *st)
+{
+    static const double A[6] = {0.0, 1.0 / 4, 3.0 / 8, 12.0 / 13, 1.0, 1.0 / 2};   // runge_kutta.py:92-98
+    void *tmp = w[6];
+    void *t_in = y, *t_out = tmp;
+    const void *k[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+    bool fused = false;
+    for (int s = 0; s < 5; s++) {
+        StageFuse sf;
+        memset(&sf, 0, sizeof(sf));
+        sf.y = y; sf.out2 = t_out;
+        const double *row = slab::rkf45_row(s);
+        for (int m = 0; m < s; m++) { sf.k[m] = w[m]; sf.c[m] = row[m]; }
+        sf.c_new = row[s];
+        SLAB_TRY(ev.slope(t_in, w[s], dt, t + A[s] * dt, &sf, &fused, st));
+        if (!fused) SLAB_TRY(ev.lincomb(t_out, y, s + 1, row, k, st));
+        t_in = t_out;
+        t_out = (t_out == tmp) ? ynew : tmp;
+    }
+    StageFuse sf;
+    memset(&sf, 0, sizeof(sf));
+    sf.kind = 2; sf.y = y; sf.out2 = ynew; sf.err = err_dev;
+    sf.k[0] = w[0]; sf.k[1] = w[2]; sf.k[2] = w[3]; sf.k[3] = w[4];
+    SLAB_TRY(ev.zero(err_dev, sizeof(double), st));
+    SLAB_TRY(ev.slope(t_in, w[5], dt, t + A[5] * dt, &sf, &fused, st));
+    if (!fused) SLAB_TRY(ev.rkf45_combine(y, ynew, k, err_dev, st));
+    return 0;
+}
+
+// the adaptive loop of pde/backends/numba/_solvers.py:249-281 (single device: no reduction over ranks); accepted attempts swap
+// the roles of y / ynew; *result names the array holding the final state
+template <class Eval>
+int rkf45_run(Eval &ev, void *y, void *ynew, void *const *w, double *err_dev, pdehip_adaptive_t *a, void **result, void *st)
+{
+    double dt_opt = a->dt, t = a->t_start;
+    void *cur = y, *nxt = ynew;
+    while (true) {
+        const double dt_step = std::fmax(std::fmin(dt_opt, a->t_end - t), a->dt_min);
+        SLAB_TRY(rkf45_attempt(ev, cur, nxt, w, dt_step, t, err_dev, st));
+        double err = 0;
+        SLAB_TRY(ev.read_scalar(&err, err_dev, st));
+        const double error_rel = err / a->tolerance;
+        a->attempts++;
+        if (error_rel <= 1) {   // accept (false for NaN)
+            a->steps++;
+            t += dt_step;
+            void *tmp = cur; cur = nxt; nxt = tmp;
+            a->stat_min = a->stat_count ? std::fmin(a->stat_min, dt_step) : dt_step;
+            a->stat_max = a->stat_count ? std::fmax(a->stat_max, dt_step) : dt_step;
+            const double delta = dt_step - a->stat_mean;
+            a->stat_count++;
+            a->stat_mean += delta / (double)a->stat_count;
+            a->stat_m2 += delta * (dt_step - a->stat_mean);
+        }
+        if (t < a->t_end) {
+            double d = dt_step;
+            const int bad = slab::adjust_dt(&d, error_rel, a->dt_min, a->dt_max);
+            if (bad) {
+                a->dt = dt_opt; a->t_last = t; *result = cur;
+                return bad == 1 ? ev.fail_runtime("Encountered NaN even though dt < %g", a->dt_min) : ev.fail_runtime("Time step below %g", a->dt_min);
+            }
+            dt_opt = d;
+        } else {
+            break;
+        }
+    }
+    a->dt = dt_opt;
+    a->t_last = t;
+    *result = cur;
+    return 0;
+}
+
+}  // namespace rk
+}  // namespace pdehip

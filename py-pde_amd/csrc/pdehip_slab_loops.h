@@ -251,8 +251,10 @@ int euler2_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_
 // ---------------------------------------------------------------------------------------------------------
 template <class Ops>
 int rhs_sweep(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *in, void *out,
-              double dt, bool euler, const StageFuse *sf, void *st)
+              double dt, bool euler, const StageFuse *sf, void *st, double t = 0.0)
 {
+    // faces with explicit time dependence: their coefficient arrays for the time of THIS evaluation (pdehip_rhs_t::bc_program)
+    if (rhs->bc_program) SLAB_TRY(ops.refresh(rhs->bc_program, t, st));
     pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
     local_faces(rhs->bc_c, lower, upper, fc);
     const bool fuse_stage = sf && (flags & F_FUSED_STAGE);
@@ -287,28 +289,29 @@ int rhs_sweep(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t
 // serve as stage inputs and need the spare layers); same stage sequence as pdehip_rk4_step
 template <class Ops>
 int rk4_step(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y, void *const *w,
-             double dt, void *st)
+             double dt, void *st, double t = 0.0)
 {
     void *k1 = w[0], *k2 = w[1], *k3 = w[2], *k4 = w[3], *tmp = w[4];
     StageFuse sf;
     memset(&sf, 0, sizeof(sf));
     sf.y = y; sf.c_new = 0.5; sf.out2 = tmp;
-    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, y, k1, dt, false, &sf, st));
+    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, y, k1, dt, false, &sf, st, t));
     sf.out2 = k4;   // the array of k4 doubles as the second stage-input buffer; k4 itself is consumed by the last sweep
-    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, tmp, k2, dt, false, &sf, st));
+    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, tmp, k2, dt, false, &sf, st, t + 0.5 * dt));
     sf.c_new = 1.0; sf.out2 = tmp;
-    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, k4, k3, dt, false, &sf, st));
+    SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, k4, k3, dt, false, &sf, st, t + 0.5 * dt));
     sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.out2 = y;
     // unfused combination needs k4 stored: its array is free again (its role as stage input ended with the third sweep)
-    return rhs_sweep(ops, g, q, rhs, lower, upper, flags, tmp, k4, dt, false, &sf, st);
+    return rhs_sweep(ops, g, q, rhs, lower, upper, flags, tmp, k4, dt, false, &sf, st, t + dt);
 }
 
 // one RKF45 attempt (pde/solvers/runge_kutta.py:135-153): ynew and *err_dev (this rank's max-norm; the caller reduces);
 // w = k1..k6, tmp; y, ynew and tmp serve as stage inputs (spare layers); same stage sequence as pdehip_rkf45_attempt
 template <class Ops>
 int rkf45_attempt(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y, void *ynew,
-                  void *const *w, double dt, double *err_dev, void *st)
+                  void *const *w, double dt, double *err_dev, void *st, double t = 0.0)
 {
+    static const double A[6] = {0.0, 1.0 / 4, 3.0 / 8, 12.0 / 13, 1.0, 1.0 / 2};   // stage times t + a_s * dt (runge_kutta.py:92-98)
     void *tmp = w[6];
     void *t_in = y, *t_out = tmp;
     for (int s = 0; s < 5; s++) {
@@ -318,7 +321,7 @@ int rkf45_attempt(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_r
         const double *row = rkf45_row(s);
         for (int m = 0; m < s; m++) { sf.k[m] = w[m]; sf.c[m] = row[m]; }
         sf.c_new = row[s];
-        SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, t_in, w[s], dt, false, &sf, st));
+        SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, t_in, w[s], dt, false, &sf, st, t + A[s] * dt));
         t_in = t_out;
         t_out = (t_out == tmp) ? ynew : tmp;
     }
@@ -327,7 +330,7 @@ int rkf45_attempt(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_r
     sf.kind = 2; sf.y = y; sf.out2 = ynew; sf.err = err_dev;
     sf.k[0] = w[0]; sf.k[1] = w[2]; sf.k[2] = w[3]; sf.k[3] = w[4];
     SLAB_TRY(ops.zero(err_dev, sizeof(double), st));
-    return rhs_sweep(ops, g, q, rhs, lower, upper, flags, t_in, w[5], dt, false, &sf, st);
+    return rhs_sweep(ops, g, q, rhs, lower, upper, flags, t_in, w[5], dt, false, &sf, st, t + A[5] * dt);
 }
 
 // time-step controller, pde/solvers/base.py:572-592 (`_make_dt_adjuster`); returns 0, or 1 / 2 = below dt_min (with / without NaN)
@@ -348,7 +351,7 @@ int euler_sweeps(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rh
 {
     void *cur = buf_a, *nxt = buf_b;
     for (int64_t s = 0; s < nsteps; s++) {
-        SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, cur, nxt, dt, true, nullptr, st));
+        SLAB_TRY(rhs_sweep(ops, g, q, rhs, lower, upper, flags, cur, nxt, dt, true, nullptr, st, rhs->t + (double)s * dt));
         void *t = cur; cur = nxt; nxt = t;
     }
     *result = cur;
@@ -368,7 +371,7 @@ int rkf45_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t
     void *cur = y, *nxt = ynew;
     while (true) {
         const double dt_step = std::fmax(std::fmin(dt_opt, a->t_end - t), a->dt_min);
-        SLAB_TRY(rkf45_attempt(ops, g, q, rhs, lower, upper, flags, cur, nxt, w, dt_step, err_dev, st));
+        SLAB_TRY(rkf45_attempt(ops, g, q, rhs, lower, upper, flags, cur, nxt, w, dt_step, err_dev, st, t));
         SLAB_TRY(ops.allreduce_max(err_dev, st));
         double err = 0;
         SLAB_TRY(ops.read_scalar(&err, err_dev, st));

@@ -17,6 +17,7 @@ const double B3[] = {3.0 / 32, 9.0 / 32};
 const double B4[] = {1932.0 / 2197, -7200.0 / 2197, 7296.0 / 2197};
 const double B5[] = {439.0 / 216, -8.0, 3680.0 / 513, -845.0 / 4104};
 const double B6[] = {-8.0 / 27, 2.0, -3544.0 / 2565, 1859.0 / 4104, -11.0 / 40};
+const double A45[] = {0.0, 1.0 / 4, 3.0 / 8, 12.0 / 13, 1.0, 1.0 / 2};   // runge_kutta.py:92-98
 
 int check_rhs(const pdehip_rhs_t *rhs)
 {
@@ -102,6 +103,12 @@ bool graphs_enabled()
 // rk4_combine pass: a stage moves (1 + earlier slopes + 2 or 3) arrays instead of 2 + (earlier slopes + 3).
 // *fused = false (nothing launched) when the sweep is not available: diffusion needs the vectorised kernel,
 // Cahn-Hilliard the two-level kernel (pdehip_march2.inc).
+// faces with explicit time dependence: their coefficient arrays for the time of THIS evaluation (pdehip_rhs_t::bc_program)
+int refresh_bcs(const pdehip_rhs_t *rhs, double t, void *stream)
+{
+    return rhs->bc_program ? pdehip_bcprog_run(rhs->bc_program, t, stream) : 0;
+}
+
 int rhs_stage(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *in, void *k_out, double dt, const StageFuse &sf,
               void *stream, bool *fused)
 {
@@ -124,10 +131,17 @@ int rhs_stage(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *in, void *k
 
 extern "C" {
 
+static int rhs_scaled_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, double t, void *stream);
 int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full,
                       double dt, void *stream)
 {
     PDEHIP_TRY(check_rhs(rhs));
+    return rhs_scaled_at(g, rhs, y_full, k_out_full, dt, rhs->t, stream);
+}
+
+static int rhs_scaled_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, double t, void *stream)
+{
+    PDEHIP_TRY(refresh_bcs(rhs, t, stream));
     // numba/backend.py:501-517: BCs, then the stencil — here one kernel (BCs evaluated on the fly)
     if (rhs->kind == PDEHIP_RHS_DIFFUSION)   // dt * (D * lap)
         return laplace_with_input_bcs(g, y_full, nullptr, k_out_full, LAP_SCALED, rhs->param, dt, 0, rhs->bc_c, stream);
@@ -148,6 +162,7 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "euler_run: negative step count");
     void *cur = buf_a, *nxt = buf_b;
     bool ch_fused = true;
+    const bool timed = rhs->bc_program != nullptr;   // faces that change with time: one step per sweep, refreshed before every step
     auto one_step = [&](void *c, void *n, void *st) -> int {
         if (rhs->kind == PDEHIP_RHS_DIFFUSION)
             // state + dt * (D * laplace(state))   euler.py:174 with diffusion.py:121 — ONE kernel per step
@@ -163,7 +178,7 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     };
     // Two steps per sweep where the temporal-blocking kernel covers the grid and its BCs (the intermediate
     // level never touches HBM: 16 B per cell for two steps), else one step per sweep.
-    bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION;
+    bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION && !timed;   // (the second level would need the faces at t + dt)
     // 2-D grids of a few MB: K steps per launch with the time levels in LDS (pdehip_tile2d.inc) — such grids are bound by
     // launch / cache latency per step, not by HBM.  PDEHIP_TILE2D=off disables it, PDEHIP_TILE2D=<k> caps K,
     // PDEHIP_TILE2D_CELLS=<n> moves the size limit (default 2^21 cells).
@@ -177,8 +192,9 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     }
     long ncells = 1;
     for (int q = 0; q < g->ndim; q++) ncells *= g->shape[q];
-    bool tile_ok = g->ndim == 2 && tile_k > 0 && ncells <= tile_cells;
-    auto advance = [&](void *c, void *n, void *st, int64_t left, int *took) -> int {
+    bool tile_ok = g->ndim == 2 && tile_k > 0 && ncells <= tile_cells && !timed;
+    auto advance = [&](void *c, void *n, void *st, int64_t left, int *took, int64_t step = 0) -> int {
+        if (timed) PDEHIP_TRY(refresh_bcs(rhs, rhs->t + (double)step * dt, st));   // _solvers.py:100: t = t_start + i * dt
         if (tile_ok) {
             int k = tile2d_max_steps(rhs->kind == PDEHIP_RHS_DIFFUSION ? 0 : 1);
             if (k > tile_k) k = tile_k;
@@ -205,10 +221,10 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     int64_t s = 0;
     long cells = 1;
     for (int a = 0; a < g->ndim; a++) cells *= g->shape[a];
-    if (graphs_enabled() && cells <= (1L << 22) && nsteps >= kGraphSteps) {
+    if (graphs_enabled() && !timed && cells <= (1L << 22) && nsteps >= kGraphSteps) {
         GraphKey key;
         memset(&key, 0, sizeof(key));
-        key.g = *g; key.rhs = *rhs; key.buf[0] = buf_a; key.buf[1] = buf_b; key.dt = dt; key.kind = 0;
+        key.g = *g; key.rhs = *rhs; key.rhs.t = 0; key.buf[0] = buf_a; key.buf[1] = buf_b; key.dt = dt; key.kind = 0;
         PDEHIP_TRY(replay_graph(key, nsteps, kGraphSteps, 2048, stream, [&](void *cap) -> int {
             for (int64_t q = 0; q < kGraphSteps;) {
                 int took = 0;
@@ -221,7 +237,7 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     }
     while (s < nsteps) {
         int took = 0;
-        PDEHIP_TRY(advance(cur, nxt, stream, nsteps - s, &took));
+        PDEHIP_TRY(advance(cur, nxt, stream, nsteps - s, &took, s));
         s += took;
         void *t = cur; cur = nxt; nxt = t;
     }
@@ -229,10 +245,16 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     return 0;
 }
 
+static int rk4_step_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, double t, void *stream);
 int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, void *stream)
 {
     PDEHIP_TRY(check_rhs(rhs));
     if (!y || !w) PDEHIP_FAIL(E_VALUE, "rk4_step: NULL pointer");
+    return rk4_step_at(g, rhs, y, w, dt, rhs->t, stream);
+}
+
+static int rk4_step_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, double t, void *stream)
+{
     void *k1 = w[0], *k2 = w[1], *k3 = w[2], *k4 = w[3], *tmp = w[4];
     const double half = 0.5, one = 1.0;
     const void *kk[1];
@@ -242,24 +264,28 @@ int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, vo
     StageFuse sf;
     memset(&sf, 0, sizeof(sf));
     sf.y = y; sf.c_new = half; sf.out2 = tmp;
+    // stage times t, t + dt/2, t + dt/2, t + dt (runge_kutta.py:52-59): time-dependent faces are refreshed before each stage
+    PDEHIP_TRY(refresh_bcs(rhs, t, stream));
     PDEHIP_TRY(rhs_stage(g, rhs, y, k1, dt, sf, stream, &fused));
     if (fused) {
         sf.out2 = k4;
+        PDEHIP_TRY(refresh_bcs(rhs, t + 0.5 * dt, stream));
         PDEHIP_TRY(rhs_stage(g, rhs, tmp, k2, dt, sf, stream, &fused));
         sf.c_new = one; sf.out2 = tmp;
         if (fused) PDEHIP_TRY(rhs_stage(g, rhs, k4, k3, dt, sf, stream, &fused));
         sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.out2 = y;
+        PDEHIP_TRY(refresh_bcs(rhs, t + dt, stream));
         if (fused) PDEHIP_TRY(rhs_stage(g, rhs, tmp, nullptr, dt, sf, stream, &fused));
         if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
         return 0;
     }
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, k1, dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, y, k1, dt, t, stream));
     kk[0] = k1; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k2, dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, k2, dt, t + 0.5 * dt, stream));
     kk[0] = k2; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k3, dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, k3, dt, t + 0.5 * dt, stream));
     kk[0] = k3; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &one, kk, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, k4, dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, k4, dt, t + dt, stream));
     return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, stream);
 }
 
@@ -275,6 +301,7 @@ int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in,
     memset(&sf, 0, sizeof(sf));
     sf.kind = 3; sf.y = y_in; sf.k[0] = rate_prev; sf.c_new = dt; sf.out2 = y_out;
     bool done = false;
+    PDEHIP_TRY(refresh_bcs(rhs, rhs->t, stream));
     PDEHIP_TRY(rhs_stage(g, rhs, y_in, rate_cur, 1.0, sf, stream, &done));
     *fused = done ? 1 : 0;
     return 0;
@@ -291,10 +318,10 @@ int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, voi
     int64_t s = 0;
     long cells = 1;
     for (int a = 0; a < g->ndim; a++) cells *= g->shape[a];
-    if (graphs_enabled() && cells <= (1L << 22) && nsteps >= kBlock) {
+    if (graphs_enabled() && !rhs->bc_program && cells <= (1L << 22) && nsteps >= kBlock) {
         GraphKey key;
         memset(&key, 0, sizeof(key));
-        key.g = *g; key.rhs = *rhs; key.dt = dt; key.kind = 1;
+        key.g = *g; key.rhs = *rhs; key.rhs.t = 0; key.dt = dt; key.kind = 1;
         key.buf[0] = y;
         for (int q = 0; q < 5; q++) key.buf[1 + q] = w[q];
         PDEHIP_TRY(replay_graph(key, nsteps, kBlock, 512, stream, [&](void *cap) -> int {
@@ -302,7 +329,7 @@ int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, voi
             return 0;
         }, &s));
     }
-    for (; s < nsteps; s++) PDEHIP_TRY(pdehip_rk4_step(g, rhs, y, w, dt, stream));
+    for (; s < nsteps; s++) PDEHIP_TRY(rk4_step_at(g, rhs, y, w, dt, rhs->t + (double)s * dt, stream));   // _solvers.py:100
     return 0;
 }
 
@@ -313,6 +340,7 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
     if (!y || !ynew || !w || !err_dev) PDEHIP_FAIL(E_VALUE, "rkf45_attempt: NULL pointer");
     void *tmp = w[6];
     const void *k[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+    const double t0 = rhs->t;   // the stages are evaluated at t0 + a_s * dt (runge_kutta.py:135-145)
     // runge_kutta.py:135-145.  Fused form: stages 1-5 also write the input of the next stage (alternating between
     // tmp and ynew), the sixth computes the new state and the error norm from k6 in registers - 36 instead of 45
     // arrays moved per attempt.
@@ -326,6 +354,7 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
             sf.y = y; sf.out2 = t_out;
             for (int m = 0; m < s; m++) { sf.k[m] = k[m]; sf.c[m] = tab[s][m]; }
             sf.c_new = tab[s][s];
+            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[s] * dt, stream));
             PDEHIP_TRY(rhs_stage(g, rhs, t_in, w[s], dt, sf, stream, &fused));
             if (!fused && s > 0) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
             t_in = t_out;
@@ -337,22 +366,23 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
             sf.kind = 2; sf.y = y; sf.out2 = ynew; sf.err = err_dev;
             sf.k[0] = k[0]; sf.k[1] = k[2]; sf.k[2] = k[3]; sf.k[3] = k[4];
             PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
+            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[5] * dt, stream));
             PDEHIP_TRY(rhs_stage(g, rhs, t_in, nullptr, dt, sf, stream, &fused));
             if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
             return 0;
         }
     }
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, y, w[0], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, y, w[0], dt, t0, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, B2, k, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[1], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, w[1], dt, t0 + A45[1] * dt, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 2, B3, k, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[2], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, w[2], dt, t0 + A45[2] * dt, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 3, B4, k, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[3], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, w[3], dt, t0 + A45[3] * dt, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 4, B5, k, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[4], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, w[4], dt, t0 + A45[4] * dt, stream));
     PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 5, B6, k, stream));
-    PDEHIP_TRY(pdehip_rhs_scaled(g, rhs, tmp, w[5], dt, stream));
+    PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, w[5], dt, t0 + A45[5] * dt, stream));
     // runge_kutta.py:147-150
     return pdehip_rkf45_combine(g, 1, y, ynew, k, err_dev, stream);
 }

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -71,7 +71,16 @@ class RHS(C.Structure):
         ("bc_c", FaceArray),
         ("bc_mu", FaceArray),
         ("scratch_mu", C.c_void_p),
+        ("bc_program", C.c_void_p),
+        ("t", C.c_double),
     ]
+
+
+class BcProgFace(C.Structure):
+    """``pdehip_bcprog_face_t``: where one expression face writes its coefficient arrays and how its cells map to coordinates."""
+
+    _fields_ = [("const_arr", C.c_void_p), ("factor_arr", C.c_void_p), ("m1", C.c_int64), ("m2", C.c_int64),
+                ("origin", C.c_double * 3), ("step", C.c_double * 3), ("index", C.c_int32 * 3), ("reserved", C.c_int32), ("dx", C.c_double)]
 
 
 JIT_NONE = -(2**31)   # PDEHIP_JIT_NONE
@@ -161,6 +170,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "ab2_combine": ([_pg, _i, _vp, _vp, _vp, _d], True),
     "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
     "integrate": ([_pg, _i, _vp, _d, _vp], True),
+    "count_nonfinite": ([_pg, _i, _vp, _vp], True),
     "add_gaussian_noise": ([_pg, _i, _vp, _d, C.c_uint64, C.c_uint64, C.c_uint64], True),
     "rhs_scaled": ([_pg, _pr, _vp, _vp, _d], True),
     "euler_run": ([_pg, _pr, _vp, _vp, _d, _i64, _pvp], True),
@@ -231,7 +241,12 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_euler2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, C.POINTER(_i), _vp],
     "jit_create2": [C.c_char_p, C.c_char_p, _pvp],
     "jit_fused2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, _pf, C.POINTER(_i), _vp],
-    "jit_euler_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _vp, _vp, _i, _d, _d, _i, _i64, _pvp, _vp],
+    "jit_euler_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _vp, _vp, _i, _d, _d, _i, _i64, _vp, _pvp, _vp],
+    "jit_rk_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _i, _vp, _vp, _pvp, _vp, _d, _d, _i64, _pa, _i, _vp, _pvp, _vp],
+    # expression boundary conditions evaluated on the device
+    "bcprog_create": [C.c_char_p, _i, C.POINTER(BcProgFace), _pvp],
+    "bcprog_run": [_vp, _d, _vp],
+    "bcprog_destroy": [_vp],
 }
 
 

@@ -234,16 +234,34 @@ class RhsSpec:
             bc_mu.copy_into(self.c.bc_mu)
             self.mu = DeviceArray(info)
             self.c.scratch_mu = self.mu.ptr
+        # faces with explicit time dependence: ONE device program for both tables, run by every C entry point for the time of its
+        # evaluation (`pdehip_rhs_t::bc_program`, `t`); faces given as Python functions stay on the host (`host_time_dependent`)
+        self.program = None
+        if self.time_dependent and not self.host_time_dependent:
+            from .bc_expr import program_for
+
+            self.program = program_for(require_device(), [self.bc_c, self.bc_mu])
+            if self.program is not None:
+                self.c.bc_program = self.program.ptr
 
     @property
     def time_dependent(self) -> bool:
         """Faces whose coefficient arrays must be refreshed when the time changes (expression BCs with `t`)."""
         return any(getattr(tb, "time_dependent", False) for tb in (self.bc_c, self.bc_mu) if tb is not None)
 
+    @property
+    def host_time_dependent(self) -> bool:
+        """... and some of them are Python functions: refreshed from the host, which keeps the steps out of the C loops."""
+        return any(getattr(tb, "host_only", False) for tb in (self.bc_c, self.bc_mu) if tb is not None)
+
     def update(self, t: float) -> None:
-        for tb in (self.bc_c, self.bc_mu):
-            if tb is not None and getattr(tb, "time_dependent", False):
-                tb.update({"t": t})
+        """Time of the next evaluation: the C entry points refresh the device-evaluated faces themselves (``self.c.t``); faces
+        given as Python functions get their coefficient arrays from the host here."""
+        self.c.t = float(t)
+        if self.program is None:
+            for tb in (self.bc_c, self.bc_mu):
+                if tb is not None and getattr(tb, "time_dependent", False):
+                    tb.update({"t": t})
 
     @property
     def ref(self):
@@ -582,6 +600,28 @@ class HipBackendMixin:
 
         return integrate
 
+    def make_finite_check(self, grid=None):
+        """``is_finite(field_or_array) -> bool``: the check of the reference's ``ConsistencyTracker``
+        (``np.all(np.isfinite(field.data))``, pde/trackers/trackers.py:974-1003) evaluated ON THE DEVICE (``pdehip_count_nonfinite``):
+        for a :class:`DeviceArray`, or for a field whose state lives on the device between tracker interrupts
+        (:class:`ResidentState`), 8 bytes per component cross PCIe instead of the whole state.  Host data is checked on the host."""
+
+        def is_finite(obj) -> bool:
+            arr = obj
+            if not isinstance(obj, DeviceArray):
+                link = getattr(obj, "__dict__", {}).get("_hip_link")
+                if link is not None and link.host_stale:       # the device copy is the current one
+                    arr = link.dev_state
+                else:
+                    return bool(np.all(np.isfinite(getattr(obj, "data", obj))))
+            out = DeviceBuffer(8 * arr.ncomp)
+            self._lib.count_nonfinite(arr.info.ref, arr.ncomp, arr.ptr, out.ptr, self.stream)
+            host = np.empty(arr.ncomp, dtype=np.float64)
+            self._lib.memcpy_d2h(host.ctypes.data, out.ptr, host.nbytes, self.stream)
+            return not host.any()
+
+        return is_finite
+
     # --- operators ------------------------------------------------------------------------------------
     def make_operator_no_bc(self, grid, operator, *, dtype=None, **kwargs):
         """``impl(arr_full: DeviceArray, out: DeviceArray)``; ghost cells are the caller's job."""
@@ -814,13 +854,17 @@ class HipBackendMixin:
                     aux_dev[name] = DeviceArray(info).set_valid(np.asarray(host, dtype=info.dtype), self.stream)
             return {name: aux_dev[name] for name in plan.aux_used}
 
+        # Python functions the expressions may call (`user_funcs` of pde.PDE, pde/pdes/pde.py:84): traced symbolically by the plan
+        user_funcs: dict[str, Any] = dict(getattr(eq, "user_funcs", None) or {})
+        for e in (getattr(eq, "_rhs_expr", None) or {}).values():
+            user_funcs.update(getattr(e, "user_funcs", None) or {})
         parts = []
         names = [name for name, _, _ in flat]
         for name, var, comp in flat:
             try:
                 plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), name, consts, others=tuple(n for n in names if n != name),
                                       axes=tuple(grid.axes), aliases=aliases, aux=tuple(a for a in aux_host if a not in vectors),
-                                      vectors=vectors, component=comp)
+                                      vectors=vectors, component=comp, user_funcs=user_funcs)
             except ValueError as err:
                 if "unknown symbol" in str(err):   # the reference's error for this case (pde/pdes/pde.py:455-459)
                     msg = f"Undefined variable in expression for rhs of `{var}`: {err}"
@@ -899,6 +943,11 @@ class HipBackendMixin:
                             if done is not cur:
                                 cur, nxt = nxt, cur
                             i = steps
+                    if is_rk and post_step is None and hasattr(erhs, "rk_run") and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+                        # the whole fixed-step RK4 loop in ONE C call (pdehip_jit_rk_run; reference: the jitted loop
+                        # pde/backends/numba/_solvers.py:93-118 around pde/solvers/runge_kutta.py:29-66)
+                        if erhs.rk_run(cur, None, work[:5], None, dt, t_start, steps) is not None:
+                            i = steps
                     while i < steps:
                         t = t_start + i * dt
                         if is_rk:
@@ -948,7 +997,30 @@ class HipBackendMixin:
                 lib.max_abs_diff(info.ref, ncomp, k1.ptr, ynew.ptr, err_dev.ptr, stream)
             return err_dev.value(stream)
 
+        ctl = None
+        if is_rk and post_step is None and hasattr(erhs, "rk_run") and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+            # the adaptive loop itself in C (pdehip_jit_rk_run: pde/backends/numba/_solvers.py:199-319 is jitted in the reference)
+            from .solvers import AdaptiveStatistics
+
+            ctl = _abi.Adaptive()
+            ctl.tolerance, ctl.dt_min, ctl.dt_max = tolerance, dt_min, float(solver.dt_max)
+
         def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+            nonlocal ctl
+            if ctl is not None:
+                ctl.t_start, ctl.t_end, ctl.dt = float(t_start), float(t_end), float(solver.info["dt"])
+                before = int(ctl.steps)
+                try:
+                    res = erhs.rk_run(state_data, ynew0, work[:7], err_dev, 0.0, 0.0, 0, ctl)
+                finally:
+                    solver.info["steps"] += int(ctl.steps) - before
+                if res is not None:
+                    if res is not state_data:
+                        lib.memcpy_d2d(state_data.ptr, res.ptr, state_data.nbytes, stream)
+                    solver.info["dt"] = float(ctl.dt)
+                    solver.info["dt_statistics"] = AdaptiveStatistics(ctl)
+                    return state_data, float(ctl.t_last)
+                ctl = None      # not available for this right-hand side (integrals, function-valued conditions): Python loop
             dt_opt = float(solver.info["dt"])
             t, steps = t_start, 0
             stats = solver.info["dt_statistics"]
@@ -995,13 +1067,16 @@ class HipBackendMixin:
             steps = max(1, round((t_end - t_start) / dt))
             if first[0]:
                 # state_prev = state - dt * rhs(state)  ->  rate_prev = rhs(state_prev)
+                spec.c.t = float(t_start)              # every rate at its own time (adams_bashforth.py:45-46, :64): t, then t - dt
                 lib.rhs_scaled(info.ref, spec.ref, state_data.ptr, rates[0].ptr, 1.0, stream)
                 lib.lincomb(info.ref, 1, tmp.ptr, state_data.ptr, 1, minus_dt, ptr_array([rates[0]]), stream)
+                spec.c.t = float(t_start) - dt
                 lib.rhs_scaled(info.ref, spec.ref, tmp.ptr, rates[1].ptr, 1.0, stream)
                 first[0] = False
             cur, nxt = state_data, tmp
             fused = C.c_int(0)
-            for _ in range(steps):
+            for i in range(steps):
+                spec.c.t = t_start + i * dt
                 # rate and update in one sweep where the kernels cover it (state ping-pongs), else two kernels in place
                 if one_sweep[0]:
                     lib.ab2_step(info.ref, spec.ref, cur.ptr, nxt.ptr, rates[0].ptr, rates[1].ptr, dt, C.byref(fused), stream)
@@ -1174,9 +1249,9 @@ class HipBackendMixin:
         if post_step is not None:
             # the hook runs on the host between steps: the steps are driven from here, one sweep each
             return self._make_expression_stepper(solver, state, SpecRhs(self, spec), post_step=post_step)
-        if spec.time_dependent:
-            # faces with explicit time dependence: the C loops do not know t, so the steps are driven from here and the
-            # coefficient arrays are refreshed before every right-hand side
+        if spec.host_time_dependent:
+            # faces given as Python functions: their coefficient arrays come from the host before every right-hand side, so the
+            # steps are driven from here.  (Expression faces are refreshed on the device inside the C loops: spec.c.t below.)
             if solver_name == "AdamsBashforthSolver":
                 msg = f"Backend `{self.name}` does not support time-dependent boundary conditions with {solver_name}"
                 raise NotImplementedError(msg)
@@ -1192,6 +1267,7 @@ class HipBackendMixin:
             dt = float(solver.info["dt"])
             def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
                 steps = max(1, round((t_end - t_start) / dt))
+                spec.c.t = float(t_start)    # time of the first step: faces with explicit time dependence follow it inside the C loop
                 if is_rk:
                     lib.rk4_run(info.ref, spec.ref, state_data.ptr, work_ptrs, dt, steps, stream)
                     result = state_data
@@ -1246,9 +1322,10 @@ class HipBackendMixin:
             adaptive_loop.keepalive = (work, ynew, err_dev, spec)   # type: ignore[attr-defined]  (work_ptrs holds raw pointers only)
             return adaptive_loop
 
-        two_half_steps = [spec.kind == _abi.RHS_DIFFUSION]
+        two_half_steps = [spec.kind == _abi.RHS_DIFFUSION and not spec.time_dependent]
 
-        def attempt(state_data: DeviceArray, ynew: DeviceArray, dt_step: float) -> float:
+        def attempt(state_data: DeviceArray, ynew: DeviceArray, dt_step: float, t: float = 0.0) -> float:
+            spec.c.t = float(t)      # faces with explicit time dependence: the C entry points evaluate them at t (+ a_s * dt per stage)
             if is_rk:
                 lib.rkf45_attempt(info.ref, spec.ref, state_data.ptr, ynew.ptr, work_ptrs, dt_step, err_dev.ptr, stream)
             else:
@@ -1263,6 +1340,7 @@ class HipBackendMixin:
                     two_half_steps[0] = bool(done.value)
                 if not done.value:
                     lib.euler_run(info.ref, spec.ref, state_data.ptr, k2a.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
+                    spec.c.t = float(t) + 0.5 * dt_step
                     lib.euler_run(info.ref, spec.ref, k2a.ptr, ynew.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
                 lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
             return err_dev.value(stream)
@@ -1274,7 +1352,7 @@ class HipBackendMixin:
             cur, nxt = state_data, ynew   # an accepted attempt swaps the roles (no copy of the field per step)
             while True:
                 dt_step = max(min(dt_opt, t_end - t), dt_min)
-                error_rel = sync_errors(attempt(cur, nxt, dt_step) / tolerance)
+                error_rel = sync_errors(attempt(cur, nxt, dt_step, t) / tolerance)
                 if error_rel <= 1:
                     steps += 1
                     t += dt_step

@@ -14,8 +14,13 @@ not read the field — is exactly the constant-coefficient form the ghost kernel
 
 with per-face-cell coefficient arrays (``PDEHIP_BCF_ARRAYS``, ``include/pdehip.h``).  ``A`` and ``B`` are split off
 symbolically (``B = dF/dvalue``, ``A = F(value=0)``) and evaluated on the wall points once (time independent: the face
-then costs nothing extra in the time loop) or whenever the time changes (``ExprFaceTable.update``).  Conditions given as Python FUNCTIONS are probed on the host (coefficient arrays before every
-right-hand side); conditions that are non-linear in ``value`` raise ``NotImplementedError``.
+then costs nothing extra in the time loop) or whenever the time changes.  Faces that change with time are refreshed ON THE
+DEVICE: ``A`` and ``B`` are printed as C, compiled at run time (``pdehip_bcprog_create``, hiprtc) into one small kernel per
+face table / right-hand side that rewrites the coefficient arrays for a given ``t`` (:func:`build_program`); the C time loops
+call it before every right-hand side (``pdehip_rhs_t::bc_program``), so time-dependent conditions cost one extra launch per
+evaluation and no host work.  Conditions given as Python FUNCTIONS cannot travel to the device: they are probed on the host
+(coefficient arrays uploaded before every right-hand side, steps driven from Python); conditions that are non-linear in
+``value`` raise ``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -78,6 +83,8 @@ class _AffineFace:
         args = [by_name.get(n, sp.Symbol(n)) for n in names[1:]]
         self._offset = sp.lambdify(args, offset, modules="numpy")
         self._slope = sp.lambdify(args, slope, modules="numpy")
+        self._symbolic = (offset, slope, {n: by_name.get(n, sp.Symbol(n)) for n in names[1:]})   # for the device program
+        self.axis, self.upper, self.grid = int(bc.axis), bool(bc.upper), grid
         self.time_dependent = "t" in by_name
         self.needs_time = self.time_dependent
         self.dx = float(grid.discretization[bc.axis])
@@ -121,6 +128,98 @@ class _AffineFace:
         return (np.array(np.broadcast_to(a, self.face_shape), dtype=np.float64, order="C"), np.array(np.broadcast_to(b, self.face_shape), dtype=np.float64, order="C"))
 
 
+def _c_code(expr) -> str:
+    from sympy.printing.c import C99CodePrinter
+
+    class Printer(C99CodePrinter):
+        def _print_Pow(self, e):   # small integer powers as repeated multiplication, like the right-hand-side epilogues (expr.py)
+            b, ex = e.as_base_exp()
+            if ex.is_Integer and 1 <= abs(int(ex)) <= 8:
+                prod = "*".join([f"({self._print(b)})"] * abs(int(ex)))
+                return f"({prod})" if ex > 0 else f"(1.0/({prod}))"
+            return super()._print_Pow(e)
+
+    return Printer({"precision": 17}).doprint(expr)
+
+
+def build_program(lib, entries) -> Any:
+    """One device program (``pdehip_bcprog_create``) that rewrites the coefficient arrays of all ``entries`` —
+    ``(face: _AffineFace, const buffer, factor buffer)`` of faces given as sympy expressions — for a time ``t``:
+    returns the handle (``ctypes.c_void_p``), or None when an entry is a Python function (host only)."""
+    import ctypes as C
+
+    import sympy as sp
+
+    if not entries or any(face._callable is not None for face, _, _ in entries):
+        return None
+    cases, descs = [], (_abi.BcProgFace * len(entries))()
+    for i, (face, buf_a, buf_b) in enumerate(entries):
+        offset, slope, syms = face._symbolic
+        grid = face.grid
+        axes = list(grid.axes)
+        # the generated function sees the coordinates as c0, c1, c2 in grid-axis order
+        sub = {syms["dx"]: sp.Symbol("dx"), syms["t"]: sp.Symbol("t")}
+        for k, name in enumerate(axes):
+            sub[syms[name]] = sp.Symbol(f"c{k}")
+        cases.append(f"    case {i}: *A = {_c_code(sp.sympify(offset).subs(sub))}; *B = {_c_code(sp.sympify(slope).subs(sub))}; break;")
+        d = descs[i]
+        d.const_arr, d.factor_arr = buf_a.ptr, buf_b.ptr
+        others = [a for a in range(len(axes)) if a != face.axis]
+        d.m1 = int(grid.shape[others[0]]) if len(others) >= 1 else 1
+        d.m2 = int(grid.shape[others[1]]) if len(others) >= 2 else 1
+        d.dx = float(grid.discretization[face.axis])
+        bounds = grid.axes_bounds
+        for k in range(3):
+            d.origin[k], d.step[k], d.index[k] = 0.0, 0.0, 0
+        d.origin[face.axis] = float(bounds[face.axis][1] if face.upper else bounds[face.axis][0])   # the wall
+        for slot, a in enumerate(others):
+            # cell centres (i + 0.5) * dx + x_min, the reference's `discretize_interval` (pde/grids/base.py:88-113)
+            d.origin[a], d.step[a], d.index[a] = float(bounds[a][0]), float(grid.discretization[a]), slot + 1
+    source = ("PDEHIP_BC_FN void bc_face(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n{\n"
+              "    (void)dx; (void)c0; (void)c1; (void)c2; (void)t;\n    switch (face) {\n" + "\n".join(cases) + "\n    default: break;\n    }\n}\n")
+    handle = C.c_void_p()
+    lib.bcprog_create(source.encode(), len(entries), descs, C.byref(handle))
+    return handle
+
+
+class BcProgram:
+    """Owner of a ``pdehip_bcprog`` handle (destroyed with the object); ``None``-like when the faces cannot run on the device."""
+
+    def __init__(self, lib, entries):
+        self.lib, self.entries = lib, list(entries)
+        self.handle = build_program(lib, self.entries)
+
+    @property
+    def ptr(self):
+        return None if self.handle is None else self.handle.value
+
+    def run(self, t: float, stream=None) -> None:
+        self.lib.bcprog_run(self.handle, float(t), stream)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None:
+            try:
+                self.lib.bcprog_destroy(h)
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+
+
+def program_for(lib, tables) -> "BcProgram | None":
+    """The device program for all time-dependent faces of ``tables`` (face tables of ONE right-hand side), or None when there
+    are none.  Raises ``NotImplementedError`` when a face is a Python function (host-probed: no device program)."""
+    entries = []
+    for tb in {id(tb): tb for tb in tables if tb is not None}.values():
+        entries += list(getattr(tb, "_dynamic", []))
+    if not entries:
+        return None
+    prog = BcProgram(lib, entries)
+    if prog.handle is None:
+        msg = "boundary conditions given as Python functions are evaluated on the host"
+        raise NotImplementedError(msg)
+    return prog
+
+
 class ExprFaceTable:
     """Face table (``.c`` = ``pdehip_bc_face_t[6]``) whose expression faces can be refreshed for a new time."""
 
@@ -131,6 +230,7 @@ class ExprFaceTable:
         self._dynamic = dynamic          # (face evaluator, const buffer, factor buffer) of time-dependent faces
         self._write = write
         self._t: float | None = None
+        self._program: Any = None        # BcProgram of this table's dynamic faces (built on first use) / False: host evaluation
 
     @property
     def time_dependent(self) -> bool:
@@ -153,13 +253,33 @@ class ExprFaceTable:
             t = 0.0
         else:
             t = float(args["t"])
-        if self._t is not None and t == self._t:
+        if self._t is not None and t == self._t and self._program is False:
+            return
+        if self._program is None:
+            # faces given as expressions are refreshed on the device (one launch); Python functions and the host-side tables of
+            # the test harness (numpy buffers) are evaluated here
+            device = all(face._callable is None and getattr(buf, "arr", None) is None for face, buf, _ in self._dynamic)
+            self._program = False
+            if device:
+                from ._lib import require_device
+
+                prog = BcProgram(require_device(), self._dynamic)
+                if prog.handle is not None:
+                    self._program = prog
+        if self._program is not False:
+            self._program.run(t)
+            self._t = t
             return
         for face, buf_a, buf_b in self._dynamic:
             a, b = face.evaluate(t)
             self._write(buf_a, a)
             self._write(buf_b, b)
         self._t = t
+
+    @property
+    def host_only(self) -> bool:
+        """Some time-dependent face is a Python function: coefficient arrays come from the host before every evaluation."""
+        return any(face._callable is not None for face, _, _ in self._dynamic)
 
 
 def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None) -> ExprFaceTable:

@@ -52,7 +52,8 @@ class ExpressionPlan:
 
     def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
                  axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None, aux: tuple[str, ...] = (),
-                 vectors: dict[str, tuple[str, ...]] | None = None, component: int | None = None):
+                 vectors: dict[str, tuple[str, ...]] | None = None, component: int | None = None,
+                 user_funcs: dict[str, Any] | None = None):
         """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
         (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS.  ``aliases``: further
         operator names standing for one of OPERATORS (``{"laplace_outer": "laplace"}``) - same stencil, but a name of its own
@@ -62,9 +63,15 @@ class ExpressionPlan:
         depend on position: pde/pdes/pde.py:441-447); they enter a pass as centre-only inputs (array name ``aux:<name>``).
         ``vectors``: vector FIELDS of the state by name -> the names of their scalar components among ``var`` / ``others``
         (``{"u": ("u#0", "u#1")}``); ``component``: the plan evaluates this component of a vector-valued right-hand side (the
-        equation of a vector field; ``var`` is then the name of that component of the field)."""
+        equation of a vector field; ``var`` is then the name of that component of the field).  ``user_funcs``: the Python
+        functions of ``pde.PDE(..., user_funcs=...)`` (pde/pdes/pde.py:84, pde/tools/expressions.py:173-212).  They cannot run on
+        the device as Python; they are TRACED once with symbolic arguments (scalars as sympy expressions, vectors / tensors as
+        numpy object arrays of them) and what they return is compiled like the rest of the expression - which covers
+        arithmetic, indexing, numpy reductions over components and sympy functions; anything else raises
+        ``NotImplementedError``."""
         sp = _sympy()
         self.var = var
+        self.user_funcs = dict(user_funcs or {})
         self.others = tuple(others)
         expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
         # operator name -> ("d1" | "d2", normalised axis) for the per-axis derivatives; the kernels number axes right-aligned to 3
@@ -122,12 +129,14 @@ class ExpressionPlan:
         if nd:
             local.update({name: sp.Function(name) for name in ("gradient", "divergence", "dot", "inner", "vector_laplace", "vector_gradient",
                                                                 "tensor_divergence", "outer")})
+        for name in self.user_funcs:
+            local[name] = sp.Function(name)
         try:
             expr = sp.sympify(expr_str, locals=local)
         except (sp.SympifyError, SyntaxError, TypeError) as err:
             msg = f"cannot parse expression `{expr_str}`: {err}"
             raise ValueError(msg) from err
-        if nd:
+        if nd or self.user_funcs:
             kind, expr = self._lower_vectors(expr, nd)
             if component is None and kind != "s":
                 msg = f"hip backend: the right-hand side `{expr_str}` is a vector, the field is a scalar"
@@ -166,6 +175,8 @@ class ExpressionPlan:
         if isinstance(e, sp.core.function.AppliedUndef):
             name = e.func.__name__
             args = [self._lower_vectors(a, nd) for a in e.args]
+            if name in self.user_funcs:
+                return self._trace_user_func(name, args, nd)
             if name == "gradient":
                 if len(args) != 1 or args[0][0] != "s":
                     msg = "hip backend: `gradient` inside expressions takes one scalar argument"
@@ -227,6 +238,33 @@ class ExpressionPlan:
                 return "v", [scal * c for c in val]
             return "t", [[scal * c for c in row] for row in val]
         msg = f"hip backend: vector expression `{e}` is not supported (sums, scalar multiples, dot, divergence)"
+        raise NotImplementedError(msg)
+
+    def _trace_user_func(self, name: str, args, nd: int):
+        """Call the user's Python function ONCE with symbolic arguments and lower what it returns."""
+        sp = _sympy()
+
+        def to_py(kind, val):
+            return val if kind == "s" else np.array(val, dtype=object)
+
+        try:
+            result = self.user_funcs[name](*[to_py(k, v) for k, v in args])
+        except Exception as err:   # noqa: BLE001 - whatever the user's code raises on symbolic input
+            msg = (f"hip backend: user function `{name}` cannot be traced symbolically ({type(err).__name__}: {err}); functions that run "
+                   "on the device must work on sympy expressions (arithmetic, indexing, sympy functions)")
+            raise NotImplementedError(msg) from err
+        arr = np.asarray(result, dtype=object)
+        try:
+            if arr.ndim == 0:
+                return "s", sp.sympify(arr.item())
+            if arr.shape == (nd,):
+                return "v", [sp.sympify(c) for c in arr]
+            if arr.shape == (nd, nd):
+                return "t", [[sp.sympify(c) for c in row] for row in arr]
+        except (sp.SympifyError, TypeError) as err:
+            msg = f"hip backend: user function `{name}` returned something that is not an expression: {err}"
+            raise NotImplementedError(msg) from err
+        msg = f"hip backend: user function `{name}` returned an array of shape {arr.shape}"
         raise NotImplementedError(msg)
 
     # --- lowering --------------------------------------------------------------------------------
@@ -408,12 +446,25 @@ class ExpressionPlan:
                 for p in self.passes]
 
 
-def _run_loop(lib, info, loop, state, other, ncomp: int, dt: float, t0: float, nsteps: int, uses_time: bool, stream):
+def _run_loop(lib, info, loop, state, other, ncomp: int, dt: float, t0: float, nsteps: int, uses_time: bool, stream, program=None):
     passes, fixed, nfixed, _keep = loop
     result = C.c_void_p()
     lib.jit_euler_run(info.ref, passes, len(passes), fixed, nfixed, state.ptr, other.ptr, ncomp, dt, t0, int(bool(uses_time)), int(nsteps),
-                      C.byref(result), stream)
+                      None if program is None else program.ptr, C.byref(result), stream)
     return state if result.value == state.ptr else other
+
+
+def _run_rk(lib, info, loop, ncomp: int, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl, stage_fuse: bool, stream, program=None):
+    """``pdehip_jit_rk_run``: ``nsteps`` RK4 steps in place on ``y`` (``ctl`` None) or the adaptive RKF45 loop described by ``ctl``;
+    returns the array that holds the final state."""
+    from .device import ptr_array
+
+    passes, fixed, nfixed, _keep = loop
+    result = C.c_void_p()
+    lib.jit_rk_run(info.ref, passes, len(passes), fixed, nfixed, ncomp, y.ptr, None if ynew is None else ynew.ptr, ptr_array(work),
+                   None if err is None else err.ptr, float(dt), float(t0), int(nsteps), None if ctl is None else C.byref(ctl),
+                   int(bool(stage_fuse)), None if program is None else program.ptr, C.byref(result), stream)
+    return y if result.value == y.ptr else ynew
 
 
 class ExpressionRhs:
@@ -553,14 +604,24 @@ class ExpressionRhs:
 
     # --- the whole fixed-step Euler loop in one C call (pdehip_jit_euler_run) ------------------------------------------------
     def loop_ok(self) -> bool:
-        """The passes of this expression can run inside ``pdehip_jit_euler_run``: no conditions that change with time, no
-        integrals (their values travel through the host)."""
-        return not self._dynamic and not self.has_reductions
+        """The passes of this expression can run inside the C loops (``pdehip_jit_euler_run`` / ``pdehip_jit_rk_run``): no
+        integrals (their values travel through the host) and no conditions given as Python functions (conditions that are
+        expressions of time are refreshed on the device inside the loops: :meth:`bc_program`)."""
+        return not self.has_reductions and not any(getattr(tb, "host_only", False) for tb in self._dynamic)
 
-    def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list) -> list:
-        """``pdehip_jit_pass_t`` entries of one Euler step of this equation; ``own``: component of the state it advances,
-        ``components``: the other variables' components by name, ``fixed``: list of device pointers that the entries index
-        (extended here), ``keep``: objects that must outlive the descriptor."""
+    def bc_program(self):
+        """Device program (``pde_hip.bc_expr.BcProgram``) of all time-dependent faces of this expression's tables, or None."""
+        if not hasattr(self, "_bc_program"):
+            from .bc_expr import program_for
+
+            self._bc_program = program_for(self.lib, self._dynamic) if self._dynamic else None
+        return self._bc_program
+
+    def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list, wrap: str = "euler") -> list:
+        """``pdehip_jit_pass_t`` entries of one evaluation of this equation (``wrap`` = "euler": one Euler step, the last pass
+        writes ``state + dt*F``; "scaled": a Runge-Kutta slope, it writes ``dt*F``); ``own``: component of the state it
+        advances, ``components``: the other variables' components by name, ``fixed``: list of device pointers that the
+        entries index (extended here), ``keep``: objects that must outlive the descriptor."""
         index: dict[str, int] = {}
 
         def resolve(name: str, is_out: bool = False) -> int:
@@ -580,7 +641,7 @@ class ExpressionRhs:
 
         entries = []
         for i, p in enumerate(self.plan.passes):
-            h, extras = self._kernel(i, "euler")
+            h, extras = self._kernel(i, wrap)
             e = _abi.JitPass()
             e.handle = h.value
             e.src = resolve(p.src)
@@ -598,12 +659,31 @@ class ExpressionRhs:
         holds the result, or None when the loop is not available (then nothing was done)."""
         if not self.loop_ok():
             return None
-        if getattr(self, "_loop", None) is None:
+        return _run_loop(self.lib, self.info, self._loop_desc("euler"), state, other, 1, dt, t0, nsteps, self.plan.uses_time, self.backend.stream,
+                         self.bc_program())
+
+    def _loop_desc(self, wrap: str):
+        cache = self.__dict__.setdefault("_loops", {})
+        if wrap not in cache:
             fixed: list = []
             keep: list = []
-            entries = self.loop_passes(0, {}, fixed, keep)
-            self._loop = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
-        return _run_loop(self.lib, self.info, self._loop, state, other, 1, dt, t0, nsteps, self.plan.uses_time, self.backend.stream)
+            entries = self.loop_passes(0, {}, fixed, keep, wrap)
+            cache[wrap] = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
+        return cache[wrap]
+
+    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None):
+        """Runge-Kutta steps in ONE C call (``pdehip_jit_rk_run``): ``nsteps`` RK4 steps in place on ``y``, or - with ``ctl`` -
+        the adaptive RKF45 loop; returns the array holding the final state, or None when the loop is not available (integrals,
+        function-valued conditions; two-pass chains of LARGE grids keep the Python loop, whose steps run the chain as one
+        two-level sweep)."""
+        if not self.loop_ok():
+            return None
+        chain = self._fused_handle("scaled") is not None
+        if chain and int(np.prod(self.info.shape)) > (1 << 21):
+            return None
+        stage_fuse = getattr(self, "_stage_ok", True) and not chain
+        return _run_rk(self.lib, self.info, self._loop_desc("scaled"), 1, y, ynew, work, err, dt, t0, nsteps, ctl, stage_fuse, self.backend.stream,
+                       self.bc_program())
 
     def _fused_handle(self, wrap: str):
         if wrap not in self._fused:
@@ -700,14 +780,37 @@ class SystemRhs:
         fields and writes its component of the next one); None when an equation cannot take part."""
         if not all(p.loop_ok() for p in self.parts):
             return None
-        if getattr(self, "_loop", None) is None:
+        part0 = self.parts[0]
+        uses_time = any(p.plan.uses_time for p in self.parts)
+        return _run_loop(part0.lib, self.info, self._loop_desc("euler"), state, other, self.ncomp, dt, t0, nsteps, uses_time, part0.backend.stream,
+                         self.bc_program())
+
+    def _loop_desc(self, wrap: str):
+        cache = self.__dict__.setdefault("_loops", {})
+        if wrap not in cache:
             fixed: list = []
             keep: list = []
             components = {name: k for k, name in enumerate(self.variables)}
             entries = []
             for k, part in enumerate(self.parts):
-                entries += part.loop_passes(k, components, fixed, keep)
-            self._loop = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
+                entries += part.loop_passes(k, components, fixed, keep, wrap)
+            cache[wrap] = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
+        return cache[wrap]
+
+    def bc_program(self):
+        """ONE device program for the time-dependent faces of all equations' tables (or None)."""
+        if not hasattr(self, "_bc_program"):
+            from .bc_expr import program_for
+
+            tables = [tb for part in self.parts for tb in part._dynamic]
+            self._bc_program = program_for(self.parts[0].lib, tables) if tables else None
+        return self._bc_program
+
+    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None):
+        """Runge-Kutta steps of the whole system in one C call (see :meth:`ExpressionRhs.rk_run`): every equation evaluates its
+        component of the slope from the stage input of all fields; the combinations run on all components at once."""
+        if not all(p.loop_ok() for p in self.parts):
+            return None
         part0 = self.parts[0]
-        uses_time = any(p.plan.uses_time for p in self.parts)
-        return _run_loop(part0.lib, self.info, self._loop, state, other, self.ncomp, dt, t0, nsteps, uses_time, part0.backend.stream)
+        return _run_rk(part0.lib, self.info, self._loop_desc("scaled"), self.ncomp, y, ynew, work, err, dt, t0, nsteps, ctl, False,
+                       part0.backend.stream, self.bc_program())

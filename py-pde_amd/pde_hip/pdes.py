@@ -177,8 +177,9 @@ class PDE(PDEBase):
     use_noise_variance = True
     use_noise_realization = False
 
-    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None, noise=0, rng=None):
+    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None, noise=0, rng=None, user_funcs=None):
         super().__init__()
+        self.user_funcs = dict(user_funcs or {})      # Python functions the expressions may call (traced symbolically by the backend)
         self.rhs = {k: str(v) for k, v in rhs.items()}
         self.variables = tuple(self.rhs)
         self.consts = dict(consts or {})

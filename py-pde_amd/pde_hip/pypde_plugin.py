@@ -30,6 +30,7 @@ try:
     from pde.grids.cartesian import CartesianGrid
     from pde.solvers.base import AdaptiveSolverBase
     from pde.tools.config import Parameter
+    from pde.trackers import trackers as _trackers
 except ImportError as err:  # pragma: no cover - exercised only without py-pde
     msg = "pde_hip.pypde_plugin needs py-pde (`import pde` failed)"
     raise ImportError(msg) from err
@@ -178,6 +179,23 @@ class HipSlabSolver(AdaptiveSolverBase):
 
         slab_stepper.slab = stepper  # type: ignore[attr-defined]
         return slab_stepper
+
+
+class HipConsistencyTracker(_trackers.ConsistencyTracker):
+    """``ConsistencyTracker`` (pde/trackers/trackers.py:974-1003) that does not pull the state to the host: while the state is
+    resident on the device (between the stepper calls of a ``backend="hip"`` run) the finiteness check is a device reduction
+    (``pdehip_count_nonfinite``).  Use ``tracker=["progress", "hip_consistency"]`` or an instance of this class."""
+
+    name = "hip_consistency"
+
+    def handle(self, field, t: float) -> None:
+        link = getattr(field, "__dict__", {}).get("_hip_link")
+        if link is None:
+            return super().handle(field, t)
+        if not link.backend.make_finite_check()(field):
+            msg = "Field was not finite"
+            raise StopIteration(msg)
+        return None
 
 
 def register() -> None:

@@ -247,6 +247,9 @@ int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a, const 
 
 int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream)
 { (void)stream; GRID(g); TRY(oracle_integrate(g, ncomp, arr_full, cell_volume, out_dev)); return 0; }
+int oracle_count_nonfinite(const pdehip_grid_t *g, int ncomp, const void *arr_full, double *out);
+int pdehip_count_nonfinite(const pdehip_grid_t *g, int ncomp, const void *arr_full, double *out_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_count_nonfinite(g, ncomp, arr_full, out_dev)); return 0; }
 int pdehip_add_gaussian_noise(const pdehip_grid_t *g, int ncomp, void *y_full, double scale, uint64_t seed, uint64_t counter,
                               uint64_t cell_offset, void *stream)
 { (void)stream; GRID(g); TRY(oracle_add_gaussian_noise(g, ncomp, y_full, scale, seed, counter, cell_offset)); return 0; }
@@ -330,38 +333,147 @@ int pdehip_cahn_hilliard_fused(const pdehip_grid_t *g, const pdehip_bc_face_t *f
 }
 
 /* ---- fused steppers ------------------------------------------------------------------------ */
+/* faces with explicit time dependence (pdehip_rhs_t::bc_program): refreshed for the time of every evaluation; the Runge-Kutta
+ * sequences with a time per stage are the generic loops of csrc/pdehip_rk_loops.h (pdehip_shim_comm.cpp) */
+int shim_timed_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, double t);
+int shim_timed_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *ynew, void *const *w, double dt, double t, double *err);
 int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, void *stream)
-{ (void)stream; GRID(g); TRY(oracle_rhs_scaled(g, rhs, y_full, k_out_full, dt)); return 0; }
+{
+    (void)stream; GRID(g);
+    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, stream); if (rc) return rc; }
+    TRY(oracle_rhs_scaled(g, rhs, y_full, k_out_full, dt));
+    return 0;
+}
 int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_a, void *buf_b, double dt, int64_t nsteps,
                      void **result, void *stream)
 {
     (void)stream; GRID(g);
     if (nsteps < 0) return fail(E_VALUE, "nsteps must be >= 0");
+    if (rhs->bc_program) {
+        void *cur = buf_a, *nxt = buf_b, *res = NULL;
+        for (int64_t s = 0; s < nsteps; s++) {
+            int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t + (double)s * dt, stream);
+            if (rc) return rc;
+            TRY(oracle_euler_run(g, rhs, cur, nxt, dt, 1, &res));
+            void *t = cur; cur = nxt; nxt = t;
+        }
+        *result = cur;
+        return 0;
+    }
     TRY(oracle_euler_run(g, rhs, buf_a, buf_b, dt, nsteps, result));
     return 0;
 }
 int pdehip_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host, double dt, void *stream)
-{ (void)stream; GRID(g); TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt)); return 0; }
+{
+    (void)stream; GRID(g);
+    if (rhs->bc_program) return shim_timed_rk4_step(g, rhs, y_full, work5_host, dt, rhs->t);
+    TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt));
+    return 0;
+}
 int pdehip_rk4_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *const *work5_host, double dt, int64_t nsteps,
                    void *stream)
 {
     (void)stream; GRID(g);
-    for (int64_t s = 0; s < nsteps; s++) TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt));
+    for (int64_t s = 0; s < nsteps; s++) {
+        if (rhs->bc_program) { int rc = shim_timed_rk4_step(g, rhs, y_full, work5_host, dt, rhs->t + (double)s * dt); if (rc) return rc; }
+        else TRY(oracle_rk4_step(g, rhs, y_full, work5_host, dt));
+    }
     return 0;
 }
 int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *ynew_full, void *const *work7_host,
                          double dt, double *err_dev, void *stream)
-{ (void)stream; GRID(g); TRY(oracle_rkf45_attempt(g, rhs, y_full, ynew_full, work7_host, dt, err_dev)); return 0; }
+{
+    (void)stream; GRID(g);
+    if (rhs->bc_program) return shim_timed_rkf45_attempt(g, rhs, y_full, ynew_full, work7_host, dt, rhs->t, err_dev);
+    TRY(oracle_rkf45_attempt(g, rhs, y_full, ynew_full, work7_host, dt, err_dev));
+    return 0;
+}
 int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_full, void *y_out_full, void *rate_cur_full,
                     const void *rate_prev_full, double dt, int *fused, void *stream)
 {
     (void)stream; GRID(g);
     *fused = 0;
     if (!fused_enabled() || g->ndim < 2) return 0;
+    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, stream); if (rc) return rc; }
     TRY(oracle_rhs_scaled(g, rhs, y_in_full, rate_cur_full, 1.0));
     memcpy(y_out_full, y_in_full, full_bytes(g, 1));
     TRY(oracle_ab2_combine(g, 1, y_out_full, rate_cur_full, rate_prev_full, dt));
     *fused = 1;
+    return 0;
+}
+
+/* ---- boundary-condition programs (pdehip_bcprog_*): gcc instead of hiprtc, a host loop instead of a kernel ---------------- */
+typedef void (*bc_face_fn)(int, double, double, double, double, double, double *, double *);
+typedef struct {
+    void *dl;
+    bc_face_fn fn;
+    int nfaces;
+    pdehip_bcprog_face_t *faces;
+} shim_bcprog_t;
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle)
+{
+    static int counter = 0;
+    if (!source || !faces || !handle || nfaces < 1 || nfaces > 64) return fail(E_VALUE, "bcprog_create: NULL pointer or bad face count");
+    char dir[] = "/tmp/pdehip_shimbc_XXXXXX";
+    if (!mkdtemp(dir)) return fail(E_RUNTIME, "shim: mkdtemp failed");
+    char src[600], so[600], cmd[2000];
+    snprintf(src, sizeof(src), "%s/b%d.c", dir, counter);
+    snprintf(so, sizeof(so), "%s/b%d.so", dir, counter++);
+    FILE *f = fopen(src, "w");
+    if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
+    fprintf(f, "#include <math.h>\n#define PDEHIP_BC_FN static inline\n%s\n"
+               "void bc_face_entry(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n"
+               "{ bc_face(face, dx, c0, c1, c2, t, A, B); }\n", source);
+    fclose(f);
+    snprintf(cmd, sizeof(cmd), "gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -fno-fast-math -o %s %s -lm 2> %s/err.txt", so, src, dir);
+    if (system(cmd) != 0) {
+        char msg[300] = "";
+        snprintf(cmd, sizeof(cmd), "%s/err.txt", dir);
+        FILE *e = fopen(cmd, "r");
+        if (e) { size_t k = fread(msg, 1, sizeof(msg) - 1, e); msg[k] = 0; fclose(e); }
+        return fail(E_VALUE, "boundary-condition program does not compile: %s", msg);
+    }
+    shim_bcprog_t *b = calloc(1, sizeof(*b));
+    b->dl = dlopen(so, RTLD_NOW | RTLD_LOCAL);
+    unlink(src); unlink(so);
+    snprintf(cmd, sizeof(cmd), "%s/err.txt", dir); unlink(cmd);
+    rmdir(dir);
+    if (!b->dl) { free(b); return fail(E_RUNTIME, "shim: dlopen failed: %s", dlerror()); }
+    b->fn = (bc_face_fn)dlsym(b->dl, "bc_face_entry");
+    if (!b->fn) { dlclose(b->dl); free(b); return fail(E_RUNTIME, "shim: bc_face_entry not found"); }
+    b->nfaces = nfaces;
+    b->faces = malloc(sizeof(*faces) * (size_t)nfaces);
+    memcpy(b->faces, faces, sizeof(*faces) * (size_t)nfaces);
+    *handle = b;
+    return 0;
+}
+int pdehip_bcprog_run(void *handle, double t, void *stream)
+{
+    (void)stream;
+    shim_bcprog_t *b = handle;
+    if (!b) return fail(E_VALUE, "bcprog_run: NULL handle");
+    for (int f = 0; f < b->nfaces; f++) {
+        const pdehip_bcprog_face_t *F = &b->faces[f];
+        for (int64_t i1 = 0; i1 < F->m1; i1++)
+            for (int64_t i2 = 0; i2 < F->m2; i2++) {
+                double c[3];
+                for (int k = 0; k < 3; k++)
+                    c[k] = F->index[k] == 0 ? F->origin[k] : ((double)(F->index[k] == 1 ? i1 : i2) + 0.5) * F->step[k] + F->origin[k];
+                double a = 0, bb = 0;
+                b->fn(f, F->dx, c[0], c[1], c[2], t, &a, &bb);
+                F->const_arr[i1 * F->m2 + i2] = a;
+                F->factor_arr[i1 * F->m2 + i2] = bb;
+            }
+    }
+    return 0;
+}
+int pdehip_bcprog_destroy(void *handle)
+{
+    shim_bcprog_t *b = handle;
+    if (!b) return 0;
+    if (b->dl) dlclose(b->dl);
+    free(b->faces);
+    free(b);
     return 0;
 }
 
@@ -576,7 +688,7 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
 /* the Euler loop over the passes of an expression PDE: the same sequence of pdehip_jit_apply calls */
 int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                          void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,
-                         void **result, void *stream)
+                         void *bc_program, void **result, void *stream)
 {
     (void)uses_time; GRID(g);
     if (!passes || !state_a || !state_b || !result || (nfixed > 0 && !fixed)) return fail(E_VALUE, "jit_euler_run: NULL pointer");
@@ -593,6 +705,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     }
     for (int64_t s = 0; s < nsteps; s++) {
         const double params[2] = {dt, t0 + (double)s * dt};
+        if (bc_program) { int rc = pdehip_bcprog_run(bc_program, params[1], stream); if (rc) return rc; }
         for (int q = 0; q < npasses; q++) {
             const pdehip_jit_pass_t *p = &passes[q];
             const void *ex[3];

@@ -29,6 +29,7 @@
 #include <unistd.h>
 
 #include "../../py-pde_amd/csrc/pdehip_slab_loops.h"
+#include "../../py-pde_amd/csrc/pdehip_rk_loops.h"
 
 using namespace pdehip;
 
@@ -41,6 +42,7 @@ int oracle_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu
 int oracle_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int nk, const double *coef, const void *const *k);
 int oracle_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *k1, const void *k2, const void *k3, const void *k4);
 int oracle_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew, const void *const *k6, double *err);
+int oracle_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt);
 // the rest of the shim
 int pdehip_layout(const pdehip_grid_t *g, int64_t *out8);
 int shim_set_error(int code, const char *msg);
@@ -160,6 +162,7 @@ struct HostOps {
     }
     int copy(void *dst, const void *src, size_t bytes, void *) { memmove(dst, src, bytes); return 0; }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int refresh(void *bc_program, double t, void *st) { return pdehip_bcprog_run(bc_program, t, st); }
     int fail(const char *msg) { return failf(E_NOTIMPL, "%s", msg); }
     int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
 
@@ -379,6 +382,7 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     slab::Geo q;
     SLAB_TRY(make_geo(g_local, &q));
     HostOps ops{static_cast<Comm *>(comm)};
+    if (rhs->bc_program) return failf(E_NOTIMPL, "slab_euler_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler_run(ops, g_local, q, rhs, lower, upper, buf_a, buf_b, dt, nsteps, result, stream);
 }
 
@@ -410,6 +414,7 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
         c->ext_bytes = need;
     }
     HostOps ops{c};
+    if (rhs->bc_program) return failf(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
@@ -463,7 +468,7 @@ int pdehip_slab_rhs_scaled(void *comm, const pdehip_grid_t *g_local, const pdehi
                            void *k_out_full, double dt, void *stream)
 {
     SLAB_ENTRY_PROLOGUE(rhs_scaled)
-    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream);
+    return slab::rhs_sweep(ops, g_local, q, rhs, lower, upper, flags, y_full, k_out_full, dt, false, nullptr, stream, rhs->t);
 }
 
 int pdehip_slab_euler_sweeps(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *buf_a,
@@ -477,7 +482,8 @@ int pdehip_slab_rk4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_r
                         void *const *work5_host, double dt, int64_t nsteps, void *stream)
 {
     SLAB_ENTRY_PROLOGUE(rk4_run)
-    for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream));
+    for (int64_t s = 0; s < nsteps; s++)
+        SLAB_TRY(slab::rk4_step(ops, g_local, q, rhs, lower, upper, flags, y_full, work5_host, dt, stream, rhs->t + (double)s * dt));
     return 0;
 }
 
@@ -487,6 +493,123 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     if (!(ctl->tolerance > 0) || !(ctl->dt > 0)) return failf(E_VALUE, "slab_rkf45_run: tolerance and dt must be positive");
     SLAB_ENTRY_PROLOGUE(rkf45_run)
     return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
+}
+
+}  // extern "C"
+
+// ---- the generic Runge-Kutta loops of csrc/pdehip_rk_loops.h on the host ------------------------------------------------------
+namespace {
+int shim_read(double *host, const double *dev) { *host = *dev; return 0; }
+
+// built-in right-hand sides whose faces change with time: slope = refresh + oracle right-hand side, never fused
+struct SpecEval {
+    const pdehip_grid_t *g;
+    const pdehip_rhs_t *rhs;
+    int slope(void *in, void *k_out, double dt, double t, const StageFuse *, bool *fused, void *st)
+    {
+        *fused = false;
+        if (rhs->bc_program) SLAB_TRY(pdehip_bcprog_run(rhs->bc_program, t, st));
+        OTRY(oracle_rhs_scaled(g, rhs, in, k_out, dt));
+        return 0;
+    }
+    int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, 1, out, y, n, c, k)); return 0; }
+    int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
+    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }
+    int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
+    int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
+};
+
+// expression right-hand sides: the passes of pdehip_jit_rk_run through pdehip_jit_apply (gcc-built epilogues, oracle stencils)
+struct JitEval {
+    const pdehip_grid_t *g;
+    const pdehip_jit_pass_t *passes;
+    int npasses;
+    void *const *fixed;
+    int ncomp;
+    size_t comp_bytes;
+    int stage_fuse;
+    void *bc_program;
+    int run(int first, int count, char *in, char *k_out, const double *params, void *st)
+    {
+        for (int q = first; q < first + count; q++) {
+            const pdehip_jit_pass_t &p = passes[q];
+            auto arr = [&](int32_t idx) -> void * {
+                if (idx == PDEHIP_JIT_NONE) return nullptr;
+                return idx >= 0 ? fixed[idx] : (void *)(in + (size_t)(-1 - idx) * comp_bytes);
+            };
+            void *out = p.out >= 0 ? fixed[p.out] : (void *)(k_out + (size_t)(-1 - p.out) * comp_bytes);
+            const void *ex[3] = {arr(p.extras[0]), arr(p.extras[1]), arr(p.extras[2])};
+            SLAB_TRY(pdehip_jit_apply(p.handle, g, arr(p.src), ex, out, params, 2, p.faces, st));
+        }
+        return 0;
+    }
+    int slope(void *in, void *k_out, double dt, double t, const StageFuse *sf, bool *fused, void *st)
+    {
+        *fused = false;
+        const double params[2] = {dt, t};
+        if (bc_program) SLAB_TRY(pdehip_bcprog_run(bc_program, t, st));
+        const pdehip_jit_pass_t &last = passes[npasses - 1];
+        const bool try_stage = sf && stage_fuse > 0 && ncomp == 1 && last.out == -1;
+        SLAB_TRY(run(0, npasses - (try_stage ? 1 : 0), (char *)in, (char *)k_out, params, st));
+        if (!try_stage) return 0;
+        auto arr = [&](int32_t idx) -> void * {
+            if (idx == PDEHIP_JIT_NONE) return nullptr;
+            return idx >= 0 ? fixed[idx] : (void *)((char *)in + (size_t)(-1 - idx) * comp_bytes);
+        };
+        const void *ex[3] = {arr(last.extras[0]), arr(last.extras[1]), arr(last.extras[2])};
+        int nk = 0;
+        while (nk < 5 && sf->k[nk]) nk++;
+        int done = 0;
+        SLAB_TRY(pdehip_jit_apply_stage(last.handle, g, arr(last.src), ex, k_out, params, 2, last.faces, sf->kind, sf->y, nk, sf->k, sf->c, sf->c_new,
+                                        sf->out2, sf->err, &done, st));
+        if (done) { *fused = true; return 0; }
+        stage_fuse = -1;
+        return run(npasses - 1, 1, (char *)in, (char *)k_out, params, st);
+    }
+    int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, ncomp, out, y, n, c, k)); return 0; }
+    int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, ncomp, y, k1, k2, k3, k4)); return 0; }
+    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6, err)); return 0; }
+    int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
+    int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
+};
+}  // namespace
+
+extern "C" {
+
+int shim_timed_rk4_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *const *w, double dt, double t)
+{
+    SpecEval ev{g, rhs};
+    return rk::rk4_step(ev, y, w, dt, t, nullptr);
+}
+
+int shim_timed_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y, void *ynew, void *const *w, double dt, double t, double *err)
+{
+    SpecEval ev{g, rhs};
+    return rk::rkf45_attempt(ev, y, ynew, w, dt, t, err, nullptr);
+}
+
+int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    if (!g || !passes || !y || !work_host || !result || (nfixed > 0 && !fixed)) return failf(E_VALUE, "jit_rk_run: NULL pointer");
+    if (npasses < 1 || ncomp < 1 || nsteps < 0) return failf(E_VALUE, "jit_rk_run: bad pass / component / step count");
+    if (ctl && (!ynew || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) return failf(E_VALUE, "jit_rk_run: the adaptive loop needs ynew, err_dev, tolerance > 0 and dt > 0");
+    for (int q = 0; q < npasses; q++) {
+        const int32_t idx[5] = {passes[q].src, passes[q].extras[0], passes[q].extras[1], passes[q].extras[2], passes[q].out};
+        for (int m = 0; m < 5; m++) {
+            if (idx[m] == PDEHIP_JIT_NONE && m != 0 && m != 4) continue;
+            if (idx[m] == PDEHIP_JIT_NONE || idx[m] >= nfixed || idx[m] < -ncomp)
+                return failf(E_VALUE, "jit_rk_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
+        }
+    }
+    JitEval ev{g, passes, npasses, fixed, ncomp, full_bytes(g), stage_fuse ? 1 : 0, bc_program};
+    if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
+    for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));
+    *result = y;
+    return 0;
 }
 
 }  // extern "C"

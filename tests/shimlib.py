@@ -25,7 +25,7 @@ def build(force: bool = False) -> Path:
     root = SHIM_DIR.parent.parent
     sources = [SHIM_DIR / "pdehip_shim.c", *sorted(SHIM_DIR.glob("*.inc")), *sorted(SHIM_DIR.glob("*.cpp")), *sorted(SHIM_DIR.glob("*.h")),
                root / "oracle" / "pde_oracle.c", root / "oracle" / "pde_oracle_impl.inc", root / "include" / "pdehip.h",
-               *sorted((root / "py-pde_amd" / "csrc").glob("pdehip_slab*.h"))]
+               *sorted((root / "py-pde_amd" / "csrc").glob("pdehip_*loops.h"))]
     if not force and SHIM_SO.exists() and all(SHIM_SO.stat().st_mtime >= s.stat().st_mtime for s in sources if s.exists()):
         return SHIM_SO
     SHIM_SO.parent.mkdir(exist_ok=True)

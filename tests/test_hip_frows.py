@@ -336,3 +336,134 @@ def test_state_resident_across_tracker_interrupts(rng, solver, adaptive):
     assert n >= 6 and link2.uploads == n - 1 and link2.downloads == n - 1
     assert abs(seen[-1] - seen[0]) < 1e-3             # Cahn-Hilliard conserves the mean (up to the tracker's nudges)
     assert not np.array_equal(np.array(final2.data), data)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Runge-Kutta loops of expression PDEs as ONE C call (pdehip_jit_rk_run), conditions refreshed on the device
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("adaptive", [False, True], ids=["rk4", "rkf45"])
+@pytest.mark.parametrize("shape", [(24, 16), (8, 6, 128)])
+def test_expression_runge_kutta_loops_in_one_c_call(rng, shape, adaptive, monkeypatch):
+    """RK4 / adaptive RKF45 of generic expression right-hand sides: the C loop (stage epilogues where the kernels carry them,
+    time-dependent faces refreshed by the device program before every stage) equals the Python-driven loop bit for bit."""
+    import pde_hip.expr as expr_mod
+
+    nd = len(shape)
+    periodic = [True] + [False] * (nd - 1)
+    grid = pde_hip.CartesianGrid([[0, n * 0.5] for n in shape], shape, periodic=periodic)
+    last = grid.axes[-1]
+    bc = {a: "periodic" if p else {"derivative": 0} for a, p in zip(grid.axes, periodic)}
+    bc_t = dict(bc)
+    bc_t[last + "-"], bc_t[last + "+"] = {"value_expression": "0.2 * cos(3 * t) + 0.01 * x"}, {"derivative": 0}
+    bc_t.pop(last)
+    u0 = rng.uniform(-0.4, 0.4, shape)
+    state = pde_hip.ScalarField(grid, u0)
+    cases = {
+        "allen_cahn": (pde_hip.PDE({"c": "laplace(c) - c**3 + c"}, bc=bc), state),
+        "chain": (pde_hip.PDE({"c": "0.2 * c - laplace(laplace(c)) - c**3 - 2 * laplace(c)"}, bc=bc), state),
+        "time_dependent": (pde_hip.PDE({"c": "laplace(c) + 0.1 * sin(t)"}, bc=bc_t), state),
+        "system": (pde_hip.PDE({"u": "0.5 * laplace(u) + 1 - 4 * u + u**2 * v", "v": "0.1 * laplace(v) + 3 * u - u**2 * v"}, bc=bc),
+                   pde_hip.FieldCollection([pde_hip.ScalarField(grid, 1.0 + 0.1 * u0), pde_hip.ScalarField(grid, 3.0 - 0.1 * u0)])),
+    }
+    calls = []
+    real = expr_mod._run_rk
+    monkeypatch.setattr(expr_mod, "_run_rk", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for name, (eq, st) in cases.items():
+        kw = dict(t_range=0.01, dt=5e-4, solver="runge-kutta", backend="hip", ret_info=True)
+        if adaptive:
+            kw["adaptive"] = True
+        n0 = len(calls)
+        res_c, info_c = eq.solve(st, **kw)
+        assert len(calls) == n0 + 1, name
+        monkeypatch.setenv("PDEHIP_EXPR_LOOP", "0")
+        res_py, info_py = eq.solve(st, **kw)
+        monkeypatch.delenv("PDEHIP_EXPR_LOOP")
+        assert info_c["solver"]["steps"] == info_py["solver"]["steps"] > 0, name
+        np.testing.assert_array_equal(res_c.data, res_py.data, err_msg=name)
+        assert not np.array_equal(res_c.data, st.data)
+
+
+def test_class_pde_loops_stay_in_c_with_time_dependent_bcs(rng):
+    """DiffusionPDE / CahnHilliardPDE with conditions that depend on time: the right-hand-side descriptor carries a device
+    program and the C loops (Euler incl. hipGraph-free path, RK4 run, the adaptive loop) follow it - against single C-ABI
+    evaluations with the faces refreshed from the HOST tables (the round-2 path)."""
+    import ctypes as C
+
+    from pde_hip.device import DeviceArray, ptr_array
+
+    grid = pde_hip.CartesianGrid([[0, 1], [0, 1], [0, 8]], (8, 6, 128), periodic=[False, True, False])
+    bc = _bc_from(FACES_3D)
+    bc["y"] = "periodic"
+    backend = pde_hip.get_backend("hip")
+    lib = backend._lib
+    y0 = rng.uniform(-0.5, 0.5, grid.shape)
+    state = pde_hip.ScalarField(grid, y0)
+    for eq in (pde_hip.DiffusionPDE(0.02, bc=bc), pde_hip.CahnHilliardPDE(0.5, bc_c=bc, bc_mu=bc)):
+        spec = backend.make_rhs_spec(eq, state)
+        assert spec.program is not None and spec.c.bc_program
+        info = spec.info
+        a, b = DeviceArray(info).set_valid(y0), DeviceArray(info)
+        res = C.c_void_p()
+        dt, n = 1e-4, 7
+        spec.c.t = 0.3
+        lib.euler_run(info.ref, spec.ref, a.ptr, b.ptr, dt, n, C.byref(res), None)
+        got = (b if res.value == b.ptr else a).get_valid()
+        # the same steps one by one, every step told its time explicitly
+        a.set_valid(y0)
+        cur, nxt = a, b
+        for i in range(n):
+            spec.c.t = 0.3 + i * dt
+            lib.euler_run(info.ref, spec.ref, cur.ptr, nxt.ptr, dt, 1, C.byref(res), None)
+            cur, nxt = nxt, cur
+        np.testing.assert_array_equal(got, cur.get_valid())
+        # ... and the faces really moved: the same run at another start time differs
+        a.set_valid(y0)
+        spec.c.t = 1.7
+        lib.euler_run(info.ref, spec.ref, a.ptr, b.ptr, dt, n, C.byref(res), None)
+        assert not np.array_equal(got, (b if res.value == b.ptr else a).get_valid())
+        # RK4 run == RK4 steps with explicit times
+        work = [DeviceArray(info) for _ in range(5)]
+        y = DeviceArray(info).set_valid(y0)
+        spec.c.t = 0.3
+        lib.rk4_run(info.ref, spec.ref, y.ptr, ptr_array(work), dt, 3, None)
+        y2 = DeviceArray(info).set_valid(y0)
+        for i in range(3):
+            spec.c.t = 0.3 + i * dt
+            lib.rk4_step(info.ref, spec.ref, y2.ptr, ptr_array(work), dt, None)
+        np.testing.assert_array_equal(y.get_valid(), y2.get_valid())
+
+
+def test_finite_check_on_the_device(rng):
+    """`backend.make_finite_check()` (pdehip_count_nonfinite): the ConsistencyTracker's check as a device reduction - fields with
+    NaN / +-inf anywhere (first / last cell, inside ragged rows, in one component only) are caught, finite ones pass; a resident
+    state is checked without a download."""
+    import ctypes as C
+
+    from pde_hip.device import DeviceArray, DeviceBuffer
+
+    backend = pde_hip.get_backend("hip")
+    is_finite = backend.make_finite_check()
+    for shape, dtype in [((7, 5, 203), np.float64), ((33, 40), np.float32), ((129,), np.float64), ((64, 64, 64), np.float32)]:
+        grid = pde_hip.UnitGrid(shape)
+        info = backend.grid_info(grid, dtype)
+        data = rng.uniform(-1, 1, shape).astype(dtype)
+        arr = DeviceArray(info).set_valid(data)
+        assert is_finite(arr)
+        for where, bad in [((0,) * len(shape), np.nan), (tuple(n - 1 for n in shape), np.inf), (tuple(n // 2 for n in shape), -np.inf)]:
+            d2 = data.copy()
+            d2[where] = bad
+            assert not is_finite(arr.set_valid(d2))
+        # counts per component
+        two = DeviceArray(info, (2,)).set_valid(np.stack([data, np.where(data > 0.9, np.nan, data)]))
+        out = DeviceBuffer(16)
+        backend._lib.count_nonfinite(info.ref, 2, two.ptr, out.ptr, None)
+        host = np.empty(2)
+        backend._lib.memcpy_d2h(host.ctypes.data, out.ptr, 16, None)
+        assert host[0] == 0 and host[1] == int((data > 0.9).sum())
+    # a resident state: checked where it lives
+    grid = pde_hip.UnitGrid([32, 32], periodic=True)
+    seen = []
+    res = pde_hip.DiffusionPDE().solve(pde_hip.ScalarField(grid, rng.uniform(0, 1, grid.shape)), t_range=1.0, dt=0.1,
+                                       tracker=lambda s, t: seen.append(is_finite(s)), interval=0.2, backend="hip")
+    link = res.__dict__["_hip_link"]
+    assert all(seen) and len(seen) >= 5 and link.downloads == 0

@@ -416,6 +416,126 @@ def test_function_bcs_without_time_use_t0(hip1):
         field.laplace({"x": {"value_expression": "t"}, "y": "derivative"}, backend="hip")
 
 
+@pytest.mark.parametrize("adaptive", [False, True], ids=["rk4", "rkf45"])
+def test_runge_kutta_loops_of_expression_pdes_run_in_one_c_call(hip, adaptive, monkeypatch):
+    """VERDICT r2 missing #3: RK4 and adaptive RKF45 of generic `PDE({...})` right-hand sides are ONE C call per stepper call
+    (`pdehip_jit_rk_run`, the reference jit-compiles these loops: pde/backends/numba/_solvers.py:93-118, :199-319) - same result,
+    bit for bit, and same step counts as the Python-driven loop; single fields (stage epilogue where covered), two-pass
+    chains, multi-field systems, explicit time, time-dependent conditions."""
+    import pde_hip.expr as expr_mod
+
+    grid = pde.CartesianGrid([[0, 8], [0, 6]], [16, 12], periodic=[True, False])
+    rng = np.random.default_rng(11)
+    u0 = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=rng)
+    cases = {
+        "allen_cahn": (pde.PDE({"c": "laplace(c) - c**3 + c"}, bc={"x": "periodic", "y": {"value": 0.1}}), u0),
+        "swift_hohenberg_chain": (pde.PDE({"c": "0.2 * c - (1 + laplace(laplace(c))) - c**3 - 2 * laplace(c)"},
+                                          bc={"x": "periodic", "y": {"derivative": 0}}), u0),
+        "explicit_time_and_bc": (pde.PDE({"c": "laplace(c) + 0.1 * sin(t)"},
+                                         bc={"x": "periodic", "y-": {"value_expression": "0.2 * cos(3 * t) + 0.01 * x"}, "y+": {"derivative": 0}}), u0),
+        "brusselator": (pde.PDE({"u": "0.5 * laplace(u) + 1 - 4 * u + u**2 * v", "v": "0.1 * laplace(v) + 3 * u - u**2 * v"},
+                                bc={"x": "periodic", "y": {"derivative": 0}}),
+                        pde.FieldCollection([pde.ScalarField(grid, 1.0 + 0.1 * u0.data), pde.ScalarField(grid, 3.0 - 0.1 * u0.data)])),
+    }
+    calls = []
+    real = expr_mod._run_rk
+    monkeypatch.setattr(expr_mod, "_run_rk", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for name, (eq, state) in cases.items():
+        kw = dict(t_range=0.02, dt=1e-3, solver="runge-kutta", backend="hip", tracker=None, ret_info=True)
+        if adaptive:
+            kw["adaptive"] = True
+        n0 = len(calls)
+        res_c, info_c = eq.solve(state, **kw)
+        assert len(calls) == n0 + 1, name                      # ONE C call for the whole run
+        monkeypatch.setenv("PDEHIP_EXPR_LOOP", "0")
+        res_py, info_py = eq.solve(state, **kw)
+        monkeypatch.delenv("PDEHIP_EXPR_LOOP")
+        assert len(calls) == n0 + 1
+        assert info_c["solver"]["steps"] == info_py["solver"]["steps"] > 0, name
+        np.testing.assert_array_equal(res_c.data, res_py.data, err_msg=name)
+        if adaptive:
+            assert info_c["solver"]["dt_statistics"]["count"] == info_c["solver"]["steps"]
+            np.testing.assert_allclose(info_c["solver"]["dt"], info_py["solver"]["dt"], rtol=1e-14)
+
+
+def test_time_dependent_conditions_are_refreshed_on_the_device(hip1):
+    """VERDICT r2 missing #2: conditions that are expressions of time are compiled into a device program
+    (`pdehip_bcprog_create`) that the C loops run before every right-hand side (`pdehip_rhs_t::bc_program`): the class PDEs
+    keep their C loops (Euler, RK4, the adaptive loop, Adams-Bashforth) and agree with the reference's numpy backend."""
+    from pde_hip.backend import RhsSpec
+
+    grid = pde.CartesianGrid([[0, 4], [0, 3]], [12, 9])
+    state = pde.ScalarField.random_uniform(grid, -0.3, 0.3, rng=np.random.default_rng(5))
+    bc = {"x-": {"value_expression": "0.1 * sin(4 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.2 * cos(t)"},
+          "y-": {"value": 0.1}, "y+": {"type": "mixed_expression", "value": "0.5 + 0.1 * t", "const": "0.1 * x"}}
+    eq = pde.DiffusionPDE(0.3, bc=bc)
+    spec = hip1.make_rhs_spec(eq, state)
+    assert isinstance(spec, RhsSpec) and spec.time_dependent and not spec.host_time_dependent and spec.program is not None
+    assert spec.c.bc_program == spec.program.ptr
+    monkey = pytest.MonkeyPatch()
+    monkey.setitem(pde.config, "default_backend", "scipy")
+    try:
+        for solver, kw in [("euler", {}), ("runge-kutta", {}), ("runge-kutta", {"adaptive": True}), ("adams-bashforth", {})]:
+            common = dict(t_range=0.05, dt=1e-3, solver=solver, tracker=None, ret_info=True, **kw)
+            ref, iref = eq.solve(state, backend="numpy", **common)
+            got, info = eq.solve(state, backend="hip", **common)
+            assert info["solver"]["steps"] == iref["solver"]["steps"], solver
+            assert max_rel(got.data, ref.data) < 1e-10, (solver, kw)
+    finally:
+        monkey.undo()
+
+
+def test_consistency_tracker_checks_on_the_device(hip1):
+    """VERDICT r2 missing #6: `tracker="hip_consistency"` - the reference's ConsistencyTracker (pde/trackers/trackers.py:974-1003)
+    with the finiteness check as a device reduction: the state is NOT downloaded at the interrupts; a run that blows up is
+    stopped like with the reference's tracker."""
+    from pde_hip.pypde_plugin import HipConsistencyTracker
+
+    grid = pde.UnitGrid([16, 16], periodic=True)
+    state = pde.ScalarField.random_uniform(grid, -1, 1, rng=np.random.default_rng(2))
+    tracker = HipConsistencyTracker(interrupts=0.02)
+    res = pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=tracker)
+    link = res.__dict__["_hip_link"]
+    assert (link.uploads, link.downloads) == (1, 0)          # five interrupts, no download
+    assert np.isfinite(res.data).all() and link.downloads == 1
+    # unstable step: the field overflows; the tracker ends the run (StopIteration is caught by the controller)
+    res2, info = pde.DiffusionPDE(1.0).solve(state, t_range=1000.0, dt=1.0, backend="hip", tracker=HipConsistencyTracker(interrupts=50.0), ret_info=True)
+    assert info["controller"]["t_final"] < 1000.0
+    assert not np.isfinite(res2.data).all()
+    # by name, and on host data the reference's own check is used
+    from pde.trackers.base import TrackerBase
+
+    assert isinstance(TrackerBase.from_data("hip_consistency"), HipConsistencyTracker)
+    tracker.handle(state, 0.0)
+    is_finite = hip1.make_finite_check()
+    assert is_finite(state) and not is_finite(np.array([1.0, np.inf]))
+
+
+def test_user_funcs_are_traced_symbolically(hip1, monkeypatch):
+    """`pde.PDE(..., user_funcs=...)` (pde/pdes/pde.py:84): the Python functions are called once with symbolic arguments and
+    what they return is compiled into the kernels - the reference's own example (tests/pdes/test_pde_class.py:324-342:
+    `get_x(gradient(u))`), scalar functions, functions of several fields; what cannot be traced is refused."""
+    import sympy
+
+    monkeypatch.setitem(pde.config, "default_backend", "scipy")
+    grid = pde.UnitGrid([16, 12], periodic=[True, False])
+    field = pde.ScalarField.random_normal(grid, rng=np.random.default_rng(4))
+    eq = pde.PDE({"u": "get_x(gradient(u))"}, user_funcs={"get_x": lambda arr: arr[0]}, bc="auto_periodic_neumann")
+    rate = hip1.native_to_numpy(hip1.make_pde_rhs(eq, field)(hip1.numpy_to_native(field.data, grid), 0.0))
+    np.testing.assert_allclose(rate, field.gradient("auto_periodic_neumann", backend="scipy").data[0], rtol=1e-12, atol=1e-12)
+    # scalar function with sympy inside, and a function of two arguments
+    eq2 = pde.PDE({"u": "laplace(f(u)) + g(u, gradient_squared(u))"},
+                  user_funcs={"f": lambda c: c**3 - c, "g": lambda c, q: sympy.tanh(c) * 0.1 + 0.5 * q})
+    ref2 = pde.PDE({"u": "laplace(u**3 - u) + tanh(u) * 0.1 + 0.5 * gradient_squared(u)"})
+    a = eq2.solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
+    b = ref2.solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
+    np.testing.assert_allclose(a.data, b.data, rtol=1e-12, atol=1e-14)
+    # numpy ufuncs do not work on symbols: refused (NotImplementedError lets backend="auto" move on)
+    eq3 = pde.PDE({"u": "h(u)"}, user_funcs={"h": lambda c: np.sin(c)})
+    with pytest.raises(NotImplementedError, match="cannot be traced symbolically"):
+        eq3.solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
+
+
 def test_state_stays_resident_between_tracker_interrupts(hip1):
     """SURVEY §8 f4 / VERDICT r1 missing #1: no full-field PCIe round trip per tracker interrupt.  Uploads / downloads are
     counted on the link object: a run whose trackers never read `state.data` moves the field once in each direction."""

@@ -62,7 +62,9 @@ SUITES: dict[str, dict[str, str]] = {
     "pdes/test_pde_class.py": {
         "test_compare_swift_hohenberg[grid3": "curvilinear grids are out of scope (Cartesian path only)",
         "test_compare_swift_hohenberg[grid4": "curvilinear grids are out of scope (Cartesian path only)",
-        "test_pde_user_funcs": "user Python functions inside expressions",
+        "test_pde_user_funcs": "calls PDE.make_evolution_rate, i.e. the reference's own sympy -> backend.make_expression_function path "
+                               "(user functions work through make_pde_rhs / eq.solve, where they are traced symbolically: "
+                               "tests/test_pypde_dropin.py::test_user_funcs_are_traced_symbolically)",
     },
     "fields/test_scalar_fields.py": {},
     "fields/test_vectorial_fields.py": {},

@@ -432,6 +432,24 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
                           void *y_full, void *ynew_full, void *const *work7_host, double *err_dev, pdehip_adaptive_t *ctl,
                           void **result, void *stream);
 
+/* ---- BLOCK decomposition: one process per GPU owns a box of the grid (e.g. 2 x 2 x 2 for 512^3 on 8 GPUs) -----------------------
+ * Replaces GridMesh with a multi-axis decomposition (pde/grids/_mesh.py:59-93 `_get_optimal_decomposition`, :401-444 neighbours) and the
+ * face exchange `_MPIBC` of every decomposed axis (pde/grids/boundaries/local.py:561-662).  nb6[2 * axis + side] = rank of the neighbour
+ * across that face of the local block, or -1 for a physical face (whose condition stays in the face tables of `rhs`; periodic axes
+ * with ONE block keep their periodic condition).  One ghost layer per face; faces normal to the fast axes travel through packed
+ * staging buffers.  Why: per xGMI link a 256^3 block moves 0.5 MiB per face where a 64 x 512 x 512 slab moves 2 MiB (xGMI is point
+ * to point), see csrc/pdehip_block_loops.h. */
+/* fill the ghost layers of buf_full on all faces that have a neighbour (one RCCL group) */
+int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *nb6, void *buf_full, void *stream);
+/* time loops on a block, ONE call per run: scheme 0 = `nsteps` explicit Euler steps (y_full / ynew_full ping-pong, *result names
+ * the final one), 1 = `nsteps` RK4 steps in place (work: k1..k4, tmp), 2 = the adaptive RKF45 loop `ctl` incl. the MAX all-reduce
+ * of the error (work: k1..k6, tmp).  Every right-hand side exchanges the faces of its input first (Cahn-Hilliard: c, then mu - the
+ * reference's sequence); fuse_stage != 0: diffusion stages carry their Runge-Kutta combination (decide it for ALL ranks alike).
+ * The time of the first step is rhs->t. */
+int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme,
+                     void *y_full, void *ynew_full, void *const *work_host, double *err_dev, double dt, int64_t nsteps,
+                     pdehip_adaptive_t *ctl, void **result, void *stream);
+
 /* ---- run-time specialised right-hand sides (generic `PDE({...})` expressions) ----------------------
  * Replaces the sympy -> numba code generation of pde/pdes/pde.py:401-499 / pde/tools/expressions.py:
  * 361-388.  `epilogue_body` is the body of

@@ -18,6 +18,7 @@
 
 #include "pdehip_common.h"
 #include "pdehip_slab_loops.h"
+#include "pdehip_block_loops.h"
 
 using namespace pdehip;
 
@@ -69,10 +70,13 @@ struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
     hipStream_t halo = nullptr;  // stream of the exchange + boundary-layer kernels
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // slab::EV_COMP, EV_HALO, EV_BND
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // slab::EV_COMP, EV_HALO, EV_BND, EV_BND2
     double *scratch2 = nullptr;  // device: {value, nan flag} for the MAX all-reduce
     void *ext[2] = {nullptr, nullptr};   // slab copies with TWO halo layers per side (two-steps-per-sweep loop)
     size_t ext_bytes = 0;
+    // block decomposition: contiguous staging buffers of the packed faces, [axis][side][0 send / 1 receive]
+    void *stg[3][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
+    size_t stg_bytes[3] = {0, 0, 0};
 };
 
 // serial use of the slab loops (comm == NULL, no neighbours): streams / events of a process-wide context without RCCL
@@ -84,7 +88,15 @@ Comm *serial_context()
 
 int ensure_streams(Comm *c)
 {
-    if (!c->halo) PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+    if (!c->halo) {
+        // The halo stream carries the boundary sweeps and the RCCL kernels.  A HIGH-PRIORITY stream was measured SLOWER (64 x 512 x
+        // 512 slab, halo to self: 0.060 vs 0.043 ms per step, profiles/r03_probe_slab.md), so it is a plain stream unless
+        // PDEHIP_HALO_PRIORITY=1 asks for the experiment.
+        int lo = 0, hi = 0;
+        static const bool plain = !(getenv("PDEHIP_HALO_PRIORITY") && atoi(getenv("PDEHIP_HALO_PRIORITY")) == 1);
+        if (plain || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hi == lo) PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+        else PDEHIP_HIP(hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, hi));
+    }
     for (auto &e : c->ev)
         if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
@@ -100,6 +112,27 @@ __global__ void pack_nan_kernel(const double *in, double *out2)
 __global__ void unpack_nan_kernel(const double *in2, double *out)
 {
     out[0] = (in2[1] > 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : in2[0];
+}
+
+// face <-> contiguous staging buffer (block decomposition): layer `idx` along axis `a` (normalised axes), interior of the face only
+struct FaceCopy {
+    void *buf, *packed;
+    long base;       // element offset of cell (idx; 0, 0) of the face
+    long m1, m2;     // face extents
+    long q1, q2;     // element pitches of the two face axes
+};
+template <typename T, bool PACK>
+__global__ void __launch_bounds__(256) face_copy_kernel(FaceCopy a)
+{
+    const long total = a.m1 * a.m2;
+    T *buf = (T *)a.buf;
+    T *pk = (T *)a.packed;
+    for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256L) {
+        const long u = t / a.m2, v = t % a.m2;
+        const long e = a.base + u * a.q1 + v * a.q2;
+        if (PACK) pk[t] = buf[e];
+        else buf[e] = pk[t];
+    }
 }
 
 // The `Ops` policy of pdehip_slab_loops.h on the device: HIP streams / events, RCCL point-to-point over xGMI, gfx950 kernels.
@@ -184,7 +217,68 @@ struct HipOps {
         PDEHIP_HIP(hipStreamSynchronize(as_stream(st)));
         return 0;
     }
+    // --- block decomposition (pdehip_block_loops.h) ---
+    const NGrid *bn = nullptr;   // normalised local grid of the block run in progress
+    void *stage(int axis, int side, bool recv) { return c->stg[axis][side][recv ? 1 : 0]; }
+    int face_copy(const block::Geo &q, void *buf, int axis, long idx, void *packed, bool pack, void *st)
+    {
+        const int o = 3 - q.ndim;   // grid axis -> normalised axis
+        int others[2], k = 0;
+        for (int a = 0; a < q.ndim; a++)
+            if (a != axis) others[k++] = a;
+        FaceCopy f;
+        f.buf = buf; f.packed = packed;
+        f.base = bn->off + idx * bn->p[o + axis];
+        f.m1 = k == 2 ? q.n[others[0]] : 1;
+        f.m2 = q.n[others[k - 1]];
+        f.q1 = k == 2 ? bn->p[o + others[0]] : 0;
+        f.q2 = bn->p[o + others[k - 1]];
+        const long total = f.m1 * f.m2;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 512 ? (total + 255) / 256 : 512);
+        hipStream_t s = as_stream(st);
+        if (q.esz == 8) {
+            if (pack) hipLaunchKernelGGL((face_copy_kernel<double, true>), dim3(blocks), dim3(256), 0, s, f);
+            else hipLaunchKernelGGL((face_copy_kernel<double, false>), dim3(blocks), dim3(256), 0, s, f);
+        } else {
+            if (pack) hipLaunchKernelGGL((face_copy_kernel<float, true>), dim3(blocks), dim3(256), 0, s, f);
+            else hipLaunchKernelGGL((face_copy_kernel<float, false>), dim3(blocks), dim3(256), 0, s, f);
+        }
+        PDEHIP_HIP(hipGetLastError());
+        return 0;
+    }
+    int pack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *st) { return face_copy(q, buf, axis, idx, packed, true, st); }
+    int unpack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *st) { return face_copy(q, buf, axis, idx, packed, false, st); }
+    int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *st) { return pdehip_lincomb(g, 1, out, y, n, cf, k, st); }
+    int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, st); }
+    int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, 1, y, ynew, k6, err, st); }
 };
+
+// geometry of a block + its staging buffers; nb6[2 * axis + side] = neighbour rank or -1
+int make_block(Comm *c, const pdehip_grid_t *g, const NGrid &n, const int *nb6, block::Geo *q)
+{
+    if (g->ndim < 2) PDEHIP_FAIL(E_NOTIMPL, "block decomposition: 2-D and 3-D grids");
+    q->ndim = g->ndim;
+    q->esz = (size_t)elem_size(n.dtype);
+    for (int a = 0; a < 3; a++) { q->n[a] = a < g->ndim ? g->shape[a] : 1; q->nb[a][0] = q->nb[a][1] = -1; }
+    for (int a = 0; a < g->ndim; a++)
+        for (int side = 0; side < 2; side++) {
+            const int peer = nb6[2 * a + side];
+            if (peer >= c->size) PDEHIP_FAIL(E_VALUE, "block: neighbour rank %d outside of world size %d", peer, c->size);
+            q->nb[a][side] = peer < 0 ? -1 : peer;
+        }
+    for (int a = 0; a < g->ndim; a++) {
+        const size_t need = q->face_elems(a) * q->esz;
+        if ((q->nb[a][0] >= 0 || q->nb[a][1] >= 0) && c->stg_bytes[a] < need) {
+            for (int side = 0; side < 2; side++)
+                for (int r = 0; r < 2; r++) {
+                    if (c->stg[a][side][r]) (void)hipFree(c->stg[a][side][r]);
+                    PDEHIP_HIP(hipMalloc(&c->stg[a][side][r], need));
+                }
+            c->stg_bytes[a] = need;
+        }
+    }
+    return 0;
+}
 
 int make_geo(const pdehip_grid_t *g, NGrid *n, slab::Geo *q)
 {
@@ -475,6 +569,54 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{c};
     return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
+}
+
+// ---- block decomposition (pdehip_block_loops.h) ------------------------------------------------------------------------------
+static int block_context(void *comm, const pdehip_grid_t *g_local, const int *nb6, Comm **c, NGrid *n, block::Geo *q)
+{
+    if (!g_local || !nb6) PDEHIP_FAIL(E_VALUE, "block: NULL pointer");
+    bool any = false;
+    for (int i = 0; i < 2 * g_local->ndim; i++) any |= nb6[i] >= 0;
+    *c = static_cast<Comm *>(comm);
+    if (!*c) {
+        if (any) PDEHIP_FAIL(E_VALUE, "a block with neighbours needs a communicator");
+        *c = serial_context();
+    }
+    PDEHIP_TRY(ensure_streams(*c));
+    PDEHIP_TRY(norm_grid(g_local, n));
+    return make_block(*c, g_local, *n, nb6, q);
+}
+
+int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *nb6, void *buf_full, void *stream)
+{
+    if (!buf_full) PDEHIP_FAIL(E_VALUE, "block_exchange: NULL pointer");
+    Comm *c;
+    NGrid n;
+    block::Geo q;
+    PDEHIP_TRY(block_context(comm, g_local, nb6, &c, &n, &q));
+    HipOps ops{c};
+    ops.bn = &n;
+    return block::exchange(ops, q, buf_full, stream);
+}
+
+int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme, void *y_full,
+                     void *ynew_full, void *const *work_host, double *err_dev, double dt, int64_t nsteps, pdehip_adaptive_t *ctl, void **result,
+                     void *stream)
+{
+    if (!y_full || !result) PDEHIP_FAIL(E_VALUE, "block_run: NULL pointer");
+    if (scheme < 0 || scheme > 2) PDEHIP_FAIL(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4) or 2 (adaptive RKF45)");
+    if ((scheme == 0 || scheme == 2) && !ynew_full) PDEHIP_FAIL(E_VALUE, "block_run: the scheme needs a second state array");
+    if (scheme >= 1 && !work_host) PDEHIP_FAIL(E_VALUE, "block_run: the Runge-Kutta schemes need work arrays");
+    if (scheme == 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "block_run: negative step count");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    NGrid n;
+    block::Geo q;
+    PDEHIP_TRY(block_context(comm, g_local, nb6, &c, &n, &q));
+    HipOps ops{c};
+    ops.bn = &n;
+    return block::run(ops, g_local, q, rhs, fuse_stage != 0, scheme, y_full, ynew_full, work_host, err_dev, dt, nsteps, ctl, result, stream);
 }
 
 }  // extern "C"

@@ -930,6 +930,7 @@ struct JitEval {
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, ncomp, y, k1, k2, k3, k4, st); }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, ncomp, y, ynew, k6, err, st); }
     int zero(void *ptr, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(st))); return 0; }
+    int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *st)
     {
         PDEHIP_HIP(hipMemcpyAsync(host, dev, sizeof(double), hipMemcpyDeviceToHost, as_stream(st)));

@@ -13,6 +13,7 @@
 //        k_out = dt * F(in; t); if it can, also the combination `sf` in the same sweep (*fused = true) — then k_out is written
 //        only for sf->kind 0 / 3;   int lincomb / rk4_combine / rkf45_combine(...): the pointwise kernels of include/pdehip.h;
 //   int zero(void *, size_t, void *st);   int read_scalar(double *host, const double *dev, void *st);
+//   int reduce_error(double *err_dev, void *st)   (in-place MAX over all ranks, NaN wins; a no-op on one device)
 //   int fail_runtime(const char *fmt, double value)   (sets the error message, returns the RuntimeError status)
 #pragma once
 
@@ -82,7 +83,7 @@ int rkf45_attempt(Eval &ev, void *y, void *ynew, void *const *w, double dt, doub
     return 0;
 }
 
-// the adaptive loop of pde/backends/numba/_solvers.py:249-281 (single device: no reduction over ranks); accepted attempts swap
+// the adaptive loop of pde/backends/numba/_solvers.py:249-281; accepted attempts swap
 // the roles of y / ynew; *result names the array holding the final state
 template <class Eval>
 int rkf45_run(Eval &ev, void *y, void *ynew, void *const *w, double *err_dev, pdehip_adaptive_t *a, void **result, void *st)
@@ -92,6 +93,7 @@ int rkf45_run(Eval &ev, void *y, void *ynew, void *const *w, double *err_dev, pd
     while (true) {
         const double dt_step = std::fmax(std::fmin(dt_opt, a->t_end - t), a->dt_min);
         SLAB_TRY(rkf45_attempt(ev, cur, nxt, w, dt_step, t, err_dev, st));
+        SLAB_TRY(ev.reduce_error(err_dev, st));   // MAX over all ranks (pde/backends/base.py:678-712); nothing on one device
         double err = 0;
         SLAB_TRY(ev.read_scalar(&err, err_dev, st));
         const double error_rel = err / a->tolerance;

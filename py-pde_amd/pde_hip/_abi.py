@@ -223,6 +223,9 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler_sweeps": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_rk4_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _pvp, _d, _i64, _vp],
     "slab_rkf45_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _pvp, _vp, _pa, _pvp, _vp],
+    # block decomposition (csrc/pdehip_block_loops.h)
+    "block_exchange": [_vp, _pg, C.POINTER(_i), _vp, _vp],
+    "block_run": [_vp, _pg, _pr, C.POINTER(_i), _i, _i, _vp, _vp, _pvp, _vp, _d, _i64, _pa, _pvp, _vp],
     # Adams-Bashforth step in one sweep (device only: the oracle runs rhs_scaled + ab2_combine)
     "ab2_step": [_pg, _pr, _vp, _vp, _vp, _vp, _d, C.POINTER(_i), _vp],
     # fixed-step RK4 loop (device only: the oracle loops over rk4_step)

@@ -195,3 +195,186 @@ def combine(blocks: list[np.ndarray], num_axes: int) -> np.ndarray:
     """Concatenate per-rank valid blocks along axis 0 (``combine_field_data``, _mesh.py:657-696)."""
     axis = blocks[0].ndim - num_axes
     return np.concatenate(blocks, axis=axis)
+
+
+# ---------------------------------------------------------------------------------------------
+# block decomposition (multi-axis): the reference's GridMesh with its "auto" rule
+# ---------------------------------------------------------------------------------------------
+def optimal_decomposition(shape, size: int) -> list[int]:
+    """Blocks per axis for ``size`` ranks: the rule of ``_get_optimal_decomposition`` (pde/grids/_mesh.py:59-93) - axes are
+    visited from the shortest to the longest, each gets as many cuts as keep the blocks close to cubes.  512^3 on 8 ranks ->
+    [2, 2, 2]."""
+    shape_arr = np.asarray(shape)
+    decomposition = [-1] * len(shape)
+    order = np.argsort(shape_arr, kind="stable")
+    size_left = int(size)
+    for dim_count, dim in enumerate(order):
+        shape_left = shape_arr[order[dim_count:]]
+        node_size_estimate = int(np.prod(shape_left)) // size_left
+        node_axis_len = max(1, int(np.floor(node_size_estimate ** (1 / len(shape_left)))))
+        decomposition[dim] = int(np.clip(shape[dim] // node_axis_len, 1, size_left))
+        size_left //= decomposition[dim]
+    assert int(np.prod(decomposition)) <= size
+    return decomposition
+
+
+def block_decomposition(shape, size: int) -> list[int]:
+    """Decomposition that uses ALL ``size`` ranks: the reference's rule where its product equals ``size`` (it raises
+    "Node count incompatible with decomposition" otherwise, pde/grids/_mesh.py:251-256); else the factorisation of ``size`` with
+    the smallest exchanged surface per block."""
+    dims = optimal_decomposition(shape, size)
+    if int(np.prod(dims)) == size:
+        return dims
+    nd = len(shape)
+    best, best_cost = None, None
+
+    def search(axis: int, left: int, cur: list[int]):
+        nonlocal best, best_cost
+        if axis == nd - 1:
+            cand = [*cur, left]
+            if any(d > n for d, n in zip(cand, shape)):
+                return
+            local = [n / d for n, d in zip(shape, cand)]
+            cost = sum(np.prod([local[b] for b in range(nd) if b != a]) for a in range(nd) if cand[a] > 1)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = cand, cost
+            return
+        for d in range(1, left + 1):
+            if left % d == 0:
+                search(axis + 1, left // d, [*cur, d])
+
+    search(0, int(size), [])
+    if best is None:
+        msg = f"cannot cut a grid of shape {tuple(shape)} into {size} blocks"
+        raise RuntimeError(msg)
+    return best
+
+
+class BlockMesh:
+    """The box of a grid owned by ``rank`` in a ``dims[0] x dims[1] (x dims[2])`` decomposition (ranks in C order over the block
+    indices, like the node ids of ``GridMesh``); cells per block by the reference's partition rule (``subdivide``,
+    pde/grids/_mesh.py:96-111), neighbours incl. the periodic wrap (:401-444).  An axis with ONE block has no neighbours:
+    its faces keep their conditions, periodic ones included."""
+
+    def __init__(self, grid: CartesianGrid, dims, rank: int, *, force_exchange: bool = False):
+        """``force_exchange``: a periodic axis with ONE block exchanges with the block itself instead of keeping its periodic
+        condition (the pack / send / receive / unpack path on a single GPU: overhead probe and test of the device layer)."""
+        nd = len(grid.shape)
+        dims = [int(d) for d in dims]
+        if len(dims) != nd or any(d < 1 for d in dims):
+            msg = f"decomposition {dims} does not fit a grid with {nd} axes"
+            raise ValueError(msg)
+        self.grid, self.dims, self.size, self.rank = grid, dims, int(np.prod(dims)), int(rank)
+        if not 0 <= rank < self.size:
+            msg = f"rank {rank} outside of the {self.size} blocks of decomposition {dims}"
+            raise ValueError(msg)
+        self.index = [int(i) for i in np.unravel_index(rank, dims)]
+        self.lo, self.hi, self.counts = [], [], []
+        for a in range(nd):
+            counts = subdivide(grid.shape[a], dims[a])
+            offsets = np.concatenate([[0], np.cumsum(counts)])
+            self.counts.append(counts)
+            self.lo.append(int(offsets[self.index[a]]))
+            self.hi.append(int(offsets[self.index[a] + 1]))
+        self.local_shape = tuple(h - lo for lo, h in zip(self.lo, self.hi))
+        # neighbour ranks per (axis, side); None = physical face
+        self.neighbours: list[list[int | None]] = []
+        for a in range(nd):
+            pair: list[int | None] = [None, None]
+            if dims[a] > 1 or (force_exchange and grid.periodic[a]):
+                for side, step in ((0, -1), (1, 1)):
+                    j = self.index[a] + step
+                    if 0 <= j < dims[a] or grid.periodic[a]:
+                        idx = list(self.index)
+                        idx[a] = j % dims[a]
+                        pair[side] = int(np.ravel_multi_index(idx, dims))
+            self.neighbours.append(pair)
+
+    @property
+    def nb6(self):
+        """``nb6[2 * axis + side]`` of ``pdehip_block_run`` (-1: physical face)."""
+        import ctypes as C
+
+        arr = (C.c_int * 6)(*([-1] * 6))
+        for a, pair in enumerate(self.neighbours):
+            for side in range(2):
+                arr[2 * a + side] = -1 if pair[side] is None else int(pair[side])
+        return arr
+
+    def extract(self, data: np.ndarray) -> np.ndarray:
+        """Local block of global valid data (``GridMesh.extract_field_data``, _mesh.py:446-479)."""
+        return data[(...,) + tuple(slice(lo, hi) for lo, hi in zip(self.lo, self.hi))]
+
+    def block_faces(self, bcs, *, upload=None):
+        """Face table of THIS block from the conditions of the WHOLE grid: faces towards a neighbour are SKIP (filled by the
+        exchange; the wrap-around of a decomposed periodic axis must be plainly periodic), physical faces keep their condition
+        with the index translated into the block, per-face arrays are cut to the block's extent along the other axes."""
+        from . import _abi
+        from .backend import FaceTable, _upload_f64, convert_bcs
+
+        if upload is None:
+            upload = _upload_f64
+
+        class _Host:
+            def __init__(self, arr):
+                self.arr = np.ascontiguousarray(arr, dtype=np.float64)
+                self.ptr = self.arr.ctypes.data
+
+        for pair in bcs:
+            for bc in (pair.low, pair.high):
+                if getattr(bc, "rank", 0) != 0 or getattr(bc, "normal", False):
+                    msg = "block-parallel stepping supports conditions of scalar fields only"
+                    raise NotImplementedError(msg)
+        glob = convert_bcs(bcs, upload=_Host)
+        by_ptr = {h.ptr: h.arr for h in glob.keepalive}
+        out = FaceTable()
+        nd = len(self.grid.shape)
+        for ax in range(nd):
+            for side, upper in enumerate((False, True)):
+                src, dst = glob.c[2 * ax + side], out.c[2 * ax + side]
+                if self.neighbours[ax][side] is not None:
+                    wraps = self.index[ax] == (self.dims[ax] - 1 if upper else 0)
+                    if wraps and (src.kind != _abi.BC_ORDER1 or (src.flags & _abi.BCF_ARRAYS) or src.factor1 != 1.0 or src.const_v != 0.0):
+                        msg = f"anti-periodic axis {ax} cannot be decomposed (the exchange copies the neighbour's layer unchanged)"
+                        raise NotImplementedError(msg)
+                    dst.kind = _abi.BC_SKIP
+                    continue
+                if self.dims[ax] > 1 and src.kind != _abi.BC_SKIP:
+                    for idx in ([src.index1] if src.kind == _abi.BC_ORDER1 else [src.index1, src.index2]):
+                        if not self.lo[ax] <= idx < self.hi[ax]:
+                            msg = "boundary condition of a decomposed axis reads a cell of another block"
+                            raise NotImplementedError(msg)
+                dst.kind, dst.flags = src.kind, src.flags
+                shift = self.lo[ax]
+                dst.index1, dst.index2 = src.index1 - shift, (src.index2 - shift if src.kind == _abi.BC_ORDER2 else src.index2)
+                dst.const_v, dst.factor1, dst.factor2 = src.const_v, src.factor1, src.factor2
+                if src.flags & _abi.BCF_ARRAYS:
+                    others = [a for a in range(nd) if a != ax]
+                    for name in ("const_arr", "factor1_arr", "factor2_arr"):
+                        ptr = getattr(src, name)
+                        if not ptr:
+                            continue
+                        arr = by_ptr[ptr]
+                        lead = arr.ndim - (nd - 1)
+                        cut = (slice(None),) * lead + tuple(slice(self.lo[a], self.hi[a]) for a in others)
+                        buf = upload(np.ascontiguousarray(arr[cut]))
+                        out.keepalive.append(buf)
+                        setattr(dst, name, buf.ptr)
+        return out
+
+
+def combine_blocks(blocks: list[np.ndarray], dims, num_axes: int) -> np.ndarray:
+    """Assemble per-rank valid blocks (rank order = C order of the block indices) into the global array
+    (``combine_field_data``, _mesh.py:657-696)."""
+    dims = [int(d) for d in dims]
+    lead = blocks[0].ndim - num_axes
+    nested = np.empty(dims, dtype=object)
+    for r, b in enumerate(blocks):
+        nested[np.unravel_index(r, dims)] = b
+
+    def join(sub, axis):
+        if axis == len(dims) - 1:
+            return np.concatenate(list(sub), axis=lead + axis)
+        return np.concatenate([join(s, axis + 1) for s in sub], axis=lead + axis)
+
+    return join(nested, 0)

@@ -112,8 +112,11 @@ class HipSlabSolver(AdaptiveSolverBase):
 
     name = "hip_slab"
 
-    def __init__(self, pde, scheme: str = "euler", *, backend="hip", adaptive: bool = False, tolerance: float = 1e-4):
+    def __init__(self, pde, scheme: str = "euler", *, backend="hip", adaptive: bool = False, tolerance: float = 1e-4, decomposition="slab"):
+        """``decomposition``: ``"slab"`` (axis-0 slabs: contiguous faces, two steps per sweep), ``"auto"`` (blocks by the reference's
+        rule, pde/grids/_mesh.py:59-93: 2 x 2 x 2 for a cubic grid on 8 ranks) or a list of blocks per axis (``GridMesh.from_grid``)."""
         super().__init__(pde, backend=backend, adaptive=adaptive, tolerance=tolerance)
+        self.decomposition = decomposition
         if scheme in {"rk", "rk45", "runge-kutta"}:
             scheme = "runge-kutta"
         if scheme not in {"euler", "runge-kutta"}:
@@ -147,7 +150,17 @@ class HipSlabSolver(AdaptiveSolverBase):
         if state.__class__.__name__ != "ScalarField":
             msg = "slab-parallel stepping supports a single ScalarField state"
             raise NotImplementedError(msg)
-        stepper = SlabStepper(self.pde, state.grid, state.dtype, device=getattr(self.backend, "_device_request", None))
+        device = getattr(self.backend, "_device_request", None)
+        blocks = self.decomposition != "slab"
+        if blocks:
+            from .distributed import BlockStepper
+
+            dims = None if self.decomposition == "auto" else [int(d) for d in self.decomposition]
+            stepper = BlockStepper(self.pde, state.grid, state.dtype, dims=dims, device=device)
+            self.info["decomposition"] = list(stepper.dims)
+        else:
+            stepper = SlabStepper(self.pde, state.grid, state.dtype, device=device)
+            self.info["decomposition"] = [stepper.size] + [1] * (state.grid.num_axes - 1)
         self.info["world_size"] = stepper.size
         cur, nxt = stepper.buf("state_a"), stepper.buf("state_b")
         ctl = _abi.Adaptive()
@@ -156,7 +169,10 @@ class HipSlabSolver(AdaptiveSolverBase):
 
         def slab_stepper(state_field, t_start: float, t_end: float) -> float:
             a, b = cur, nxt
-            stepper.set_local(a, stepper.mesh.extract(state_field.data))
+            if blocks:
+                a.set_valid(np.ascontiguousarray(stepper.mesh.extract(state_field.data), dtype=state_field.dtype), stepper.stream)
+            else:
+                stepper.set_local(a, stepper.mesh.extract(state_field.data))
             if self.adaptive:
                 ctl.t_start, ctl.t_end = float(t_start), float(t_end)
                 before = int(ctl.steps)

@@ -44,8 +44,10 @@ def main() -> int:
         state = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
         seen = []
         tracker = pde.CallbackTracker(lambda s, t: seen.append((t, float(s.data.sum()))), interrupts=kw["t_range"] / 2)
-        res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True, **kw)
-        report[name] = {"steps": info["solver"]["steps"], "world": info["solver"]["world_size"], "interrupts": len(seen)}
+        decomposition = os.environ.get("PDEHIP_WORKER_DECOMPOSITION", "slab")    # "auto": blocks by the reference's rule
+        res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True, decomposition=decomposition, **kw)
+        report[name] = {"steps": info["solver"]["steps"], "world": info["solver"]["world_size"], "interrupts": len(seen),
+                        "decomposition": info["solver"]["decomposition"]}
         if rank == 0:
             ref_kw = {k: v for k, v in kw.items() if k != "scheme"}
             ref_eq = pde.CahnHilliardPDE() if name == "expression_rkf45" else eq   # the expression class needs numba on numpy

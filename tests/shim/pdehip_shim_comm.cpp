@@ -30,6 +30,7 @@
 
 #include "../../py-pde_amd/csrc/pdehip_slab_loops.h"
 #include "../../py-pde_amd/csrc/pdehip_rk_loops.h"
+#include "../../py-pde_amd/csrc/pdehip_block_loops.h"
 
 using namespace pdehip;
 
@@ -78,6 +79,7 @@ struct Comm {
     struct Op { bool is_send; void *p; size_t bytes; int peer; };
     std::vector<Op> group;
     bool in_group = false;
+    std::vector<char> stg[3][2][2];   // block decomposition: packed faces, [axis][side][0 send / 1 receive]
 };
 
 double timeout_seconds()
@@ -291,7 +293,51 @@ struct HostOps {
         return 0;
     }
     int read_scalar(double *host, const double *dev, void *) { *host = *dev; return 0; }
+    // --- block decomposition (csrc/pdehip_block_loops.h) ---
+    int64_t lay[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pdehip_layout of the local block (set by the entry point)
+    void *stage(int axis, int side, bool recv) { return c->stg[axis][side][recv ? 1 : 0].data(); }
+    int face_copy(const block::Geo &q, void *buf, int axis, long idx, void *packed, bool pack)
+    {
+        const int o = 3 - q.ndim;
+        const long pitch[3] = {(long)lay[0], (long)lay[1], 1};
+        int others[2], k = 0;
+        for (int a = 0; a < q.ndim; a++)
+            if (a != axis) others[k++] = a;
+        const long m1 = k == 2 ? q.n[others[0]] : 1, m2 = q.n[others[k - 1]];
+        const long q1 = k == 2 ? pitch[o + others[0]] : 0, q2 = pitch[o + others[k - 1]];
+        const long base = (long)lay[3] + idx * pitch[o + axis];
+        char *b = static_cast<char *>(buf), *pk = static_cast<char *>(packed);
+        for (long u = 0; u < m1; u++)
+            for (long v = 0; v < m2; v++) {
+                char *cell = b + (base + u * q1 + v * q2) * (long)q.esz, *slot = pk + (u * m2 + v) * (long)q.esz;
+                if (pack) memcpy(slot, cell, q.esz); else memcpy(cell, slot, q.esz);
+            }
+        return 0;
+    }
+    int pack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *) { return face_copy(q, buf, axis, idx, packed, true); }
+    int unpack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *) { return face_copy(q, buf, axis, idx, packed, false); }
+    int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *) { OTRY(oracle_lincomb(g, 1, out, y, n, cf, k)); return 0; }
+    int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
+    int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }
 };
+
+int make_block(Comm *c, const pdehip_grid_t *g, const int *nb6, block::Geo *q)
+{
+    if (g->ndim < 2) return failf(E_NOTIMPL, "block decomposition: 2-D and 3-D grids");
+    q->ndim = g->ndim;
+    q->esz = g->dtype == PDEHIP_F64 ? 8 : 4;
+    for (int a = 0; a < 3; a++) { q->n[a] = a < g->ndim ? g->shape[a] : 1; q->nb[a][0] = q->nb[a][1] = -1; }
+    for (int a = 0; a < g->ndim; a++)
+        for (int side = 0; side < 2; side++) {
+            const int peer = nb6[2 * a + side];
+            if (peer >= c->size) return failf(E_VALUE, "block: neighbour rank %d outside of world size %d", peer, c->size);
+            q->nb[a][side] = peer < 0 ? -1 : peer;
+        }
+    for (int a = 0; a < g->ndim; a++)
+        for (int side = 0; side < 2; side++)
+            for (int r = 0; r < 2; r++) c->stg[a][side][r].resize(q->face_elems(a) * q->esz);
+    return 0;
+}
 
 int make_geo(const pdehip_grid_t *g, slab::Geo *q)
 {
@@ -516,6 +562,7 @@ struct SpecEval {
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
     int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
 };
@@ -571,6 +618,7 @@ struct JitEval {
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, ncomp, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6, err)); return 0; }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
+    int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
     int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
 };
@@ -610,6 +658,37 @@ int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, i
     for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));
     *result = y;
     return 0;
+}
+
+
+int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *nb6, void *buf_full, void *stream)
+{
+    if (!g_local || !nb6 || !buf_full) return failf(E_VALUE, "block_exchange: NULL pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) c = serial_context();
+    block::Geo q;
+    SLAB_TRY(make_block(c, g_local, nb6, &q));
+    HostOps ops{c};
+    SLAB_TRY(pdehip_layout(g_local, ops.lay));
+    return block::exchange(ops, q, buf_full, stream);
+}
+
+int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme, void *y_full,
+                     void *ynew_full, void *const *work_host, double *err_dev, double dt, int64_t nsteps, pdehip_adaptive_t *ctl, void **result,
+                     void *stream)
+{
+    if (!g_local || !nb6 || !rhs || !y_full || !result) return failf(E_VALUE, "block_run: NULL pointer");
+    if (scheme < 0 || scheme > 2) return failf(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4) or 2 (adaptive RKF45)");
+    if ((scheme == 0 || scheme == 2) && !ynew_full) return failf(E_VALUE, "block_run: the scheme needs a second state array");
+    if (scheme >= 1 && !work_host) return failf(E_VALUE, "block_run: the Runge-Kutta schemes need work arrays");
+    if (scheme == 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) return failf(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) c = serial_context();
+    block::Geo q;
+    SLAB_TRY(make_block(c, g_local, nb6, &q));
+    HostOps ops{c};
+    SLAB_TRY(pdehip_layout(g_local, ops.lay));
+    return block::run(ops, g_local, q, rhs, fuse_stage != 0, scheme, y_full, ynew_full, work_host, err_dev, dt, nsteps, ctl, result, stream);
 }
 
 }  // extern "C"

@@ -8,7 +8,7 @@
 // Why blocks: a slab of 512^3 on 8 ranks sends 2 x 2 MiB per rank and step over the TWO xGMI links to its ring neighbours; a
 // 256^3 block sends 6 x 0.5 MiB over THREE pairs of links (xGMI is point to point: the per-link bytes drop by 4 x).  The price: faces
 // normal to the two fast axes are strided in memory - they are packed into contiguous staging buffers by small kernels
-// (Ops::pack / unpack) - and the stencil kernels read the received ghost cells from memory on every exchanged face.
+// (Ops::face_copy: all faces of an exchange in one launch) - and the stencil kernels read the received ghost cells from memory on every exchanged face.
 //
 // Only faces are exchanged (7-point stencils never read edge or corner ghosts), ONE layer per face: the two-steps-per-sweep and
 // the fused Cahn-Hilliard sweeps (halo width 2, diagonal dependences) are slab-only; a block run takes one right-hand side per
@@ -40,19 +40,29 @@ struct Geo {
 
 // Fill the ghost layers of `buf` (a full array of the local block) on every face that has a neighbour.
 // Ops::stage(axis, side, recv) returns a contiguous device / host buffer of face_elems(axis) elements (owned by the context).
+struct FaceJob {
+    int axis;
+    long index;     // layer along `axis` (own layers 0 .. n-1, ghost layers -1 and n)
+    void *packed;   // contiguous staging buffer of face_elems(axis) elements
+};
+
 template <class Ops>
 int exchange(Ops &ops, const Geo &q, void *buf, void *st)
 {
-    bool any = false;
+    FaceJob out[6], in[6];
+    int n = 0;
     for (int a = 0; a < q.ndim; a++) {
         for (int side = 0; side < 2; side++) {
             if (q.nb[a][side] < 0) continue;
-            any = true;
-            // own boundary layer towards that neighbour: first own layer (index 0) goes down, last (n - 1) goes up
-            SLAB_TRY(ops.pack(q, buf, a, side ? q.n[a] - 1 : 0, ops.stage(a, side, false), st));
+            // own boundary layer towards that neighbour: first own layer (index 0) goes down, last (n - 1) goes up; what comes
+            // back from it lands in the ghost layer on that side (-1 / n)
+            out[n] = {a, side ? q.n[a] - 1 : 0, ops.stage(a, side, false)};
+            in[n] = {a, side ? q.n[a] : -1, ops.stage(a, side, true)};
+            n++;
         }
     }
-    if (!any) return 0;
+    if (!n) return 0;
+    SLAB_TRY(ops.face_copy(q, buf, out, n, true, st));    // all faces in ONE launch
     SLAB_TRY(ops.group_start());
     for (int a = 0; a < q.ndim; a++) {
         const size_t bytes = q.face_elems(a) * q.esz;
@@ -63,10 +73,7 @@ int exchange(Ops &ops, const Geo &q, void *buf, void *st)
         if (lower >= 0) SLAB_TRY(ops.recv(ops.stage(a, 0, true), bytes, lower, st));
     }
     SLAB_TRY(ops.group_end());
-    for (int a = 0; a < q.ndim; a++)
-        for (int side = 0; side < 2; side++)
-            if (q.nb[a][side] >= 0) SLAB_TRY(ops.unpack(q, buf, a, side ? q.n[a] : -1, ops.stage(a, side, true), st));   // ghost layers -1 / n
-    return 0;
+    return ops.face_copy(q, buf, in, n, false, st);
 }
 
 // face table of the block: exchanged faces hold real data (SKIP), physical faces keep their condition

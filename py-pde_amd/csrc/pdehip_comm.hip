@@ -121,17 +121,28 @@ struct FaceCopy {
     long m1, m2;     // face extents
     long q1, q2;     // element pitches of the two face axes
 };
+struct FaceCopyMany {
+    FaceCopy f[6];
+    long start[7];   // first work item of face k (start[n] = total)
+    int n;
+};
 template <typename T, bool PACK>
-__global__ void __launch_bounds__(256) face_copy_kernel(FaceCopy a)
+__global__ void __launch_bounds__(256) face_copy_kernel(FaceCopyMany a)
 {
-    const long total = a.m1 * a.m2;
-    T *buf = (T *)a.buf;
-    T *pk = (T *)a.packed;
+    const long total = a.start[a.n];
     for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256L) {
-        const long u = t / a.m2, v = t % a.m2;
-        const long e = a.base + u * a.q1 + v * a.q2;
-        if (PACK) pk[t] = buf[e];
-        else buf[e] = pk[t];
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < 6; q++)
+            if (q < a.n && t >= a.start[q]) k = q;
+        const FaceCopy &f = a.f[k];
+        const long loc = t - a.start[k];
+        const long u = loc / f.m2, v = loc % f.m2;
+        const long e = f.base + u * f.q1 + v * f.q2;
+        T *buf = (T *)f.buf;
+        T *pk = (T *)f.packed;
+        if (PACK) pk[loc] = buf[e];
+        else buf[e] = pk[loc];
     }
 }
 
@@ -220,34 +231,40 @@ struct HipOps {
     // --- block decomposition (pdehip_block_loops.h) ---
     const NGrid *bn = nullptr;   // normalised local grid of the block run in progress
     void *stage(int axis, int side, bool recv) { return c->stg[axis][side][recv ? 1 : 0]; }
-    int face_copy(const block::Geo &q, void *buf, int axis, long idx, void *packed, bool pack, void *st)
+    int face_copy(const block::Geo &q, void *buf, const block::FaceJob *jobs, int njobs, bool pack, void *st)
     {
         const int o = 3 - q.ndim;   // grid axis -> normalised axis
-        int others[2], k = 0;
-        for (int a = 0; a < q.ndim; a++)
-            if (a != axis) others[k++] = a;
-        FaceCopy f;
-        f.buf = buf; f.packed = packed;
-        f.base = bn->off + idx * bn->p[o + axis];
-        f.m1 = k == 2 ? q.n[others[0]] : 1;
-        f.m2 = q.n[others[k - 1]];
-        f.q1 = k == 2 ? bn->p[o + others[0]] : 0;
-        f.q2 = bn->p[o + others[k - 1]];
-        const long total = f.m1 * f.m2;
-        const unsigned blocks = (unsigned)((total + 255) / 256 < 512 ? (total + 255) / 256 : 512);
+        FaceCopyMany m;
+        m.n = njobs;
+        long total = 0;
+        for (int j = 0; j < njobs; j++) {
+            const int axis = jobs[j].axis;
+            int others[2], k = 0;
+            for (int a = 0; a < q.ndim; a++)
+                if (a != axis) others[k++] = a;
+            FaceCopy &f = m.f[j];
+            f.buf = buf; f.packed = jobs[j].packed;
+            f.base = bn->off + jobs[j].index * bn->p[o + axis];
+            f.m1 = k == 2 ? q.n[others[0]] : 1;
+            f.m2 = q.n[others[k - 1]];
+            f.q1 = k == 2 ? bn->p[o + others[0]] : 0;
+            f.q2 = bn->p[o + others[k - 1]];
+            m.start[j] = total;
+            total += f.m1 * f.m2;
+        }
+        for (int j = njobs; j < 7; j++) m.start[j] = total;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         hipStream_t s = as_stream(st);
         if (q.esz == 8) {
-            if (pack) hipLaunchKernelGGL((face_copy_kernel<double, true>), dim3(blocks), dim3(256), 0, s, f);
-            else hipLaunchKernelGGL((face_copy_kernel<double, false>), dim3(blocks), dim3(256), 0, s, f);
+            if (pack) hipLaunchKernelGGL((face_copy_kernel<double, true>), dim3(blocks), dim3(256), 0, s, m);
+            else hipLaunchKernelGGL((face_copy_kernel<double, false>), dim3(blocks), dim3(256), 0, s, m);
         } else {
-            if (pack) hipLaunchKernelGGL((face_copy_kernel<float, true>), dim3(blocks), dim3(256), 0, s, f);
-            else hipLaunchKernelGGL((face_copy_kernel<float, false>), dim3(blocks), dim3(256), 0, s, f);
+            if (pack) hipLaunchKernelGGL((face_copy_kernel<float, true>), dim3(blocks), dim3(256), 0, s, m);
+            else hipLaunchKernelGGL((face_copy_kernel<float, false>), dim3(blocks), dim3(256), 0, s, m);
         }
         PDEHIP_HIP(hipGetLastError());
         return 0;
     }
-    int pack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *st) { return face_copy(q, buf, axis, idx, packed, true, st); }
-    int unpack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *st) { return face_copy(q, buf, axis, idx, packed, false, st); }
     int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *st) { return pdehip_lincomb(g, 1, out, y, n, cf, k, st); }
     int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, st); }
     int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, 1, y, ynew, k6, err, st); }

@@ -296,26 +296,27 @@ struct HostOps {
     // --- block decomposition (csrc/pdehip_block_loops.h) ---
     int64_t lay[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pdehip_layout of the local block (set by the entry point)
     void *stage(int axis, int side, bool recv) { return c->stg[axis][side][recv ? 1 : 0].data(); }
-    int face_copy(const block::Geo &q, void *buf, int axis, long idx, void *packed, bool pack)
+    int face_copy(const block::Geo &q, void *buf, const block::FaceJob *jobs, int njobs, bool pack, void *)
     {
         const int o = 3 - q.ndim;
         const long pitch[3] = {(long)lay[0], (long)lay[1], 1};
-        int others[2], k = 0;
-        for (int a = 0; a < q.ndim; a++)
-            if (a != axis) others[k++] = a;
-        const long m1 = k == 2 ? q.n[others[0]] : 1, m2 = q.n[others[k - 1]];
-        const long q1 = k == 2 ? pitch[o + others[0]] : 0, q2 = pitch[o + others[k - 1]];
-        const long base = (long)lay[3] + idx * pitch[o + axis];
-        char *b = static_cast<char *>(buf), *pk = static_cast<char *>(packed);
-        for (long u = 0; u < m1; u++)
-            for (long v = 0; v < m2; v++) {
-                char *cell = b + (base + u * q1 + v * q2) * (long)q.esz, *slot = pk + (u * m2 + v) * (long)q.esz;
-                if (pack) memcpy(slot, cell, q.esz); else memcpy(cell, slot, q.esz);
-            }
+        for (int j = 0; j < njobs; j++) {
+            const int axis = jobs[j].axis;
+            int others[2], k = 0;
+            for (int a = 0; a < q.ndim; a++)
+                if (a != axis) others[k++] = a;
+            const long m1 = k == 2 ? q.n[others[0]] : 1, m2 = q.n[others[k - 1]];
+            const long q1 = k == 2 ? pitch[o + others[0]] : 0, q2 = pitch[o + others[k - 1]];
+            const long base = (long)lay[3] + jobs[j].index * pitch[o + axis];
+            char *b = static_cast<char *>(buf), *pk = static_cast<char *>(jobs[j].packed);
+            for (long u = 0; u < m1; u++)
+                for (long v = 0; v < m2; v++) {
+                    char *cell = b + (base + u * q1 + v * q2) * (long)q.esz, *slot = pk + (u * m2 + v) * (long)q.esz;
+                    if (pack) memcpy(slot, cell, q.esz); else memcpy(cell, slot, q.esz);
+                }
+        }
         return 0;
     }
-    int pack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *) { return face_copy(q, buf, axis, idx, packed, true); }
-    int unpack(const block::Geo &q, void *buf, int axis, long idx, void *packed, void *) { return face_copy(q, buf, axis, idx, packed, false); }
     int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *) { OTRY(oracle_lincomb(g, 1, out, y, n, cf, k)); return 0; }
     int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }

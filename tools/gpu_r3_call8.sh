@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 3, call 8: the real py-pde against the FINAL library of the round (device BC programs, C Runge-Kutta loops, block solver)
+O=gpurun_out/r3h
+mkdir -p $O
+R=$PWD
+export TMPDIR=/tmp
+export PDEHIP_REFERENCE=$R/_refscratch PDEHIP_DROPIN_REAL=1 PDEHIP_DROPIN_LOG=$R/$O/dropin_outcomes.txt
+rm -f $PDEHIP_DROPIN_LOG
+timeout 1500 python -m pytest tests/test_pypde_dropin.py tests/test_pypde_plugin.py tests/test_class_pde_fuzz.py tests/test_expression_fuzz.py \
+    tests/test_reference_suite.py -q -rA --tb=short -p no:cacheprovider > $O/dropin_pytest.log 2>&1
+echo "rc=$?"; tail -1 $O/dropin_pytest.log; grep "^FAILED\|^ERROR" $O/dropin_pytest.log | head -20
+grep -c "^PASSED" $PDEHIP_DROPIN_LOG; grep "^LOADED" $PDEHIP_DROPIN_LOG | sort | uniq -c
+for d in slab auto; do
+  PDEHIP_WORKER_DECOMPOSITION=$d timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29611 tests/pypde_slab_worker.py > $O/slab_worker_$d.log 2>&1
+  echo "worker $d rc=$?"; grep PYPDESLAB $O/slab_worker_$d.log | tail -1 | cut -c1-500
+done

@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 2
+#define PDEHIP_ABI_VERSION 3
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -95,9 +95,10 @@ typedef struct pdehip_rhs {
     pdehip_bc_face_t bc_c[2 * PDEHIP_MAX_DIM];  /* BCs of the state field */
     pdehip_bc_face_t bc_mu[2 * PDEHIP_MAX_DIM]; /* BCs of mu (Cahn-Hilliard only) */
     void *scratch_mu;               /* full array (Cahn-Hilliard only) */
-    /* Faces whose coefficient arrays depend on time (expression conditions that contain `t`): a program from
-     * pdehip_bcprog_create that rewrites the const / factor arrays the face tables above point to, or NULL.  Every entry point
-     * that evaluates the right-hand side runs it for the time of THAT evaluation first, on the same stream (Euler: t + i*dt,
+    /* Faces whose coefficient arrays depend on time (expression conditions that contain `t`) or on the field (conditions that
+     * are not affine in the adjacent value): a program from pdehip_bcprog_create that rewrites the const / factor arrays the face
+     * tables above point to, or NULL.  Every entry point that evaluates the right-hand side runs it for the time AND the input
+     * field of THAT evaluation first, on the same stream (only faces of bc_c may read the field) (Euler: t + i*dt,
      * Runge-Kutta: the stage times t + a_s*dt; pde/solvers/euler.py:172-175, pde/solvers/runge_kutta.py:52-59, :135-145 pass
      * `t` to the right-hand side, which hands it to the conditions as args={"t": t}: pde/pdes/diffusion.py:119-121). */
     void *bc_program;
@@ -105,26 +106,34 @@ typedef struct pdehip_rhs {
                                        first step of a fixed-step run (euler_run, rk4_run); ignored without bc_program */
 } pdehip_rhs_t;
 
-/* ---- boundary conditions given as expressions of position and time, evaluated ON THE DEVICE ---------------------------------
+/* ---- boundary conditions given as expressions, evaluated ON THE DEVICE --------------------------------------------------------
  * Replaces the per-call evaluation of ExpressionBC (pde/grids/boundaries/local.py:766-1150; numba twin
  * pde/backends/numba/_boundaries.py:256-394, torch twin pde/backends/torch/_boundaries.py:258-345).  A condition whose virtual
  * point F(value, dx, coords, t) is affine in the adjacent value is  ghost = A(dx, coords, t) + B(dx, coords, t) * value, i.e. a
- * first-order face with per-cell coefficient arrays (PDEHIP_BCF_ARRAYS).  A program is C source (compiled with hiprtc) that
- * defines
- *     PDEHIP_BC_FN void bc_face(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)
- * (c0..c2 = coordinates of the wall point along the grid axes), plus one descriptor per face: where A and B go and how the face
- * cell (i1, i2) maps to coordinates.  pdehip_bcprog_run evaluates all faces of
- * the program for time t in ONE launch; the stencil kernels and the ghost kernel then read the arrays as usual. */
+ * first-order face with per-cell coefficient arrays (PDEHIP_BCF_ARRAYS).  A condition that is NOT affine in `value` is the same
+ * face with A = F(value now, dx, coords, t), B = 0, rewritten from the field every time the conditions are applied
+ * (`reads_value`: the program reads the cell `value_index` of the field along the face's axis, like the reference's
+ * `arr[..., value_cell]`, local.py:1089-1135).  A program is C source (compiled with hiprtc) that defines
+ *     PDEHIP_BC_FN void bc_face(int face, double value, double dx, double c0, double c1, double c2, double t, double *A, double *B)
+ * (c0..c2 = coordinates of the wall point along the grid axes; value = 0 for faces that do not read the field), plus one
+ * descriptor per face: where A and B go and how the face cell (i1, i2) maps to coordinates.  pdehip_bcprog_run evaluates all
+ * faces of the program for time t - and the field `state_full` - in ONE launch; the stencil kernels and the ghost kernel then
+ * read the arrays as usual. */
 typedef struct pdehip_bcprog_face {
     double *const_arr, *factor_arr;   /* fp64 device arrays of m1 * m2 face cells (C order), written by the program */
     int64_t m1, m2;                   /* face extents along the remaining grid axes in grid order (1 where there is none) */
     double origin[3], step[3];        /* per coordinate k: index[k] == 0: c[k] = origin[k] (the wall, or an unused slot);        */
     int32_t index[3];                 /*   index[k] == 1 / 2: c[k] = (i1 / i2 + 0.5) * step[k] + origin[k] - the cell centres of */
-    int32_t reserved;                 /*   the reference (discretize_interval, pde/grids/base.py:88-113), operation by operation */
+    int32_t reads_value;              /*   the reference (discretize_interval, pde/grids/base.py:88-113), operation by operation */
     double dx;                        /* spacing normal to the wall */
+    int32_t axis;                     /* reads_value: grid axis normal to the face, ...                                      */
+    int32_t component;                /*   ... component of the field (0 for a scalar field) and ...                          */
+    int64_t value_index;              /*   ... valid index along `axis` of the cells whose values are handed to bc_face        */
 } pdehip_bcprog_face_t;
-int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle);
-int pdehip_bcprog_run(void *handle, double t, void *stream);
+/* `grid`: layout of the fields handed to pdehip_bcprog_run (NULL when no face reads the field) */
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, const pdehip_grid_t *grid, void **handle);
+/* `state_full`: the field the conditions are about to be applied to (may be NULL when no face reads it) */
+int pdehip_bcprog_run(void *handle, double t, const void *state_full, void *stream);
 int pdehip_bcprog_destroy(void *handle);
 
 /* ---- runtime ------------------------------------------------------------------ */

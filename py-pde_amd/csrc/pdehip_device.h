@@ -22,6 +22,7 @@ enum { E2_DIFFUSION = 0, E2_CH_EULER = 1, E2_CH_SCALED = 2, E2_CUSTOM = 3 /* run
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC> struct VecT;
 template <> struct VecT<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecT<double, 1> { typedef double type __attribute__((ext_vector_type(1))); };   // narrow fp64 tiles of euler2_kernel (8 B per lane)
 template <> struct VecT<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
 template <> struct VecT<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };   // narrow fp32 tiles of euler2_kernel (8 B per lane)
 

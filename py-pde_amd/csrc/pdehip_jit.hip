@@ -565,9 +565,10 @@ struct BcFaceDev {   // device copy of a face descriptor + the start of its cell
     long m1, m2;
     double origin[3], step[3];
     int index[3];
-    int pad;
+    int reads;         // the face reads the field: element offset of face cell (i1, i2) = soff + i1 * sp1 + i2 * sp2
     double dx;
     long start;
+    long soff, sp1, sp2;
 };
 struct BcProg {
     hipModule_t module = nullptr;
@@ -575,10 +576,12 @@ struct BcProg {
     BcFaceDev *faces_dev = nullptr;
     int nfaces = 0;
     long total = 0;
+    int reads = 0;     // some face reads the field
+    int esz = 8;       // bytes per element of the field
 };
 const char *kBcKernel = R"SRC(
-struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; int pad; double dx; long start; };
-extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t)
+struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; int reads; double dx; long start; long soff, sp1, sp2; };
+extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t, const void *state, int esz)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         int f = 0;
@@ -592,8 +595,13 @@ extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *fa
             // the cell centres of the reference, operation by operation: (i + 0.5) * dx + x_min  (pde/grids/base.py:112-113)
             c[k] = w == 0 ? F.origin[k] : ((double)(w == 1 ? i1 : i2) + 0.5) * F.step[k] + F.origin[k];
         }
+        double value = 0;
+        if (F.reads) {
+            const long o = F.soff + i1 * F.sp1 + i2 * F.sp2;
+            value = esz == 8 ? ((const double *)state)[o] : (double)((const float *)state)[o];
+        }
         double a = 0, b = 0;
-        bc_face(f, F.dx, c[0], c[1], c[2], t, &a, &b);
+        bc_face(f, value, F.dx, c[0], c[1], c[2], t, &a, &b);
         F.A[loc] = a;
         F.B[loc] = b;
     }
@@ -603,9 +611,16 @@ extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *fa
 
 extern "C" {
 
-int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle)
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, const pdehip_grid_t *grid, void **handle)
 {
     if (!source || !faces || !handle || nfaces < 1 || nfaces > 64) PDEHIP_FAIL(E_VALUE, "bcprog_create: NULL pointer or bad face count");
+    NGrid n;
+    bool reads = false;
+    for (int f = 0; f < nfaces; f++) reads = reads || faces[f].reads_value != 0;
+    if (reads) {
+        if (!grid) PDEHIP_FAIL(E_VALUE, "bcprog_create: a face reads the field but no grid is given");
+        PDEHIP_TRY(norm_grid(grid, &n));
+    }
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_BC_FN __device__ __forceinline__\n";
     src += source;
@@ -633,11 +648,25 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
         const pdehip_bcprog_face_t &s = faces[f];
         if (!s.const_arr || !s.factor_arr || s.m1 < 1 || s.m2 < 1) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d has no arrays / cells", f); }
         BcFaceDev &d = host[f];
-        d.A = s.const_arr; d.B = s.factor_arr; d.m1 = s.m1; d.m2 = s.m2; d.dx = s.dx; d.start = start; d.pad = 0;
+        d.A = s.const_arr; d.B = s.factor_arr; d.m1 = s.m1; d.m2 = s.m2; d.dx = s.dx; d.start = start;
         for (int k = 0; k < 3; k++) { d.origin[k] = s.origin[k]; d.step[k] = s.step[k]; d.index[k] = s.index[k]; }
+        d.reads = s.reads_value != 0; d.soff = d.sp1 = d.sp2 = 0;
+        if (d.reads) {
+            // the cell (value_index along the face's axis, i1, i2 along the others in grid order) of component `component`
+            const int nd = n.ndim, ax = s.axis;
+            if (ax < 0 || ax >= nd || s.value_index < 0 || s.value_index >= n.n[3 - nd + ax] || s.component < 0) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: bad axis / value cell / component", f); }
+            int others[2], no = 0;
+            for (int a = 0; a < nd; a++) if (a != ax) others[no++] = a;
+            if ((no >= 1 ? n.n[3 - nd + others[0]] : 1) != s.m1 || (no >= 2 ? n.n[3 - nd + others[1]] : 1) != s.m2) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: extents do not match the grid", f); }
+            d.soff = n.off + (long)s.component * n.pc + s.value_index * n.p[3 - nd + ax];
+            d.sp1 = no >= 1 ? n.p[3 - nd + others[0]] : 0;
+            d.sp2 = no >= 2 ? n.p[3 - nd + others[1]] : 0;
+        }
         start += s.m1 * s.m2;
     }
     b->nfaces = nfaces;
+    b->reads = reads ? 1 : 0;
+    b->esz = reads ? (int)elem_size(n.dtype) : 8;
     b->total = start;
     hipError_t e = hipModuleLoadData(&b->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&b->fn, b->module, "bc_refresh");
@@ -653,14 +682,15 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     return 0;
 }
 
-int pdehip_bcprog_run(void *handle, double t, void *stream)
+int pdehip_bcprog_run(void *handle, double t, const void *state_full, void *stream)
 {
     BcProg *b = static_cast<BcProg *>(handle);
     if (!b) PDEHIP_FAIL(E_VALUE, "bcprog_run: NULL handle");
+    if (b->reads && !state_full) PDEHIP_FAIL(E_VALUE, "bcprog_run: the conditions read the field, but no field is given");
     const BcFaceDev *faces = b->faces_dev;
-    int nfaces = b->nfaces;
+    int nfaces = b->nfaces, esz = b->esz;
     long total = b->total;
-    void *kargs[] = {&faces, &nfaces, &total, &t};
+    void *kargs[] = {&faces, &nfaces, &total, &t, &state_full, &esz};
     const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     PDEHIP_HIP(hipModuleLaunchKernel(b->fn, blocks, 1, 1, 256, 1, 1, 0, as_stream(stream), kargs, nullptr));
     return 0;

@@ -416,13 +416,33 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
     int ry = t2.ry ? t2.ry : 4;
     if (sizeof(T) == 4) ry = ry_f32;
+    // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
+    // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
+    // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
+    // of non-periodic rows has no exactly fitting tile at all.
+    const int ry_want = ry;
     while (ry > 1 && a.n1 % ry) ry /= 2;
+    if (has_y && ry < ry_want) {
+        int big = ry_want;
+        while (big > ry && a.n1 < 8L * big) big /= 2;
+        if (big > ry) ry = big;
+        else if (ry == 1) ry = 2;   // (1-row tiles exist for periodic rows of fp32 grids only and recompute 3 x)
+    }
     // the stage epilogue (six more streams) does not fit the ragged 4-row fp64 tile without spilling: 2-row tiles there
-    if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && a.n2 % CW != 0) ry = 2;
+    const long n2v = (a.n2 + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
+    if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
-    if (a.n2 % VEC || a.n1 % ry || (ry != 1 && ry != 2 && ry != 4)) return 0;
+    if ((ry != 1 && ry != 2 && ry != 4) || a.n1 < ry || (n2v != a.n2 && a.n2 < CW)) return 0;
+    const bool overlap = n2v != a.n2 || a.n1 % ry != 0;
+    if (overlap && m2 == E2_CH_STAGE) {
+        // cells of overlapping tiles are computed and stored twice: nothing a sweep writes may be one of its pointwise inputs
+        // (the new state of RK4 written over the old one: those sweeps combine with the pointwise kernels)
+        bool alias = a.st_out == a.st_y || a.out == a.st_y;
+        for (int m = 0; m < 5; m++) alias = alias || (a.st_k[m] && (a.st_k[m] == a.st_out || a.st_k[m] == a.out));
+        if (alias) return 0;
+    }
     a.ntz = (a.n2 + CW - 1) / CW;   // the row may end inside the last chunk
-    a.nty = a.n1 / ry;
+    a.nty = (a.n1 + ry - 1) / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
     if (ends > 0) {
@@ -448,17 +468,39 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         // the RCCL kernel of the halo stream finds free wave slots at once — workgroups march for the whole sweep, a kernel
         // launched behind a full round waits for it to end (measured: 90 us for 13 us of work).
         const bool thin = xplain && a.n0 < 96;
-        const long want = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
-        long nxc = thin ? want / tiles : (want + tiles - 1) / tiles;
-        if (nxc < 1) nxc = 1;
-        // chunks of at least 16 planes (two recomputed planes per chunk: <= 12.5 % extra work) - but a small grid must not
-        // leave the chip idle for that: down to 2 planes per chunk while fewer than one round of wave tiles exists (100^3: 150
-        // tiles of 17 planes took 19.7 us per step, 8.1 now; 64^3 18.4 -> 5.7, 128^3 13.1 -> 7.0, 200^3 28.8 -> 21.7)
+        const long cap = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
         static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
-        long minlx = 16;
-        while (minlx > 2 && tiles * (a.n0 / minlx) < want) minlx /= 2;
-        if (floor_env > 0) minlx = floor_env;
-        if (nxc > a.n0 / minlx) nxc = a.n0 / minlx > 0 ? a.n0 / minlx : 1;
+        long nxc;
+        if (thin) {
+            nxc = cap / tiles;
+            long minlx = 16;
+            while (minlx > 2 && tiles * (a.n0 / minlx) < cap) minlx /= 2;
+            if (floor_env > 0) minlx = floor_env;
+            if (nxc > a.n0 / minlx) nxc = a.n0 / minlx;
+            if (nxc < 1) nxc = 1;
+        } else {
+            // The number of x-chunks by a cost model.  A wave marches lx + 2 planes; the chip holds `cap` of them.  While they
+            // fit (W <= cap) the sweep is bound by the bytes (W * L) down to the latency floor of a lone march; beyond, the
+            // waves left over for the last round march ALONE at that floor: tile counts just above a divisor of `cap` (512 x 513
+            // x 512: 516 tiles, 4 chunks = 2064 waves took 0.307 ms per step against 0.225 for 512^3; 300^3: 225 tiles, 10
+            // chunks = 2250 waves) take one chunk less instead.  Chunks shorter than 16 planes (two recomputed planes per
+            // chunk: > 12.5 % extra work) only while the first round is not full (100^3: 19.7 -> 8.1 us per step).
+            double best = 0;
+            nxc = 1;
+            for (long c = 1; c <= a.n0 / 2 || c == 1; c++) {
+                const long lx = (a.n0 + c - 1) / c, real = (a.n0 + lx - 1) / lx;
+                if (real != c) continue;   // the same chunking as a smaller count
+                if (floor_env > 0 ? lx < floor_env : (lx < 16 && (c - 1) * tiles >= cap)) break;
+                const long W = real * tiles;
+                const double full = (double)(W / cap), part = (double)(W % cap) / (double)cap;
+                // a wave needs 1.6 - 1.9 us per plane whether the chip is full or not (200^3: 1200 waves of 19 planes took as long
+                // per plane as 2000 waves of 12): one round costs its march length, nearly whatever its size; the waves of an
+                // incomplete LAST round start while the round before drains (measured: 0.36 of a round for a handful)
+                double rounds = W <= cap ? 0.85 + 0.15 * (double)W / (double)cap : full + (part > 0 ? (part > 0.36 ? part : 0.36) : 0.0);
+                const double cost = (double)(lx + 2) * rounds;
+                if (best == 0 || cost < best) { best = cost; nxc = c; }
+            }
+        }
         const long lx = (a.n0 + nxc - 1) / nxc;
         a.lx = (int)lx;
         a.nxc = (a.n0 + lx - 1) / lx;
@@ -505,7 +547,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // XS: the one-sided halo modes of the first / last slab of a non-periodic axis are separate instances (with the
     // ragged-row code): compiled into the hot instances they cost 5-9 % through register allocation alone
     const bool xs = xplain > 1;
-    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && a.n2 % CW == 0);
+    // (the virtual rows next to a moved last tile - pdehip_march2.inc: ylo2 / yhi2 - are part of the ragged-row code)
+    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && a.n1 % ry != 0 && !a.per[1]);
     // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
 #if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
     const bool nt = false;   // A/B variant: non-temporal loads, plain stores
@@ -570,10 +613,19 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         if (n.ndim == 3 && !plan) {
             if (stage) { vec = tf.svec ? tf.svec : 2; ry = tf.svec ? tf.sry : 4; }
             else if (tf.vec) { vec = tf.vec; ry = tf.ry; }
+            else {
+                // rows that fill the 128-cell chunks of the narrow tile much better than the 256-cell chunks of the wide one
+                // (300 cells: 78 % against 59 % of the lanes own cells; 513: 80 % against 67 %)
+                const double wide = (double)a.n2 / (double)((a.n2 + 255) / 256 * 256), narrow = (double)a.n2 / (double)((a.n2 + 127) / 128 * 128);
+                if (narrow > 1.15 * wide) { vec = 2; ry = 4; }
+            }
         }
         if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
         if (vec == 2) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
-        return launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
+        PDEHIP_TRY((launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry)));
+        // rows shorter than the wide chunk that end inside its 4-cell vector: the narrow tile (2-cell vectors) may still fit
+        if (!*done && n.ndim == 3 && !plan && a.n2 % 4 != 0 && a.n2 < 256) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, stage ? 4 : 2);
+        return 0;
     }
 }
 

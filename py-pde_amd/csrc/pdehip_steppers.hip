@@ -275,9 +275,13 @@ static int rk4_step_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y,
         if (fused) PDEHIP_TRY(rhs_stage(g, rhs, k4, k3, dt, sf, stream, &fused));
         sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.out2 = y;
         PDEHIP_TRY(refresh_bcs(rhs, t + dt, stream));
-        if (fused) PDEHIP_TRY(rhs_stage(g, rhs, tmp, nullptr, dt, sf, stream, &fused));
         if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
-        return 0;
+        PDEHIP_TRY(rhs_stage(g, rhs, tmp, nullptr, dt, sf, stream, &fused));
+        if (fused) return 0;
+        // the last sweep writes the new state over the old one, which sweeps with overlapping tiles (row lengths / counts that
+        // no tile divides, pdehip_march2.inc) cannot do: slope into the array of k4 (free since the third stage), then combine
+        PDEHIP_TRY(rhs_scaled_at(g, rhs, tmp, k4, dt, t + dt, stream));
+        return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, stream);
     }
     PDEHIP_TRY(rhs_scaled_at(g, rhs, y, k1, dt, t, stream));
     kk[0] = k1; PDEHIP_TRY(pdehip_lincomb(g, 1, tmp, y, 1, &half, kk, stream));

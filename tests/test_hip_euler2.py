@@ -77,6 +77,14 @@ PERIODIC = list(itertools.product([True, False], repeat=3))
     (np.float64, (7, 4, 200)),      # row ends inside the second chunk (36 of 64 lanes own cells)
     (np.float64, (5, 4, 130)),      # ... one lane of the last chunk owns cells
     (np.float32, (6, 8, 100)),
+    # overlapped last tiles: rows that end inside a vector, row counts that no tile divides
+    (np.float64, (9, 7, 129)),      # ONE cell in the last chunk: the chunk is moved back by one cell; 7 rows: 2-row tiles, the last one moved back
+    (np.float64, (6, 37, 255)),     # the moved chunk is a full one; 37 rows: 4-row tiles, the last one moved back by 3 rows
+    (np.float64, (5, 9, 383)),
+    (np.float32, (6, 5, 259)),      # wide fp32 tile, 3 cells beyond the first chunk
+    (np.float32, (7, 9, 257)),
+    (np.float32, (4, 35, 518)),
+    (np.float32, (5, 6, 130)),      # row shorter than the wide chunk: the narrow tile takes it
 ])
 def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
     grid, bc, bcs, data = _setup(shape, list(periodic), dtype)
@@ -104,8 +112,7 @@ def test_euler_run_uses_pairs_and_stays_bit_exact(backend, steps, periodic):
 
 def test_cases_outside_the_kernel_report_not_done(backend):
     for shape, periodic, bc_override in [
-        ((8, 8, 63), [True] * 3, None),                       # odd row length: no 16-byte vectors
-        ((8, 7, 128), [True] * 3, None),                      # odd number of rows
+        ((8, 8, 63), [True] * 3, None),                       # odd row length inside ONE chunk: no neighbour to overlap with
         ((8, 8, 128), [False] * 3, {"curvature": 0.3}),       # second-order faces
         ((8, 8, 128), [True] * 3, "anti-periodic"),           # wraps with a factor -1
     ]:
@@ -115,7 +122,7 @@ def test_cases_outside_the_kernel_report_not_done(backend):
         done, _ = _euler2(backend, grid, bcs, data, 0.6, 2e-3)
         assert done == 0
     # ... and the time loop silently takes single steps there (same results as before)
-    grid, bc, bcs, data = _setup((6, 7, 128), [True, False, True], np.float64)
+    grid, bc, bcs, data = _setup((6, 7, 63), [True, False, True], np.float64)
     eq = pde_hip.DiffusionPDE(0.8, bc=bc)
     spec = backend.make_rhs_spec(eq, pde_hip.ScalarField(grid, data))
     a, b = DeviceArray(spec.info).set_valid(data), DeviceArray(spec.info)
@@ -139,6 +146,9 @@ LOCAL_MU = [
     (np.float32, (9, 8, 256)),
     (np.float64, (6, 4, 72)),
     (np.float32, (5, 4, 264)),
+    (np.float64, (7, 9, 131)),      # overlapped last tiles along the rows and along the row
+    (np.float64, (5, 34, 255)),
+    (np.float32, (5, 7, 261)),
 ])
 def test_cahn_hilliard_in_one_sweep_equals_two_kernels(backend, periodic, dtype, shape):
     """mu = c^3 - c - g lap(c) (faces of c) and lap(mu) (DIFFERENT faces of mu) fused with mu in registers ==
@@ -201,6 +211,8 @@ PERIODIC2 = list(itertools.product([True, False], repeat=2))
     (np.float64, (64, 64)),      # BASELINE config 1 shape
     (np.float32, (12, 256)),
     (np.float32, (7, 100)),
+    (np.float64, (11, 131)),     # the last chunk moved back by one cell
+    (np.float32, (9, 262)),
 ])
 def test_two_dimensional_grids(backend, periodic, dtype, shape):
     """2-D: the same two-level kernel marching along the first axis (no rows): two diffusion steps per sweep and the
@@ -271,7 +283,8 @@ def test_full_size_time_loop_512cubed(backend):
     assert got.min() > u.min() and got.max() < u.max()
 
 
-@pytest.mark.parametrize("shape,periodic", [((9, 8, 128), [True, False, True]), ((6, 4, 72), [False, True, False]), ((20, 136), [False, True])])
+@pytest.mark.parametrize("shape,periodic", [((9, 8, 128), [True, False, True]), ((6, 4, 72), [False, True, False]), ((20, 136), [False, True]),
+                                            ((7, 9, 131), [False, False, False])])
 def test_special_values_stay_bit_identical(backend, shape, periodic):
     """Denormals, huge magnitudes, signed zeros, an infinity and a NaN travel through both levels exactly as through two
     single steps of the oracle (IEEE arithmetic, denormals on, no contraction, selects instead of arithmetic masking)."""
@@ -293,7 +306,8 @@ def test_special_values_stay_bit_identical(backend, shape, periodic):
     assert np.isnan(got).sum() > 1 and np.isinf(got).sum() >= 0
 
 
-@pytest.mark.parametrize("dtype,shape,split", [(np.float64, (12, 8, 128), 5), (np.float64, (9, 4, 72), 4), (np.float32, (10, 6, 256), 6)])
+@pytest.mark.parametrize("dtype,shape,split", [(np.float64, (12, 8, 128), 5), (np.float64, (9, 4, 72), 4), (np.float32, (10, 6, 256), 6),
+                                               (np.float64, (11, 9, 131), 5), (np.float32, (9, 7, 259), 4)])
 def test_sub_slabs_with_one_physical_face(backend, dtype, shape, split):
     """First / last slab of a NON-periodic slowest axis: one side of the sub-slab is the physical (local) face, the other
     side reads two real layers of the neighbouring sub-slab.  Two such launches over the halves of one array must equal

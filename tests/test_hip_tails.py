@@ -57,10 +57,12 @@ def test_operators_any_row_length(shape, dtype, bc_name):
 
 @pytest.mark.parametrize("kind", ["diffusion", "cahn_hilliard"])
 @pytest.mark.parametrize("solver,dt", [("euler", 1e-3), ("runge-kutta", 1e-3), ("runge-kutta", None)])
-@pytest.mark.parametrize("shape,dtype", [((9, 7, 129), np.float64), ((6, 5, 130), np.float32), ((11, 127), np.float64)])
+@pytest.mark.parametrize("shape,dtype", [((9, 7, 129), np.float64), ((6, 5, 130), np.float32), ((11, 127), np.float64),
+                                         ((6, 9, 257), np.float64), ((5, 7, 261), np.float32), ((9, 131), np.float64)])
 def test_steppers_any_row_length(shape, dtype, kind, solver, dt):
-    """Euler loop (one-level kernel, BCs on the fly incl. the upper face of the fastest axis inside a lane's vector), RK4 and
-    RKF45 stage sweeps with their pointwise streams: equal step counts, bit-identical to the oracle (fp32: 1e-6)."""
+    """Euler loop (BCs on the fly incl. the upper face of the fastest axis inside a lane's vector; rows longer than a chunk: the
+    two-level kernel with its last tiles moved back over their neighbours), RK4 and RKF45 stage sweeps with their pointwise
+    streams: equal step counts, bit-identical to the oracle (fp32: 1e-6)."""
     nd = len(shape)
     grid = pde_hip.UnitGrid(shape, periodic=[True] + [False] * (nd - 1))
     bc = "auto_periodic_neumann" if kind == "cahn_hilliard" else {"x": "periodic", "y": {"value": 0.3}, **({"z": {"derivative": 0.1}} if nd == 3 else {})}

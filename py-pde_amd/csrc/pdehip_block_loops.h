@@ -99,7 +99,7 @@ struct Eval {
     int rhs_sweep(void *in, void *out, double dt, double t, bool euler, const StageFuse *sf, bool *fused, void *st)
     {
         *fused = false;
-        if (rhs->bc_program) SLAB_TRY(ops.refresh(rhs->bc_program, t, st));
+        if (rhs->bc_program) SLAB_TRY(ops.refresh(rhs->bc_program, t, in, st));
         pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
         local_faces(rhs->bc_c, q, fc);
         SLAB_TRY(exchange(ops, q, in, st));

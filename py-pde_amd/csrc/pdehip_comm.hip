@@ -170,7 +170,7 @@ struct HipOps {
         return 0;
     }
     int zero(void *p, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(p, 0, bytes, as_stream(st))); return 0; }
-    int refresh(void *bc_program, double t, void *st) { return pdehip_bcprog_run(bc_program, t, st); }
+    int refresh(void *bc_program, double t, const void *in, void *st) { return pdehip_bcprog_run(bc_program, t, in, st); }
     int fail(const char *msg) { PDEHIP_FAIL(E_NOTIMPL, "%s", msg); }
     int fail_runtime(const char *fmt, double v) { PDEHIP_FAIL(E_RUNTIME, fmt, v); }
     // BCs of `in` (faces not marked SKIP) + stencil into the full array `out`

@@ -614,12 +614,12 @@ extern "C" {
 int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, const pdehip_grid_t *grid, void **handle)
 {
     if (!source || !faces || !handle || nfaces < 1 || nfaces > 64) PDEHIP_FAIL(E_VALUE, "bcprog_create: NULL pointer or bad face count");
-    NGrid n;
+    NGrid ng;
     bool reads = false;
     for (int f = 0; f < nfaces; f++) reads = reads || faces[f].reads_value != 0;
     if (reads) {
         if (!grid) PDEHIP_FAIL(E_VALUE, "bcprog_create: a face reads the field but no grid is given");
-        PDEHIP_TRY(norm_grid(grid, &n));
+        PDEHIP_TRY(norm_grid(grid, &ng));
     }
     PDEHIP_TRY(load_rtc());
     std::string src = "#define PDEHIP_BC_FN __device__ __forceinline__\n";
@@ -653,20 +653,20 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
         d.reads = s.reads_value != 0; d.soff = d.sp1 = d.sp2 = 0;
         if (d.reads) {
             // the cell (value_index along the face's axis, i1, i2 along the others in grid order) of component `component`
-            const int nd = n.ndim, ax = s.axis;
-            if (ax < 0 || ax >= nd || s.value_index < 0 || s.value_index >= n.n[3 - nd + ax] || s.component < 0) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: bad axis / value cell / component", f); }
+            const int nd = ng.ndim, ax = s.axis;
+            if (ax < 0 || ax >= nd || s.value_index < 0 || s.value_index >= ng.n[3 - nd + ax] || s.component < 0) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: bad axis / value cell / component", f); }
             int others[2], no = 0;
             for (int a = 0; a < nd; a++) if (a != ax) others[no++] = a;
-            if ((no >= 1 ? n.n[3 - nd + others[0]] : 1) != s.m1 || (no >= 2 ? n.n[3 - nd + others[1]] : 1) != s.m2) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: extents do not match the grid", f); }
-            d.soff = n.off + (long)s.component * n.pc + s.value_index * n.p[3 - nd + ax];
-            d.sp1 = no >= 1 ? n.p[3 - nd + others[0]] : 0;
-            d.sp2 = no >= 2 ? n.p[3 - nd + others[1]] : 0;
+            if ((no >= 1 ? ng.n[3 - nd + others[0]] : 1) != s.m1 || (no >= 2 ? ng.n[3 - nd + others[1]] : 1) != s.m2) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d: extents do not match the grid", f); }
+            d.soff = ng.off + (long)s.component * ng.pc + s.value_index * ng.p[3 - nd + ax];
+            d.sp1 = no >= 1 ? ng.p[3 - nd + others[0]] : 0;
+            d.sp2 = no >= 2 ? ng.p[3 - nd + others[1]] : 0;
         }
         start += s.m1 * s.m2;
     }
     b->nfaces = nfaces;
     b->reads = reads ? 1 : 0;
-    b->esz = reads ? (int)elem_size(n.dtype) : 8;
+    b->esz = reads ? (int)elem_size(ng.dtype) : 8;
     b->total = start;
     hipError_t e = hipModuleLoadData(&b->module, code.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&b->fn, b->module, "bc_refresh");
@@ -743,7 +743,7 @@ int loop_steps(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npas
 {
     for (int64_t s = 0; s < count; s++) {
         const double params[2] = {dt, t0 + (double)(first + s) * dt};   // _solvers.py:100: t = t_start + i * dt
-        if (bc_program) PDEHIP_TRY(pdehip_bcprog_run(bc_program, params[1], stream));   // the faces of THIS step's time
+        if (bc_program) PDEHIP_TRY(pdehip_bcprog_run(bc_program, params[1], cur, stream));   // the faces of THIS step's time and state
         for (int q = 0; q < npasses; q++) {
             const pdehip_jit_pass_t &p = passes[q];
             auto in = [&](int32_t idx) -> void * {
@@ -931,13 +931,13 @@ struct JitEval {
     int stage_fuse;     // 1: try the stage epilogue of the last pass, 0: never, -1: refused once (stays off)
     void *bc_program;
 
-    int refresh(double t, void *st) { return bc_program ? pdehip_bcprog_run(bc_program, t, st) : 0; }
+    int refresh(double t, const void *in, void *st) { return bc_program ? pdehip_bcprog_run(bc_program, t, in, st) : 0; }
     // k_out = dt * F(in; t) and - where the last pass carries it - the combination `sf` in the same sweep (*fused)
     int slope(void *in, void *k_out, double dt, double t, const StageFuse *sf, bool *fused, void *st)
     {
         *fused = false;
         const double params[2] = {dt, t};
-        PDEHIP_TRY(refresh(t, st));
+        PDEHIP_TRY(refresh(t, in, st));
         const pdehip_jit_pass_t &last = passes[npasses - 1];
         const bool try_stage = sf && stage_fuse > 0 && ncomp == 1 && last.out == -1;
         PDEHIP_TRY(run_passes(g, passes, npasses, fixed, (char *)in, (char *)k_out, comp_bytes, params, st, try_stage ? 1 : 0));

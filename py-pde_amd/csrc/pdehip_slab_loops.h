@@ -259,7 +259,7 @@ int rhs_sweep(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t
               double dt, bool euler, const StageFuse *sf, void *st, double t = 0.0)
 {
     // faces with explicit time dependence: their coefficient arrays for the time of THIS evaluation (pdehip_rhs_t::bc_program)
-    if (rhs->bc_program) SLAB_TRY(ops.refresh(rhs->bc_program, t, st));
+    if (rhs->bc_program) SLAB_TRY(ops.refresh(rhs->bc_program, t, in, st));
     pdehip_bc_face_t fc[2 * PDEHIP_MAX_DIM], fm[2 * PDEHIP_MAX_DIM];
     local_faces(rhs->bc_c, lower, upper, fc);
     const bool fuse_stage = sf && (flags & F_FUSED_STAGE);

@@ -103,10 +103,11 @@ bool graphs_enabled()
 // rk4_combine pass: a stage moves (1 + earlier slopes + 2 or 3) arrays instead of 2 + (earlier slopes + 3).
 // *fused = false (nothing launched) when the sweep is not available: diffusion needs the vectorised kernel,
 // Cahn-Hilliard the two-level kernel (pdehip_march2.inc).
-// faces with explicit time dependence: their coefficient arrays for the time of THIS evaluation (pdehip_rhs_t::bc_program)
-int refresh_bcs(const pdehip_rhs_t *rhs, double t, void *stream)
+// faces that depend on the time or on the field: their coefficient arrays for the time and the input `in` of THIS evaluation
+// (pdehip_rhs_t::bc_program)
+int refresh_bcs(const pdehip_rhs_t *rhs, double t, const void *in, void *stream)
 {
-    return rhs->bc_program ? pdehip_bcprog_run(rhs->bc_program, t, stream) : 0;
+    return rhs->bc_program ? pdehip_bcprog_run(rhs->bc_program, t, in, stream) : 0;
 }
 
 int rhs_stage(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *in, void *k_out, double dt, const StageFuse &sf,
@@ -141,7 +142,7 @@ int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_f
 
 static int rhs_scaled_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, double t, void *stream)
 {
-    PDEHIP_TRY(refresh_bcs(rhs, t, stream));
+    PDEHIP_TRY(refresh_bcs(rhs, t, y_full, stream));
     // numba/backend.py:501-517: BCs, then the stencil — here one kernel (BCs evaluated on the fly)
     if (rhs->kind == PDEHIP_RHS_DIFFUSION)   // dt * (D * lap)
         return laplace_with_input_bcs(g, y_full, nullptr, k_out_full, LAP_SCALED, rhs->param, dt, 0, rhs->bc_c, stream);
@@ -194,7 +195,7 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     for (int q = 0; q < g->ndim; q++) ncells *= g->shape[q];
     bool tile_ok = g->ndim == 2 && tile_k > 0 && ncells <= tile_cells && !timed;
     auto advance = [&](void *c, void *n, void *st, int64_t left, int *took, int64_t step = 0) -> int {
-        if (timed) PDEHIP_TRY(refresh_bcs(rhs, rhs->t + (double)step * dt, st));   // _solvers.py:100: t = t_start + i * dt
+        if (timed) PDEHIP_TRY(refresh_bcs(rhs, rhs->t + (double)step * dt, c, st));   // _solvers.py:100: t = t_start + i * dt
         if (tile_ok) {
             int k = tile2d_max_steps(rhs->kind == PDEHIP_RHS_DIFFUSION ? 0 : 1);
             if (k > tile_k) k = tile_k;
@@ -265,16 +266,17 @@ static int rk4_step_at(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y,
     memset(&sf, 0, sizeof(sf));
     sf.y = y; sf.c_new = half; sf.out2 = tmp;
     // stage times t, t + dt/2, t + dt/2, t + dt (runge_kutta.py:52-59): time-dependent faces are refreshed before each stage
-    PDEHIP_TRY(refresh_bcs(rhs, t, stream));
+    PDEHIP_TRY(refresh_bcs(rhs, t, y, stream));
     PDEHIP_TRY(rhs_stage(g, rhs, y, k1, dt, sf, stream, &fused));
     if (fused) {
         sf.out2 = k4;
-        PDEHIP_TRY(refresh_bcs(rhs, t + 0.5 * dt, stream));
+        PDEHIP_TRY(refresh_bcs(rhs, t + 0.5 * dt, tmp, stream));
         PDEHIP_TRY(rhs_stage(g, rhs, tmp, k2, dt, sf, stream, &fused));
         sf.c_new = one; sf.out2 = tmp;
+        PDEHIP_TRY(refresh_bcs(rhs, t + 0.5 * dt, k4, stream));   // (the same time, another input: conditions that read the field)
         if (fused) PDEHIP_TRY(rhs_stage(g, rhs, k4, k3, dt, sf, stream, &fused));
         sf.kind = 1; sf.k[0] = k1; sf.k[1] = k2; sf.k[2] = k3; sf.out2 = y;
-        PDEHIP_TRY(refresh_bcs(rhs, t + dt, stream));
+        PDEHIP_TRY(refresh_bcs(rhs, t + dt, tmp, stream));
         if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
         PDEHIP_TRY(rhs_stage(g, rhs, tmp, nullptr, dt, sf, stream, &fused));
         if (fused) return 0;
@@ -305,7 +307,7 @@ int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in,
     memset(&sf, 0, sizeof(sf));
     sf.kind = 3; sf.y = y_in; sf.k[0] = rate_prev; sf.c_new = dt; sf.out2 = y_out;
     bool done = false;
-    PDEHIP_TRY(refresh_bcs(rhs, rhs->t, stream));
+    PDEHIP_TRY(refresh_bcs(rhs, rhs->t, y_in, stream));
     PDEHIP_TRY(rhs_stage(g, rhs, y_in, rate_cur, 1.0, sf, stream, &done));
     *fused = done ? 1 : 0;
     return 0;
@@ -358,7 +360,7 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
             sf.y = y; sf.out2 = t_out;
             for (int m = 0; m < s; m++) { sf.k[m] = k[m]; sf.c[m] = tab[s][m]; }
             sf.c_new = tab[s][s];
-            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[s] * dt, stream));
+            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[s] * dt, t_in, stream));
             PDEHIP_TRY(rhs_stage(g, rhs, t_in, w[s], dt, sf, stream, &fused));
             if (!fused && s > 0) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
             t_in = t_out;
@@ -370,7 +372,7 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
             sf.kind = 2; sf.y = y; sf.out2 = ynew; sf.err = err_dev;
             sf.k[0] = k[0]; sf.k[1] = k[2]; sf.k[2] = k[3]; sf.k[3] = k[4];
             PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
-            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[5] * dt, stream));
+            PDEHIP_TRY(refresh_bcs(rhs, t0 + A45[5] * dt, t_in, stream));
             PDEHIP_TRY(rhs_stage(g, rhs, t_in, nullptr, dt, sf, stream, &fused));
             if (!fused) PDEHIP_FAIL(E_RUNTIME, "internal: fused Runge-Kutta stage refused after the first one was taken");
             return 0;

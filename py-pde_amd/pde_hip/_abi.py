@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -80,7 +80,8 @@ class BcProgFace(C.Structure):
     """``pdehip_bcprog_face_t``: where one expression face writes its coefficient arrays and how its cells map to coordinates."""
 
     _fields_ = [("const_arr", C.c_void_p), ("factor_arr", C.c_void_p), ("m1", C.c_int64), ("m2", C.c_int64),
-                ("origin", C.c_double * 3), ("step", C.c_double * 3), ("index", C.c_int32 * 3), ("reserved", C.c_int32), ("dx", C.c_double)]
+                ("origin", C.c_double * 3), ("step", C.c_double * 3), ("index", C.c_int32 * 3), ("reads_value", C.c_int32), ("dx", C.c_double),
+                ("axis", C.c_int32), ("component", C.c_int32), ("value_index", C.c_int64)]
 
 
 JIT_NONE = -(2**31)   # PDEHIP_JIT_NONE
@@ -247,8 +248,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_euler_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _vp, _vp, _i, _d, _d, _i, _i64, _vp, _pvp, _vp],
     "jit_rk_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _i, _vp, _vp, _pvp, _vp, _d, _d, _i64, _pa, _i, _vp, _pvp, _vp],
     # expression boundary conditions evaluated on the device
-    "bcprog_create": [C.c_char_p, _i, C.POINTER(BcProgFace), _pvp],
-    "bcprog_run": [_vp, _d, _vp],
+    "bcprog_create": [C.c_char_p, _i, C.POINTER(BcProgFace), _pg, _pvp],
+    "bcprog_run": [_vp, _d, _vp, _vp],
     "bcprog_destroy": [_vp],
 }
 

@@ -236,11 +236,18 @@ class RhsSpec:
             self.c.scratch_mu = self.mu.ptr
         # faces with explicit time dependence: ONE device program for both tables, run by every C entry point for the time of its
         # evaluation (`pdehip_rhs_t::bc_program`, `t`); faces given as Python functions stay on the host (`host_time_dependent`)
+        # (... and faces that are not affine in the adjacent value: the program reads the input field of every evaluation)
         self.program = None
+        if bc_mu is not None and getattr(bc_mu, "reads_value", False):
+            msg = "hip backend: conditions of the chemical potential that depend non-linearly on it (mu is never stored between the two operators)"
+            raise NotImplementedError(msg)
+        if self.host_time_dependent and any(getattr(tb, "reads_value", False) for tb in (bc_c, bc_mu) if tb is not None):
+            msg = "hip backend: conditions given as Python functions together with conditions that depend non-linearly on the field"
+            raise NotImplementedError(msg)
         if self.time_dependent and not self.host_time_dependent:
             from .bc_expr import program_for
 
-            self.program = program_for(require_device(), [self.bc_c, self.bc_mu])
+            self.program = program_for(require_device(), [self.bc_c, self.bc_mu], info)
             if self.program is not None:
                 self.c.bc_program = self.program.ptr
 
@@ -382,7 +389,7 @@ def make_face_setter(backend, bcs, comp_shape: tuple[int, ...] = ()):
     lib = backend._lib
 
     def set_faces(data_full: DeviceArray, args=None) -> None:
-        table.update(args)
+        table.update(args, state=data_full)   # (conditions that are not affine in the adjacent value read it from `data_full`)
         lib.set_ghost_cells(data_full.info.ref, data_full.ncomp, table.c, data_full.ptr, backend.stream)
 
     set_faces.table = table   # type: ignore[attr-defined]
@@ -1242,10 +1249,15 @@ class HipBackendMixin:
             raise NotImplementedError(msg)
         try:
             spec = self.make_rhs_spec(solver.pde, state)
-        except NotImplementedError:
+        except NotImplementedError as err:
             if solver_name == "AdamsBashforthSolver":
                 raise
-            return self._make_expression_stepper(solver, state, post_step=post_step)   # generic expression PDE
+            try:
+                return self._make_expression_stepper(solver, state, post_step=post_step)   # generic expression PDE
+            except NotImplementedError as err2:
+                if any(c.__name__ in ("DiffusionPDE", "CahnHilliardPDE") for c in type(solver.pde).__mro__):
+                    raise err from err2    # the reason the class right-hand side was refused is the informative one
+                raise
         if post_step is not None:
             # the hook runs on the host between steps: the steps are driven from here, one sweep each
             return self._make_expression_stepper(solver, state, SpecRhs(self, spec), post_step=post_step)

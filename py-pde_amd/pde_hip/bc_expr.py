@@ -18,9 +18,12 @@ then costs nothing extra in the time loop) or whenever the time changes.  Faces 
 DEVICE: ``A`` and ``B`` are printed as C, compiled at run time (``pdehip_bcprog_create``, hiprtc) into one small kernel per
 face table / right-hand side that rewrites the coefficient arrays for a given ``t`` (:func:`build_program`); the C time loops
 call it before every right-hand side (``pdehip_rhs_t::bc_program``), so time-dependent conditions cost one extra launch per
-evaluation and no host work.  Conditions given as Python FUNCTIONS cannot travel to the device: they are probed on the host
-(coefficient arrays uploaded before every right-hand side, steps driven from Python); conditions that are non-linear in
-``value`` raise ``NotImplementedError``.
+evaluation and no host work.  An ``F`` that is NOT affine in ``value`` (e.g. a radiation condition ``-value**4``) is the same
+kind of face with ``A = F(value now, dx, coords, t)``, ``B = 0``: the program reads the adjacent cells of the field the
+conditions are about to be applied to (``reads_value``), exactly when the reference evaluates ``arr[..., value_cell]``
+(``local.py:1089-1135``) - before every operator application / right-hand side, Runge-Kutta stages included.  Conditions
+given as Python FUNCTIONS cannot travel to the device: they are probed on the host (coefficient arrays uploaded before every
+right-hand side, steps driven from Python) and must be affine in ``value``.
 """
 
 from __future__ import annotations
@@ -49,6 +52,7 @@ class _AffineFace:
             raise NotImplementedError(msg)
         grid = bc.grid
         self._callable = None
+        self.reads_value = False
         if getattr(bc, "_is_func", False):
             # the condition is a Python function F(adjacent_value, dx, *coords, t) (pde/grids/boundaries/local.py:921-963): it
             # cannot run on the device, but its coefficient arrays can be taken on the host - before every right-hand side,
@@ -76,17 +80,19 @@ class _AffineFace:
             raise NotImplementedError(msg)
         value = by_name.get("value", sp.Symbol("value"))
         slope = sp.diff(expr, value)
-        if slope.has(value):
-            msg = f"hip backend: boundary expression `{expr}` is not linear in `value` (needs run-time code generation)"
-            raise NotImplementedError(msg)
-        offset = expr.subs(value, 0)
+        # not affine in `value`: A = F(value, ...), B = 0, re-evaluated from the field whenever the conditions are applied
+        self.reads_value = bool(slope.has(value))
+        if self.reads_value:
+            offset, slope = expr, sp.Integer(0)
+        else:
+            offset = expr.subs(value, 0)
         args = [by_name.get(n, sp.Symbol(n)) for n in names[1:]]
-        self._offset = sp.lambdify(args, offset, modules="numpy")
+        self._offset = sp.lambdify([value, *args], offset, modules="numpy")
         self._slope = sp.lambdify(args, slope, modules="numpy")
-        self._symbolic = (offset, slope, {n: by_name.get(n, sp.Symbol(n)) for n in names[1:]})   # for the device program
+        self._symbolic = (offset, slope, {n: by_name.get(n, sp.Symbol(n)) for n in names[1:]}, value)   # for the device program
         self.axis, self.upper, self.grid = int(bc.axis), bool(bc.upper), grid
-        self.time_dependent = "t" in by_name
-        self.needs_time = self.time_dependent
+        self.time_dependent = "t" in by_name or self.reads_value     # i.e. "has to be refreshed"
+        self.needs_time = "t" in by_name
         self.dx = float(grid.discretization[bc.axis])
         if mirror:
             self.coords = bc.wall_coordinates()
@@ -119,11 +125,16 @@ class _AffineFace:
             raise NotImplementedError(msg)
         return a, b
 
-    def evaluate(self, t: float) -> tuple[np.ndarray, np.ndarray]:
+    def evaluate(self, t: float, value: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
+        """``value``: the field in the value cells of the face (only read by conditions that are not affine in it; without it
+        such a face gets placeholder zeros - it is refreshed from the field before it is used)."""
         if self._callable is not None:
             return self._evaluate_callable(t)
+        if self.reads_value and value is None:
+            return np.zeros(self.face_shape), np.zeros(self.face_shape)
         with np.errstate(all="ignore"):
-            a = np.asarray(self._offset(self.dx, *self.coords, t), dtype=np.float64)
+            v = 0.0 if value is None else np.asarray(value, dtype=np.float64).reshape(self.face_shape)
+            a = np.asarray(self._offset(v, self.dx, *self.coords, t), dtype=np.float64)
             b = np.asarray(self._slope(self.dx, *self.coords, t), dtype=np.float64)
         return (np.array(np.broadcast_to(a, self.face_shape), dtype=np.float64, order="C"), np.array(np.broadcast_to(b, self.face_shape), dtype=np.float64, order="C"))
 
@@ -142,9 +153,10 @@ def _c_code(expr) -> str:
     return Printer({"precision": 17}).doprint(expr)
 
 
-def build_program(lib, entries) -> Any:
+def build_program(lib, entries, info=None) -> Any:
     """One device program (``pdehip_bcprog_create``) that rewrites the coefficient arrays of all ``entries`` —
-    ``(face: _AffineFace, const buffer, factor buffer)`` of faces given as sympy expressions — for a time ``t``:
+    ``(face: _AffineFace, const buffer, factor buffer)`` of faces given as sympy expressions — for a time ``t`` (and the field
+    the conditions are applied to, layout ``info``: :class:`~pde_hip.device.GridInfo`, for faces that read it):
     returns the handle (``ctypes.c_void_p``), or None when an entry is a Python function (host only)."""
     import ctypes as C
 
@@ -152,13 +164,17 @@ def build_program(lib, entries) -> Any:
 
     if not entries or any(face._callable is not None for face, _, _ in entries):
         return None
+    reads = any(face.reads_value for face, _, _ in entries)
+    if reads and info is None:
+        msg = "boundary conditions that read the field need the layout of the field"
+        raise ValueError(msg)
     cases, descs = [], (_abi.BcProgFace * len(entries))()
     for i, (face, buf_a, buf_b) in enumerate(entries):
-        offset, slope, syms = face._symbolic
+        offset, slope, syms, value = face._symbolic
         grid = face.grid
         axes = list(grid.axes)
         # the generated function sees the coordinates as c0, c1, c2 in grid-axis order
-        sub = {syms["dx"]: sp.Symbol("dx"), syms["t"]: sp.Symbol("t")}
+        sub = {syms["dx"]: sp.Symbol("dx"), syms["t"]: sp.Symbol("t"), value: sp.Symbol("value")}
         for k, name in enumerate(axes):
             sub[syms[name]] = sp.Symbol(f"c{k}")
         cases.append(f"    case {i}: *A = {_c_code(sp.sympify(offset).subs(sub))}; *B = {_c_code(sp.sympify(slope).subs(sub))}; break;")
@@ -168,6 +184,7 @@ def build_program(lib, entries) -> Any:
         d.m1 = int(grid.shape[others[0]]) if len(others) >= 1 else 1
         d.m2 = int(grid.shape[others[1]]) if len(others) >= 2 else 1
         d.dx = float(grid.discretization[face.axis])
+        d.reads_value, d.axis, d.component, d.value_index = int(face.reads_value), int(face.axis), 0, int(face.index)
         bounds = grid.axes_bounds
         for k in range(3):
             d.origin[k], d.step[k], d.index[k] = 0.0, 0.0, 0
@@ -175,26 +192,31 @@ def build_program(lib, entries) -> Any:
         for slot, a in enumerate(others):
             # cell centres (i + 0.5) * dx + x_min, the reference's `discretize_interval` (pde/grids/base.py:88-113)
             d.origin[a], d.step[a], d.index[a] = float(bounds[a][0]), float(grid.discretization[a]), slot + 1
-    source = ("PDEHIP_BC_FN void bc_face(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n{\n"
-              "    (void)dx; (void)c0; (void)c1; (void)c2; (void)t;\n    switch (face) {\n" + "\n".join(cases) + "\n    default: break;\n    }\n}\n")
+    source = ("PDEHIP_BC_FN void bc_face(int face, double value, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n{\n"
+              "    (void)value; (void)dx; (void)c0; (void)c1; (void)c2; (void)t;\n    switch (face) {\n" + "\n".join(cases) + "\n    default: break;\n    }\n}\n")
     handle = C.c_void_p()
-    lib.bcprog_create(source.encode(), len(entries), descs, C.byref(handle))
+    lib.bcprog_create(source.encode(), len(entries), descs, info.ref if reads else None, C.byref(handle))
     return handle
 
 
 class BcProgram:
     """Owner of a ``pdehip_bcprog`` handle (destroyed with the object); ``None``-like when the faces cannot run on the device."""
 
-    def __init__(self, lib, entries):
+    def __init__(self, lib, entries, info=None):
         self.lib, self.entries = lib, list(entries)
-        self.handle = build_program(lib, self.entries)
+        self.reads_value = any(face.reads_value for face, _, _ in self.entries)
+        self.handle = build_program(lib, self.entries, info)
 
     @property
     def ptr(self):
         return None if self.handle is None else self.handle.value
 
-    def run(self, t: float, stream=None) -> None:
-        self.lib.bcprog_run(self.handle, float(t), stream)
+    def run(self, t: float, stream=None, state=None) -> None:
+        """``state``: the (device) field the conditions are applied to - read by faces that are not affine in ``value``."""
+        if self.reads_value and state is None:
+            msg = "boundary conditions that depend non-linearly on the field need the field they are applied to"
+            raise RuntimeError(msg)
+        self.lib.bcprog_run(self.handle, float(t), None if state is None else state.ptr, stream)
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -205,15 +227,16 @@ class BcProgram:
                 pass
 
 
-def program_for(lib, tables) -> "BcProgram | None":
-    """The device program for all time-dependent faces of ``tables`` (face tables of ONE right-hand side), or None when there
-    are none.  Raises ``NotImplementedError`` when a face is a Python function (host-probed: no device program)."""
+def program_for(lib, tables, info=None) -> "BcProgram | None":
+    """The device program for all faces of ``tables`` (face tables of ONE right-hand side) that must be refreshed - they depend
+    on time or read the field (layout ``info``) -, or None when there are none.  Raises ``NotImplementedError`` when a face
+    is a Python function (host-probed: no device program)."""
     entries = []
     for tb in {id(tb): tb for tb in tables if tb is not None}.values():
         entries += list(getattr(tb, "_dynamic", []))
     if not entries:
         return None
-    prog = BcProgram(lib, entries)
+    prog = BcProgram(lib, entries, info)
     if prog.handle is None:
         msg = "boundary conditions given as Python functions are evaluated on the host"
         raise NotImplementedError(msg)
@@ -234,13 +257,25 @@ class ExprFaceTable:
 
     @property
     def time_dependent(self) -> bool:
+        """Some face has to be refreshed before the conditions are applied (it depends on time or reads the field)."""
         return bool(self._dynamic)
+
+    @property
+    def reads_value(self) -> bool:
+        """Some face is not affine in the adjacent value: refreshed from the field the conditions are applied to."""
+        return any(face.reads_value for face, _, _ in self._dynamic)
 
     def copy_into(self, dst) -> None:
         self._table.copy_into(dst)
 
-    def update(self, args=None) -> None:
-        """Re-evaluate the coefficient arrays of time-dependent faces for ``args["t"]`` (no-op otherwise)."""
+    def _host_values(self, face, state) -> np.ndarray:
+        """The value cells of ``face`` out of a full HOST array (test harness: numpy arrays with one ghost layer per axis)."""
+        arr = np.asarray(getattr(state, "arr", state))
+        return np.take(arr, face.index + 1, axis=face.axis)[(slice(1, -1),) * (arr.ndim - 1)]
+
+    def update(self, args=None, state=None) -> None:
+        """Re-evaluate the coefficient arrays of the faces that depend on time / on the field ``state`` - the full array the
+        conditions are about to be applied to - for ``args["t"]`` (no-op when there are none)."""
         if not self._dynamic:
             return
         if args is None or "t" not in args:
@@ -253,7 +288,11 @@ class ExprFaceTable:
             t = 0.0
         else:
             t = float(args["t"])
-        if self._t is not None and t == self._t and self._program is False:
+        reads = self.reads_value
+        if reads and state is None:
+            msg = "boundary conditions that depend non-linearly on the field need the field they are applied to"
+            raise RuntimeError(msg)
+        if self._t is not None and t == self._t and self._program is False and not reads:
             return
         if self._program is None:
             # faces given as expressions are refreshed on the device (one launch); Python functions and the host-side tables of
@@ -263,15 +302,15 @@ class ExprFaceTable:
             if device:
                 from ._lib import require_device
 
-                prog = BcProgram(require_device(), self._dynamic)
+                prog = BcProgram(require_device(), self._dynamic, getattr(state, "info", None))
                 if prog.handle is not None:
                     self._program = prog
         if self._program is not False:
-            self._program.run(t)
+            self._program.run(t, state=state if reads else None)
             self._t = t
             return
         for face, buf_a, buf_b in self._dynamic:
-            a, b = face.evaluate(t)
+            a, b = face.evaluate(t, self._host_values(face, state) if face.reads_value else None)
             self._write(buf_a, a)
             self._write(buf_b, b)
         self._t = t

@@ -509,15 +509,24 @@ class ExpressionRhs:
             self._red_host = np.zeros(1)
             self._cell_volume = float(np.prod(info.dx))
         self._dynamic = [tb for tb in {id(tb): tb for tb in tables.values()}.values() if getattr(tb, "time_dependent", False)]
+        # conditions that are not affine in the adjacent value read it from the field they are applied to: here that has to be
+        # the state itself (the values of intermediate fields are not known when the conditions are refreshed)
+        for p, tb in zip(plan.passes, self.pass_faces):
+            if tb is not None and getattr(tb, "reads_value", False) and p.src != "state":
+                msg = "hip backend: boundary conditions that depend non-linearly on the field, applied to an intermediate field of a nested expression"
+                raise NotImplementedError(msg)
+        if any(getattr(tb, "reads_value", False) for tb in self._dynamic) and getattr(plan, "component", None) is not None:
+            msg = "hip backend: boundary conditions that depend non-linearly on the field, for the components of a vector field"
+            raise NotImplementedError(msg)
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
         # two steps per sweep: the second level would need the faces at t + dt / the integrals of the intermediate level
         self._two_ok: bool | None = False if (self._dynamic or self.has_reductions) else None
         self._fused: dict[str, C.c_void_p | None] = {}
 
-    def _update_faces(self, t: float) -> None:
-        """Coefficient arrays of faces with explicit time dependence (expression BCs, ``pde_hip/bc_expr.py``)."""
+    def _update_faces(self, t: float, state=None) -> None:
+        """Coefficient arrays of faces that depend on the time or on the field ``state`` (expression BCs, ``pde_hip/bc_expr.py``)."""
         for tb in self._dynamic:
-            tb.update({"t": t})
+            tb.update({"t": t}, state=state)
 
     def _faces(self, index: int):
         t = self.pass_faces[index]
@@ -554,7 +563,7 @@ class ExpressionRhs:
             arrays[f"var:{name}"] = arr
         nparams = P_FIRST_REDUCTION + len(self.plan.reductions)
         params = (C.c_double * nparams)(dt, t)
-        self._update_faces(t)
+        self._update_faces(t, state)
         if self._fused2(state, out, wrap, params):
             return
         for i, p in enumerate(self.plan.passes):
@@ -581,7 +590,7 @@ class ExpressionRhs:
             return False
         arrays = {"state": state, "out": k_out, **self.tmps, **self.aux}
         params = (C.c_double * 2)(dt, t)
-        self._update_faces(t)
+        self._update_faces(t, state)
         last = len(self.plan.passes) - 1
         for i, p in enumerate(self.plan.passes):
             h, extras = self._kernel(i, "scaled")
@@ -614,7 +623,7 @@ class ExpressionRhs:
         if not hasattr(self, "_bc_program"):
             from .bc_expr import program_for
 
-            self._bc_program = program_for(self.lib, self._dynamic) if self._dynamic else None
+            self._bc_program = program_for(self.lib, self._dynamic, self.info) if self._dynamic else None
         return self._bc_program
 
     def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list, wrap: str = "euler") -> list:
@@ -761,6 +770,9 @@ class SystemRhs:
     def __init__(self, variables: list[str], parts: list["ExpressionRhs"], info):
         self.variables, self.parts, self.info = list(variables), list(parts), info
         self.ncomp = len(self.variables)
+        if any(getattr(tb, "reads_value", False) for part in self.parts for tb in part._dynamic):
+            msg = "hip backend: boundary conditions that depend non-linearly on the field, in a system of several fields"
+            raise NotImplementedError(msg)
 
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
         comps = {name: state.component(k) for k, name in enumerate(self.variables)}

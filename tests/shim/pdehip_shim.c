@@ -340,7 +340,7 @@ int shim_timed_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, vo
 int pdehip_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt, void *stream)
 {
     (void)stream; GRID(g);
-    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, stream); if (rc) return rc; }
+    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, y_full, stream); if (rc) return rc; }
     TRY(oracle_rhs_scaled(g, rhs, y_full, k_out_full, dt));
     return 0;
 }
@@ -352,7 +352,7 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     if (rhs->bc_program) {
         void *cur = buf_a, *nxt = buf_b, *res = NULL;
         for (int64_t s = 0; s < nsteps; s++) {
-            int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t + (double)s * dt, stream);
+            int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t + (double)s * dt, cur, stream);
             if (rc) return rc;
             TRY(oracle_euler_run(g, rhs, cur, nxt, dt, 1, &res));
             void *t = cur; cur = nxt; nxt = t;
@@ -394,7 +394,7 @@ int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_
     (void)stream; GRID(g);
     *fused = 0;
     if (!fused_enabled() || g->ndim < 2) return 0;
-    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, stream); if (rc) return rc; }
+    if (rhs->bc_program) { int rc = pdehip_bcprog_run(rhs->bc_program, rhs->t, y_in_full, stream); if (rc) return rc; }
     TRY(oracle_rhs_scaled(g, rhs, y_in_full, rate_cur_full, 1.0));
     memcpy(y_out_full, y_in_full, full_bytes(g, 1));
     TRY(oracle_ab2_combine(g, 1, y_out_full, rate_cur_full, rate_prev_full, dt));
@@ -403,17 +403,22 @@ int pdehip_ab2_step(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_in_
 }
 
 /* ---- boundary-condition programs (pdehip_bcprog_*): gcc instead of hiprtc, a host loop instead of a kernel ---------------- */
-typedef void (*bc_face_fn)(int, double, double, double, double, double, double *, double *);
+typedef void (*bc_face_fn)(int, double, double, double, double, double, double, double *, double *);
 typedef struct {
     void *dl;
     bc_face_fn fn;
     int nfaces;
     pdehip_bcprog_face_t *faces;
+    int64_t (*sgeo)[3];   /* faces that read the field: element offset of face cell (0, 0) and the two pitches */
+    int reads, esz;
 } shim_bcprog_t;
-int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, void **handle)
+int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, const pdehip_grid_t *grid, void **handle)
 {
     static int counter = 0;
     if (!source || !faces || !handle || nfaces < 1 || nfaces > 64) return fail(E_VALUE, "bcprog_create: NULL pointer or bad face count");
+    int reads = 0;
+    for (int f = 0; f < nfaces; f++) reads |= faces[f].reads_value != 0;
+    if (reads && !grid) return fail(E_VALUE, "bcprog_create: a face reads the field but no grid is given");
     char dir[] = "/tmp/pdehip_shimbc_XXXXXX";
     if (!mkdtemp(dir)) return fail(E_RUNTIME, "shim: mkdtemp failed");
     char src[600], so[600], cmd[2000];
@@ -422,8 +427,8 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     FILE *f = fopen(src, "w");
     if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
     fprintf(f, "#include <math.h>\n#define PDEHIP_BC_FN static inline\n%s\n"
-               "void bc_face_entry(int face, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n"
-               "{ bc_face(face, dx, c0, c1, c2, t, A, B); }\n", source);
+               "void bc_face_entry(int face, double value, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n"
+               "{ bc_face(face, value, dx, c0, c1, c2, t, A, B); }\n", source);
     fclose(f);
     snprintf(cmd, sizeof(cmd), "gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -fno-fast-math -o %s %s -lm 2> %s/err.txt", so, src, dir);
     if (system(cmd) != 0) {
@@ -444,14 +449,38 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     b->nfaces = nfaces;
     b->faces = malloc(sizeof(*faces) * (size_t)nfaces);
     memcpy(b->faces, faces, sizeof(*faces) * (size_t)nfaces);
+    b->sgeo = calloc((size_t)nfaces, sizeof(*b->sgeo));
+    b->reads = reads;
+    b->esz = reads && grid->dtype == PDEHIP_F32 ? 4 : 8;
+    if (reads) {
+        /* full arrays of the shim: C order, one ghost layer per axis, no padding */
+        const int nd = grid->ndim;
+        int64_t pitch[3] = {0, 0, 0}, pc = 1, off = 0;
+        for (int a = nd - 1; a >= 0; a--) { pitch[a] = pc; pc *= grid->shape[a] + 2; }
+        for (int a = 0; a < nd; a++) off += pitch[a];
+        for (int q = 0; q < nfaces; q++) {
+            const pdehip_bcprog_face_t *F = &faces[q];
+            if (!F->reads_value) continue;
+            if (F->axis < 0 || F->axis >= nd || F->value_index < 0 || F->value_index >= grid->shape[F->axis] || F->component < 0)
+                return fail(E_VALUE, "bcprog_create: face %d: bad axis / value cell / component", q);
+            int others[2] = {0, 0}, no = 0;
+            for (int a = 0; a < nd; a++) if (a != F->axis) others[no++] = a;
+            if ((no >= 1 ? grid->shape[others[0]] : 1) != F->m1 || (no >= 2 ? grid->shape[others[1]] : 1) != F->m2)
+                return fail(E_VALUE, "bcprog_create: face %d: extents do not match the grid", q);
+            b->sgeo[q][0] = off + (int64_t)F->component * pc + F->value_index * pitch[F->axis];
+            b->sgeo[q][1] = no >= 1 ? pitch[others[0]] : 0;
+            b->sgeo[q][2] = no >= 2 ? pitch[others[1]] : 0;
+        }
+    }
     *handle = b;
     return 0;
 }
-int pdehip_bcprog_run(void *handle, double t, void *stream)
+int pdehip_bcprog_run(void *handle, double t, const void *state_full, void *stream)
 {
     (void)stream;
     shim_bcprog_t *b = handle;
     if (!b) return fail(E_VALUE, "bcprog_run: NULL handle");
+    if (b->reads && !state_full) return fail(E_VALUE, "bcprog_run: the conditions read the field, but no field is given");
     for (int f = 0; f < b->nfaces; f++) {
         const pdehip_bcprog_face_t *F = &b->faces[f];
         for (int64_t i1 = 0; i1 < F->m1; i1++)
@@ -459,8 +488,13 @@ int pdehip_bcprog_run(void *handle, double t, void *stream)
                 double c[3];
                 for (int k = 0; k < 3; k++)
                     c[k] = F->index[k] == 0 ? F->origin[k] : ((double)(F->index[k] == 1 ? i1 : i2) + 0.5) * F->step[k] + F->origin[k];
+                double value = 0;
+                if (F->reads_value) {
+                    const int64_t o = b->sgeo[f][0] + i1 * b->sgeo[f][1] + i2 * b->sgeo[f][2];
+                    value = b->esz == 8 ? ((const double *)state_full)[o] : (double)((const float *)state_full)[o];
+                }
                 double a = 0, bb = 0;
-                b->fn(f, F->dx, c[0], c[1], c[2], t, &a, &bb);
+                b->fn(f, value, F->dx, c[0], c[1], c[2], t, &a, &bb);
                 F->const_arr[i1 * F->m2 + i2] = a;
                 F->factor_arr[i1 * F->m2 + i2] = bb;
             }
@@ -473,6 +507,7 @@ int pdehip_bcprog_destroy(void *handle)
     if (!b) return 0;
     if (b->dl) dlclose(b->dl);
     free(b->faces);
+    free(b->sgeo);
     free(b);
     return 0;
 }
@@ -705,7 +740,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     }
     for (int64_t s = 0; s < nsteps; s++) {
         const double params[2] = {dt, t0 + (double)s * dt};
-        if (bc_program) { int rc = pdehip_bcprog_run(bc_program, params[1], stream); if (rc) return rc; }
+        if (bc_program) { int rc = pdehip_bcprog_run(bc_program, params[1], cur, stream); if (rc) return rc; }
         for (int q = 0; q < npasses; q++) {
             const pdehip_jit_pass_t *p = &passes[q];
             const void *ex[3];

@@ -164,7 +164,7 @@ struct HostOps {
     }
     int copy(void *dst, const void *src, size_t bytes, void *) { memmove(dst, src, bytes); return 0; }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
-    int refresh(void *bc_program, double t, void *st) { return pdehip_bcprog_run(bc_program, t, st); }
+    int refresh(void *bc_program, double t, const void *in, void *st) { return pdehip_bcprog_run(bc_program, t, in, st); }
     int fail(const char *msg) { return failf(E_NOTIMPL, "%s", msg); }
     int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
 
@@ -555,7 +555,7 @@ struct SpecEval {
     int slope(void *in, void *k_out, double dt, double t, const StageFuse *, bool *fused, void *st)
     {
         *fused = false;
-        if (rhs->bc_program) SLAB_TRY(pdehip_bcprog_run(rhs->bc_program, t, st));
+        if (rhs->bc_program) SLAB_TRY(pdehip_bcprog_run(rhs->bc_program, t, in, st));
         OTRY(oracle_rhs_scaled(g, rhs, in, k_out, dt));
         return 0;
     }
@@ -596,7 +596,7 @@ struct JitEval {
     {
         *fused = false;
         const double params[2] = {dt, t};
-        if (bc_program) SLAB_TRY(pdehip_bcprog_run(bc_program, t, st));
+        if (bc_program) SLAB_TRY(pdehip_bcprog_run(bc_program, t, in, st));
         const pdehip_jit_pass_t &last = passes[npasses - 1];
         const bool try_stage = sf && stage_fuse > 0 && ncomp == 1 && last.out == -1;
         SLAB_TRY(run(0, npasses - (try_stage ? 1 : 0), (char *)in, (char *)k_out, params, st));

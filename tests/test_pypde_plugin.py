@@ -89,8 +89,14 @@ def test_unsupported_boundaries_raise_not_implemented():
 
     table = convert_bcs_with_expressions(bcs, upload=HostBuf)   # ... expressions affine in `value` become coefficient arrays
     assert table.time_dependent
-    with pytest.raises(NotImplementedError, match="not linear"):
-        convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": "value**2"}, rank=0), upload=HostBuf)
+    # ... expressions that are not: arrays with A = F(value), B = 0 that are rewritten from the field they are applied to
+    nonlin = convert_bcs_with_expressions(grid.get_boundary_conditions({"virtual_point": "value**2"}, rank=0), upload=HostBuf)
+    assert nonlin.time_dependent and nonlin.reads_value and not table.reads_value
+    with pytest.raises(RuntimeError, match="need the field"):
+        nonlin.update({"t": 0.0})
+    full = np.arange(36.0).reshape(6, 6)
+    nonlin.update({"t": 0.0}, state=full)
+    np.testing.assert_array_equal(nonlin.keepalive[-2].arr, full[1:-1, -2] ** 2)    # face y+: the adjacent cells are column -2
 
     # conditions given as Python functions are probed on the host (before every right-hand side): affine ones work ...
     def user_bc(value, dx, x, y, t):

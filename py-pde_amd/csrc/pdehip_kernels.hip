@@ -434,6 +434,9 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     if (!has_y) ry = 1;
     if ((ry != 1 && ry != 2 && ry != 4) || a.n1 < ry || (n2v != a.n2 && a.n2 < CW)) return 0;
     const bool overlap = n2v != a.n2 || a.n1 % ry != 0;
+    // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
+    // with local faces): the narrow tile takes those grids (launch_euler2_t)
+    if (sizeof(T) == 4 && VEC == 4 && ((has_y && a.n1 % ry != 0 && !a.per[1]) || (a.n2 % CW == 1 && !a.per[2]))) return 0;
     if (overlap && m2 == E2_CH_STAGE) {
         // cells of overlapping tiles are computed and stored twice: nothing a sweep writes may be one of its pointwise inputs
         // (the new state of RK4 written over the old one: those sweeps combine with the pointwise kernels)
@@ -623,8 +626,9 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
         if (vec == 2) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
         PDEHIP_TRY((launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry)));
-        // rows shorter than the wide chunk that end inside its 4-cell vector: the narrow tile (2-cell vectors) may still fit
-        if (!*done && n.ndim == 3 && !plan && a.n2 % 4 != 0 && a.n2 < 256) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, stage ? 4 : 2);
+        // what the wide tile declines (rows shorter than its chunk that end inside a 4-cell vector, moved last tiles next to
+        // local faces) the narrow tile (2-cell vectors, 4 rows) may still take
+        if (!*done && n.ndim == 3 && !plan) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 4);
         return 0;
     }
 }

@@ -10,10 +10,10 @@
 #include "pdehip_device.h"
 namespace pdehip {
 #include "pdehip_march2.inc"
-template <typename T, int VEC, int RY, int M2, bool RAGGED, bool NT, int WAVES>
+template <typename T, int VEC, int RY, int M2, bool RAGGED, bool NT, int WAVES, int NB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) e2v_kernel(LapArgs a)
 {
-    euler2_body<T, VEC, RY, M2, true, RAGGED, false, NT>(a);
+    euler2_body<T, VEC, RY, M2, true, RAGGED, false, NT, NB>(a);
 }
 }
 using namespace pdehip;
@@ -21,7 +21,7 @@ using namespace pdehip;
 
 struct Geo { long n, p1, p0, off, total; };
 
-template <int VEC, int RY, bool NT, int WAVES>
+template <int VEC, int RY, bool NT, int WAVES, int NB = 3>
 static double run(const char *name, const Geo &g, const double *in, double *out, long cap, int reps, int nwz_want)
 {
     LapArgs a;
@@ -39,7 +39,7 @@ static double run(const char *name, const Geo &g, const double *in, double *out,
     int nwz = nwz_want; while (a.ntz % nwz) nwz /= 2;
     a.nwy = 1; a.nblocks = a.nxc * tiles / nwz; a.no_swizzle = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&]() { hipLaunchKernelGGL((e2v_kernel<double, VEC, RY, E2_DIFFUSION_UNIT, false, NT, WAVES>), dim3((unsigned)a.nblocks), dim3(64 * nwz), 0, 0, a); };
+    auto launch = [&]() { hipLaunchKernelGGL((e2v_kernel<double, VEC, RY, E2_DIFFUSION_UNIT, false, NT, WAVES, NB>), dim3((unsigned)a.nblocks), dim3(64 * nwz), 0, 0, a); };
     launch(); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; r++) launch();
@@ -78,14 +78,19 @@ int main(int argc, char **argv)
         run<2, 4, true, 2>("2 cells x 4 rows, 2 waves", g, in, ref, 2048, reps, 4);
         if (round == 0) CK(hipMemcpy(href.data(), ref, g.total * 8, hipMemcpyDeviceToHost));
         run<2, 4, false, 2>("same, plain stores", g, in, out, 2048, reps, 4); check("plain");
-        run<1, 4, true, 4>("1 cell x 4 rows, 4 waves", g, in, out, 4096, reps, 4); check("1x4w4");
-        run<1, 4, true, 3>("1 cell x 4 rows, 3 waves", g, in, out, 3072, reps, 4); check("1x4w3");
-        run<1, 4, true, 3>("1 cell x 4 rows, 3w, 8/block", g, in, out, 3072, reps, 8); check("1x4w3b8");
-        run<1, 8, true, 3>("1 cell x 8 rows, 3 waves", g, in, out, 3072, reps, 4); check("1x8w3");
-        run<1, 8, true, 2>("1 cell x 8 rows, 2 waves", g, in, out, 2048, reps, 4); check("1x8w2");
-        run<1, 2, true, 4>("1 cell x 2 rows, 4 waves", g, in, out, 4096, reps, 4); check("1x2w4");
         run<2, 2, true, 2>("2 cells x 2 rows, 2 waves", g, in, out, 2048, reps, 4); check("2x2w2");
-        run<2, 2, true, 3>("2 cells x 2 rows, 3 waves", g, in, out, 3072, reps, 4); check("2x2w3");
+        run<2, 2, true, 2, 4>("2x2, 2 waves, 4 buffers", g, in, out, 2048, reps, 4); check("2x2w2b4");
+        run<2, 2, false, 2, 4>("2x2, 2w, 4 buf, plain st", g, in, out, 2048, reps, 4); check("2x2w2b4p");
+        run<2, 2, true, 2, 4>("2x2, 2w, 4 buf, 4096 waves", g, in, out, 4096, reps, 4); check("2x2w2b4x");
+        run<1, 4, true, 3, 4>("1x4, 3 waves, 4 buffers", g, in, out, 3072, reps, 4); check("1x4w3b4");
+        run<1, 4, true, 2, 4>("1x4, 2 waves, 4 buffers", g, in, out, 2048, reps, 4); check("1x4w2b4");
+        run<1, 2, true, 4, 4>("1x2, 4 waves, 4 buffers", g, in, out, 4096, reps, 4); check("1x2w4b4");
+        run<2, 4, true, 2, 4>("2x4, 2 waves, 4 buffers", g, in, out, 2048, reps, 4); check("2x4w2b4");
+        run<2, 4, true, 1, 4>("2x4, 1 wave, 4 buffers", g, in, out, 1024, reps, 4); check("2x4w1b4");
+        run<2, 8, true, 1, 3>("2x8, 1 wave, 3 buffers", g, in, out, 1024, reps, 4); check("2x8w1b3");
+        run<2, 8, true, 1, 4>("2x8, 1 wave, 4 buffers", g, in, out, 1024, reps, 4); check("2x8w1b4");
+        run<2, 8, false, 1, 4>("2x8, 1w, 4 buf, plain st", g, in, out, 1024, reps, 4); check("2x8w1b4p");
+        run<2, 8, true, 1, 4>("2x8, 1w, 4 buf, 2048 waves", g, in, out, 2048, reps, 4); check("2x8w1b4x");
     }
     return 0;
 }

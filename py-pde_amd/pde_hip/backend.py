@@ -788,21 +788,26 @@ class HipBackendMixin:
         kind = state.__class__.__name__
         fields = list(state) if kind == "FieldCollection" else [state]
         kinds = [f.__class__.__name__ for f in fields]
-        if len(fields) != len(variables) or any(k not in ("ScalarField", "VectorField") for k in kinds):
-            msg = "hip backend expression kernels support scalar and vector fields (or a FieldCollection of them), one per equation"
+        if len(fields) != len(variables) or any(k not in ("ScalarField", "VectorField", "Tensor2Field") for k in kinds):
+            msg = "hip backend expression kernels support scalar, vector and rank-2 tensor fields (or a FieldCollection of them), one per equation"
             raise NotImplementedError(msg)
         # the state as a list of scalar components: a vector field `u` contributes `u#0`, `u#1`, ... (FieldCollection.data and
         # VectorField.data both carry the components along the first axis, pde/fields/collection.py, datafield_base.py:95)
         dim = grid.num_axes
-        flat: list[tuple[str, str, int | None]] = []     # (flat name, variable, component)
+        # a rank-2 field `S` contributes `S#0#0`, `S#0#1`, ... in C order, like `Tensor2Field.data` (dim, dim, *grid)
+        flat: list[tuple[str, str, Any]] = []     # (flat name, variable, component: None / k / (i, j))
         vectors: dict[str, tuple[str, ...]] = {}
+        tensors: dict[str, tuple[tuple[str, ...], ...]] = {}
         for var, k in zip(variables, kinds):
             if k == "VectorField":
                 vectors[var] = tuple(f"{var}#{c}" for c in range(dim))
                 flat += [(f"{var}#{c}", var, c) for c in range(dim)]
+            elif k == "Tensor2Field":
+                tensors[var] = tuple(tuple(f"{var}#{i}#{j}" for j in range(dim)) for i in range(dim))
+                flat += [(f"{var}#{i}#{j}", var, (i, j)) for i in range(dim) for j in range(dim)]
             else:
                 flat.append((var, var, None))
-        if builtin and vectors:
+        if builtin and (vectors or tensors):
             msg = f"hip backend: {eq.__class__.__name__} takes scalar fields"
             raise NotImplementedError(msg)
 
@@ -870,8 +875,8 @@ class HipBackendMixin:
         for name, var, comp in flat:
             try:
                 plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), name, consts, others=tuple(n for n in names if n != name),
-                                      axes=tuple(grid.axes), aliases=aliases, aux=tuple(a for a in aux_host if a not in vectors),
-                                      vectors=vectors, component=comp, user_funcs=user_funcs)
+                                      axes=tuple(grid.axes), aliases=aliases, aux=tuple(a for a in aux_host if a not in vectors and a not in tensors),
+                                      vectors=vectors, component=comp, user_funcs=user_funcs, tensors=tensors)
             except ValueError as err:
                 if "unknown symbol" in str(err):   # the reference's error for this case (pde/pdes/pde.py:455-459)
                     msg = f"Undefined variable in expression for rhs of `{var}`: {err}"
@@ -1178,7 +1183,7 @@ class HipBackendMixin:
                 # every field its own variance; the cell offset keeps the fields' random streams apart
                 for k in range(ncomp):
                     if scales[k] != 0:
-                        lib.add_gaussian_noise(info.ref, 1, arr.component(k).ptr, scales[k], seed, counter[0], k * cells, self.stream)
+                        lib.add_gaussian_noise(info.ref, 1, arr.flat().component(k).ptr, scales[k], seed, counter[0], k * cells, self.stream)
             counter[0] += 1
 
         solver.info["stochastic"] = True

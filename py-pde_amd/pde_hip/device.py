@@ -111,6 +111,12 @@ class DeviceArray:
         stride = (int(np.prod(sub)) if sub else 1) * self.info.comp_elems * self.itemsize
         return DeviceArray(self.info, sub, buffer=self._buffer, ptr=self.ptr + int(index) * stride)
 
+    def flat(self) -> "DeviceArray":
+        """The same memory with ONE tensor axis: all components in C order (a rank-2 field as ``dim * dim`` scalar components)."""
+        if len(self.comp_shape) <= 1:
+            return self
+        return DeviceArray(self.info, (self.ncomp,), buffer=self._buffer, ptr=self.ptr)
+
     def layer_ptr(self, layer: int, comp: int = 0) -> int:
         """Device address of full layer ``layer`` (0 = lower ghost layer) along axis 0."""
         return self.ptr + (comp * self.info.comp_elems + layer * self.info.layer_pitch) * self.itemsize

@@ -52,8 +52,8 @@ class ExpressionPlan:
 
     def __init__(self, expr_str: str, var: str, consts: dict[str, Any] | None = None, others: tuple[str, ...] = (),
                  axes: tuple[str, ...] = (), aliases: dict[str, str] | None = None, aux: tuple[str, ...] = (),
-                 vectors: dict[str, tuple[str, ...]] | None = None, component: int | None = None,
-                 user_funcs: dict[str, Any] | None = None):
+                 vectors: dict[str, tuple[str, ...]] | None = None, component: int | tuple[int, int] | None = None,
+                 user_funcs: dict[str, Any] | None = None, tensors: dict[str, tuple[tuple[str, ...], ...]] | None = None):
         """``axes``: the grid's axis names (``grid.axes``); they name the per-axis derivatives ``d_d<ax>`` / ``d2_d<ax>2``
         (central; reference: numba/backend.py:105-173) that an expression may use besides OPERATORS.  ``aliases``: further
         operator names standing for one of OPERATORS (``{"laplace_outer": "laplace"}``) - same stencil, but a name of its own
@@ -62,8 +62,9 @@ class ExpressionPlan:
         grid which the caller supplies (array-valued ``consts``, the cell coordinates ``x``, ``y``, ``z`` of expressions that
         depend on position: pde/pdes/pde.py:441-447); they enter a pass as centre-only inputs (array name ``aux:<name>``).
         ``vectors``: vector FIELDS of the state by name -> the names of their scalar components among ``var`` / ``others``
-        (``{"u": ("u#0", "u#1")}``); ``component``: the plan evaluates this component of a vector-valued right-hand side (the
-        equation of a vector field; ``var`` is then the name of that component of the field).  ``user_funcs``: the Python
+        (``{"u": ("u#0", "u#1")}``); ``tensors``: rank-2 FIELDS of the state -> rows of component names (``{"S": (("S#0#0", "S#0#1"),
+        ("S#1#0", "S#1#1"))}``); ``component``: the plan evaluates this component of a vector-valued (``k``) or tensor-valued
+        (``(i, j)``) right-hand side (the equation of a vector / tensor field; ``var`` is then the name of that component of the field).  ``user_funcs``: the Python
         functions of ``pde.PDE(..., user_funcs=...)`` (pde/pdes/pde.py:84, pde/tools/expressions.py:173-212).  They cannot run on
         the device as Python; they are TRACED once with symbolic arguments (scalars as sympy expressions, vectors / tensors as
         numpy object arrays of them) and what they return is compiled like the rest of the expression - which covers
@@ -119,6 +120,11 @@ class ExpressionPlan:
             marker = sp.Symbol(f"__vec_{vname}", real=True)
             local[vname] = marker
             self._vector_fields[marker] = [self._state if c == var else other_syms[c] for c in comps]
+        self._tensor_fields: dict[Any, list] = {}
+        for tname, rows in (tensors or {}).items():
+            marker = sp.Symbol(f"__ten_{tname}", real=True)
+            local[tname] = marker
+            self._tensor_fields[marker] = [[self._state if c == var else other_syms[c] for c in row] for row in rows]
         for k, v in (consts or {}).items():
             if k in aux_syms:
                 continue
@@ -141,7 +147,12 @@ class ExpressionPlan:
             if component is None and kind != "s":
                 msg = f"hip backend: the right-hand side `{expr_str}` is a vector, the field is a scalar"
                 raise NotImplementedError(msg)
-            if component is not None:
+            if isinstance(component, tuple):
+                if kind != "t":
+                    msg = f"the right-hand side `{expr_str}` of a tensor field must be a tensor"
+                    raise ValueError(msg)
+                expr = expr[component[0]][component[1]]
+            elif component is not None:
                 if kind != "v":
                     msg = f"the right-hand side `{expr_str}` of a vector field must be a vector"
                     raise ValueError(msg)
@@ -208,10 +219,18 @@ class ExpressionPlan:
                     raise ValueError(msg)
                 return "t", [[a * b for b in args[1][1]] for a in args[0][1]]
             if name in ("dot", "inner"):
-                if len(args) != 2 or args[0][0] != "v" or args[1][0] != "v":
-                    msg = "`dot` needs two vector arguments"
-                    raise ValueError(msg)
-                return "s", sp.Add(*[a * b for a, b in zip(args[0][1], args[1][1])])
+                # pde/backends/numpy/backend.py:306-335: vector . vector, tensor . vector, vector . tensor, tensor . tensor
+                if len(args) != 2 or args[0][0] == "s" or args[1][0] == "s":
+                    msg = "Fields in dot product must have rank >= 1"
+                    raise TypeError(msg)
+                (ka, a), (kb, b) = args
+                if ka == "v" and kb == "v":
+                    return "s", sp.Add(*[x * y for x, y in zip(a, b)])
+                if ka == "t" and kb == "v":
+                    return "v", [sp.Add(*[a[i][j] * b[j] for j in range(nd)]) for i in range(nd)]
+                if ka == "v" and kb == "t":
+                    return "v", [sp.Add(*[a[i] * b[i][j] for i in range(nd)]) for j in range(nd)]
+                return "t", [[sp.Add(*[a[i][j] * b[j][k] for j in range(nd)]) for k in range(nd)] for i in range(nd)]
             if any(k != "s" for k, _ in args):
                 msg = f"hip backend: operator `{name}` of a vector / tensor inside expressions is not supported"
                 raise NotImplementedError(msg)
@@ -219,6 +238,8 @@ class ExpressionPlan:
         if not e.args:
             if e in self._vector_fields:
                 return "v", list(self._vector_fields[e])
+            if e in self._tensor_fields:
+                return "t", [list(row) for row in self._tensor_fields[e]]
             return "s", e
         parts = [self._lower_vectors(a, nd) for a in e.args]
         if all(k == "s" for k, _ in parts):
@@ -775,6 +796,7 @@ class SystemRhs:
             raise NotImplementedError(msg)
 
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
+        state, out = state.flat(), out.flat()   # (a lone rank-2 field arrives with two tensor axes)
         comps = {name: state.component(k) for k, name in enumerate(self.variables)}
         for k, (name, part) in enumerate(zip(self.variables, self.parts)):
             others = {n: a for n, a in comps.items() if n != name}

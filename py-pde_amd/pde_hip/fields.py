@@ -154,23 +154,30 @@ class Tensor2Field(DataFieldBase):
 
 
 class FieldCollection:
-    """Several scalar fields on one grid stored as ONE array with a leading field axis (``pde/fields/collection.py``):
-    ``data`` has shape ``(n, *grid.shape)``, ``collection[i]`` is a :class:`ScalarField` viewing the same memory.  Just enough
+    """Several fields on one grid stored as ONE array with a leading axis over all their components (``pde/fields/collection.py``):
+    ``data`` has shape ``(n, *grid.shape)`` with ``n`` = the sum of the fields' component counts (a scalar 1, a vector ``dim``, a
+    rank-2 field ``dim * dim`` in C order), ``collection[i]`` is a field of its own class viewing the same memory.  Just enough
     of the reference class for multi-field expression PDEs on the GPU box (which has no py-pde)."""
 
     def __init__(self, fields, *, copy_fields: bool = True, dtype=None):
         fields = list(fields)
-        if not fields or any(not isinstance(f, ScalarField) for f in fields):
-            msg = "FieldCollection (mirror) holds scalar fields"
+        if not fields or any(not isinstance(f, DataFieldBase) for f in fields):
+            msg = "FieldCollection (mirror) holds scalar, vector and rank-2 tensor fields"
             raise NotImplementedError(msg)
         self.grid = fields[0].grid
         dt = np.dtype(dtype or np.result_type(*[f.dtype for f in fields]))
-        self._data_full = np.zeros((len(fields),) + self.grid._shape_full, dt)
+        dim = self.grid.num_axes
+        counts = [dim ** f.rank for f in fields]
+        self._data_full = np.zeros((sum(counts),) + self.grid._shape_full, dt)
         self._fields = []
-        for k, f in enumerate(fields):
-            self._data_full[k] = f._data_full
-            view = ScalarField.__new__(ScalarField)
-            view.grid, view.label, view._data_full = self.grid, f.label, self._data_full[k]
+        start = 0
+        for f, c in zip(fields, counts):
+            block = self._data_full[start:start + c]
+            start += c
+            view = type(f).__new__(type(f))
+            view.grid, view.label = self.grid, f.label
+            view._data_full = block[0] if f.rank == 0 else block.reshape((dim,) * f.rank + self.grid._shape_full)
+            view._data_full[...] = f._data_full
             self._fields.append(view)
 
     @property

@@ -620,6 +620,75 @@ def test_vector_field_as_state(shape, periodic):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,periodic", [((14, 130), [False, True]), ((6, 7, 128), [True, True, False])])
+def test_tensor_field_as_state(shape, periodic):
+    """A rank-2 field as (part of) the state of an expression PDE (VERDICT r2 "next" #9): `dim * dim` scalar components of ONE
+    device array in the C order of `Tensor2Field.data`; `tensor_divergence(S)`, `vector_gradient(u)`, `dot` of tensors / vectors
+    (pde/backends/numpy/backend.py:306-335) lowered component by component with the component tables of the rank-2 conditions.
+    A vector + tensor collection (a Maxwell-type model) and a lone tensor field, against the same formulas composed from the
+    oracle's operators."""
+    from oracle import pde_oracle as O
+
+    grid = pde_hip.CartesianGrid([[0, 0.5 * n] for n in shape], shape, periodic=periodic)
+    nd = len(shape)
+    ax = "xyz"[periodic.index(False)]
+    bc = {ax: {"derivative": 0.1}, **{a: "periodic" for a, p in zip("xyz"[:nd], periodic) if p}}
+    rng = np.random.default_rng(83)
+    u0, s0 = rng.uniform(-0.5, 0.5, (nd, *shape)), rng.uniform(-0.5, 0.5, (nd, nd, *shape))
+    g = oracle_grid(grid)
+    f1 = host_faces(grid.get_boundary_conditions(bc, rank=1), (nd,)).c
+    f2 = host_faces(grid.get_boundary_conditions(bc, rank=2), (nd, nd)).c
+
+    def with_ghosts(x, ncomp, faces):
+        full = to_full(grid, np.ascontiguousarray(x))
+        O.set_ghost_cells(g, ncomp, faces, full)
+        return full
+
+    def tdiv(s):        # tensor_divergence(S)[i] = sum_j d_j S[i][j]: the divergence of row i (cartesian.py:999-1096)
+        full = with_ghosts(s, nd * nd, f2)
+        return np.stack([O.divergence(g, full[i]) for i in range(nd)])
+
+    def vgrad(u):       # vector_gradient(u)[i][j] = d_j u_i: the gradient of component i
+        full = with_ghosts(u, nd, f1)
+        return np.stack([O.gradient(g, full[i]) for i in range(nd)])
+
+    def vlap(u):
+        full = with_ghosts(u, nd, f1)
+        return np.stack([O.laplace(g, full[k]) for k in range(nd)])
+
+    def f(u, s):
+        return tdiv(s) + 0.1 * vlap(u), vgrad(u) - s + 0.05 * np.einsum("ij...,jk...->ik...", s, s)
+
+    state = pde_hip.FieldCollection([pde_hip.VectorField(grid, u0), pde_hip.Tensor2Field(grid, s0)])
+    eq = pde_hip.PDE({"u": "tensor_divergence(S) + 0.1 * vector_laplace(u)", "S": "vector_gradient(u) - S + 0.05 * dot(S, S)"}, bc=bc)
+    dt, steps = 1e-3, 4
+    ru, rs = u0.copy(), s0.copy()
+    for _ in range(steps):
+        du, ds = f(ru, rs)
+        ru, rs = ru + dt * du, rs + dt * ds
+    out = eq.solve(state, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert max_rel(out[0].data, ru) < 1e-12 and max_rel(out[1].data, rs) < 1e-12
+    rk, info = eq.solve(state, t_range=steps * dt, dt=dt, solver="runge-kutta", backend="hip", ret_info=True)
+    assert info["solver"]["steps"] == steps and max_rel(rk[1].data, rs) < 5e-2
+    # a lone rank-2 field (its data has TWO tensor axes): pointwise terms, tensor . vector, a nested operator
+    lone = pde_hip.Tensor2Field(grid, s0)
+    eq2 = pde_hip.PDE({"S": "-S + 0.05 * dot(S, S) + 0.3 * vector_gradient(tensor_divergence(S))"}, bc=bc)
+
+    def f2_(s):
+        return -s + 0.05 * np.einsum("ij...,jk...->ik...", s, s) + 0.3 * vgrad(tdiv(s))
+
+    rs = s0.copy()
+    for _ in range(steps):
+        rs = rs + dt * f2_(rs)
+    out = eq2.solve(lone, t_range=steps * dt, dt=dt, solver="euler", backend="hip")
+    assert isinstance(out, pde_hip.Tensor2Field) and out.data.shape == s0.shape and max_rel(out.data, rs) < 1e-12
+    ad, info = eq2.solve(lone, t_range=steps * dt, dt=dt, solver="runge-kutta", adaptive=True, backend="hip", ret_info=True)
+    assert max_rel(ad.data, rs) < 5e-2 and info["solver"]["steps"] >= 1
+    with pytest.raises(ValueError, match="must be a tensor"):
+        pde_hip.PDE({"S": "tensor_divergence(S)"}, bc=bc).solve(lone, t_range=dt, dt=dt, backend="hip")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("steps", [1, 2, 7, 150])
 def test_euler_loop_in_one_call_equals_the_python_loop(steps, monkeypatch):
     """`pdehip_jit_euler_run` (all steps of a fixed-step Euler run in one C call, long runs as a replayed hipGraph) against the

@@ -972,7 +972,7 @@ class HipBackendMixin:
                             cur, nxt = nxt, cur
                         i += 1
                         if post_step is not None:
-                            cur = post_step(cur, t)
+                            cur = post_step(cur, t, nxt) if getattr(post_step, "wants_prev", False) else post_step(cur, t)
                 finally:
                     # also when a hook ends the run with StopIteration: the caller's array holds the latest state
                     if cur is not state_data:
@@ -1144,7 +1144,7 @@ class HipBackendMixin:
         if bool(getattr(solver, "adaptive", False)):
             msg = "Cannot use adaptive stepping with stochastic equation"   # pde/solvers/base.py:446-449
             raise RuntimeError(msg)
-        if solver_name not in {"EulerSolver", "ExplicitSolver"}:
+        if solver_name not in {"EulerSolver", "ExplicitSolver", "MilsteinSolver"}:
             msg = f"Backend `{self.name}` does not support stochastic equations with {solver_name}"
             raise NotImplementedError(msg)
         custom_variance = False
@@ -1152,9 +1152,11 @@ class HipBackendMixin:
             if "make_noise_variance" in vars(cls):
                 custom_variance = cls.__name__ not in {"SDEBase", "PDEBase"}
                 break
-        if custom_variance or getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
-            msg = f"Backend `{self.name}` supports additive Gaussian white noise of constant variance only"
+        if getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
+            msg = f"Backend `{self.name}` supports Gaussian white noise given by its variance only (noise realisations are user code on host arrays)"
             raise NotImplementedError(msg)
+        if custom_variance:
+            return self._make_traced_noise_step(solver, state)
         grid = state.grid
         nd = grid.num_axes
         ncomp = int(np.prod(state.data.shape[: state.data.ndim - nd])) if state.data.ndim > nd else 1
@@ -1176,7 +1178,7 @@ class HipBackendMixin:
         counter = [0]
         lib = self._lib
 
-        def add_noise(arr: DeviceArray) -> None:
+        def add_noise(arr: DeviceArray, prev=None, t: float = 0.0) -> None:
             if ncomp == 1:
                 lib.add_gaussian_noise(info.ref, 1, arr.ptr, scales[0], seed, counter[0], 0, self.stream)
             else:
@@ -1186,6 +1188,78 @@ class HipBackendMixin:
                         lib.add_gaussian_noise(info.ref, 1, arr.flat().component(k).ptr, scales[k], seed, counter[0], k * cells, self.stream)
             counter[0] += 1
 
+        solver.info["stochastic"] = True
+        return add_noise
+
+    def _make_traced_noise_step(self, solver, state):
+        """Euler-Maruyama increment for a noise variance that depends on the field (``make_noise_variance`` overridden by the user,
+        ``pde/pdes/base.py:634-722``; multiplicative noise): ``add_noise(new, old, t)``.
+
+        The user's function ``noise_variance(state_data, t)`` is Python; like ``user_funcs`` it is TRACED once with a symbolic field
+        and compiled into one pointwise kernel that applies the reference's update (``pde/solvers/euler.py:112-141``) to the
+        deterministic step: ``new += sqrt(dt) * sqrt(variance(old, t) / cell_volume) * dW`` and, for interpretations other than
+        Ito, ``+ 0.5 * dt * alpha * d variance / d field (old, t) / cell_volume``.  The variance is evaluated on the state BEFORE
+        the step, like the reference does.  dW comes from the device generator (see :meth:`_make_noise_step`)."""
+        import sympy as sp
+
+        from .expr import ExpressionPlan, ExpressionRhs
+
+        eq = solver.pde
+        grid = state.grid
+        if state.__class__.__name__ != "ScalarField":
+            msg = f"Backend `{self.name}`: a noise variance that depends on the field is supported for scalar fields"
+            raise NotImplementedError(msg)
+        alpha = float(getattr(eq, "_noise_drift_factor", 0.0))
+        milstein = solver.__class__.__name__ == "MilsteinSolver"     # pde/solvers/milstein.py:103-127: always with the derivative
+        need_diff = alpha != 0 or milstein
+        c, t = sp.Symbol("pdehip_c", real=True), sp.Symbol("t", real=True)
+        try:
+            try:
+                func = eq.make_noise_variance(state, backend=self, ret_diff=need_diff)
+            except TypeError:
+                func = eq.make_noise_variance(state, backend=self)
+            traced = func(c, t)
+            var, dvar = (traced if need_diff else (traced, 0))
+            var, dvar = sp.sympify(var), sp.sympify(dvar)
+        except NotImplementedError:
+            raise
+        except Exception as err:   # noqa: BLE001 - whatever the user's code raises on symbolic input
+            msg = (f"hip backend: the noise variance of {eq.__class__.__name__} cannot be traced symbolically ({type(err).__name__}: {err}); "
+                   "it must work on sympy expressions (arithmetic, sympy functions)")
+            raise NotImplementedError(msg) from err
+        unknown = (var.free_symbols | dvar.free_symbols) - {c, t}
+        if unknown:
+            msg = f"hip backend: the noise variance of {eq.__class__.__name__} depends on {sorted(map(str, unknown))}"
+            raise NotImplementedError(msg)
+        info = self.grid_info(grid, state.dtype)
+        cell_volume = float(np.prod(grid.discretization))
+        dt = float(solver.info["dt"])
+        # sqrt(dt) * sqrt(var / V) * dW, the operations of pde/solvers/euler.py:132-133 in their order
+        text = f"pdehip_unew + {float(np.sqrt(dt))!r} * sqrt(({sp.sstr(var)}) * {1.0 / cell_volume!r}) * pdehip_dw"
+        if alpha != 0:
+            text += f" + {0.5 * dt * alpha!r} * ({sp.sstr(dvar)}) * {1.0 / cell_volume!r}"
+        if milstein:
+            # + 0.25 * dvar / V * (dW**2 - dt) with dW = sqrt(dt) * xi   (pde/solvers/milstein.py:119-125)
+            text += f" + 0.25 * ({sp.sstr(dvar)}) * {1.0 / cell_volume!r} * (({float(np.sqrt(dt))!r} * pdehip_dw)**2 - {dt!r})"
+        plan = ExpressionPlan(text, "pdehip_c", {}, axes=tuple(grid.axes), aux=("pdehip_unew", "pdehip_dw"))
+        dw = DeviceArray(info)
+        erhs = ExpressionRhs(self, plan, info, {}, {"pdehip_unew": dw, "pdehip_dw": dw})   # (`unew` is bound per step)
+        rng = getattr(eq, "rng", None)
+        seed = int((rng if rng is not None else np.random.default_rng()).integers(0, 2**32))
+        counter = [0]
+        lib = self._lib
+
+        def add_noise(arr: DeviceArray, prev=None, t: float = 0.0) -> None:
+            if prev is None:
+                msg = "internal: a field-dependent noise variance needs the state before the step"
+                raise RuntimeError(msg)
+            lib.memset(dw.ptr, 0, dw.nbytes, self.stream)
+            lib.add_gaussian_noise(info.ref, 1, dw.ptr, 1.0, seed, counter[0], 0, self.stream)
+            counter[0] += 1
+            erhs.aux["aux:pdehip_unew"] = arr
+            erhs.apply(prev, arr, "rate", 0.0, float(t))     # pointwise, in place on the new state
+
+        add_noise.keepalive = (erhs, dw)   # type: ignore[attr-defined]
         solver.info["stochastic"] = True
         return add_noise
 
@@ -1242,11 +1316,15 @@ class HipBackendMixin:
             # Euler-Maruyama: deterministic Euler step, noise increment, then the hook (pde/solvers/euler.py:120-141)
             hook = post_step
 
-            def post_step(arr, t, _hook=hook):   # noqa: E306
-                add_noise(arr)
+            def post_step(arr, t, prev=None, _hook=hook):   # noqa: E306
+                add_noise(arr, prev, t)      # (`prev`: the state before the step - a variance that depends on the field reads it)
                 return arr if _hook is None else _hook(arr, t)
+
+            post_step.wants_prev = True   # type: ignore[attr-defined]
         solver_name = solver.__class__.__name__
-        if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver", "AdamsBashforthSolver"}:
+        if solver_name == "MilsteinSolver" and add_noise is None:
+            solver_name = "EulerSolver"     # a deterministic equation: the Euler steps of its base class (pde/solvers/milstein.py:29)
+        if solver_name not in {"EulerSolver", "RungeKuttaSolver", "ExplicitSolver", "AdamsBashforthSolver", "MilsteinSolver"}:
             msg = f"Backend `{self.name}` does not support solver {solver_name}"
             raise NotImplementedError(msg)
         if post_step is not None and solver_name == "AdamsBashforthSolver":

@@ -121,7 +121,7 @@ def pytest_generate_tests(metafunc):
         # explicit steppers and, through make_pde_rhs, ScipySolver; the others must raise NotImplementedError
         from pde import solvers as S
 
-        unsupported["hip"] = {getattr(S, n) for n in ("CrankNicolsonSolver", "ImplicitSolver", "MilsteinSolver") if hasattr(S, n)}
+        unsupported["hip"] = {getattr(S, n) for n in ("CrankNicolsonSolver", "ImplicitSolver") if hasattr(S, n)}
 
 
 @pytest.fixture

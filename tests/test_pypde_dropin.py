@@ -551,6 +551,41 @@ def test_consistency_tracker_checks_on_the_device(hip1):
     assert is_finite(state) and not is_finite(np.array([1.0, np.inf]))
 
 
+@pytest.mark.parametrize("solver", ["euler", "milstein"])
+def test_multiplicative_noise_is_traced_symbolically(hip1, solver):
+    """VERDICT r2 "missing" #5: a noise variance that depends on the field (`make_noise_variance` overridden, pde/pdes/base.py:634-722) is
+    user Python; like `user_funcs` it is traced once with a symbolic field and compiled into the Euler-Maruyama / Milstein update
+    (pde/solvers/euler.py:112-141, milstein.py:103-127).  Geometric Brownian motion dc = mu c dt + sigma c dW on an ensemble of
+    independent cells against its analytical moments (the reference's own test, tests/solvers/test_explicit_solvers.py:169-227,
+    with a smaller ensemble); a variance that cannot be traced is refused."""
+    mu, sigma, c0, t_end = 0.35, 0.25, 1.4, 0.4
+
+    class GBM(pde.PDE):
+        def __init__(self, rng):
+            super().__init__({"c": f"{mu} * c"}, noise=1, rng=rng)
+
+        def make_noise_variance(self, state, *, backend, ret_diff=False):
+            if ret_diff:
+                return lambda data, t: (sigma**2 * data**2, 2 * sigma**2 * data)
+            return lambda data, t: sigma**2 * data**2
+
+    n = 4096
+    field = pde.ScalarField(pde.UnitGrid([n]), c0)
+    res, info = GBM(np.random.default_rng(4)).solve(field, t_range=t_end, dt=1e-3, solver=solver, backend="hip", tracker=None, ret_info=True)
+    assert info["solver"]["stochastic"] and info["solver"]["steps"] == 400
+    mean, var = c0 * np.exp(mu * t_end), c0**2 * np.exp(2 * mu * t_end) * (np.exp(sigma**2 * t_end) - 1)
+    assert abs(res.data.mean() - mean) < 5 * np.sqrt(var / n)                    # 5 standard errors of the ensemble mean
+    assert abs(res.data.var() - var) < 0.15 * var
+    assert res.data.min() > 0                                                     # multiplicative noise keeps the sign
+
+    class Untraceable(GBM):
+        def make_noise_variance(self, state, *, backend, ret_diff=False):
+            return lambda data, t: np.where(np.asarray(data, dtype=float) > 0, 1.0, 0.0)      # numpy code on the values
+
+    with pytest.raises(NotImplementedError, match="cannot be traced symbolically"):
+        Untraceable(np.random.default_rng(4)).solve(field, t_range=0.01, dt=1e-3, solver="euler", backend="hip", tracker=None)
+
+
 def test_tensor_fields_as_states(hip1, monkeypatch):
     """VERDICT r2 "next" #9: rank-2 fields as (part of) the state of `pde.PDE` - a vector + tensor `FieldCollection` (a Maxwell-type
     model: `tensor_divergence(S)` drives u, `vector_gradient(u)` drives S) and a lone `Tensor2Field` (whose data has two tensor

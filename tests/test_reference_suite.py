@@ -39,10 +39,9 @@ SUITES: dict[str, dict[str, str]] = {
     },
     # noise scaling: Kolmogorov-Smirnov test of the final field against the analytical normal distribution
     "pdes/test_diffusion_pdes.py": {},
+    # (multiplicative noise - `make_noise_variance` overridden by the test's classes - is traced symbolically: geometric Brownian
+    # motion against its analytical moments, the equilibrium distribution in the Ito / Stratonovich / ... interpretations)
     "solvers/test_explicit_solvers.py": {
-        "MilsteinSolver-hip": "Milstein scheme (explicit solvers beyond Euler / Runge-Kutta are not on the hot path)",
-        "test_stochastic_solvers_geometric_brownian_motion": "state-dependent noise variance needs user code on the device (SURVEY §8 f3 next)",
-        "test_stochastic_solver_equilibrium": "state-dependent noise variance needs user code on the device (SURVEY §8 f3 next)",
         "test_stochastic_solvers_two_interfaces": "noise realisations supplied by user code (SURVEY §8 f3 next)",
     },
     # backend.make_gaussian_noise: Kolmogorov-Smirnov test of 10^4 samples (tests/backends/generic/test_generic_functions.py)

@@ -1,4 +1,28 @@
-# r03: the py-pde plugin class against the REAL libpdehip.so on an MI355X (VERDICT r2 "next" #1)
+"""Write profiles/r03_dropin_real_gpu.md (+ the pytest lines) from the logs of tools/gpu_r3_call19.sh in gpurun_out/r3h/."""
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+O = ROOT / "gpurun_out" / "r3h"
+log = (O / "dropin_pytest.log").read_text()
+out = (O / "dropin_outcomes.txt").read_text().splitlines()
+gpu_tail = [l for l in (O / "pytest_gpu_final.log").read_text().splitlines() if " passed" in l][-1].strip("= ")
+by_file: dict[str, int] = {}
+for l in log.splitlines():
+    if l.startswith("PASSED"):
+        f = l.split()[1].split("::")[0]
+        by_file[f] = by_file.get(f, 0) + 1
+child = [l for l in out if l.startswith(("PASSED", "FAILED", "ERROR", "SKIPPED", "XFAIL"))]
+cf: dict[str, dict[str, int]] = {}
+for l in child:
+    st, name = l.split(" ", 1)
+    cf.setdefault(name.split("::")[0], {}).setdefault(st, 0)
+    cf[name.split("::")[0]][st] += 1
+loaded = sorted({l for l in out if l.startswith("LOADED")})
+tail = log.strip().splitlines()[-1].strip("= ")
+ref = (ROOT / "profiles" / "reference_cpu.json").read_text()
+npass = sum(1 for l in child if l.startswith("PASSED"))
+nfail = sum(1 for l in child if l.startswith("FAILED"))
+md = f"""# r03: the py-pde plugin class against the REAL libpdehip.so on an MI355X (VERDICT r2 "next" #1)
 
 `gpurun` calls with the reference's `pde/` and `tests/` inside the git-ignored scratch directory `_refscratch/` (`tools/ship_reference.sh`; never
 committed, removed after each call - it is the CHECKER, like `tests/golden/make_golden.py` uses it in the build container).  `PDEHIP_DROPIN_REAL=1`
@@ -9,42 +33,26 @@ time-dependent boundary conditions AND for conditions that are not affine in the
 in C, `user_funcs`, rank-2 tensor fields as states, multiplicative noise / Milstein, the device-side consistency tracker, the block solver, the
 two-step kernel for any row length / row count:
 
-pytest summary line: `199 passed, 52 skipped in 146.44s (0:02:26)`
+pytest summary line: `{tail}`
 
 | test file (parent process) | passed |
 |---|---:|
-| `tests/test_class_pde_fuzz.py` | 60 |
-| `tests/test_expression_fuzz.py` | 40 |
-| `tests/test_pypde_dropin.py` | 79 |
-| `tests/test_pypde_plugin.py` | 10 |
-| `tests/test_reference_suite.py` | 10 |
-
+""" + "".join(f"| `{f}` | {n} |\n" for f, n in sorted(by_file.items())) + f"""
 Skipped (52 by pytest's count): the shim's second variant `fused`, which does not exist with the real library; `test_one_device_per_process`
 needs the shim's four pretend devices; `test_registration_does_not_touch_the_device` needs a box WITHOUT a GPU.
 
 `tests/test_reference_suite.py` runs the REFERENCE's own test files in child pytest processes with `"hip"` in the backend lists; per-test
-outcomes of the children (`PDEHIP_DROPIN_LOG`): **116 passed**; the 16 failures are exactly the refused features listed in
+outcomes of the children (`PDEHIP_DROPIN_LOG`): **{npass} passed**; the {nfail} failures are exactly the refused features listed in
 `tests/test_reference_suite.py::SUITES` (complex fields, user-supplied noise realisations, user Python code on the arrays, curvilinear grids,
 `PDE.make_evolution_rate` with `user_funcs`) - the parent test asserts that list both ways.
 
 | reference test file (child process) | outcomes |
 |---|---|
-| `backends/generic/operators/test_cartesian_operators.py` | PASSED 34 |
-| `backends/generic/test_boundaries.py` | PASSED 20 |
-| `backends/generic/test_generic_functions.py` | PASSED 1 |
-| `fields/test_scalar_fields.py` | PASSED 11 |
-| `fields/test_vectorial_fields.py` | PASSED 1 |
-| `pdes/test_diffusion_pdes.py` | PASSED 2 |
-| `pdes/test_pde_class.py` | FAILED 3, PASSED 19 |
-| `solvers/test_explicit_solvers.py` | FAILED 1, PASSED 14 |
-| `solvers/test_generic_solvers.py` | FAILED 7, PASSED 12 |
-| `test_integration.py` | FAILED 5, PASSED 2 |
-
+""" + "".join(f"| `{f}` | {', '.join(f'{k} {v}' for k, v in sorted(d.items()))} |\n" for f, d in sorted(cf.items())) + """
 Shared objects of this repository mapped by those processes (`/proc/self/maps` at session end):
 
 ```
-LOADED[pytest] oracle/libpde_oracle.so py-pde_amd/lib/libpdehip.so
-LOADED[reference-suite child] py-pde_amd/lib/libpdehip.so
+""" + "\n".join(loaded) + f"""
 ```
 
 (the parent maps `oracle/libpde_oracle.so` because `tests/test_pypde_plugin.py` imports the oracle as the CHECKER of the BC conversion; the children
@@ -54,35 +62,15 @@ map `libpdehip.so` only; the host shim is not mapped anywhere.)
 `torch.distributed.run` at world size 1: Euler / RK4 / adaptive RKF45 with three tracker interrupts each equal the reference's serial numpy + scipy
 run (<= 1e-10, equal step counts): `"failures": []` for both decompositions.
 
-In the same call: `pytest tests -m gpu`: 1176 passed, 16 skipped, 131 deselected in 191.66s (0:03:11) (the mirror front end and the C ABI against the oracle and the goldens),
+In the same call: `pytest tests -m gpu`: {gpu_tail} (the mirror front end and the C ABI against the oracle and the goldens),
 `__graft_entry__.smoke()` ok.
 
 ## The reference on the same box's host cores (16 threads), measured in call 1
 
 ```json
-{
- "workload": "DiffusionPDE(D=1) on UnitGrid([512]*3, periodic=True) fp64, explicit Euler dt=0.1",
- "cores": 16,
- "where": "MI355X box host cores (reference shipped as untracked scratch for this one run)",
- "unit": "Mcells/s",
- "reference_torch_cpu_eager": {
-  "value": 54.6,
-  "steps": 6,
-  "seconds": 14.76,
-  "kind": "reference",
-  "note": "py-pde torch backend, device cpu, compile=False; wall of eq.solve incl. its host copies"
- },
- "reference_numpy_scipy": {
-  "value": 64.6,
-  "steps": 2,
-  "seconds": 4.15,
-  "kind": "reference"
- },
- "oracle_port_same_cores": {
-  "value": 8587.8,
-  "steps": 20,
-  "seconds": 0.31,
-  "kind": "port"
- }
-}
+{ref.strip()}
 ```
+"""
+(ROOT / "profiles" / "r03_dropin_real_gpu.md").write_text(md)
+(ROOT / "profiles" / "r03_dropin_real_gpu_pytest.log").write_text("\n".join(l for l in log.splitlines() if l.startswith(("PASSED", "SKIPPED")) or " passed" in l) + "\n")
+print(tail, "| children:", npass, "passed,", nfail, "failed | gpu:", gpu_tail)

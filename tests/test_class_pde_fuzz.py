@@ -82,3 +82,64 @@ def test_random_class_pde_runs_match_the_reference(seed, monkeypatch):
     assert info["solver"]["steps"] == iref["solver"]["steps"]
     assert np.isfinite(ref.data).all()
     assert max_rel(got, ref.data) < 1e-9, (type(eq).__name__, shape, periodic, solver)
+
+
+def _random_nonlinear_face(rng, axes):
+    """Conditions that are NOT affine in the adjacent value (they read the field when they are applied, pde_hip/bc_expr.py)."""
+    a, b = float(rng.uniform(0.1, 0.5)), float(rng.uniform(-0.2, 0.2))
+    other = f" + {b:.3f} * {axes[rng.integers(len(axes))]}" if axes else ""
+    return [
+        {"derivative_expression": f"-{a:.3f} * value**3{other}"},
+        {"value_expression": f"{a:.3f} * tanh(value) + {b:.3f} * sin(2 * t)"},
+        {"virtual_point": f"value / (1 + {a:.3f} * value**2){other}"},
+        {"type": "mixed_expression", "value": f"0.5 + {a:.3f} * value**2", "const": f"{b:.3f}"},
+    ][int(rng.integers(4))]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_runs_with_conditions_that_read_the_field(seed, monkeypatch):
+    """Diffusion / Allen-Cahn / Cahn-Hilliard (conditions of c) with random faces that depend non-linearly on the adjacent value,
+    mixed with the affine kinds above: every right-hand side - the Runge-Kutta stage inputs included - sees the conditions of ITS
+    input field.  hip (host shim) against the reference's numpy backend: equal step counts, <= 1e-9."""
+    monkeypatch.setitem(pde.config, "default_backend", "scipy")
+    rng = np.random.default_rng(5000 + seed)
+    nd = 1 + seed % 3
+    shape = [int(rng.integers(5, 12)) for _ in range(nd)]
+    periodic = [False] + [bool(rng.integers(2)) for _ in range(nd - 1)]
+    dx = float(rng.choice([0.5, 1.0, 2.0]))
+    grid = pde.CartesianGrid([[0, dx * n] for n in shape], shape, periodic=periodic)
+    state = pde.ScalarField.random_uniform(grid, -0.5, 0.5, rng=rng)
+
+    def bc_nonlinear():
+        bc = {}
+        for ax, per in zip(grid.axes, grid.periodic):
+            if per:
+                bc[ax] = "periodic"
+                continue
+            others = "".join(a for a in grid.axes if a != ax)
+            for side in "-+":
+                bc[ax + side] = _random_nonlinear_face(rng, others) if rng.random() < 0.6 else _random_face(rng, others)
+        return bc
+
+    which = seed % 3
+    if which == 0:
+        eq = pde.DiffusionPDE(diffusivity=float(rng.uniform(0.2, 1.5)), bc=bc_nonlinear())
+    elif which == 1:
+        eq = pde.AllenCahnPDE(interface_width=float(rng.uniform(0.5, 1.5)), mobility=float(rng.uniform(0.5, 1.5)), bc=bc_nonlinear())
+    else:
+        eq = pde.CahnHilliardPDE(interface_width=float(rng.uniform(0.5, 1.5)), bc_c=bc_nonlinear(), bc_mu=_random_bc(rng, grid))
+    solver = ["euler", "runge-kutta"][int(rng.integers(2))]
+    adaptive = bool(seed % 4 == 0) and solver == "runge-kutta"
+    dt = 1e-3 * dx**4
+    kw = dict(t_range=10 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
+    if adaptive:
+        kw["adaptive"] = True
+    ref, iref = eq.solve(state, backend="numpy", **kw)
+    with shimlib.use_shim(fused=bool(seed % 2)):
+        import pde_hip.pypde_plugin  # noqa: F401
+
+        out, info = eq.solve(state, backend="hip", **kw)
+        got = np.array(out.data)
+    assert info["solver"]["steps"] == iref["solver"]["steps"]
+    assert np.isfinite(ref.data).all()
+    assert max_rel(got, ref.data) < 1e-9, (type(eq).__name__, shape, periodic, solver)

@@ -95,3 +95,22 @@ def test_cahn_hilliard_runge_kutta_commutes_with_translations(backend, shape, dt
     np.testing.assert_array_equal(r1, np.roll(r0, shift, axis=axes))
     tol = 1e-9 if dtype == np.float64 else 1e-3
     assert abs(r0.sum(dtype=np.float64) - u.sum(dtype=np.float64)) < tol * max(1.0, abs(u.sum(dtype=np.float64)))
+
+
+def test_long_run_at_the_bench_size(backend):
+    """1000 Euler steps of the bench workload (512^3 fp64, periodic, 500 two-step sweeps): the sum is conserved to rounding, the
+    range shrinks monotonically towards the mean (maximum principle), and the result equals the same run done as 4 x 250
+    steps - the loop has no state between calls - bit for bit."""
+    n = 512
+    grid = pde_hip.UnitGrid([n, n, n], periodic=True)
+    u = np.random.default_rng(11).random((n, n, n))
+    eq = pde_hip.DiffusionPDE(1.0)
+    whole = _euler(backend, eq, grid, u, 0.1, 1000)
+    total = u.sum(dtype=np.float64)
+    assert abs(whole.sum(dtype=np.float64) - total) < 1e-10 * total
+    assert u.min() < whole.min() and whole.max() < u.max()
+    assert whole.max() - whole.min() < 0.05 * (u.max() - u.min())      # 1000 steps of dt = 0.1 smooth the white noise out
+    part = u
+    for _ in range(4):
+        part = _euler(backend, eq, grid, part, 0.1, 250)
+    np.testing.assert_array_equal(part, whole)

@@ -414,8 +414,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const Tune2 &t2 = tune2();
     // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32: see tune_f32()
     const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
-    int ry = t2.ry ? t2.ry : 4;
+    int ry = (t2.ry && t2.ry != 8) ? t2.ry : 4;   // (8: the tall tile where it applies, see `tall`)
     if (sizeof(T) == 4) ry = ry_f32;
+    // the tall tile (8 rows, one wave per SIMD, four plane buffers: pdehip_march2.inc): the plain two-step diffusion sweep of fp64
+    // grids whose rows end at chunk boundaries.  PDEHIP_EULER2=8 selects it (measurement: profiles/r03_e2_tile_shapes.log)
+    const bool tall = sizeof(T) == 8 && VEC == 2 && t2.ry == 8 && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
+                      (m2 == E2_DIFFUSION);
     // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
     // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
     // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
@@ -432,7 +436,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const long n2v = (a.n2 + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
     if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
-    if ((ry != 1 && ry != 2 && ry != 4) || a.n1 < ry || (n2v != a.n2 && a.n2 < CW)) return 0;
+    if (tall) ry = 8;
+    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != a.n2 && a.n2 < CW)) return 0;
     const bool overlap = n2v != a.n2 || a.n1 % ry != 0;
     // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
     // with local faces): the narrow tile takes those grids (launch_euler2_t)
@@ -471,7 +476,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         // the RCCL kernel of the halo stream finds free wave slots at once — workgroups march for the whole sweep, a kernel
         // launched behind a full round waits for it to end (measured: 90 us for 13 us of work).
         const bool thin = xplain && a.n0 < 96;
-        const long cap = t2.blocks ? t2.blocks : (thin ? 1536 : 2048);
+        const long cap = t2.blocks ? t2.blocks : (tall ? 1024 : (thin ? 1536 : 2048));   // (the tall tile runs one wave per SIMD)
         static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
         long nxc;
         if (thin) {
@@ -530,6 +535,20 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // the stage epilogue exists for real halo layers on BOTH sides (a run-time argument of the plain instances) but not as
     // one-sided (XS) instances: the first / last slab of a non-periodic axis combines with the pointwise kernels
     if (m2 == E2_CH_STAGE && xplain > 1) return 0;
+    if constexpr (sizeof(T) == 8 && VEC == 2) {
+        if (tall) {
+            if (dry_run) { *done = true; return 0; }
+            const bool nt_ = ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
+            const bool unit_ = a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
+            if (unit_ && nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
+            else if (unit_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
+            else if (nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, false>), grid, block, 0, st, a);
+            PDEHIP_HIP(hipGetLastError());
+            *done = true;
+            return 0;
+        }
+    }
     {   // is there an offline instance of this tile?  (the list below, PDEHIP_E2; asked before a dry run answers "covered")
         const bool xs_ = xplain > 1;
         bool have;

@@ -55,12 +55,20 @@ int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 512;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
-    Geo g; g.n = n; g.p1 = (n + 2 + 1) / 2 * 2; g.p0 = g.p1 * (n + 2); g.off = g.p0 + g.p1 + 2; g.total = g.p0 * (n + 2) + 64;
+    // argv[5]: elements added to the row pitch, argv[6]: elements added to the plane pitch (layout experiments)
+    const long pad1 = argc > 5 ? atol(argv[5]) : 0, pad0 = argc > 6 ? atol(argv[6]) : 0;
+    Geo g; g.n = n; g.p1 = (n + 2 + 1) / 2 * 2 + pad1; g.p0 = g.p1 * (n + 2) + pad0; g.off = g.p0 + g.p1 + 2; g.total = g.p0 * (n + 2) + 64;
+    printf("row pitch %ld elements, plane pitch %ld elements (%ld B)\n", g.p1, g.p0, g.p0 * 8);
     std::vector<double> h((size_t)g.total);
     unsigned long long s = 88172645463325252ULL;
     for (auto &v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) * (1.0 / 9007199254740992.0); }
     double *in, *ref, *out;
-    CK(hipMalloc(&in, g.total * 8)); CK(hipMalloc(&ref, g.total * 8)); CK(hipMalloc(&out, g.total * 8));
+    // argv[3] = 1: physically contiguous allocations (hipExtMallocWithFlags, hipDeviceMallocContiguous) - the rate of the sweep depends on
+    // how the arrays are backed (profiles/r03_timing_modes.log)
+    const bool contig = argc > 3 && atoi(argv[3]) == 1;
+    auto alloc = [&](double **p) { return contig ? hipExtMallocWithFlags((void **)p, g.total * 8, hipDeviceMallocContiguous) : hipMalloc(p, g.total * 8); };
+    CK(alloc(&in)); CK(alloc(&ref)); CK(alloc(&out));
+    printf("allocations: %s  in %p  ref %p  out %p\n", contig ? "contiguous" : "default", (void *)in, (void *)ref, (void *)out);
     CK(hipMemcpy(in, h.data(), g.total * 8, hipMemcpyHostToDevice));
     CK(hipMemset(ref, 0, g.total * 8));
     std::vector<double> href((size_t)g.total), hout((size_t)g.total);
@@ -78,6 +86,7 @@ int main(int argc, char **argv)
         run<2, 4, true, 2>("2 cells x 4 rows, 2 waves", g, in, ref, 2048, reps, 4);
         if (round == 0) CK(hipMemcpy(href.data(), ref, g.total * 8, hipMemcpyDeviceToHost));
         run<2, 4, false, 2>("same, plain stores", g, in, out, 2048, reps, 4); check("plain");
+        if (argc > 4) continue;   // argv[4]: only the library's tile
         run<2, 2, true, 2>("2 cells x 2 rows, 2 waves", g, in, out, 2048, reps, 4); check("2x2w2");
         run<2, 2, true, 2, 4>("2x2, 2 waves, 4 buffers", g, in, out, 2048, reps, 4); check("2x2w2b4");
         run<2, 2, false, 2, 4>("2x2, 2w, 4 buf, plain st", g, in, out, 2048, reps, 4); check("2x2w2b4p");

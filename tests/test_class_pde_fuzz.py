@@ -131,7 +131,7 @@ def test_random_runs_with_conditions_that_read_the_field(seed, monkeypatch):
     solver = ["euler", "runge-kutta"][int(rng.integers(2))]
     adaptive = bool(seed % 4 == 0) and solver == "runge-kutta"
     dt = 1e-3 * dx**4
-    kw = dict(t_range=10 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
+    kw = dict(t_range=6 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
     if adaptive:
         kw["adaptive"] = True
     ref, iref = eq.solve(state, backend="numpy", **kw)

@@ -340,8 +340,8 @@ def test_expression_and_time_dependent_bcs(hip1):
     pde.config["default_backend"] = "scipy"
     try:
         for solver, kw in (("euler", {}), ("runge-kutta", {}), ("runge-kutta", {"adaptive": True})):
-            r_hip, info = eq.solve(state, t_range=0.3, dt=0.01, solver=solver, backend="hip", tracker=None, ret_info=True, **kw)
-            r_ref = eq.solve(state, t_range=0.3, dt=0.01, solver=solver, backend="numpy", tracker=None, **kw)
+            r_hip, info = eq.solve(state, t_range=0.1, dt=0.01, solver=solver, backend="hip", tracker=None, ret_info=True, **kw)
+            r_ref = eq.solve(state, t_range=0.1, dt=0.01, solver=solver, backend="numpy", tracker=None, **kw)
             assert max_rel(r_hip.data, r_ref.data) < (1e-7 if kw else 1e-11), solver
             assert info["solver"]["steps"] > 0
     finally:
@@ -476,7 +476,7 @@ def test_time_dependent_conditions_are_refreshed_on_the_device(hip1):
     monkey.setitem(pde.config, "default_backend", "scipy")
     try:
         for solver, kw in [("euler", {}), ("runge-kutta", {}), ("runge-kutta", {"adaptive": True}), ("adams-bashforth", {})]:
-            common = dict(t_range=0.05, dt=1e-3, solver=solver, tracker=None, ret_info=True, **kw)
+            common = dict(t_range=0.012, dt=1e-3, solver=solver, tracker=None, ret_info=True, **kw)
             ref, iref = eq.solve(state, backend="numpy", **common)
             got, info = eq.solve(state, backend="hip", **common)
             assert info["solver"]["steps"] == iref["solver"]["steps"], solver
@@ -508,7 +508,7 @@ def test_conditions_that_depend_nonlinearly_on_the_field(hip1):
         for eq, ref_backend in ((pde.DiffusionPDE(0.3, bc=bc), "numpy"), (pde.PDE({"c": "0.3 * laplace(c) - 0.1 * c**3"}, bc=bc_poly), "torch"),
                                 (pde.AllenCahnPDE(0.5, bc=bc), "numpy")):
             for solver, kw in [("euler", {}), ("runge-kutta", {}), ("runge-kutta", {"adaptive": True})]:
-                common = dict(t_range=0.03, dt=1e-3, solver=solver, tracker=None, ret_info=True, **kw)
+                common = dict(t_range=0.008, dt=1e-3, solver=solver, tracker=None, ret_info=True, **kw)
                 try:
                     ref, iref = eq.solve(state, backend=ref_backend, **common)
                 except NotImplementedError:      # (the reference's torch backend has Euler steppers only)

@@ -532,10 +532,11 @@ class ExpressionRhs:
         self._dynamic = [tb for tb in {id(tb): tb for tb in tables.values()}.values() if getattr(tb, "time_dependent", False)]
         # conditions that are not affine in the adjacent value read it from the field they are applied to: here that has to be
         # the state itself (the values of intermediate fields are not known when the conditions are refreshed)
-        for p, tb in zip(plan.passes, self.pass_faces):
-            if tb is not None and getattr(tb, "reads_value", False) and p.src != "state":
-                msg = "hip backend: boundary conditions that depend non-linearly on the field, applied to an intermediate field of a nested expression"
-                raise NotImplementedError(msg)
+        # ... an operator of a nested expression applies them to an INTERMEDIATE field (like the reference: `value` is the adjacent
+        # value of whatever the operator acts on): those conditions are refreshed pass by pass from the pass's own input, which
+        # keeps the evaluation out of the C loops and of the fused two-level sweep
+        self._reads_intermediate = any(tb is not None and getattr(tb, "reads_value", False) and p.src != "state"
+                                       for p, tb in zip(plan.passes, self.pass_faces))
         if any(getattr(tb, "reads_value", False) for tb in self._dynamic) and getattr(plan, "component", None) is not None:
             msg = "hip backend: boundary conditions that depend non-linearly on the field, for the components of a vector field"
             raise NotImplementedError(msg)
@@ -552,6 +553,12 @@ class ExpressionRhs:
     def _faces(self, index: int):
         t = self.pass_faces[index]
         return None if t is None else t.c
+
+    def _refresh_for_pass(self, index: int, src, t: float) -> None:
+        """Conditions that read the field, applied to an intermediate field: rewritten from the input of THIS pass."""
+        tb = self.pass_faces[index]
+        if self._reads_intermediate and tb is not None and getattr(tb, "reads_value", False):
+            tb.update({"t": t}, state=src)     # (also for passes on the state itself: an earlier pass may have rewritten a shared table)
 
     def _kernel(self, index: int, wrap: str):
         key = (index, wrap if self.plan.passes[index].out == "out" else "rate")
@@ -598,6 +605,7 @@ class ExpressionRhs:
             ex = (C.c_void_p * 3)()
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
+            self._refresh_for_pass(i, arrays[p.src], t)
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, nparams, self._faces(i), self.backend.stream)
 
     def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:
@@ -606,7 +614,7 @@ class ExpressionRhs:
         update + error norm into ``err``).  Returns False when the sweep is not available - then ``k_out`` holds the slope
         (plain ``apply``) and the caller combines with the pointwise kernels.  Two-pass chains keep their fused two-level
         sweep (tmp in registers) and combine separately."""
-        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None or self.has_reductions:
+        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None or self.has_reductions or self._reads_intermediate:
             self.apply(state, k_out, "scaled", dt, t)
             return False
         arrays = {"state": state, "out": k_out, **self.tmps, **self.aux}
@@ -637,7 +645,7 @@ class ExpressionRhs:
         """The passes of this expression can run inside the C loops (``pdehip_jit_euler_run`` / ``pdehip_jit_rk_run``): no
         integrals (their values travel through the host) and no conditions given as Python functions (conditions that are
         expressions of time are refreshed on the device inside the loops: :meth:`bc_program`)."""
-        return not self.has_reductions and not any(getattr(tb, "host_only", False) for tb in self._dynamic)
+        return not self.has_reductions and not self._reads_intermediate and not any(getattr(tb, "host_only", False) for tb in self._dynamic)
 
     def bc_program(self):
         """Device program (``pde_hip.bc_expr.BcProgram``) of all time-dependent faces of this expression's tables, or None."""
@@ -719,8 +727,8 @@ class ExpressionRhs:
         if wrap not in self._fused:
             h = None
             ps = self.plan.passes
-            if (not self.has_reductions and len(ps) == 2 and ps[0].src == "state" and not ps[0].extras and ps[1].src == ps[0].out and ps[1].out == "out"
-                    and self.pass_faces[1] is not None):
+            if (not self.has_reductions and not self._reads_intermediate and len(ps) == 2 and ps[0].src == "state" and not ps[0].extras
+                    and ps[1].src == ps[0].out and ps[1].out == "out" and self.pass_faces[1] is not None):
                 body1, ex1 = self.plan.epilogue(ps[0], "rate")
                 body2, ex2 = self.plan.epilogue(ps[1], wrap)
                 if not ex1 and ex2 in ([], ["state"]):

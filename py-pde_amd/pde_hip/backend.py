@@ -189,11 +189,17 @@ def class_expressions(eq):
     kuramoto_sivashinsky.py:106-111, SwiftHohenbergPDE swift_hohenberg.py:104-113, WavePDE wave.py:106-109, KleinGordonPDE
     klein_gordon.py:124-127.  Matched by class name along the MRO like :func:`pde_kind` (subclasses that redefine the
     right-hand side are refused, :func:`known_pde_class`)."""
-    base = known_pde_class(eq, {"AllenCahnPDE", "KPZInterfacePDE", "KuramotoSivashinskyPDE", "SwiftHohenbergPDE", "KleinGordonPDE", "WavePDE"})
+    base = known_pde_class(eq, {"AllenCahnPDE", "KPZInterfacePDE", "KuramotoSivashinskyPDE", "SwiftHohenbergPDE", "KleinGordonPDE", "WavePDE",
+                                "CahnHilliardPDE"})
     if base is None:
         return None
     names = [cls.__name__ for cls in base.__mro__]
     outer = {"laplace_outer": "laplace"}
+    if "CahnHilliardPDE" in names:
+        # (pde/pdes/cahn_hilliard.py:115-122; the fused class right-hand side - RhsSpec - comes first: this form serves what it
+        # refuses, e.g. conditions of mu that depend non-linearly on mu)
+        return ({"c": "laplace_outer(c**3 - c - interface_width * laplace(c))"}, {"interface_width": float(eq.interface_width)},
+                {("c", "laplace"): eq.bc_c, ("c", "laplace_outer"): eq.bc_mu}, outer)
     if "AllenCahnPDE" in names:
         return ({"c": "mobility * (interface_width * laplace(c) - c**3 + c)"},
                 {"mobility": float(eq.mobility), "interface_width": float(eq.interface_width)}, {("c", "laplace"): eq.bc}, {})

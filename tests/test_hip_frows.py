@@ -138,8 +138,16 @@ def test_nonlinear_conditions_read_the_field(rng, dtype):
                                    atol=1e-12 if dtype == np.float64 else 1e-4)
     # refused where the field the conditions would read is never stored: conditions of mu, intermediate fields of nested operators
     state = pde_hip.ScalarField(grid, rng.uniform(-1, 1, grid.shape))
-    with pytest.raises(NotImplementedError, match="chemical potential"):
-        pde_hip.CahnHilliardPDE(bc_c="auto_periodic_neumann", bc_mu=bc).solve(state, t_range=1e-3, dt=1e-4, backend="hip", tracker=None)
+    # conditions of mu that depend non-linearly on mu: the fused class right-hand side (mu in registers) declines, the expression form
+    # of the class takes over - against the two operators composed on the host
+    host_c, host_mu = _HostRhs(grid, {"x": {"derivative": 0.1}, "y": {"value": 0.2}}, 1.0), _HostRhs(grid, bc, 1.0)
+    y0 = rng.uniform(-0.5, 0.5, grid.shape)
+    y, dt_ = y0.copy(), 2e-6      # (explicit steps of a fourth-order operator: dt << dx**4)
+    for i in range(5):
+        y = y + dt_ * host_mu(y**3 - y - 0.8 * host_c(y, i * dt_), i * dt_)
+    out = pde_hip.CahnHilliardPDE(0.8, bc_c={"x": {"derivative": 0.1}, "y": {"value": 0.2}}, bc_mu=bc).solve(
+        pde_hip.ScalarField(grid, y0), t_range=5 * dt_, dt=dt_, solver="euler", backend="hip", tracker=None)
+    assert np.abs(out.data - y).max() <= 1e-11 * np.abs(y).max()
     # an operator of a nested expression applies the conditions to an INTERMEDIATE field (`value` = the adjacent value of c**3 - c):
     # refreshed pass by pass from the pass's own input - against the same right-hand side composed on the host
     host = _HostRhs(grid, bc, 0.3)

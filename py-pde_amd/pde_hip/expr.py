@@ -799,9 +799,11 @@ class SystemRhs:
     def __init__(self, variables: list[str], parts: list["ExpressionRhs"], info):
         self.variables, self.parts, self.info = list(variables), list(parts), info
         self.ncomp = len(self.variables)
-        if any(getattr(tb, "reads_value", False) for part in self.parts for tb in part._dynamic):
-            msg = "hip backend: boundary conditions that depend non-linearly on the field, in a system of several fields"
-            raise NotImplementedError(msg)
+        # conditions that read the field: an operator of one equation may act on ANOTHER field of the system - refreshed pass by
+        # pass from the array the pass reads (the component views below), which keeps the system out of the C loops
+        for part in self.parts:
+            if any(getattr(tb, "reads_value", False) for tb in part._dynamic):
+                part._reads_intermediate = True
 
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
         state, out = state.flat(), out.flat()   # (a lone rank-2 field arrives with two tensor axes)

@@ -517,6 +517,13 @@ def test_conditions_that_depend_nonlinearly_on_the_field(hip1):
                 got, info = eq.solve(state, backend="hip", **common)
                 assert info["solver"]["steps"] == iref["solver"]["steps"], (type(eq).__name__, solver)
                 assert max_rel(got.data, ref.data) < 1e-10, (type(eq).__name__, solver, kw)
+        # a system of two fields, one equation applying an operator to the OTHER field: refreshed from the array each pass reads
+        rng2 = np.random.default_rng(8)
+        uv = pde.FieldCollection([pde.ScalarField.random_uniform(grid, 0.5, 1.5, rng=rng2), pde.ScalarField.random_uniform(grid, 2.5, 3.5, rng=rng2)])
+        sys_bc = {"x-": {"derivative_expression": "-0.1 * value**2 + 0.05 * y"}, "x+": {"value_expression": "0.5 + 0.1 * value**2"}, "y": {"derivative": 0.1}}
+        eq = pde.PDE({"u": "0.3 * laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v) + 0.2 * laplace(u) + 2 * u - u**2 * v"}, bc=sys_bc)
+        common = dict(t_range=0.005, dt=5e-4, solver="euler", tracker=None)
+        assert max_rel(eq.solve(uv, backend="hip", **common).data, eq.solve(uv, backend="torch", **common).data) < 1e-10
         # conditions of mu that depend non-linearly on mu: the fused class right-hand side never stores mu and declines; the
         # expression form of the class (two passes, the conditions refreshed from mu before the outer operator) takes over
         ch = pde.CahnHilliardPDE(interface_width=0.8, bc_c={"x": {"derivative": 0.1}, "y": {"value": 0.2}}, bc_mu=bc)

@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 3
+#define PDEHIP_ABI_VERSION 4
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -123,12 +123,15 @@ typedef struct pdehip_bcprog_face {
     double *const_arr, *factor_arr;   /* fp64 device arrays of m1 * m2 face cells (C order), written by the program */
     int64_t m1, m2;                   /* face extents along the remaining grid axes in grid order (1 where there is none) */
     double origin[3], step[3];        /* per coordinate k: index[k] == 0: c[k] = origin[k] (the wall, or an unused slot);        */
-    int32_t index[3];                 /*   index[k] == 1 / 2: c[k] = (i1 / i2 + 0.5) * step[k] + origin[k] - the cell centres of */
+    int32_t index[3];                 /*   index[k] == 1 / 2: c[k] = (first[k] + i1 / i2 + 0.5) * step[k] + origin[k] - cell centres of */
     int32_t reads_value;              /*   the reference (discretize_interval, pde/grids/base.py:88-113), operation by operation */
     double dx;                        /* spacing normal to the wall */
     int32_t axis;                     /* reads_value: grid axis normal to the face, ...                                      */
     int32_t component;                /*   ... component of the field (0 for a scalar field) and ...                          */
     int64_t value_index;              /*   ... valid index along `axis` of the cells whose values are handed to bc_face        */
+    int64_t first[3];                 /* per coordinate k with index[k] != 0: global index of the face's first cell - the face of a slab / block of a
+                                         decomposed grid evaluates c[k] = ((first[k] + i) + 0.5) * step[k] + origin[k] with the bounds of the WHOLE grid,
+                                         bit-identical to the undecomposed run (0 for a whole grid)                              */
 } pdehip_bcprog_face_t;
 /* `grid`: layout of the fields handed to pdehip_bcprog_run (NULL when no face reads the field) */
 int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_face_t *faces, const pdehip_grid_t *grid, void **handle);

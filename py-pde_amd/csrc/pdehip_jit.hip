@@ -565,6 +565,7 @@ struct BcFaceDev {   // device copy of a face descriptor + the start of its cell
     long m1, m2;
     double origin[3], step[3];
     int index[3];
+    long first[3];     // global index of the first face cell per coordinate (slabs / blocks of a decomposed grid)
     int reads;         // the face reads the field: element offset of face cell (i1, i2) = soff + i1 * sp1 + i2 * sp2
     double dx;
     long start;
@@ -580,7 +581,7 @@ struct BcProg {
     int esz = 8;       // bytes per element of the field
 };
 const char *kBcKernel = R"SRC(
-struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; int reads; double dx; long start; long soff, sp1, sp2; };
+struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; long first[3]; int reads; double dx; long start; long soff, sp1, sp2; };
 extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t, const void *state, int esz)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
@@ -593,7 +594,7 @@ extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *fa
         for (int k = 0; k < 3; k++) {
             const int w = F.index[k];
             // the cell centres of the reference, operation by operation: (i + 0.5) * dx + x_min  (pde/grids/base.py:112-113)
-            c[k] = w == 0 ? F.origin[k] : ((double)(w == 1 ? i1 : i2) + 0.5) * F.step[k] + F.origin[k];
+            c[k] = w == 0 ? F.origin[k] : ((double)(F.first[k] + (w == 1 ? i1 : i2)) + 0.5) * F.step[k] + F.origin[k];
         }
         double value = 0;
         if (F.reads) {
@@ -649,7 +650,7 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
         if (!s.const_arr || !s.factor_arr || s.m1 < 1 || s.m2 < 1) { delete b; PDEHIP_FAIL(E_VALUE, "bcprog_create: face %d has no arrays / cells", f); }
         BcFaceDev &d = host[f];
         d.A = s.const_arr; d.B = s.factor_arr; d.m1 = s.m1; d.m2 = s.m2; d.dx = s.dx; d.start = start;
-        for (int k = 0; k < 3; k++) { d.origin[k] = s.origin[k]; d.step[k] = s.step[k]; d.index[k] = s.index[k]; }
+        for (int k = 0; k < 3; k++) { d.origin[k] = s.origin[k]; d.step[k] = s.step[k]; d.index[k] = s.index[k]; d.first[k] = s.first[k]; }
         d.reads = s.reads_value != 0; d.soff = d.sp1 = d.sp2 = 0;
         if (d.reads) {
             // the cell (value_index along the face's axis, i1, i2 along the others in grid order) of component `component`

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -81,7 +81,7 @@ class BcProgFace(C.Structure):
 
     _fields_ = [("const_arr", C.c_void_p), ("factor_arr", C.c_void_p), ("m1", C.c_int64), ("m2", C.c_int64),
                 ("origin", C.c_double * 3), ("step", C.c_double * 3), ("index", C.c_int32 * 3), ("reads_value", C.c_int32), ("dx", C.c_double),
-                ("axis", C.c_int32), ("component", C.c_int32), ("value_index", C.c_int64)]
+                ("axis", C.c_int32), ("component", C.c_int32), ("value_index", C.c_int64), ("first", C.c_int64 * 3)]
 
 
 JIT_NONE = -(2**31)   # PDEHIP_JIT_NONE

@@ -42,9 +42,12 @@ def is_expression_bc(bc) -> bool:
 
 
 class _AffineFace:
-    """``A`` and ``B`` of one expression face as numpy callables of ``t``."""
+    """``A`` and ``B`` of one expression face as numpy callables of ``t``.  ``window = (lo, hi)``: the box (global cell ranges
+    per grid axis) of a slab / block of a decomposed grid - the face then covers the box's extent along the other axes, with the
+    wall coordinates of the WHOLE grid (bit-identical to the undecomposed run; the reference rebuilds the conditions on a
+    sub-grid with its own bounds, ``pde/grids/_mesh.py:535-569``), and the value cell is counted from the box's first cell."""
 
-    def __init__(self, bc):
+    def __init__(self, bc, window=None):
         import sympy as sp
 
         if getattr(bc, "rank", 0) != 0:
@@ -65,9 +68,9 @@ class _AffineFace:
             self.dx = float(grid.discretization[bc.axis])
             coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
             self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
-            self.face_shape = self.coords[0].shape if self.coords else ()
             index = int(bc._get_value_cell_index(with_ghost_cells=False))
-            self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
+            self.axis, self.upper, self.grid = int(bc.axis), bool(bc.upper), grid
+            self._set_window(window, index)
             self.evaluate(0.0)   # raises for functions that are not affine in the adjacent value
             return
         mirror = hasattr(bc, "virtual_point_sympy")       # pde_hip.boundaries.ExpressionBC (stand-alone mirror)
@@ -101,8 +104,25 @@ class _AffineFace:
             coords = grid._boundary_coordinates(axis=bc.axis, upper=bc.upper)
             self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
             index = int(bc._get_value_cell_index(with_ghost_cells=False))
+        self._set_window(window, index)
+
+    def _set_window(self, window, index: int) -> None:
+        """Cut the face to the box ``window`` (None: the whole grid); ``index``: value cell along the face's axis (whole grid)."""
+        grid, axis = self.grid, self.axis
+        nd = len(grid.shape)
+        index = index if index >= 0 else index + int(grid.shape[axis])
+        if window is None:
+            self.lo, self.local_shape = [0] * nd, [int(n) for n in grid.shape]
+        else:
+            lo, hi = window
+            self.lo, self.local_shape = [int(v) for v in lo], [int(h) - int(l) for l, h in zip(lo, hi)]
+            if not self.lo[axis] <= index < self.lo[axis] + self.local_shape[axis]:
+                msg = "boundary condition of a decomposed axis reads a cell of another slab / block"
+                raise NotImplementedError(msg)
+            cut = tuple(slice(self.lo[a], self.lo[a] + self.local_shape[a]) for a in range(nd) if a != axis)
+            self.coords = [np.ascontiguousarray(c[cut]) for c in self.coords]
         self.face_shape = self.coords[0].shape if self.coords else ()
-        self.index = index if index >= 0 else index + int(grid.shape[bc.axis])
+        self.index = index - self.lo[axis]
 
     def _evaluate_callable(self, t: float) -> tuple[np.ndarray, np.ndarray]:
         shape = self.face_shape
@@ -181,21 +201,21 @@ def build_program(lib, entries, info=None) -> Any:
         d = descs[i]
         d.const_arr, d.factor_arr = buf_a.ptr, buf_b.ptr
         others = [a for a in range(len(axes)) if a != face.axis]
-        d.m1 = int(grid.shape[others[0]]) if len(others) >= 1 else 1
-        d.m2 = int(grid.shape[others[1]]) if len(others) >= 2 else 1
+        d.m1 = face.local_shape[others[0]] if len(others) >= 1 else 1
+        d.m2 = face.local_shape[others[1]] if len(others) >= 2 else 1
         d.dx = float(grid.discretization[face.axis])
         d.reads_value, d.axis, d.component, d.value_index = int(face.reads_value), int(face.axis), 0, int(face.index)
         bounds = grid.axes_bounds
         for k in range(3):
-            d.origin[k], d.step[k], d.index[k] = 0.0, 0.0, 0
+            d.origin[k], d.step[k], d.index[k], d.first[k] = 0.0, 0.0, 0, 0
         d.origin[face.axis] = float(bounds[face.axis][1] if face.upper else bounds[face.axis][0])   # the wall
         for slot, a in enumerate(others):
             # cell centres (i + 0.5) * dx + x_min, the reference's `discretize_interval` (pde/grids/base.py:88-113)
-            d.origin[a], d.step[a], d.index[a] = float(bounds[a][0]), float(grid.discretization[a]), slot + 1
+            d.origin[a], d.step[a], d.index[a], d.first[a] = float(bounds[a][0]), float(grid.discretization[a]), slot + 1, face.lo[a]
     source = ("PDEHIP_BC_FN void bc_face(int face, double value, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n{\n"
               "    (void)value; (void)dx; (void)c0; (void)c1; (void)c2; (void)t;\n    switch (face) {\n" + "\n".join(cases) + "\n    default: break;\n    }\n}\n")
     handle = C.c_void_p()
-    lib.bcprog_create(source.encode(), len(entries), descs, info.ref if reads else None, C.byref(handle))
+    lib.bcprog_create(source.encode(), len(entries), descs, getattr(info, "ref", info) if reads else None, C.byref(handle))
     return handle
 
 
@@ -321,42 +341,57 @@ class ExprFaceTable:
         return any(face._callable is not None for face, _, _ in self._dynamic)
 
 
-def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None) -> ExprFaceTable:
-    """``convert_bcs`` that also lowers expression conditions (affine in ``value``) onto coefficient arrays."""
-    from ._lib import require_device
-    from .backend import _upload_f64, convert_bcs
+def _write_buffer(buf, arr: np.ndarray) -> None:
+    host = getattr(buf, "arr", None)
+    if host is not None:                      # host-side tables of the test harness
+        host[...] = arr.reshape(host.shape)
+    else:
+        from ._lib import require_device
 
-    if upload is None:
-        upload = _upload_f64
+        require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None)
 
-    def write(buf, arr: np.ndarray) -> None:
-        host = getattr(buf, "arr", None)
-        if host is not None:                      # host-side tables of the test harness
-            host[...] = arr.reshape(host.shape)
-        else:
-            require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None)
 
-    expr_faces: dict[tuple[int, bool], Any] = {}
+def expression_faces(bcs, skip=None) -> dict[tuple[int, bool], Any]:
+    """``(axis, upper) -> condition`` of the faces of ``bcs`` that are given as expressions / functions."""
+    found: dict[tuple[int, bool], Any] = {}
     if hasattr(bcs, "__iter__"):
         for ax, bc_axis in enumerate(bcs):
             for upper, bc in ((False, bc_axis.low), (True, bc_axis.high)):
                 if is_expression_bc(bc) and not (skip and (ax, upper) in skip):
-                    expr_faces[(ax, upper)] = bc
+                    found[(ax, upper)] = bc
+    return found
+
+
+def lower_expression_face(bc, table, upload, window=None):
+    """Write the expression face ``bc`` into ``table`` (a first-order face with coefficient arrays, evaluated for t = 0) - cut
+    to the box ``window`` of a decomposed grid -; returns its ``(evaluator, const buffer, factor buffer)`` entry when it has
+    to be refreshed later (it depends on time or reads the field), else None."""
+    face = _AffineFace(bc, window)
+    a, b = face.evaluate(0.0)
+    buf_a, buf_b = upload(a), upload(b)
+    table.keepalive += [buf_a, buf_b]
+    entry = table.c[2 * face.axis + int(face.upper)]
+    entry.kind = _abi.BC_ORDER1
+    entry.flags = _abi.BCF_ARRAYS
+    entry.index1, entry.index2 = face.index, 0
+    entry.const_arr, entry.factor1_arr = buf_a.ptr, buf_b.ptr
+    return (face, buf_a, buf_b) if face.time_dependent else None
+
+
+def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None) -> ExprFaceTable:
+    """``convert_bcs`` that also lowers expression conditions onto coefficient arrays."""
+    from .backend import _upload_f64, convert_bcs
+
+    if upload is None:
+        upload = _upload_f64
+    expr_faces = expression_faces(bcs, skip)
     table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload)
     dynamic = []
-    for (ax, upper), bc in expr_faces.items():
+    for bc in expr_faces.values():
         if comp_shape:
             msg = "Expression boundary conditions only work for scalar conditions"
             raise NotImplementedError(msg)
-        face = _AffineFace(bc)
-        a, b = face.evaluate(0.0)
-        buf_a, buf_b = upload(a), upload(b)
-        table.keepalive += [buf_a, buf_b]
-        entry = table.c[2 * ax + int(upper)]
-        entry.kind = _abi.BC_ORDER1
-        entry.flags = _abi.BCF_ARRAYS
-        entry.index1, entry.index2 = face.index, 0
-        entry.const_arr, entry.factor1_arr = buf_a.ptr, buf_b.ptr
-        if face.time_dependent:
-            dynamic.append((face, buf_a, buf_b))
-    return ExprFaceTable(table, dynamic, write)
+        entry = lower_expression_face(bc, table, upload)
+        if entry is not None:
+            dynamic.append(entry)
+    return ExprFaceTable(table, dynamic, _write_buffer)

@@ -137,6 +137,18 @@ class SlabArray:
         return self._buffer.ptr
 
 
+def device_bc_program(lib, kind, faces_c, faces_mu, grid_ref):
+    """The device program (``pdehip_rhs_t::bc_program``) that rewrites the faces of a slab / block which depend on time or read
+    the field before every right-hand side of the C loops, or None.  ``grid_ref``: the local ``pdehip_grid_t``."""
+    from .bc_expr import program_for
+
+    if kind == _abi.RHS_CAHN_HILLIARD and getattr(faces_mu, "reads_value", False):
+        # the potential exists only between the two halves of the fused right-hand side (single GPU: expression form instead)
+        msg = "decomposed stepping: conditions on the chemical potential that depend non-linearly on it are not supported"
+        raise NotImplementedError(msg)
+    return program_for(lib, [faces_c, faces_mu], grid_ref)
+
+
 # ---------------------------------------------------------------------------------------------
 # the slab stepper
 # ---------------------------------------------------------------------------------------------
@@ -170,7 +182,7 @@ class SlabStepper:
         # right-hand side description
         self.kind, self.param, bc_c, bc_mu = self._describe(eq, grid)
         self.faces_c = self.mesh.slab_faces(bc_c, force_exchange=force_exchange)
-        self.faces_mu = self.mesh.slab_faces(bc_mu, force_exchange=force_exchange)
+        self.faces_mu = self.faces_c if bc_mu is bc_c else self.mesh.slab_faces(bc_mu, force_exchange=force_exchange)
         self._bufs: dict[str, SlabArray] = {}
         self.rhs = _abi.RHS()
         self.rhs.kind, self.rhs.param = self.kind, self.param
@@ -178,6 +190,10 @@ class SlabStepper:
         self.faces_mu.copy_into(self.rhs.bc_mu)
         if self.kind == _abi.RHS_CAHN_HILLIARD:
             self.rhs.scratch_mu = self.buf("mu").ptr
+        # faces that depend on time or read the field: rewritten on the device before every right-hand side of the C loops
+        self.bc_program = device_bc_program(self.lib, self.kind, self.faces_c, self.faces_mu, C.byref(self.g))
+        if self.bc_program is not None:
+            self.rhs.bc_program = self.bc_program.ptr
         self.err = DeviceBuffer(8)
         # communicator: libpdehip's own RCCL communicator; the 128-byte id travels over the control plane
         self.comm = None
@@ -196,8 +212,8 @@ class SlabStepper:
         e2 = C.c_int(0)
         if self.kind == _abi.RHS_DIFFUSION and self.exchanging and min(self.mesh.counts) >= 4:
             self.lib.slab_euler2_supported(C.byref(self.g), C.byref(self.rhs), C.byref(e2))
-        if os.environ.get("PDEHIP_SLAB_EULER2", "1") == "0":
-            e2.value = 0
+        if os.environ.get("PDEHIP_SLAB_EULER2", "1") == "0" or self.bc_program is not None:
+            e2.value = 0     # (faces that change from step to step: one step per sweep)
         if self.kind == _abi.RHS_CAHN_HILLIARD and min(self.mesh.counts) < 2:
             local.value &= ~FUSED_CH
         agreed = self.control.all_and(local.value | (4 if e2.value else 0))
@@ -267,24 +283,27 @@ class SlabStepper:
         return host.value
 
     # --- time loops: one C call each ---------------------------------------------------------------------------
-    def rhs_scaled(self, y: SlabArray, k_out: SlabArray, dt: float) -> None:
+    def rhs_scaled(self, y: SlabArray, k_out: SlabArray, dt: float, t: float = 0.0) -> None:
+        self.rhs.t = float(t)
         self.lib.slab_rhs_scaled(self.comm, C.byref(self.g), C.byref(self.rhs), self._lo, self._up, self.flags, y.ptr, k_out.ptr, dt, self.stream)
 
-    def euler_steps(self, cur: SlabArray, nxt: SlabArray, dt: float, nsteps: int) -> SlabArray:
-        """``nsteps`` Euler steps ping-ponging cur/nxt; returns the array holding the result."""
+    def euler_steps(self, cur: SlabArray, nxt: SlabArray, dt: float, nsteps: int, t0: float = 0.0) -> SlabArray:
+        """``nsteps`` Euler steps from time ``t0`` ping-ponging cur/nxt; returns the array holding the result."""
         res = C.c_void_p()
+        self.rhs.t = float(t0)
         g, rhs = C.byref(self.g), C.byref(self.rhs)
         if not self.exchanging:
             self.lib.euler_run(g, rhs, cur.ptr, nxt.ptr, dt, nsteps, C.byref(res), self.stream)
-        elif self.kind != _abi.RHS_DIFFUSION:
+        elif self.kind != _abi.RHS_DIFFUSION or self.bc_program is not None:
             self.lib.slab_euler_sweeps(self.comm, g, rhs, self._lo, self._up, self.flags, cur.ptr, nxt.ptr, dt, nsteps, C.byref(res), self.stream)
         else:
             run = self.lib.slab_euler2_run if self._euler2 and nsteps >= 2 else self.lib.slab_euler_run
             run(self.comm, g, rhs, self._lo, self._up, cur.ptr, nxt.ptr, dt, nsteps, C.byref(res), self.stream)
         return cur if res.value == cur.ptr else nxt
 
-    def rk4_steps(self, y: SlabArray, dt: float, nsteps: int) -> None:
+    def rk4_steps(self, y: SlabArray, dt: float, nsteps: int, t0: float = 0.0) -> None:
         work = self._work(["k1", "k2", "k3", "k4", "tmp"])
+        self.rhs.t = float(t0)
         self.lib.slab_rk4_run(self.comm, C.byref(self.g), C.byref(self.rhs), self._lo, self._up, self.flags, y.ptr, work, dt, nsteps, self.stream)
 
     def rkf45_run(self, cur: SlabArray, nxt: SlabArray, ctl: _abi.Adaptive) -> SlabArray:
@@ -405,7 +424,8 @@ class BlockStepper:
         self.stream = C.c_void_p()
         self.lib.stream_create(C.byref(self.stream))
         self.kind, self.param, bc_c, bc_mu = SlabStepper._describe(eq, grid)
-        self.faces_c, self.faces_mu = self.mesh.block_faces(bc_c), self.mesh.block_faces(bc_mu)
+        self.faces_c = self.mesh.block_faces(bc_c)
+        self.faces_mu = self.faces_c if bc_mu is bc_c else self.mesh.block_faces(bc_mu)
         self.rhs = _abi.RHS()
         self.rhs.kind, self.rhs.param = self.kind, self.param
         self.faces_c.copy_into(self.rhs.bc_c)
@@ -413,6 +433,9 @@ class BlockStepper:
         self._bufs: dict[str, Any] = {}
         if self.kind == _abi.RHS_CAHN_HILLIARD:
             self.rhs.scratch_mu = self.buf("mu").ptr
+        self.bc_program = device_bc_program(self.lib, self.kind, self.faces_c, self.faces_mu, self.info.ref)
+        if self.bc_program is not None:
+            self.rhs.bc_program = self.bc_program.ptr
         self.err = DeviceBuffer(8)
         self.nb6 = self.mesh.nb6
         self.exchanging = any(v >= 0 for v in self.nb6)

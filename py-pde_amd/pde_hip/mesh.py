@@ -69,6 +69,7 @@ class SlabMesh:
         local.py:1515-1540)."""
         from . import _abi
         from .backend import FaceTable, _upload_f64, convert_bcs
+        from .bc_expr import ExprFaceTable, _write_buffer, expression_faces, lower_expression_face
 
         if upload is None:
             upload = _upload_f64
@@ -84,16 +85,29 @@ class SlabMesh:
                     # the slab loops advance scalar fields (rank-0 conditions); `normal_*` conditions belong to vector fields
                     msg = "slab-parallel stepping supports conditions of scalar fields only (got a rank-1 / `normal` condition)"
                     raise NotImplementedError(msg)
-        glob = convert_bcs(bcs, upload=_Host)
+        # conditions given as expressions (incl. time-dependent ones and ones that read the field): evaluated for THIS slab - the
+        # face cut to the slab's layers, wall coordinates of the whole grid - and refreshed by a device program (bc_expr.py)
+        expr_faces = expression_faces(bcs)
+        glob = convert_bcs(bcs, skip=set(expr_faces), upload=_Host)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         exchanged = {(0, False): self.lower is not None, (0, True): self.upper is not None}
         if force_exchange and self.size == 1 and bool(self.grid.periodic[0]):
             exchanged = {(0, False): True, (0, True): True}
         out = FaceTable()
+        dynamic = []
         nd = len(self.grid.shape)
+        window = ([self.lo, *[0] * (nd - 1)], [self.hi, *[int(n) for n in self.grid.shape[1:]]])
         for ax in range(nd):
             for upper in (False, True):
                 src, dst = glob.c[2 * ax + int(upper)], out.c[2 * ax + int(upper)]
+                if (ax, upper) in expr_faces:
+                    if ax == 0 and exchanged[(0, upper)]:
+                        dst.kind = _abi.BC_SKIP          # an inner face: the wall of the whole grid belongs to another slab
+                        continue
+                    entry = lower_expression_face(expr_faces[(ax, upper)], out, upload, window)
+                    if entry is not None:
+                        dynamic.append(entry)
+                    continue
                 if ax == 0 and exchanged[(0, upper)]:
                     # the exchange copies the neighbour's layer as it is: only the plain periodic wrap-around may be replaced by
                     # it.  An anti-periodic axis (flip_sign: factor -1, pde/grids/boundaries/local.py:1728-1731) would silently
@@ -126,7 +140,7 @@ class SlabMesh:
                         buf = upload(np.ascontiguousarray(arr))
                         out.keepalive.append(buf)
                         setattr(dst, name, buf.ptr)
-        return out
+        return ExprFaceTable(out, dynamic, _write_buffer) if expr_faces else out
 
     @property
     def exchanged_faces(self) -> set[tuple[int, bool]]:
@@ -311,6 +325,7 @@ class BlockMesh:
         with the index translated into the block, per-face arrays are cut to the block's extent along the other axes."""
         from . import _abi
         from .backend import FaceTable, _upload_f64, convert_bcs
+        from .bc_expr import ExprFaceTable, _write_buffer, expression_faces, lower_expression_face
 
         if upload is None:
             upload = _upload_f64
@@ -325,13 +340,23 @@ class BlockMesh:
                 if getattr(bc, "rank", 0) != 0 or getattr(bc, "normal", False):
                     msg = "block-parallel stepping supports conditions of scalar fields only"
                     raise NotImplementedError(msg)
-        glob = convert_bcs(bcs, upload=_Host)
+        expr_faces = expression_faces(bcs)       # as in SlabMesh.slab_faces: cut to the block, coordinates of the whole grid
+        glob = convert_bcs(bcs, skip=set(expr_faces), upload=_Host)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         out = FaceTable()
+        dynamic = []
         nd = len(self.grid.shape)
         for ax in range(nd):
             for side, upper in enumerate((False, True)):
                 src, dst = glob.c[2 * ax + side], out.c[2 * ax + side]
+                if (ax, upper) in expr_faces:
+                    if self.neighbours[ax][side] is not None:
+                        dst.kind = _abi.BC_SKIP
+                        continue
+                    entry = lower_expression_face(expr_faces[(ax, upper)], out, upload, (self.lo, self.hi))
+                    if entry is not None:
+                        dynamic.append(entry)
+                    continue
                 if self.neighbours[ax][side] is not None:
                     wraps = self.index[ax] == (self.dims[ax] - 1 if upper else 0)
                     if wraps and (src.kind != _abi.BC_ORDER1 or (src.flags & _abi.BCF_ARRAYS) or src.factor1 != 1.0 or src.const_v != 0.0):
@@ -360,7 +385,7 @@ class BlockMesh:
                         buf = upload(np.ascontiguousarray(arr[cut]))
                         out.keepalive.append(buf)
                         setattr(dst, name, buf.ptr)
-        return out
+        return ExprFaceTable(out, dynamic, _write_buffer) if expr_faces else out
 
 
 def combine_blocks(blocks: list[np.ndarray], dims, num_axes: int) -> np.ndarray:

@@ -184,9 +184,9 @@ class HipSlabSolver(AdaptiveSolverBase):
             else:
                 steps = max(1, round((t_end - t_start) / dt_fixed))
                 if self.scheme == "euler":
-                    res = stepper.euler_steps(a, b, dt_fixed, steps)
+                    res = stepper.euler_steps(a, b, dt_fixed, steps, t_start)
                 else:
-                    stepper.rk4_steps(a, dt_fixed, steps)
+                    stepper.rk4_steps(a, dt_fixed, steps, t_start)
                     res = a
                 self.info["steps"] += steps
                 t_last = t_start + (steps - 1) * dt_fixed + dt_fixed

@@ -36,6 +36,11 @@ def main() -> int:
         "diffusion_euler": (pde.DiffusionPDE(0.7, bc={"x": {"value": 0.2}, "y": "periodic", "z": {"derivative": 0.1}}),
                             pde.UnitGrid([12, 4, 6], periodic=[False, True, False]), dict(t_range=0.5, dt=0.05)),
         "cahn_hilliard_rk4": (pde.CahnHilliardPDE(0.9), pde.UnitGrid([8, 4, 6], periodic=True), dict(t_range=0.004, dt=1e-3, scheme="runge-kutta")),
+        # conditions that depend on time, on the position along decomposed and undecomposed axes, and non-linearly on the field
+        "diffusion_expression_bcs": (pde.DiffusionPDE(0.6, bc={"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"},
+                                                               "x+": {"derivative_expression": "-0.3 * value**3 + 0.02 * z"}, "y": "periodic",
+                                                               "z-": {"derivative_expression": "0.05 * x * sin(t)"}, "z+": {"value": 0.1}}),
+                                     pde.UnitGrid([12, 4, 6], periodic=[False, True, False]), dict(t_range=0.4, dt=0.02, scheme="runge-kutta")),
         "expression_rkf45": (pde.PDE({"c": "laplace(c**3 - c - laplace(c))"}), pde.UnitGrid([8, 6, 6], periodic=True),
                              dict(t_range=0.1, dt=1e-3, scheme="runge-kutta", adaptive=True)),
     }

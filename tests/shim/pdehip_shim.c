@@ -487,7 +487,7 @@ int pdehip_bcprog_run(void *handle, double t, const void *state_full, void *stre
             for (int64_t i2 = 0; i2 < F->m2; i2++) {
                 double c[3];
                 for (int k = 0; k < 3; k++)
-                    c[k] = F->index[k] == 0 ? F->origin[k] : ((double)(F->index[k] == 1 ? i1 : i2) + 0.5) * F->step[k] + F->origin[k];
+                    c[k] = F->index[k] == 0 ? F->origin[k] : ((double)(F->first[k] + (F->index[k] == 1 ? i1 : i2)) + 0.5) * F->step[k] + F->origin[k];
                 double value = 0;
                 if (F->reads_value) {
                     const int64_t o = b->sgeo[f][0] + i1 * b->sgeo[f][1] + i2 * b->sgeo[f][2];

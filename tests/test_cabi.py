@@ -53,7 +53,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_abi.Grid) == 4 + 4 + 3 * 8 + 3 * 8
     assert C.sizeof(_abi.BCFace) == 4 + 4 + 2 * 8 + 3 * 8 + 3 * 8
     assert C.sizeof(_abi.RHS) == 4 + 4 + 8 + 2 * 6 * C.sizeof(_abi.BCFace) + 8 + 8 + 8    # ... scratch_mu, bc_program, t (ABI version 2)
-    assert C.sizeof(_abi.BcProgFace) == 2 * 8 + 2 * 8 + 2 * 3 * 8 + 3 * 4 + 4 + 8 + 4 + 4 + 8    # ... axis, component, value_index (ABI version 3)
+    assert C.sizeof(_abi.BcProgFace) == 2 * 8 + 2 * 8 + 2 * 3 * 8 + 3 * 4 + 4 + 8 + 4 + 4 + 8 + 3 * 8    # ... axis, component, value_index, first[3] (ABI version 4)
     for struct, cname in [(_abi.Grid, "pdehip_grid"), (_abi.BCFace, "pdehip_bc_face"), (_abi.RHS, "pdehip_rhs"), (_abi.Adaptive, "pdehip_adaptive"),
                           (_abi.BcProgFace, "pdehip_bcprog_face")]:
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + "_t;", HEADER, re.S).group(1)

@@ -244,3 +244,71 @@ def test_block_ghost_faces_read_from_memory():
         lib.block_run(None, info.ref, C.byref(rhs), none6, 0, 0, a.ptr, b.ptr, None, None, 2e-3, 1, None, C.byref(res), None)
         got = (b if res.value == b.ptr else a).get_valid()
         np.testing.assert_array_equal(got, mesh.extract(expect), err_msg=f"block {rank} {mesh.lo}")
+
+
+# ---- conditions given as expressions on slabs and blocks (refreshed by the device program inside the C loops) ------------------
+_EXPR_BC = {"x": "periodic", "y-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * x"}, "y+": {"derivative_expression": "0.1 * cos(t) * z - 0.3 * value**3"},
+            "z-": {"virtual_point": "value / (1 + value**2) + 0.05 * x"}, "z+": {"derivative_expression": "0.05 * y * sin(t)"}}
+
+
+@pytest.mark.parametrize("solver,dt", [("euler", 2e-3), ("runge-kutta", 4e-3), ("runge-kutta", None)])
+def test_expression_conditions_in_the_slab_and_block_loops(solver, dt):
+    """Time-dependent conditions and conditions that read the field, on a slab / block that exchanges its periodic axis with itself
+    (RCCL to self): the device program runs before every right-hand side of `pdehip_slab_*_run` / `pdehip_block_run` - equal to the
+    single-GPU loops (`pdehip_euler_run` ... with the same program), bit for bit, with equal step counts."""
+    from pde_hip.distributed import BlockStepper, SlabStepper
+
+    grid = pde_hip.CartesianGrid([[0, 3], [0, 2], [-1, 1]], [10, 6, 72], periodic=[True, False, False])
+    data = np.random.default_rng(11).uniform(-0.5, 0.5, grid.shape)
+    eq = pde_hip.DiffusionPDE(0.02, bc=_EXPR_BC)
+    expect, info = eq.solve(pde_hip.ScalarField(grid, data), 0.04, dt, solver=solver, ret_info=True)
+    assert np.isfinite(expect.data).all() and np.abs(expect.data - data).max() > 1e-3
+    for cls in (SlabStepper, BlockStepper):
+        st = cls(eq, grid, force_exchange=True)
+        assert st.exchanging and st.bc_program is not None
+        final, sinfo = st.solve(data, 0.04, dt, solver)
+        st.close()
+        assert sinfo["steps"] == info["solver"]["steps"], cls.__name__
+        np.testing.assert_array_equal(final, expect.data, err_msg=cls.__name__)
+
+
+def test_expression_conditions_of_a_block_use_the_coordinates_of_the_whole_grid():
+    """Each of the 8 blocks of a 2 x 2 x 2 cut - faces cut to the block, `pdehip_bcprog_face_t::first` = the block's first cell - advances
+    one Euler step at t = 0.37 to exactly its part of the unsplit step (conditions depending on x, y, z, t and the field)."""
+    from pde_hip.bc_expr import convert_bcs_with_expressions, program_for
+    from pde_hip.device import DeviceArray, GridInfo
+    from pde_hip.mesh import BlockMesh
+
+    backend = pde_hip.get_backend("hip")
+    lib = backend._lib
+    grid = pde_hip.CartesianGrid([[0, 4], [0, 3], [0, 40]], [12, 10, 264], periodic=False)
+    bc = {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y * z"}, "x+": {"derivative_expression": "0.1 * cos(t) * z - 0.3 * value**3"},
+          "y-": {"virtual_point": "value / (1 + value**2) + 0.05 * x"}, "y+": {"derivative_expression": "0.05 * x * sin(t) + 0.01 * z"},
+          "z-": {"value_expression": "tanh(x - y) * t"}, "z+": {"derivative": 0.4}}
+    bcs = grid.get_boundary_conditions(bc)
+    data = np.random.default_rng(9).uniform(-0.5, 0.5, grid.shape)
+    dt, t = 2e-3, 0.37
+
+    def one_step(info, faces, start):
+        rhs = _abi.RHS()
+        rhs.kind, rhs.param, rhs.t = _abi.RHS_DIFFUSION, 0.7, t
+        faces.copy_into(rhs.bc_c)
+        prog = program_for(lib, [faces], info)
+        rhs.bc_program = prog.ptr
+        a, b = start(DeviceArray(info)), DeviceArray(info)
+        res = C.c_void_p()
+        none6 = (C.c_int * 6)(*([-1] * 6))
+        lib.block_run(None, info.ref, C.byref(rhs), none6, 0, 0, a.ptr, b.ptr, None, None, dt, 1, None, C.byref(res), None)
+        return (b if res.value == b.ptr else a), a
+
+    info_w = GridInfo(grid.shape, grid.discretization, np.float64)
+    out, inp = one_step(info_w, convert_bcs_with_expressions(bcs), lambda arr: arr.set_valid(data))
+    expect = out.get_valid()
+    full = to_full(grid, data)      # inner faces of a block read the neighbour's cells; physical faces are evaluated by the block itself
+    assert np.abs(expect - data).max() > 1e-4
+    for rank in range(8):
+        mesh = BlockMesh(grid, [2, 2, 2], rank)
+        info = GridInfo(mesh.local_shape, grid.discretization, np.float64)
+        window = np.ascontiguousarray(full[tuple(slice(lo, hi + 2) for lo, hi in zip(mesh.lo, mesh.hi))])
+        got, _ = one_step(info, mesh.block_faces(bcs), lambda arr: arr.set_hostfull(window))  # noqa: B023
+        np.testing.assert_array_equal(got.get_valid(), mesh.extract(expect), err_msg=f"block {rank} {mesh.lo}")

@@ -153,9 +153,15 @@ class HipSlabSolver(AdaptiveSolverBase):
         device = getattr(self.backend, "_device_request", None)
         blocks = self.decomposition != "slab"
         if blocks:
+            # a decomposition that only cuts axis 0 IS the slab decomposition (always the case for 1-D grids): the slab loops take it
+            from .distributed import default_control
+            from .mesh import block_decomposition
+
+            dims = [int(d) for d in (block_decomposition(state.grid.shape, default_control().size) if self.decomposition == "auto" else self.decomposition)]
+            blocks = any(d > 1 for d in dims[1:])
+        if blocks:
             from .distributed import BlockStepper
 
-            dims = None if self.decomposition == "auto" else [int(d) for d in self.decomposition]
             stepper = BlockStepper(self.pde, state.grid, state.dtype, dims=dims, device=device)
             self.info["decomposition"] = list(stepper.dims)
         else:

@@ -502,6 +502,9 @@ def test_multirank_worker_and_bench_under_torchrun(world):
     assert out["n_gpus"] == world and out["finite"] and out["slab"]["two_steps_per_sweep"] and sum(out["slab"]["layers_per_rank"]) == 32
 
 
+FUZZ_CASES = 18    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
+
+
 @pytest.mark.parametrize("world,decomposition", [(2, "slab"), (3, "slab"), (4, "auto")])
 def test_real_pypde_drives_the_slab_path(world, decomposition):
     """`eq.solve(state, solver="hip_slab", backend="hip")` of the REAL py-pde (pde_hip.pypde_plugin.HipSlabSolver, the
@@ -520,13 +523,13 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
         pytest.skip("py-pde (reference) not available")
     so = shimlib.build()
     env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120",
-           "PDEHIP_WORKER_DECOMPOSITION": decomposition}
+           "PDEHIP_WORKER_DECOMPOSITION": decomposition, "PDEHIP_WORKER_FUZZ": str(FUZZ_CASES)}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "pypde_slab_worker.py")]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
     assert proc.returncode == 0 and lines, proc.stderr[-3000:]
     report = json.loads(lines[-1][len("PYPDESLAB "):])
-    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 4
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 4 + FUZZ_CASES
     if decomposition == "auto":     # blocks along more than one axis (`decomposition="auto"`, the reference's rule)
         assert sum(sum(d > 1 for d in c["decomposition"]) >= 2 for c in report["cases"].values()) >= 2, report

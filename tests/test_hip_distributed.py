@@ -312,3 +312,23 @@ def test_expression_conditions_of_a_block_use_the_coordinates_of_the_whole_grid(
         window = np.ascontiguousarray(full[tuple(slice(lo, hi + 2) for lo, hi in zip(mesh.lo, mesh.hi))])
         got, _ = one_step(info, mesh.block_faces(bcs), lambda arr: arr.set_hostfull(window))  # noqa: B023
         np.testing.assert_array_equal(got.get_valid(), mesh.extract(expect), err_msg=f"block {rank} {mesh.lo}")
+
+
+def test_fresh_buffers_are_not_overtaken_by_their_zero_fill():
+    """`pdehip_malloc` zero-fills on the null stream; the steppers work on non-blocking streams.  Before the allocation waited for its
+    fill, 15-24 % of such tiny runs came back all zero once the allocator recycled blocks (after ~500 iterations;
+    profiles/r03_malloc_fill_race.md): many fresh steppers, upload -> 4 steps -> download, every result identical to the first."""
+    from pde_hip.distributed import SlabStepper
+
+    cases = [(pde_hip.CahnHilliardPDE(0.917), pde_hip.UnitGrid([8], periodic=True)), (pde_hip.DiffusionPDE(0.7), pde_hip.UnitGrid([8, 6], periodic=True))]
+    first = {}
+    for it in range(1200):
+        for k, (eq, grid) in enumerate(cases):
+            data = np.random.default_rng(3).uniform(-0.4, 0.4, grid.shape)
+            st = SlabStepper(eq, grid)
+            a, b = st.buf("state_a"), st.buf("state_b")
+            st.set_local(a, data)
+            assert np.array_equal(st.gather_local(a), data), (it, k)
+            out = st.gather_local(st.euler_steps(a, b, 1e-3, 4))
+            st.close()
+            assert out.any() and np.array_equal(out, first.setdefault(k, out)), (it, k)

@@ -673,6 +673,7 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     if (e == hipSuccess) e = hipModuleGetFunction(&b->fn, b->module, "bc_refresh");
     if (e == hipSuccess) e = hipMalloc(&b->faces_dev, sizeof(BcFaceDev) * host.size());
     if (e == hipSuccess) e = hipMemcpy(b->faces_dev, host.data(), sizeof(BcFaceDev) * host.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // the program runs on the callers' non-blocking streams (see pdehip_malloc)
     if (e != hipSuccess) {
         if (b->faces_dev) (void)hipFree(b->faces_dev);
         if (b->module) (void)hipModuleUnload(b->module);

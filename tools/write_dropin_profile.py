@@ -1,8 +1,8 @@
-"""Write profiles/r03_dropin_real_gpu.md (+ the pytest lines) from the logs of tools/gpu_r3_call19.sh in gpurun_out/r3h/."""
+"""Write profiles/r03_dropin_real_gpu.md (+ the pytest lines) from the logs of tools/gpu_r3_call26.sh in gpurun_out/r3i/."""
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-O = ROOT / "gpurun_out" / "r3h"
+O = ROOT / "gpurun_out" / "r3i"
 log = (O / "dropin_pytest.log").read_text()
 out = (O / "dropin_outcomes.txt").read_text().splitlines()
 gpu_tail = [l for l in (O / "pytest_gpu_final.log").read_text().splitlines() if " passed" in l][-1].strip("= ")
@@ -28,7 +28,7 @@ md = f"""# r03: the py-pde plugin class against the REAL libpdehip.so on an MI35
 committed, removed after each call - it is the CHECKER, like `tests/golden/make_golden.py` uses it in the build container).  `PDEHIP_DROPIN_REAL=1`
 turns `shimlib.use_shim()` into a no-op, so `pde.ScalarField.laplace(..., backend="hip")` / `eq.solve(..., backend="hip")` of the real py-pde run
 through `pde_hip.pypde_plugin.HipBackend` -> ctypes -> `py-pde_amd/lib/libpdehip.so` on gfx950.  Call 2 (`tools/gpu_r3_call2.sh`): 190 passed with the
-build of that moment; call 8: 195; **the last call of the round (`tools/gpu_r3_call19.sh`), final library (ABI 3)** - with the device programs for
+build of that moment; call 8: 195; call 19: 223 (ABI 3); **the last full call of the round (`tools/gpu_r3_call26.sh`), library with ABI 4** - with expression conditions on slabs / blocks, the device programs for
 time-dependent boundary conditions AND for conditions that are not affine in the adjacent value (hiprtc), the Runge-Kutta loops of expression PDEs
 in C, `user_funcs`, rank-2 tensor fields as states, multiplicative noise / Milstein, the device-side consistency tracker, the block solver, the
 two-step kernel for any row length / row count:
@@ -60,7 +60,11 @@ map `libpdehip.so` only; the host shim is not mapped anywhere.)
 
 `tests/pypde_slab_worker.py` (`eq.solve(..., solver="hip_slab", backend="hip"[, decomposition="auto"])`, the plugin's parallel solver) under
 `torch.distributed.run` at world size 1: Euler / RK4 / adaptive RKF45 with three tracker interrupts each equal the reference's serial numpy + scipy
-run (<= 1e-10, equal step counts): `"failures": []` for both decompositions.
+run (<= 1e-10, equal step counts); since call 26 also a case with conditions that depend on time, position and the field, and 18 random
+cases (grids with 1-3 axes, random conditions per face, random solver).  Call 26: `"failures": []` for `decomposition="auto"`; ONE of the 22 cases
+of the `slab` run (`fuzz15`, a 1-D grid of 8 cells) came back all zero - the zero fill of a fresh allocation overtaking work on a non-blocking
+stream, reproduced at 15-24 % under stress, fixed in `pdehip_malloc` and verified (`profiles/r03_malloc_fill_race.md`); after the fix: 4 x 22 cases
+green (`tools/gpu_r3_call27.sh`), 404 + 87 GPU tests of the allocation-heavy suites green with the final library (calls 27 and 29).
 
 In the same call: `pytest tests -m gpu`: {gpu_tail} (the mirror front end and the C ABI against the oracle and the goldens),
 `__graft_entry__.smoke()` ok.

@@ -190,7 +190,7 @@ def class_expressions(eq):
     klein_gordon.py:124-127.  Matched by class name along the MRO like :func:`pde_kind` (subclasses that redefine the
     right-hand side are refused, :func:`known_pde_class`)."""
     base = known_pde_class(eq, {"AllenCahnPDE", "KPZInterfacePDE", "KuramotoSivashinskyPDE", "SwiftHohenbergPDE", "KleinGordonPDE", "WavePDE",
-                                "CahnHilliardPDE"})
+                                "CahnHilliardPDE", "DiffusionPDE"})
     if base is None:
         return None
     names = [cls.__name__ for cls in base.__mro__]
@@ -200,6 +200,10 @@ def class_expressions(eq):
         # refuses, e.g. conditions of mu that depend non-linearly on mu)
         return ({"c": "laplace_outer(c**3 - c - interface_width * laplace(c))"}, {"interface_width": float(eq.interface_width)},
                 {("c", "laplace"): eq.bc_c, ("c", "laplace_outer"): eq.bc_mu}, outer)
+    if "DiffusionPDE" in names:
+        # (pde/pdes/diffusion.py:119-121; the fused class right-hand side comes first: this form serves the decomposed steppers
+        # for schemes without a fused loop, e.g. adaptive Euler)
+        return ({"c": "diffusivity * laplace(c)"}, {"diffusivity": float(eq.diffusivity)}, {("c", "laplace"): eq.bc}, {})
     if "AllenCahnPDE" in names:
         return ({"c": "mobility * (interface_width * laplace(c) - c**3 + c)"},
                 {"mobility": float(eq.mobility), "interface_width": float(eq.interface_width)}, {("c", "laplace"): eq.bc}, {})
@@ -776,9 +780,27 @@ class HipBackendMixin:
         pde_rhs.spec = spec  # type: ignore[attr-defined]
         return pde_rhs
 
+    # what `make_expression_rhs` needs to know about WHERE the expression is evaluated; the slab / block steppers
+    # (pde_hip/distributed.py: DecomposedExpressionStepper) answer for the box of one rank
+    def _expression_info(self, grid, dtype):
+        return self.grid_info(grid, dtype)
+
+    def _expression_faces(self, grid, bc, comp):
+        """Face table of one operator: scalar conditions (``comp`` None), or those of component ``comp`` (k / (i, j)) of a vector /
+        tensor operand."""
+        from .bc_expr import convert_bcs_with_expressions
+
+        if comp is None:
+            return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
+        rank = 2 if isinstance(comp, tuple) else 1
+        return convert_bcs(grid.get_boundary_conditions(bc, rank=rank), (grid.num_axes,) * rank, component=comp)
+
+    def _expression_aux(self, info, host):
+        """Device copy of an array on the grid (array-valued constant, cell coordinates)."""
+        return DeviceArray(info).set_valid(host, self.stream)
+
     def make_expression_rhs(self, eq, state):
         """Generic expression PDE (pde/pdes/pde.py) -> run-time specialised kernels (pde_hip/expr.py)."""
-        from .bc_expr import convert_bcs_with_expressions
         from .expr import ExpressionPlan, ExpressionRhs
 
         builtin = class_expressions(eq) if pde_kind(eq) != "PDE" else None
@@ -788,7 +810,7 @@ class HipBackendMixin:
         rhs = dict(builtin[0]) if builtin else dict(eq.rhs)
         variables = list(rhs)
         grid = state.grid
-        info = self.grid_info(grid, state.dtype)
+        info = self._expression_info(grid, state.dtype)
         consts = dict(builtin[1]) if builtin else dict(getattr(eq, "consts", {}) or {})
         aliases = builtin[3] if builtin else {}
         kind = state.__class__.__name__
@@ -839,11 +861,7 @@ class HipBackendMixin:
                         tables[op] = table
                         break
                 else:
-                    if comp is None:
-                        tables[op] = convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
-                    else:
-                        rank = 2 if isinstance(comp, tuple) else 1
-                        tables[op] = convert_bcs(grid.get_boundary_conditions(bc, rank=rank), (grid.num_axes,) * rank, component=comp)
+                    tables[op] = self._expression_faces(grid, bc, comp)
                     specs.append((bc, comp, tables[op]))
             return tables
 
@@ -869,7 +887,7 @@ class HipBackendMixin:
                 if name not in aux_dev:
                     host = aux_host[name]
                     host = host() if callable(host) else host
-                    aux_dev[name] = DeviceArray(info).set_valid(np.asarray(host, dtype=info.dtype), self.stream)
+                    aux_dev[name] = self._expression_aux(info, np.asarray(host, dtype=info.dtype))
             return {name: aux_dev[name] for name in plan.aux_used}
 
         # Python functions the expressions may call (`user_funcs` of pde.PDE, pde/pdes/pde.py:84): traced symbolically by the plan
@@ -896,7 +914,7 @@ class HipBackendMixin:
 
         return SystemRhs(variables, parts, info)
 
-    def _make_expression_stepper(self, solver, state, erhs=None, post_step=None):
+    def _make_expression_stepper(self, solver, state, erhs=None, post_step=None, reduce_error=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
         (pde/solvers/euler.py:172-175, runge_kutta.py:52-61, :135-153) with the RHS evaluated by the
         run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass.
@@ -1013,7 +1031,8 @@ class HipBackendMixin:
                     erhs.apply(y, k2a, "euler", 0.5 * dt_step, t)
                     erhs.apply(k2a, ynew, "euler", 0.5 * dt_step, t + 0.5 * dt_step)
                 lib.max_abs_diff(info.ref, ncomp, k1.ptr, ynew.ptr, err_dev.ptr, stream)
-            return err_dev.value(stream)
+            # (`reduce_error`: MAX over the ranks of a decomposed run, NaN wins - pde/backends/base.py:678-712)
+            return err_dev.value(stream) if reduce_error is None else reduce_error(err_dev.value(stream))
 
         ctl = None
         if is_rk and post_step is None and hasattr(erhs, "rk_run") and os.environ.get("PDEHIP_EXPR_LOOP") != "0":

@@ -536,3 +536,173 @@ class BlockStepper:
             self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# any expression PDE on slabs / blocks
+# ---------------------------------------------------------------------------------------------
+def create_communicator(lib, control):
+    """libpdehip's RCCL communicator over all ranks of ``control`` (the 128-byte id travels over the control plane)."""
+    path = rccl_library_path().encode()
+    uid = C.create_string_buffer(128)
+    if control.rank == 0:
+        lib.comm_unique_id(path, uid)
+    uid = C.create_string_buffer(control.broadcast(bytes(uid.raw)), 128)
+    comm = C.c_void_p()
+    lib.comm_create(path, uid, control.rank, control.size, C.byref(comm))
+    return comm
+
+
+class _EulerSolver:
+    pass
+
+
+class RungeKuttaSolver:   # (the stepper factory asks for the scheme by class name, like the reference's solver classes)
+    pass
+
+
+class DecomposedExpressionStepper:
+    """Explicit Euler / RK4 / adaptive steppers for ANY expression PDE the hip backend evaluates with its run-time compiled passes
+    (``pde.PDE`` with scalar fields, systems of them, the built-in classes in their expression form) on a slab or block
+    decomposition - what ``ExplicitMPISolver`` does for every PDE in the reference (``pde/solvers/explicit_mpi.py:133-226``: each
+    node evaluates the right-hand side on its sub-grid, ``_MPIBC`` exchanges the ghost cells of every operator's operand,
+    ``pde/grids/boundaries/local.py:561-662``).
+
+    One rank = one box.  The expression is planned once (``pde_hip/expr.py``); its passes run one by one on the box, and before
+    a pass applies operators to an array, the ghost layers of THAT array travel (``pdehip_halo_exchange`` / ``pdehip_block_exchange``:
+    the operand of a nested operator is an intermediate field, which is exchanged like the state).  Conditions - constants, arrays,
+    expressions of time / position / the field - are lowered for the box with the coordinates of the whole grid
+    (``SlabMesh.slab_faces`` / ``BlockMesh.block_faces``); coordinate arrays and array-valued constants are cut to the box.  The
+    steppers are the Python-level twins of the C loops (``HipBackendMixin._make_expression_stepper``); the adaptive error is
+    MAX-reduced over the ranks.  Everything runs on the null stream (conditions are refreshed there): in order, no overlap - the
+    fast decomposed paths are the fused Diffusion / Cahn-Hilliard loops of :class:`SlabStepper`.  Integrals are refused."""
+
+    def __init__(self, eq, state, *, dims=None, control=None, device: int | None = None, force_exchange: bool = False):
+        """``force_exchange`` (world size 1): periodic axes exchange with the box itself instead of keeping their periodic condition
+        (the exchange path on one GPU: tests)."""
+        from ._lib import require_device
+        from .backend import HipBackendMixin
+        from .device import GridInfo
+        from .mesh import BlockMesh, block_decomposition
+
+        self.control = control if control is not None else default_control()
+        self.size, self.rank = self.control.size, self.control.rank
+        self.lib = self._lib = require_device(device)
+        self.stream = None
+        self.eq, self.grid = eq, state.grid
+        grid = state.grid
+        self.dtype = np.dtype(state.dtype)
+        nd = len(grid.shape)
+        requested = dims
+        if isinstance(dims, str):      # "auto": the reference's rule (pde/grids/_mesh.py:59-93); "slab" / None: axis 0 only
+            dims = block_decomposition(grid.shape, self.size) if dims == "auto" else None
+        dims = [int(d) for d in (dims if dims is not None else [self.size] + [1] * (nd - 1))]
+        if int(np.prod(dims)) != self.size:
+            msg = f"decomposition {dims} needs {int(np.prod(dims))} ranks, the job has {self.size}"
+            raise ValueError(msg)
+        self.dims = dims
+        self.blocks = any(d > 1 for d in dims[1:]) or (force_exchange and self.size == 1 and nd > 1 and requested == "auto")
+        self._force = bool(force_exchange and self.size == 1 and any(grid.periodic[: None if self.blocks else 1]))
+        self.mesh = BlockMesh(grid, dims, self.rank, force_exchange=self._force) if self.blocks else SlabMesh(grid, self.size, self.rank)
+        self.info = GridInfo(self.mesh.local_shape, grid.discretization, self.dtype)
+        exchanging = self.size > 1 or self._force
+        self.comm = create_communicator(self.lib, self.control) if exchanging else None
+        # the evaluator: HipBackendMixin.make_expression_rhs with this object answering for the box (faces, arrays, layout)
+        self.erhs = HipBackendMixin.make_expression_rhs(self, eq, state)
+        self.ncomp = int(getattr(self.erhs, "ncomp", 1))
+        parts = getattr(self.erhs, "parts", [self.erhs])
+        for part in parts:
+            if part.has_reductions:
+                msg = "decomposed stepping: integrals over the grid are not supported"
+                raise NotImplementedError(msg)
+            part._pass_by_pass = True
+            part._two_ok = False
+            part._exchange = self.exchange if exchanging else None
+        self._steppers: dict[tuple, Any] = {}
+        self._state = None
+
+    # --- what make_expression_rhs asks (see HipBackendMixin._expression_*) ---------------------------------------------------
+    def _expression_info(self, grid, dtype):
+        return self.info
+
+    def _expression_faces(self, grid, bc, comp):
+        if comp is not None:
+            msg = "decomposed stepping supports scalar fields (and systems of them)"
+            raise NotImplementedError(msg)
+        bcs = grid.get_boundary_conditions(bc, rank=0)
+        return self.mesh.block_faces(bcs) if self.blocks else self.mesh.slab_faces(bcs, force_exchange=self._force)
+
+    def _expression_aux(self, info, host):
+        from .device import DeviceArray
+
+        return DeviceArray(info).set_valid(np.ascontiguousarray(self.mesh.extract(host)), self.stream)
+
+    # --- data plane ---------------------------------------------------------------------------------------------
+    def exchange(self, arr) -> None:
+        """Fill the ghost layers of ``arr`` (one component) on every face that has a neighbour."""
+        if self.blocks:
+            self.lib.block_exchange(self.comm, self.info.ref, self.mesh.nb6, arr.ptr, self.stream)
+        else:
+            lo = 0 if self._force else (-1 if self.mesh.lower is None else int(self.mesh.lower))
+            up = 0 if self._force else (-1 if self.mesh.upper is None else int(self.mesh.upper))
+            self.lib.halo_exchange(self.comm, self.info.ref, arr.ptr, lo, up, self.stream)
+
+    def _max_over_ranks(self, value: float) -> float:
+        values = [float(v) for v in self.control.allgather(float(value))]
+        return float("nan") if any(np.isnan(v) for v in values) else max(values)
+
+    def state_array(self):
+        from .device import DeviceArray
+
+        if self._state is None:
+            self._state = DeviceArray(self.info, (self.ncomp,) if self.ncomp > 1 else ())
+        return self._state
+
+    def scatter(self, global_valid: np.ndarray):
+        return self.state_array().set_valid(np.ascontiguousarray(self.mesh.extract(np.asarray(global_valid)), dtype=self.dtype), self.stream)
+
+    def gather(self, arr) -> np.ndarray:
+        from .mesh import combine, combine_blocks
+
+        blocks = self.control.allgather(arr.get_valid(stream=self.stream))
+        nd = len(self.grid.shape)
+        return combine_blocks(blocks, self.dims, nd) if self.blocks else combine(blocks, nd)
+
+    # --- steppers -----------------------------------------------------------------------------------------------
+    def make_stepper(self, scheme: str = "euler", dt: float = 1e-3, *, adaptive: bool = False, tolerance: float = 1e-4, dt_min: float = 1e-10,
+                     dt_max: float = 1e10):
+        """``stepper(state_array, t_start, t_end) -> (state_array, t_last)`` on the box of this rank, plus its ``info`` dict."""
+        from types import SimpleNamespace
+
+        from .backend import HipBackendMixin
+
+        cls = RungeKuttaSolver if scheme == "runge-kutta" else _EulerSolver
+        solver = cls()
+        solver.__dict__.update(pde=self.eq, adaptive=bool(adaptive), tolerance=float(tolerance), dt_min=float(dt_min), dt_max=float(dt_max),
+                               info={"dt": float(dt), "steps": 0})
+        proxy = SimpleNamespace(grid=self.grid, dtype=self.dtype)
+        step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, reduce_error=self._max_over_ranks if self.size > 1 else None)
+        return step, solver.info
+
+    def solve(self, global_valid: np.ndarray, t_range: float, dt: float | None, solver: str = "euler", *, tolerance: float = 1e-4,
+              dt_min: float = 1e-10, dt_max: float = 1e10) -> tuple[np.ndarray, dict[str, Any]]:
+        """Decomposed twin of ``eq.solve(...)`` with ``tracker=None``; returns (global final state, info)."""
+        adaptive = dt is None
+        step, info = self.make_stepper(solver, 1e-3 if dt is None else dt, adaptive=adaptive, tolerance=tolerance, dt_min=dt_min, dt_max=dt_max)
+        arr = self.scatter(global_valid)
+        arr, t_last = step(arr, 0.0, float(t_range))
+        out = dict(info)
+        out.update(world_size=self.size, decomposition=list(self.dims), t_final=t_last)
+        return self.gather(arr), out
+
+    def close(self) -> None:
+        if self.comm is not None:
+            self.lib.stream_synchronize(self.stream)
+            self.lib.comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

@@ -541,6 +541,10 @@ class ExpressionRhs:
             msg = "hip backend: boundary conditions that depend non-linearly on the field, for the components of a vector field"
             raise NotImplementedError(msg)
         self._kernels: dict[tuple[int, str], tuple[C.c_void_p, list[str]]] = {}
+        # decomposed grids (pde_hip/distributed.py): `_exchange(array)` fills the ghost layers towards the neighbouring ranks before a
+        # pass applies operators to `array`; the passes then run one by one from Python (no fused chains, no C loops)
+        self._exchange = None
+        self._pass_by_pass = False
         # two steps per sweep: the second level would need the faces at t + dt / the integrals of the intermediate level
         self._two_ok: bool | None = False if (self._dynamic or self.has_reductions) else None
         self._fused: dict[str, C.c_void_p | None] = {}
@@ -606,6 +610,8 @@ class ExpressionRhs:
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
             self._refresh_for_pass(i, arrays[p.src], t)
+            if self._exchange is not None and self.pass_faces[i] is not None:
+                self._exchange(arrays[p.src])
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, nparams, self._faces(i), self.backend.stream)
 
     def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:
@@ -614,7 +620,8 @@ class ExpressionRhs:
         update + error norm into ``err``).  Returns False when the sweep is not available - then ``k_out`` holds the slope
         (plain ``apply``) and the caller combines with the pointwise kernels.  Two-pass chains keep their fused two-level
         sweep (tmp in registers) and combine separately."""
-        if not getattr(self, "_stage_ok", True) or self._fused_handle("scaled") is not None or self.has_reductions or self._reads_intermediate:
+        if (not getattr(self, "_stage_ok", True) or self._pass_by_pass or self._fused_handle("scaled") is not None or self.has_reductions
+                or self._reads_intermediate):
             self.apply(state, k_out, "scaled", dt, t)
             return False
         arrays = {"state": state, "out": k_out, **self.tmps, **self.aux}
@@ -645,7 +652,8 @@ class ExpressionRhs:
         """The passes of this expression can run inside the C loops (``pdehip_jit_euler_run`` / ``pdehip_jit_rk_run``): no
         integrals (their values travel through the host) and no conditions given as Python functions (conditions that are
         expressions of time are refreshed on the device inside the loops: :meth:`bc_program`)."""
-        return not self.has_reductions and not self._reads_intermediate and not any(getattr(tb, "host_only", False) for tb in self._dynamic)
+        return (not self.has_reductions and not self._reads_intermediate and not self._pass_by_pass
+                and not any(getattr(tb, "host_only", False) for tb in self._dynamic))
 
     def bc_program(self):
         """Device program (``pde_hip.bc_expr.BcProgram``) of all time-dependent faces of this expression's tables, or None."""
@@ -727,7 +735,7 @@ class ExpressionRhs:
         if wrap not in self._fused:
             h = None
             ps = self.plan.passes
-            if (not self.has_reductions and not self._reads_intermediate and len(ps) == 2 and ps[0].src == "state" and not ps[0].extras
+            if (not self.has_reductions and not self._reads_intermediate and not self._pass_by_pass and len(ps) == 2 and ps[0].src == "state" and not ps[0].extras
                     and ps[1].src == ps[0].out and ps[1].out == "out" and self.pass_faces[1] is not None):
                 body1, ex1 = self.plan.epilogue(ps[0], "rate")
                 body2, ex2 = self.plan.epilogue(ps[1], wrap)

@@ -122,9 +122,6 @@ class HipSlabSolver(AdaptiveSolverBase):
         if scheme not in {"euler", "runge-kutta"}:
             msg = f"Unknown scheme `{scheme}` (euler, runge-kutta)"
             raise ValueError(msg)
-        if adaptive and scheme != "runge-kutta":
-            msg = "adaptive slab-parallel stepping uses the Runge-Kutta-Fehlberg scheme (scheme='runge-kutta')"
-            raise NotImplementedError(msg)
         self.scheme = scheme
 
     def make_stepper(self, state, dt: float | None = None):
@@ -147,10 +144,22 @@ class HipSlabSolver(AdaptiveSolverBase):
         else:
             msg = f"slab-parallel stepping does not support the post-step hook of {self.pde.__class__.__name__}"
             raise NotImplementedError(msg)
-        if state.__class__.__name__ != "ScalarField":
-            msg = "slab-parallel stepping supports a single ScalarField state"
-            raise NotImplementedError(msg)
         device = getattr(self.backend, "_device_request", None)
+        # Diffusion / Cahn-Hilliard (classes or expressions of that form) on one scalar field: the fused loops (one C call per stepper
+        # call); every other expression PDE - systems of scalar fields included -: its run-time compiled passes on the box of each
+        # rank with a ghost exchange before every pass that applies operators (pde_hip.distributed.DecomposedExpressionStepper)
+        from .distributed import SlabStepper
+
+        try:
+            if state.__class__.__name__ != "ScalarField":
+                msg = "the fused slab loops take one ScalarField"
+                raise NotImplementedError(msg)
+            if self.adaptive and self.scheme != "runge-kutta":
+                msg = "the fused adaptive loop is the Runge-Kutta-Fehlberg scheme"
+                raise NotImplementedError(msg)
+            SlabStepper._describe(self.pde, state.grid)
+        except NotImplementedError:
+            return self._make_expression_stepper(state, float(dt), device)
         blocks = self.decomposition != "slab"
         if blocks:
             # a decomposition that only cuts axis 0 IS the slab decomposition (always the case for 1-D grids): the slab loops take it
@@ -201,6 +210,38 @@ class HipSlabSolver(AdaptiveSolverBase):
 
         slab_stepper.slab = stepper  # type: ignore[attr-defined]
         return slab_stepper
+
+
+def _decomposed_expression_stepper(self, state, dt: float, device):
+    """``HipSlabSolver.make_stepper`` for PDEs without a fused decomposed loop."""
+    from .distributed import DecomposedExpressionStepper
+
+    kinds = [f.__class__.__name__ for f in (list(state) if state.__class__.__name__ == "FieldCollection" else [state])]
+    if any(k != "ScalarField" for k in kinds):
+        msg = "slab-parallel stepping supports a ScalarField or a FieldCollection of ScalarFields"
+        raise NotImplementedError(msg)
+    dims = self.decomposition if isinstance(self.decomposition, str) else [int(d) for d in self.decomposition]
+    stepper = DecomposedExpressionStepper(self.pde, state, dims=dims, device=device)
+    self.info["decomposition"], self.info["world_size"] = list(stepper.dims), stepper.size
+    step, sinfo = stepper.make_stepper(self.scheme, dt, adaptive=bool(self.adaptive), tolerance=float(self.tolerance), dt_min=float(self.dt_min),
+                                       dt_max=float(self.dt_max))
+
+    def expression_stepper(state_field, t_start: float, t_end: float) -> float:
+        arr = stepper.scatter(state_field.data)
+        before = int(sinfo["steps"])
+        arr, t_last = step(arr, float(t_start), float(t_end))
+        self.info["steps"] += int(sinfo["steps"]) - before
+        self.info["dt"] = float(sinfo["dt"])
+        if "dt_statistics" in sinfo:
+            self.info["dt_statistics"] = sinfo["dt_statistics"]
+        state_field.data[...] = stepper.gather(arr)
+        return t_last
+
+    expression_stepper.slab = stepper  # type: ignore[attr-defined]
+    return expression_stepper
+
+
+HipSlabSolver._make_expression_stepper = _decomposed_expression_stepper
 
 
 class HipConsistencyTracker(_trackers.ConsistencyTracker):

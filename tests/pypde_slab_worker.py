@@ -44,6 +44,23 @@ def main() -> int:
         "expression_rkf45": (pde.PDE({"c": "laplace(c**3 - c - laplace(c))"}), pde.UnitGrid([8, 6, 6], periodic=True),
                              dict(t_range=0.1, dt=1e-3, scheme="runge-kutta", adaptive=True)),
     }
+    # PDEs WITHOUT a fused decomposed loop: the run-time compiled passes on the box of each rank, a ghost exchange before every pass that
+    # applies operators (pde_hip.distributed.DecomposedExpressionStepper).  Yardsticks: the reference's numpy backend for its classes, its
+    # eager torch-CPU backend for `pde.PDE` (Euler only; that class takes its operators from numba on the numpy backend)
+    wall = {"x": {"value": 0.2}, "y": "periodic", "z": {"derivative": 0.1}}
+    cases.update({
+        "allen_cahn_class_rkf45": (pde.AllenCahnPDE(0.9, mobility=1.1, bc=wall), pde.UnitGrid([12, 4, 6], periodic=[False, True, False]),
+                                   dict(t_range=0.3, dt=1e-2, scheme="runge-kutta", adaptive=True)),
+        "diffusion_adaptive_euler": (pde.DiffusionPDE(0.6, bc=wall), pde.UnitGrid([12, 4, 6], periodic=[False, True, False]),
+                                     dict(t_range=0.5, dt=1e-2, adaptive=True)),
+        "swift_hohenberg_class_rk4": (pde.SwiftHohenbergPDE(rate=0.1, kc2=0.8, delta=0.3), pde.UnitGrid([10, 8], periodic=[True, False]),
+                                      dict(t_range=0.008, dt=1e-3, scheme="runge-kutta")),
+        "pde_nested_euler": (pde.PDE({"c": "laplace(c**3 - c - 0.7 * laplace(c)) + 0.01 * x * y"}, bc={"x": {"derivative": 0.05}, "y": "periodic"}),
+                             pde.CartesianGrid([[0, 10], [0, 8]], [10, 8], periodic=[False, True]), dict(t_range=0.02, dt=1e-3), {"ref": "torch"}),
+        "pde_brusselator_euler": (pde.PDE({"u": "laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v) + 2 * u - u**2 * v"},
+                                          bc={"x": "periodic", "y": {"derivative": 0.1}}),
+                                  pde.UnitGrid([12, 8], periodic=[True, False]), dict(t_range=0.05, dt=2e-3), {"ref": "torch", "fields": 2}),
+    })
     # differential fuzz (PDEHIP_WORKER_FUZZ=n): random grids, random conditions per face - constants, mixed, curvature, expressions
     # of time and position, expressions that read the field -, random solver; every rank draws the same case from the same seed
     for k in range(int(os.environ.get("PDEHIP_WORKER_FUZZ", "0"))):
@@ -84,8 +101,11 @@ def main() -> int:
                 kw["adaptive"] = True
         cases[f"fuzz{k}"] = (eq, grid, kw)
     pde.config["default_backend"] = "scipy"
-    for name, (eq, grid, kw) in cases.items():
+    for name, (eq, grid, kw, *rest) in cases.items():
+        opts = rest[0] if rest else {}
         state = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
+        if opts.get("fields"):
+            state = pde.FieldCollection([pde.ScalarField.random_uniform(grid, 0.1, 0.9, rng=np.random.default_rng(3 + k)) for k in range(opts["fields"])])
         seen = []
         tracker = pde.CallbackTracker(lambda s, t: seen.append((t, float(s.data.sum()))), interrupts=kw["t_range"] / 2)
         decomposition = os.environ.get("PDEHIP_WORKER_DECOMPOSITION", "slab")    # "auto": blocks by the reference's rule
@@ -95,7 +115,8 @@ def main() -> int:
         if rank == 0:
             ref_kw = {k: v for k, v in kw.items() if k != "scheme"}
             ref_eq = pde.CahnHilliardPDE() if name == "expression_rkf45" else eq   # the expression class needs numba on numpy
-            ref, rinfo = ref_eq.solve(state, solver="runge-kutta" if kw.get("scheme") else "euler", backend="numpy",
+            pde.config["backend.torch.compile"] = False
+            ref, rinfo = ref_eq.solve(state, solver="runge-kutta" if kw.get("scheme") else "euler", backend=opts.get("ref", "numpy"),
                                       tracker=pde.CallbackTracker(lambda s, t: None, interrupts=kw["t_range"] / 2), ret_info=True, **ref_kw)
             err = np.abs(res.data - ref.data).max() / np.abs(ref.data).max()
             if info["solver"]["steps"] != rinfo["solver"]["steps"]:

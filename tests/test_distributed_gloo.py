@@ -312,6 +312,92 @@ def test_slab_faces_cut_expression_conditions_to_the_slab():
         SlabMesh(grid, 2, 0).slab_faces(far, upload=Host)
 
 
+# ---- any expression PDE on decomposed grids (the run-time compiled passes + a ghost exchange before every pass with operators) ---------
+GENERIC_CASES = {
+    "allen_cahn2d": (lambda: pde_hip.PDE({"c": "laplace(c) - c**3 + c"}, bc={"x": "periodic", "y": {"derivative": 0.1}}),
+                     lambda: pde_hip.CartesianGrid([[0, 6], [0, 4]], [12, 8], periodic=[True, False]), 0.2, 0.01, "euler", 1),
+    "nested3d_rk4": (lambda: pde_hip.PDE({"c": "laplace(c**3 - c - 0.8 * laplace(c)) + 0.1 * x"},
+                                         bc={"x-": {"value_expression": "0.1*sin(t) + 0.05*y"}, "x+": {"derivative": 0}, "y": "periodic", "z": {"derivative": 0}}),
+                     lambda: pde_hip.CartesianGrid([[0, 8], [0, 4], [0, 6]], [8, 4, 6], periodic=[False, True, False]), 0.004, 1e-3, "runge-kutta", 1),
+    "brusselator2d": (lambda: pde_hip.PDE({"u": "laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v + 0.2 * u) + 2 * u - u**2 * v"},
+                                          bc={"x": "periodic", "y-": {"derivative_expression": "-0.2 * value**3"}, "y+": {"value": 0.5}}),
+                      lambda: pde_hip.UnitGrid([10, 8], periodic=[True, False]), 0.05, 0.005, "runge-kutta", 2),
+    "ddx2d": (lambda: pde_hip.PDE({"c": "0.3 * d2_dx2(c) + 0.5 * d_dy(c) - c * d_dx(c)"}, bc={"x": "periodic", "y": {"value": 0.1}}),
+              lambda: pde_hip.UnitGrid([12, 8], periodic=[True, False]), 0.1, 0.01, "euler", 1),
+    "kpz1d_adaptive": (lambda: pde_hip.PDE({"h": "0.5 * laplace(h) + 0.3 * gradient_squared(h)"}), lambda: pde_hip.UnitGrid([16], periodic=True),
+                       0.5, None, "runge-kutta", 1),
+    "swift_hohenberg_adaptive_euler": (lambda: pde_hip.PDE({"c": "-0.54 * c - 1.6 * laplace(c) - laplace(laplace(c)) + 0.3 * c**2 - c**3"}),
+                                       lambda: pde_hip.UnitGrid([10, 8], periodic=[True, False]), 0.01, None, "euler", 1),
+}
+
+
+def _generic_state(grid, nfields):
+    data = np.random.default_rng(7).uniform(-0.5, 0.5, ((nfields,) if nfields > 1 else ()) + tuple(grid.shape))
+    state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d) for d in data]) if nfields > 1 else pde_hip.ScalarField(grid, data)
+    return data, state
+
+
+def solve_generic_cases(rank, size):
+    from pde_hip.distributed import DecomposedExpressionStepper
+
+    out = {}
+    for name, (mk_eq, mk_grid, t_range, dt, solver, nfields) in GENERIC_CASES.items():
+        eq, grid = mk_eq(), mk_grid()
+        data, state = _generic_state(grid, nfields)
+        for dims in ("slab", "auto"):
+            stepper = DecomposedExpressionStepper(eq, state, dims=dims)
+            final, info = stepper.solve(data, t_range, dt, solver)
+            stepper.close()
+            out[name, dims] = (final, info["steps"], list(stepper.dims))
+    return out
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_any_expression_pde_on_decomposed_grids(size):
+    """`DecomposedExpressionStepper`: expression PDEs WITHOUT a fused decomposed loop - nested operators (their intermediate fields are
+    exchanged like the state), first derivatives, `gradient_squared`, explicit coordinates, a two-field system with an operator on a
+    combination of both fields, conditions that depend on time / read the field, Euler / RK4 / adaptive RKF45 / adaptive Euler (error
+    MAX-reduced over the ranks) - on slabs and on the blocks of the reference's rule: BIT-EXACT against the serial run, equal step
+    counts (what `ExplicitMPISolver` does for every PDE, pde/solvers/explicit_mpi.py:133-226)."""
+    import shimlib
+
+    results = run_distributed("solve_generic_cases", size)
+    multi_axis = 0
+    with shimlib.use_shim():
+        for name, (mk_eq, mk_grid, t_range, dt, solver, nfields) in GENERIC_CASES.items():
+            eq, grid = mk_eq(), mk_grid()
+            data, state = _generic_state(grid, nfields)
+            expect, info = eq.solve(state, t_range, dt, solver=solver, ret_info=True)
+            assert np.isfinite(expect.data).all() and np.abs(expect.data - data).max() > 1e-4
+            for rank in range(size):
+                for dims in ("slab", "auto"):
+                    final, steps, used = results[rank][name, dims]
+                    np.testing.assert_array_equal(final, expect.data, err_msg=f"{name} {dims} {used} rank {rank}")
+                    assert steps == info["solver"]["steps"], (name, dims)
+                    multi_axis += sum(d > 1 for d in used) >= 2
+    assert size < 4 or multi_axis > 0
+
+
+def test_decomposed_expression_stepper_exchanging_with_itself():
+    """World size 1 with `force_exchange`: periodic axes travel through the exchange (slab: axis 0; blocks: every periodic axis)."""
+    import shimlib
+    from pde_hip.distributed import DecomposedExpressionStepper
+
+    with shimlib.use_shim():
+        for name in ("allen_cahn2d", "nested3d_rk4", "brusselator2d"):
+            mk_eq, mk_grid, t_range, dt, solver, nfields = GENERIC_CASES[name]
+            eq, grid = mk_eq(), mk_grid()
+            data, state = _generic_state(grid, nfields)
+            expect, info = eq.solve(state, t_range, dt, solver=solver, ret_info=True)
+            for dims in ("slab", "auto"):
+                stepper = DecomposedExpressionStepper(eq, state, dims=dims, force_exchange=True)
+                final, sinfo = stepper.solve(data, t_range, dt, solver)
+                assert (stepper.comm is not None) == (stepper.blocks or bool(grid.periodic[0])), (name, dims)
+                stepper.close()
+                np.testing.assert_array_equal(final, expect.data, err_msg=f"{name} {dims}")
+                assert sinfo["steps"] == info["solver"]["steps"]
+
+
 # ---- block decomposition (VERDICT r2 missing #1: 2 x 2 x 2 instead of slabs) ------------------------------------------------
 BLOCK_CASES = {
     "diff3d_periodic": (lambda: pde_hip.DiffusionPDE(0.8), lambda: pde_hip.UnitGrid([8, 6, 10], periodic=True), 1.0, 0.1, "euler"),
@@ -530,6 +616,6 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
     assert proc.returncode == 0 and lines, proc.stderr[-3000:]
     report = json.loads(lines[-1][len("PYPDESLAB "):])
-    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 4 + FUZZ_CASES
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 9 + FUZZ_CASES
     if decomposition == "auto":     # blocks along more than one axis (`decomposition="auto"`, the reference's rule)
         assert sum(sum(d > 1 for d in c["decomposition"]) >= 2 for c in report["cases"].values()) >= 2, report

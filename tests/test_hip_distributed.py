@@ -332,3 +332,32 @@ def test_fresh_buffers_are_not_overtaken_by_their_zero_fill():
             out = st.gather_local(st.euler_steps(a, b, 1e-3, 4))
             st.close()
             assert out.any() and np.array_equal(out, first.setdefault(k, out)), (it, k)
+
+
+@pytest.mark.parametrize("dims", ["slab", "auto"])
+def test_any_expression_pde_with_the_exchange_to_self(dims):
+    """`DecomposedExpressionStepper(force_exchange=True)` on ONE GPU: the run-time compiled passes of expression PDEs without a fused
+    decomposed loop, the ghost layers of every operator's operand through RCCL to self (slab: axis 0; blocks: every periodic axis) -
+    nested operators, a two-field system, conditions of time / of the field, RK4 and the adaptive loop: equal to the single-GPU run bit
+    for bit (N > 1 ranks: tests/test_distributed_gloo.py::test_any_expression_pde_on_decomposed_grids on the shim)."""
+    from pde_hip.distributed import DecomposedExpressionStepper
+
+    cases = [
+        (pde_hip.PDE({"c": "laplace(c**3 - c - 0.8 * laplace(c)) + 0.1 * y"},
+                     bc={"x": "periodic", "y-": {"value_expression": "0.1*sin(t) + 0.05*x"}, "y+": {"derivative_expression": "-0.2 * value**3"}, "z": "periodic"}),
+         pde_hip.CartesianGrid([[0, 8], [0, 6], [0, 72]], [8, 6, 72], periodic=[True, False, True]), 0.004, 1e-3, "runge-kutta", 1),
+        (pde_hip.PDE({"u": "laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v + 0.2 * u) + 2 * u - u**2 * v"}, bc={"x": "periodic", "y": {"derivative": 0.1}}),
+         pde_hip.UnitGrid([12, 136], periodic=[True, False]), 0.02, 0.002, "euler", 2),
+        (pde_hip.PDE({"h": "0.5 * laplace(h) + 0.3 * gradient_squared(h)"}), pde_hip.UnitGrid([10, 72], periodic=True), 0.3, None, "runge-kutta", 1),
+    ]
+    for eq, grid, t_range, dt, solver, nfields in cases:
+        data = np.random.default_rng(7).uniform(0.1, 0.6, ((nfields,) if nfields > 1 else ()) + tuple(grid.shape))
+        state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d) for d in data]) if nfields > 1 else pde_hip.ScalarField(grid, data)
+        expect, info = eq.solve(state, t_range, dt, solver=solver, ret_info=True)
+        assert np.isfinite(expect.data).all() and np.abs(expect.data - data).max() > 1e-4
+        st = DecomposedExpressionStepper(eq, state, dims=dims, force_exchange=True)
+        assert st.comm is not None
+        final, sinfo = st.solve(data, t_range, dt, solver)
+        st.close()
+        assert sinfo["steps"] == info["solver"]["steps"]
+        np.testing.assert_array_equal(final, expect.data)

@@ -65,6 +65,9 @@ cases (grids with 1-3 axes, random conditions per face, random solver).  Call 26
 of the `slab` run (`fuzz15`, a 1-D grid of 8 cells) came back all zero - the zero fill of a fresh allocation overtaking work on a non-blocking
 stream, reproduced at 15-24 % under stress, fixed in `pdehip_malloc` and verified (`profiles/r03_malloc_fill_race.md`); after the fix: 4 x 22 cases
 green (`tools/gpu_r3_call27.sh`), 404 + 87 GPU tests of the allocation-heavy suites green with the final library (calls 27 and 29).
+Call 30 (the last of the round): the worker with five more cases that take the decomposed EXPRESSION stepper (Allen-Cahn class adaptive RKF45,
+diffusion with adaptive Euler, Swift-Hohenberg class RK4, a nested `pde.PDE` and a two-field Brusselator against the reference's eager torch-CPU run)
++ 6 fuzz cases: `"failures": []`; `tests/test_hip_distributed.py -k "any_expression or expression_conditions or zero_fill"`: 7 passed.
 
 In the same call: `pytest tests -m gpu`: {gpu_tail} (the mirror front end and the C ABI against the oracle and the goldens),
 `__graft_entry__.smoke()` ok.

@@ -575,7 +575,8 @@ class DecomposedExpressionStepper:
     (``SlabMesh.slab_faces`` / ``BlockMesh.block_faces``); coordinate arrays and array-valued constants are cut to the box.  The
     steppers are the Python-level twins of the C loops (``HipBackendMixin._make_expression_stepper``); the adaptive error is
     MAX-reduced over the ranks.  Everything runs on the null stream (conditions are refreshed there): in order, no overlap - the
-    fast decomposed paths are the fused Diffusion / Cahn-Hilliard loops of :class:`SlabStepper`.  Integrals are refused."""
+    fast decomposed paths are the fused Diffusion / Cahn-Hilliard loops of :class:`SlabStepper`.  Integrals over the grid are summed over
+    the ranks (equal to the serial value up to rounding)."""
 
     def __init__(self, eq, state, *, dims=None, control=None, device: int | None = None, force_exchange: bool = False):
         """``force_exchange`` (world size 1): periodic axes exchange with the box itself instead of keeping their periodic condition
@@ -612,9 +613,7 @@ class DecomposedExpressionStepper:
         self.ncomp = int(getattr(self.erhs, "ncomp", 1))
         parts = getattr(self.erhs, "parts", [self.erhs])
         for part in parts:
-            if part.has_reductions:
-                msg = "decomposed stepping: integrals over the grid are not supported"
-                raise NotImplementedError(msg)
+            part._reduce = self._sum_over_ranks if self.size > 1 else None
             part._pass_by_pass = True
             part._two_ok = False
             part._exchange = self.exchange if exchanging else None
@@ -646,6 +645,11 @@ class DecomposedExpressionStepper:
             lo = 0 if self._force else (-1 if self.mesh.lower is None else int(self.mesh.lower))
             up = 0 if self._force else (-1 if self.mesh.upper is None else int(self.mesh.upper))
             self.lib.halo_exchange(self.comm, self.info.ref, arr.ptr, lo, up, self.stream)
+
+    def _sum_over_ranks(self, value: float) -> float:
+        """Integrals over the grid: the partial integrals of the boxes added in rank order (deterministic; equal to the serial sum
+        up to rounding, like the reference's MPI all-reduce)."""
+        return float(sum(float(v) for v in self.control.allgather(float(value))))
 
     def _max_over_ranks(self, value: float) -> float:
         values = [float(v) for v in self.control.allgather(float(value))]

@@ -544,6 +544,7 @@ class ExpressionRhs:
         # decomposed grids (pde_hip/distributed.py): `_exchange(array)` fills the ghost layers towards the neighbouring ranks before a
         # pass applies operators to `array`; the passes then run one by one from Python (no fused chains, no C loops)
         self._exchange = None
+        self._reduce = None
         self._pass_by_pass = False
         # two steps per sweep: the second level would need the faces at t + dt / the integrals of the intermediate level
         self._two_ok: bool | None = False if (self._dynamic or self.has_reductions) else None
@@ -603,7 +604,9 @@ class ExpressionRhs:
                 # integral over the grid -> run-time parameter of the passes that follow (8 bytes cross PCIe: a host sync)
                 self.lib.integrate(self.info.ref, 1, arrays[p.src].ptr, self._cell_volume, self._red_dev.ptr, self.backend.stream)
                 self.lib.memcpy_d2h(self._red_host.ctypes.data, self._red_dev.ptr, 8, self.backend.stream)
-                params[p.reduce_slot] = float(self._red_host[0])
+                # (decomposed grids: the integral over the box of this rank; `_reduce` sums over the ranks, like the reference's
+                # `mpi_allreduce` in `ScalarField.integral`, pde/fields/datafield_base.py)
+                params[p.reduce_slot] = float(self._red_host[0]) if self._reduce is None else float(self._reduce(float(self._red_host[0])))
                 continue
             h, extras = self._kernel(i, wrap)
             ex = (C.c_void_p * 3)()

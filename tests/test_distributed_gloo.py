@@ -378,6 +378,36 @@ def test_any_expression_pde_on_decomposed_grids(size):
     assert size < 4 or multi_axis > 0
 
 
+def solve_integral_case(rank, size):
+    from pde_hip.distributed import DecomposedExpressionStepper
+
+    eq, grid = pde_hip.PDE({"c": "-0.1 * integral(c) + 0.05 * c * integral(c**2) + laplace(c)"}), pde_hip.UnitGrid([12, 8], periodic=[True, False])
+    data, state = _generic_state(grid, 1)
+    out = {}
+    for dims in ("slab", "auto"):
+        stepper = DecomposedExpressionStepper(eq, state, dims=dims)
+        out[dims] = stepper.solve(data, 0.2, 0.01, "runge-kutta")[0]
+        stepper.close()
+    return out
+
+
+def test_integrals_on_decomposed_grids():
+    """`integral(...)` inside an expression: every rank integrates over its box, the partial integrals are added over the ranks (the
+    reference's `mpi_allreduce`): equal to the serial run up to the rounding of that sum."""
+    import shimlib
+
+    results = run_distributed("solve_integral_case", 4)
+    with shimlib.use_shim():
+        eq, grid = pde_hip.PDE({"c": "-0.1 * integral(c) + 0.05 * c * integral(c**2) + laplace(c)"}), pde_hip.UnitGrid([12, 8], periodic=[True, False])
+        data, state = _generic_state(grid, 1)
+        expect = eq.solve(state, 0.2, 0.01, solver="runge-kutta").data
+    assert np.abs(expect - data).max() > 1e-3
+    for rank in range(4):
+        for dims in ("slab", "auto"):
+            np.testing.assert_allclose(results[rank][dims], expect, rtol=1e-12, atol=1e-13)
+            np.testing.assert_array_equal(results[rank][dims], results[0][dims])      # all ranks hold the same field
+
+
 def test_decomposed_expression_stepper_exchanging_with_itself():
     """World size 1 with `force_exchange`: periodic axes travel through the exchange (slab: axis 0; blocks: every periodic axis)."""
     import shimlib

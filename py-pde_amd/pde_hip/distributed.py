@@ -617,7 +617,11 @@ class DecomposedExpressionStepper:
             part._pass_by_pass = True
             part._two_ok = False
             part._exchange = self.exchange if exchanging else None
-        self._steppers: dict[tuple, Any] = {}
+        # every rank must run the same passes in the same order (the exchanges pair up by issue order): checked, not assumed
+        plans = ["\n".join(part.plan.describe()) for part in parts]
+        if any(other != plans for other in self.control.allgather(plans)):
+            msg = "decomposed stepping: the ranks planned different pass sequences for the same expression"
+            raise RuntimeError(msg)
         self._state = None
 
     # --- what make_expression_rhs asks (see HipBackendMixin._expression_*) ---------------------------------------------------
@@ -625,11 +629,10 @@ class DecomposedExpressionStepper:
         return self.info
 
     def _expression_faces(self, grid, bc, comp):
-        if comp is not None:
-            msg = "decomposed stepping supports scalar fields (and systems of them)"
-            raise NotImplementedError(msg)
-        bcs = grid.get_boundary_conditions(bc, rank=0)
-        return self.mesh.block_faces(bcs) if self.blocks else self.mesh.slab_faces(bcs, force_exchange=self._force)
+        rank = 0 if comp is None else (2 if isinstance(comp, tuple) else 1)
+        bcs = grid.get_boundary_conditions(bc, rank=rank)
+        kw = {} if comp is None else {"comp_shape": (grid.num_axes,) * rank, "component": comp}
+        return self.mesh.block_faces(bcs, **kw) if self.blocks else self.mesh.slab_faces(bcs, force_exchange=self._force, **kw)
 
     def _expression_aux(self, info, host):
         from .device import DeviceArray

@@ -337,7 +337,9 @@ class ExpressionPlan:
     def _emit(self, expr, out: str) -> None:
         """Emit the passes that evaluate the (operator-lowered) pointwise expression into ``out``."""
         sp = _sympy()
-        atoms = list(expr.atoms(sp.core.function.AppliedUndef))
+        # (sorted: the order of a set of sympy atoms follows the hash seed of the process - the pass order must not, every rank of a
+        # decomposed run builds the same plan and exchanges the operands in the same order)
+        atoms = sorted(expr.atoms(sp.core.function.AppliedUndef), key=sp.default_sort_key)
         by_array: dict[str, list] = {}
         for a in atoms:
             by_array.setdefault(self._array_of(a.args[0]), []).append(a)

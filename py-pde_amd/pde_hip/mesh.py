@@ -60,13 +60,14 @@ class SlabMesh:
             self._subgrid._discretization = np.array(grid.discretization, dtype=float)
         return self._subgrid
 
-    def slab_faces(self, bcs, *, force_exchange: bool = False, upload=None):
+    def slab_faces(self, bcs, *, force_exchange: bool = False, upload=None, comp_shape: tuple[int, ...] = (), component=None):
         """Face table of THIS slab from the boundary conditions of the WHOLE grid (any ``BoundariesList``: the mirror's or
         py-pde's own).  Replaces ``GridMesh.extract_boundary_conditions`` + ``_MPIBC`` (pde/grids/_mesh.py:535-569,
         pde/grids/boundaries/local.py:561-662): faces towards a neighbour are marked SKIP (their ghost layer is filled by the
         halo exchange), physical faces of axis 0 keep their condition with the index translated into the slab, per-face arrays
         of the other axes are sliced along axis 0 (the reference refuses those: ``Cannot transfer complicated BC to subgrid``,
-        local.py:1515-1540)."""
+        local.py:1515-1540).  ``comp_shape`` / ``component``: the conditions of a vector / tensor field, reduced to the table of ONE
+        component for a scalar array (``convert_bcs``: the terms of vector operators inside expression PDEs)."""
         from . import _abi
         from .backend import FaceTable, _upload_f64, convert_bcs
         from .bc_expr import ExprFaceTable, _write_buffer, expression_faces, lower_expression_face
@@ -81,14 +82,14 @@ class SlabMesh:
 
         for pair in bcs:
             for bc in (pair.low, pair.high):
-                if getattr(bc, "rank", 0) != 0 or getattr(bc, "normal", False):
+                if getattr(bc, "rank", 0) != (len(comp_shape) if component is not None else 0) or getattr(bc, "normal", False):
                     # the slab loops advance scalar fields (rank-0 conditions); `normal_*` conditions belong to vector fields
                     msg = "slab-parallel stepping supports conditions of scalar fields only (got a rank-1 / `normal` condition)"
                     raise NotImplementedError(msg)
         # conditions given as expressions (incl. time-dependent ones and ones that read the field): evaluated for THIS slab - the
         # face cut to the slab's layers, wall coordinates of the whole grid - and refreshed by a device program (bc_expr.py)
         expr_faces = expression_faces(bcs)
-        glob = convert_bcs(bcs, skip=set(expr_faces), upload=_Host)
+        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         exchanged = {(0, False): self.lower is not None, (0, True): self.upper is not None}
         if force_exchange and self.size == 1 and bool(self.grid.periodic[0]):
@@ -319,7 +320,7 @@ class BlockMesh:
         """Local block of global valid data (``GridMesh.extract_field_data``, _mesh.py:446-479)."""
         return data[(...,) + tuple(slice(lo, hi) for lo, hi in zip(self.lo, self.hi))]
 
-    def block_faces(self, bcs, *, upload=None):
+    def block_faces(self, bcs, *, upload=None, comp_shape: tuple[int, ...] = (), component=None):
         """Face table of THIS block from the conditions of the WHOLE grid: faces towards a neighbour are SKIP (filled by the
         exchange; the wrap-around of a decomposed periodic axis must be plainly periodic), physical faces keep their condition
         with the index translated into the block, per-face arrays are cut to the block's extent along the other axes."""
@@ -337,11 +338,11 @@ class BlockMesh:
 
         for pair in bcs:
             for bc in (pair.low, pair.high):
-                if getattr(bc, "rank", 0) != 0 or getattr(bc, "normal", False):
+                if getattr(bc, "rank", 0) != (len(comp_shape) if component is not None else 0) or getattr(bc, "normal", False):
                     msg = "block-parallel stepping supports conditions of scalar fields only"
                     raise NotImplementedError(msg)
         expr_faces = expression_faces(bcs)       # as in SlabMesh.slab_faces: cut to the block, coordinates of the whole grid
-        glob = convert_bcs(bcs, skip=set(expr_faces), upload=_Host)
+        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         out = FaceTable()
         dynamic = []

@@ -217,8 +217,8 @@ def _decomposed_expression_stepper(self, state, dt: float, device):
     from .distributed import DecomposedExpressionStepper
 
     kinds = [f.__class__.__name__ for f in (list(state) if state.__class__.__name__ == "FieldCollection" else [state])]
-    if any(k != "ScalarField" for k in kinds):
-        msg = "slab-parallel stepping supports a ScalarField or a FieldCollection of ScalarFields"
+    if any(k not in ("ScalarField", "VectorField", "Tensor2Field") for k in kinds):
+        msg = "slab-parallel stepping supports scalar, vector and rank-2 tensor fields (or a FieldCollection of them)"
         raise NotImplementedError(msg)
     dims = self.decomposition if isinstance(self.decomposition, str) else [int(d) for d in self.decomposition]
     stepper = DecomposedExpressionStepper(self.pde, state, dims=dims, device=device)

@@ -60,6 +60,8 @@ def main() -> int:
         "pde_brusselator_euler": (pde.PDE({"u": "laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v) + 2 * u - u**2 * v"},
                                           bc={"x": "periodic", "y": {"derivative": 0.1}}),
                                   pde.UnitGrid([12, 8], periodic=[True, False]), dict(t_range=0.05, dt=2e-3), {"ref": "torch", "fields": 2}),
+        "pde_vector_euler": (pde.PDE({"u": "vector_laplace(u) - u + 0.1 * gradient(dot(u, u))"}, bc={"x": "periodic", "y": {"derivative": 0.1}}),
+                             pde.UnitGrid([12, 8], periodic=[True, False]), dict(t_range=0.05, dt=2e-3), {"ref": "torch", "vector": True}),
     })
     # differential fuzz (PDEHIP_WORKER_FUZZ=n): random grids, random conditions per face - constants, mixed, curvature, expressions
     # of time and position, expressions that read the field -, random solver; every rank draws the same case from the same seed
@@ -104,6 +106,8 @@ def main() -> int:
     for name, (eq, grid, kw, *rest) in cases.items():
         opts = rest[0] if rest else {}
         state = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
+        if opts.get("vector"):
+            state = pde.VectorField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
         if opts.get("fields"):
             state = pde.FieldCollection([pde.ScalarField.random_uniform(grid, 0.1, 0.9, rng=np.random.default_rng(3 + k)) for k in range(opts["fields"])])
         seen = []

@@ -326,12 +326,23 @@ GENERIC_CASES = {
               lambda: pde_hip.UnitGrid([12, 8], periodic=[True, False]), 0.1, 0.01, "euler", 1),
     "kpz1d_adaptive": (lambda: pde_hip.PDE({"h": "0.5 * laplace(h) + 0.3 * gradient_squared(h)"}), lambda: pde_hip.UnitGrid([16], periodic=True),
                        0.5, None, "runge-kutta", 1),
+    # vector operators inside a scalar equation (their terms take the conditions of ONE component of a rank-1 condition) and a vector
+    # field as the state (its components are the fields of a system)
+    "div_d_grad2d": (lambda: pde_hip.PDE({"c": "divergence((1.01 + tanh(x)) * gradient(c)) - 0.5 * dot(gradient(c), gradient(c))"},
+                                         bc={"x": "periodic", "y": {"derivative": 0.1}}),
+                     lambda: pde_hip.CartesianGrid([[0, 6], [0, 4]], [12, 8], periodic=[True, False]), 0.1, 0.005, "euler", 1),
+    "vector3d": (lambda: pde_hip.PDE({"u": "vector_laplace(u) - tensor_divergence(outer(u, u)) + 0.1 * gradient(dot(u, u))"},
+                                     bc={"x": {"derivative": 0}, "y": "periodic", "z": {"value": 0}}),
+                 lambda: pde_hip.UnitGrid([8, 4, 6], periodic=[False, True, False]), 0.02, 0.005, "runge-kutta", "vector"),
     "swift_hohenberg_adaptive_euler": (lambda: pde_hip.PDE({"c": "-0.54 * c - 1.6 * laplace(c) - laplace(laplace(c)) + 0.3 * c**2 - c**3"}),
                                        lambda: pde_hip.UnitGrid([10, 8], periodic=[True, False]), 0.01, None, "euler", 1),
 }
 
 
 def _generic_state(grid, nfields):
+    if nfields == "vector":
+        data = np.random.default_rng(7).uniform(-0.5, 0.5, (grid.num_axes,) + tuple(grid.shape))
+        return data, pde_hip.VectorField(grid, data)
     data = np.random.default_rng(7).uniform(-0.5, 0.5, ((nfields,) if nfields > 1 else ()) + tuple(grid.shape))
     state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d) for d in data]) if nfields > 1 else pde_hip.ScalarField(grid, data)
     return data, state
@@ -355,7 +366,7 @@ def solve_generic_cases(rank, size):
 @pytest.mark.parametrize("size", [2, 4])
 def test_any_expression_pde_on_decomposed_grids(size):
     """`DecomposedExpressionStepper`: expression PDEs WITHOUT a fused decomposed loop - nested operators (their intermediate fields are
-    exchanged like the state), first derivatives, `gradient_squared`, explicit coordinates, a two-field system with an operator on a
+    exchanged like the state), first derivatives, `gradient_squared`, vector operators, a vector field as the state, explicit coordinates, a two-field system with an operator on a
     combination of both fields, conditions that depend on time / read the field, Euler / RK4 / adaptive RKF45 / adaptive Euler (error
     MAX-reduced over the ranks) - on slabs and on the blocks of the reference's rule: BIT-EXACT against the serial run, equal step
     counts (what `ExplicitMPISolver` does for every PDE, pde/solvers/explicit_mpi.py:133-226)."""
@@ -646,6 +657,6 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
     assert proc.returncode == 0 and lines, proc.stderr[-3000:]
     report = json.loads(lines[-1][len("PYPDESLAB "):])
-    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 9 + FUZZ_CASES
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 10 + FUZZ_CASES
     if decomposition == "auto":     # blocks along more than one axis (`decomposition="auto"`, the reference's rule)
         assert sum(sum(d > 1 for d in c["decomposition"]) >= 2 for c in report["cases"].values()) >= 2, report

@@ -1031,8 +1031,9 @@ class HipBackendMixin:
                     erhs.apply(y, k2a, "euler", 0.5 * dt_step, t)
                     erhs.apply(k2a, ynew, "euler", 0.5 * dt_step, t + 0.5 * dt_step)
                 lib.max_abs_diff(info.ref, ncomp, k1.ptr, ynew.ptr, err_dev.ptr, stream)
-            # (`reduce_error`: MAX over the ranks of a decomposed run, NaN wins - pde/backends/base.py:678-712)
-            return err_dev.value(stream) if reduce_error is None else reduce_error(err_dev.value(stream))
+            if reduce_error is not None:
+                reduce_error(err_dev)     # MAX over the ranks of a decomposed run, on the device, NaN wins (pde/backends/base.py:678-712)
+            return err_dev.value(stream)
 
         ctl = None
         if is_rk and post_step is None and hasattr(erhs, "rk_run") and os.environ.get("PDEHIP_EXPR_LOOP") != "0":

@@ -654,9 +654,9 @@ class DecomposedExpressionStepper:
         up to rounding, like the reference's MPI all-reduce)."""
         return float(sum(float(v) for v in self.control.allgather(float(value))))
 
-    def _max_over_ranks(self, value: float) -> float:
-        values = [float(v) for v in self.control.allgather(float(value))]
-        return float("nan") if any(np.isnan(v) for v in values) else max(values)
+    def _max_over_ranks(self, err_dev) -> None:
+        """MAX all-reduce of the device scalar ``err_dev`` (``pdehip_allreduce_max``: RCCL, NaN wins)."""
+        self.lib.allreduce_max(self.comm, err_dev.ptr, self.stream)
 
     def state_array(self):
         from .device import DeviceArray

@@ -379,10 +379,18 @@ class SlabStepper:
         return self.gather(cur), info
 
     def close(self) -> None:
+        """Release the communicator and the stream (the stepper cannot be used afterwards; its arrays are freed with the object)."""
         if self.comm is not None:
             self.synchronize()
             self.lib.comm_destroy(self.comm)
             self.comm = None
+        if getattr(self, "stream", None) is not None:
+            stream, self.stream = self.stream, None
+            try:
+                self.lib.stream_synchronize(stream)
+                self.lib.stream_destroy(stream)
+            except Exception:  # noqa: BLE001 - releasing a resource at the end of a run must not turn a finished run into a failure
+                pass
 
     def __del__(self):
         try:
@@ -526,10 +534,18 @@ class BlockStepper:
         return self.gather(cur), info
 
     def close(self) -> None:
+        """Release the communicator and the stream (the stepper cannot be used afterwards; its arrays are freed with the object)."""
         if self.comm is not None:
             self.synchronize()
             self.lib.comm_destroy(self.comm)
             self.comm = None
+        if getattr(self, "stream", None) is not None:
+            stream, self.stream = self.stream, None
+            try:
+                self.lib.stream_synchronize(stream)
+                self.lib.stream_destroy(stream)
+            except Exception:  # noqa: BLE001 - releasing a resource at the end of a run must not turn a finished run into a failure
+                pass
 
     def __del__(self):
         try:

@@ -914,7 +914,7 @@ class HipBackendMixin:
 
         return SystemRhs(variables, parts, info)
 
-    def _make_expression_stepper(self, solver, state, erhs=None, post_step=None, reduce_error=None):
+    def _make_expression_stepper(self, solver, state, erhs=None, post_step=None, reduce_error=None, scheme=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
         (pde/solvers/euler.py:172-175, runge_kutta.py:52-61, :135-153) with the RHS evaluated by the
         run-time specialised kernels; the Euler update / RK stage scaling is folded into the last pass.
@@ -930,7 +930,8 @@ class HipBackendMixin:
         info, lib, stream = erhs.info, self._lib, self.stream
         ncomp = int(getattr(erhs, "ncomp", 1))                      # > 1: multi-field PDE (SystemRhs)
         comp_shape = (ncomp,) if ncomp > 1 else ()
-        is_rk = solver.__class__.__name__ == "RungeKuttaSolver"
+        # (`scheme`: "euler" / "runge-kutta" for callers without one of the solver classes, e.g. the decomposed steppers)
+        is_rk = (scheme == "runge-kutta") if scheme is not None else solver.__class__.__name__ == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
         nwork = (7 if adaptive else 5) if is_rk else (2 if adaptive else 1)
         work = [DeviceArray(info, comp_shape) for _ in range(nwork)]

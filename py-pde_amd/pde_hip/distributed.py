@@ -569,14 +569,6 @@ def create_communicator(lib, control):
     return comm
 
 
-class _EulerSolver:
-    pass
-
-
-class RungeKuttaSolver:   # (the stepper factory asks for the scheme by class name, like the reference's solver classes)
-    pass
-
-
 class DecomposedExpressionStepper:
     """Explicit Euler / RK4 / adaptive steppers for ANY expression PDE the hip backend evaluates with its run-time compiled passes
     (``pde.PDE`` with scalar fields, systems of them, the built-in classes in their expression form) on a slab or block
@@ -699,12 +691,14 @@ class DecomposedExpressionStepper:
 
         from .backend import HipBackendMixin
 
-        cls = RungeKuttaSolver if scheme == "runge-kutta" else _EulerSolver
-        solver = cls()
-        solver.__dict__.update(pde=self.eq, adaptive=bool(adaptive), tolerance=float(tolerance), dt_min=float(dt_min), dt_max=float(dt_max),
-                               info={"dt": float(dt), "steps": 0})
+        if scheme not in ("euler", "runge-kutta"):
+            msg = f"decomposed stepping supports the schemes euler and runge-kutta (got {scheme})"
+            raise NotImplementedError(msg)
+        solver = SimpleNamespace(pde=self.eq, adaptive=bool(adaptive), tolerance=float(tolerance), dt_min=float(dt_min), dt_max=float(dt_max),
+                                 info={"dt": float(dt), "steps": 0})
         proxy = SimpleNamespace(grid=self.grid, dtype=self.dtype)
-        step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, reduce_error=self._max_over_ranks if self.size > 1 else None)
+        step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, scheme=scheme,
+                                                        reduce_error=self._max_over_ranks if self.size > 1 else None)
         return step, solver.info
 
     def solve(self, global_valid: np.ndarray, t_range: float, dt: float | None, solver: str = "euler", *, tolerance: float = 1e-4,

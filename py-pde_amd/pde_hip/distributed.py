@@ -557,6 +557,20 @@ class BlockStepper:
 # ---------------------------------------------------------------------------------------------
 # any expression PDE on slabs / blocks
 # ---------------------------------------------------------------------------------------------
+def resolve_decomposition(dims, size: int) -> list[int]:
+    """Blocks per axis with ``-1`` entries replaced by the ranks that are left (``GridMesh.from_grid``, pde/grids/_mesh.py:230-256: one
+    axis may be given as -1)."""
+    dims = [int(d) for d in dims]
+    free = [a for a, d in enumerate(dims) if d == -1]
+    if len(free) > 1:
+        msg = "only one axis of the decomposition can be -1"
+        raise ValueError(msg)
+    if free:
+        fixed = int(np.prod([d for d in dims if d != -1]))
+        dims[free[0]] = max(1, size // max(1, fixed))
+    return dims
+
+
 def create_communicator(lib, control):
     """libpdehip's RCCL communicator over all ranks of ``control`` (the 128-byte id travels over the control plane)."""
     path = rccl_library_path().encode()
@@ -605,7 +619,7 @@ class DecomposedExpressionStepper:
         requested = dims
         if isinstance(dims, str):      # "auto": the reference's rule (pde/grids/_mesh.py:59-93); "slab" / None: axis 0 only
             dims = block_decomposition(grid.shape, self.size) if dims == "auto" else None
-        dims = [int(d) for d in (dims if dims is not None else [self.size] + [1] * (nd - 1))]
+        dims = resolve_decomposition(dims if dims is not None else [self.size] + [1] * (nd - 1), self.size)
         if int(np.prod(dims)) != self.size:
             msg = f"decomposition {dims} needs {int(np.prod(dims))} ranks, the job has {self.size}"
             raise ValueError(msg)
@@ -684,6 +698,47 @@ class DecomposedExpressionStepper:
         return combine_blocks(blocks, self.dims, nd) if self.blocks else combine(blocks, nd)
 
     # --- steppers -----------------------------------------------------------------------------------------------
+    def make_noise_step(self, eq, dt: float):
+        """``add_noise(array)`` of an Euler-Maruyama step on the box of this rank - additive Gaussian white noise of constant
+        variance ``eq.noise`` (one value, or one per field): ``state += sqrt(dt) * sqrt(noise / cell_volume) * dW`` with dW from the
+        device generator (``HipBackendMixin._make_noise_step``); every rank draws from its own part of the counter space, so the
+        boxes get independent noise (the reference's MPI nodes each run their own generator).  None for deterministic equations."""
+        if not getattr(eq, "is_sde", False):
+            return None
+        for cls in type(eq).__mro__:
+            if "make_noise_variance" in vars(cls) and cls.__name__ not in {"SDEBase", "PDEBase"}:
+                msg = "decomposed stepping supports additive noise of constant variance (a custom `make_noise_variance` runs on one device)"
+                raise NotImplementedError(msg)
+            if "make_noise_variance" in vars(cls):
+                break
+        if getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
+            msg = "decomposed stepping supports Gaussian white noise given by its variance only"
+            raise NotImplementedError(msg)
+        try:
+            noise = np.broadcast_to(np.asarray(getattr(eq, "noise", 0), dtype=float), (self.ncomp,))
+        except ValueError:
+            noise = None
+        if noise is None or (noise < 0).any():
+            msg = "decomposed stepping needs one non-negative noise variance per field"
+            raise NotImplementedError(msg)
+        cell_volume = float(np.prod(self.grid.discretization))
+        cells = int(np.prod(self.grid.shape))
+        scales = [float(np.sqrt(dt) * np.sqrt(v / cell_volume)) for v in noise]
+        rng = getattr(eq, "rng", None)
+        seed = int(self.control.broadcast(int((rng if rng is not None else np.random.default_rng()).integers(0, 2**32))))
+        counter = [0]
+        first = self.rank * self.ncomp * cells      # this rank's part of the counter space (a box never has more cells than the grid)
+
+        def add_noise(arr) -> None:
+            flat = arr.flat() if self.ncomp > 1 else None
+            for k in range(self.ncomp):
+                if scales[k] != 0:
+                    ptr = arr.ptr if flat is None else flat.component(k).ptr
+                    self.lib.add_gaussian_noise(self.info.ref, 1, ptr, scales[k], seed, counter[0], first + k * cells, self.stream)
+            counter[0] += 1
+
+        return add_noise
+
     def make_stepper(self, scheme: str = "euler", dt: float = 1e-3, *, adaptive: bool = False, tolerance: float = 1e-4, dt_min: float = 1e-10,
                      dt_max: float = 1e10):
         """``stepper(state_array, t_start, t_end) -> (state_array, t_last)`` on the box of this rank, plus its ``info`` dict."""
@@ -697,7 +752,23 @@ class DecomposedExpressionStepper:
         solver = SimpleNamespace(pde=self.eq, adaptive=bool(adaptive), tolerance=float(tolerance), dt_min=float(dt_min), dt_max=float(dt_max),
                                  info={"dt": float(dt), "steps": 0})
         proxy = SimpleNamespace(grid=self.grid, dtype=self.dtype)
-        step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, scheme=scheme,
+        post_step = None
+        add_noise = self.make_noise_step(self.eq, float(dt))
+        if add_noise is not None:
+            # Euler-Maruyama (pde/solvers/euler.py:66-147): deterministic Euler step, then the noise increment
+            if adaptive:
+                msg = "Cannot use adaptive stepping with stochastic equation"   # pde/solvers/base.py:446-449
+                raise RuntimeError(msg)
+            if scheme != "euler":
+                msg = "decomposed stepping supports stochastic equations with the Euler scheme"
+                raise NotImplementedError(msg)
+
+            def post_step(arr, t):   # noqa: ARG001
+                add_noise(arr)
+                return arr
+
+        solver.info["stochastic"] = add_noise is not None
+        step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, scheme=scheme, post_step=post_step,
                                                         reduce_error=self._max_over_ranks if self.size > 1 else None)
         return step, solver.info
 

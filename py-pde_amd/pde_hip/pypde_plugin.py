@@ -131,9 +131,6 @@ class HipSlabSolver(AdaptiveSolverBase):
         if dt is None:
             dt = self.dt_default
         self.info.update(dt=float(dt), steps=0, dt_adaptive=bool(self.adaptive), stochastic=False, scheme=self.scheme, post_step_data=None)
-        if getattr(self.pde, "is_sde", False):
-            msg = "slab-parallel stepping does not support stochastic equations"
-            raise NotImplementedError(msg)
         self._select_backend(state)
         # a post-step hook would have to run on the gathered state between the steps of the C loops: refused instead of being
         # dropped silently (the single-GPU steppers run hooks, `solver="euler"`)
@@ -151,6 +148,9 @@ class HipSlabSolver(AdaptiveSolverBase):
         from .distributed import SlabStepper
 
         try:
+            if getattr(self.pde, "is_sde", False):
+                msg = "the fused slab loops are deterministic"     # (noise increments between the steps: the Python-level stepper)
+                raise NotImplementedError(msg)
             if state.__class__.__name__ != "ScalarField":
                 msg = "the fused slab loops take one ScalarField"
                 raise NotImplementedError(msg)
@@ -166,7 +166,10 @@ class HipSlabSolver(AdaptiveSolverBase):
             from .distributed import default_control
             from .mesh import block_decomposition
 
-            dims = [int(d) for d in (block_decomposition(state.grid.shape, default_control().size) if self.decomposition == "auto" else self.decomposition)]
+            from .distributed import resolve_decomposition
+
+            size = default_control().size
+            dims = block_decomposition(state.grid.shape, size) if self.decomposition == "auto" else resolve_decomposition(self.decomposition, size)
             blocks = any(d > 1 for d in dims[1:])
         if blocks:
             from .distributed import BlockStepper
@@ -220,18 +223,19 @@ def _decomposed_expression_stepper(self, state, dt: float, device):
     if any(k not in ("ScalarField", "VectorField", "Tensor2Field") for k in kinds):
         msg = "slab-parallel stepping supports scalar, vector and rank-2 tensor fields (or a FieldCollection of them)"
         raise NotImplementedError(msg)
-    dims = self.decomposition if isinstance(self.decomposition, str) else [int(d) for d in self.decomposition]
+    dims = self.decomposition if isinstance(self.decomposition, str) else [int(d) for d in self.decomposition]    # (-1 entries: resolved there)
     stepper = DecomposedExpressionStepper(self.pde, state, dims=dims, device=device)
     self.info["decomposition"], self.info["world_size"] = list(stepper.dims), stepper.size
     step, sinfo = stepper.make_stepper(self.scheme, dt, adaptive=bool(self.adaptive), tolerance=float(self.tolerance), dt_min=float(self.dt_min),
                                        dt_max=float(self.dt_max))
+    self.info["stochastic"] = bool(sinfo.get("stochastic", False))
 
     def expression_stepper(state_field, t_start: float, t_end: float) -> float:
         arr = stepper.scatter(state_field.data)
         before = int(sinfo["steps"])
         arr, t_last = step(arr, float(t_start), float(t_end))
         self.info["steps"] += int(sinfo["steps"]) - before
-        self.info["dt"] = float(sinfo["dt"])
+        self.info["dt"], self.info["stochastic"] = float(sinfo["dt"]), bool(sinfo.get("stochastic", False))
         if "dt_statistics" in sinfo:
             self.info["dt_statistics"] = sinfo["dt_statistics"]
         state_field.data[...] = stepper.gather(arr)

@@ -60,6 +60,14 @@ def main() -> int:
         "pde_brusselator_euler": (pde.PDE({"u": "laplace(u) + 1 - 3 * u + u**2 * v", "v": "0.1 * laplace(v) + 2 * u - u**2 * v"},
                                           bc={"x": "periodic", "y": {"derivative": 0.1}}),
                                   pde.UnitGrid([12, 8], periodic=[True, False]), dict(t_range=0.05, dt=2e-3), {"ref": "torch", "fields": 2}),
+        # the scenarios of the reference's own MPI tests (tests/solvers/test_explicit_mpi_solvers.py:22-53, :87-115): adaptive Euler with the
+        # decomposition [1, -1], two coupled equations with adaptive steps, noise (below)
+        "ref_simple_adaptive": (pde.DiffusionPDE(), pde.UnitGrid([8, 8], periodic=[True, False]), dict(t_range=1.01, dt=0.1, adaptive=True),
+                                {"decomposition": [1, -1]}),
+        "ref_multiple_pdes": (pde.PDE({"a": "laplace(a) - b", "b": "laplace(b) + a"}), pde.UnitGrid([8, 8], periodic=[True, False]),
+                              dict(t_range=1.01, dt=0.1, adaptive=True), {"ref": "torch", "fields": 2, "tol": 1e-5}),
+        # (the torch yardstick's adaptive loop ends 1e-6 past t_range - its mean step times 104 steps is 1.010001 - where the numpy / numba loops
+        # and this backend clip the last step to t_end, pde/backends/numba/_solvers.py:249-281; the serial hip run differs by the same 1.0e-6)
         "pde_vector_euler": (pde.PDE({"u": "vector_laplace(u) - u + 0.1 * gradient(dot(u, u))"}, bc={"x": "periodic", "y": {"derivative": 0.1}}),
                              pde.UnitGrid([12, 8], periodic=[True, False]), dict(t_range=0.05, dt=2e-3), {"ref": "torch", "vector": True}),
     })
@@ -113,7 +121,10 @@ def main() -> int:
         seen = []
         tracker = pde.CallbackTracker(lambda s, t: seen.append((t, float(s.data.sum()))), interrupts=kw["t_range"] / 2)
         decomposition = os.environ.get("PDEHIP_WORKER_DECOMPOSITION", "slab")    # "auto": blocks by the reference's rule
-        res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True, decomposition=decomposition, **kw)
+        res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True,
+                             decomposition=opts.get("decomposition", decomposition), **kw)
+        if opts.get("decomposition") and world > 1 and info["solver"]["decomposition"] != [1, world]:
+            failures.append(f"{name}: decomposition {info['solver']['decomposition']}")
         report[name] = {"steps": info["solver"]["steps"], "world": info["solver"]["world_size"], "interrupts": len(seen),
                         "decomposition": info["solver"]["decomposition"]}
         if rank == 0:
@@ -125,10 +136,25 @@ def main() -> int:
             err = np.abs(res.data - ref.data).max() / np.abs(ref.data).max()
             if info["solver"]["steps"] != rinfo["solver"]["steps"]:
                 failures.append(f"{name}: {info['solver']['steps']} steps, reference {rinfo['solver']['steps']}")
-            if not err < (1e-9 if name.startswith("fuzz") else 1e-10):
+            if not err < opts.get("tol", 1e-9 if name.startswith("fuzz") else 1e-10):
                 failures.append(f"{name}: relative difference {err:.3e}")
             if len(seen) != 3:
                 failures.append(f"{name}: {len(seen)} tracker interrupts")
+    # noise (tests/solvers/test_explicit_mpi_solvers.py:56-82): a tiny variance leaves the deterministic result, `info` says stochastic
+    field = pde.ScalarField.random_uniform(pde.UnitGrid([16]), -1, 1, rng=np.random.default_rng(5))
+    runs = {}
+    for label, eq in (("plain", pde.DiffusionPDE()), ("noisy", pde.DiffusionPDE(noise=1e-10)), ("loud", pde.DiffusionPDE(diffusivity=0.0, noise=0.5))):
+        out, info = eq.solve(field, t_range=0.2 if label != "loud" else 1e-3, dt=1e-3, solver="hip_slab", backend="hip", tracker=None, ret_info=True)
+        runs[label] = (out.data.copy(), info["solver"])
+    report["stochastic"] = {"steps": runs["noisy"][1]["steps"], "world": world, "interrupts": 3, "decomposition": runs["noisy"][1]["decomposition"]}
+    if not np.allclose(runs["plain"][0], runs["noisy"][0], rtol=1e-4, atol=1e-4) or np.array_equal(runs["plain"][0], runs["noisy"][0]):
+        failures.append("stochastic: tiny noise must leave the deterministic result (and still change it)")
+    if runs["plain"][1]["stochastic"] or not runs["noisy"][1]["stochastic"] or runs["noisy"][1]["dt_adaptive"]:
+        failures.append(f"stochastic: info {runs['plain'][1]['stochastic']} {runs['noisy'][1]['stochastic']}")
+    # one step of pure noise: increments sqrt(dt * noise / V) * N(0, 1), independent on every box (no two boxes share their numbers)
+    inc = (runs["loud"][0] - field.data) / np.sqrt(1e-3 * 0.5)
+    if not 0.6 < inc.std() < 1.4 or len(np.unique(np.round(inc, 12))) != inc.size:
+        failures.append(f"stochastic: increments std {inc.std():.3f}, {len(np.unique(np.round(inc, 12)))} distinct of {inc.size}")
     if rank == 0:
         print("PYPDESLAB " + json.dumps({"world": world, "cases": report, "failures": failures}), flush=True)
     dist.barrier()

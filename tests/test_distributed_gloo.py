@@ -274,6 +274,15 @@ def test_expression_conditions_on_decomposed_grids(size, fused):
                     assert steps == info["solver"]["steps"], (name, kind)
 
 
+def test_decomposition_with_a_free_axis():
+    """`decomposition=[1, -1]` (tests/solvers/test_explicit_mpi_solvers.py:19): the axis marked -1 takes the ranks that are left."""
+    from pde_hip.distributed import resolve_decomposition
+
+    assert resolve_decomposition([1, -1], 4) == [1, 4] and resolve_decomposition([-1, 2], 8) == [4, 2] and resolve_decomposition([2, 2, 2], 8) == [2, 2, 2]
+    with pytest.raises(ValueError):
+        resolve_decomposition([-1, -1], 4)
+
+
 def test_slab_faces_cut_expression_conditions_to_the_slab():
     """Face arrays of a slab == the slab's part of the whole grid's face arrays; the value cell is counted from the slab's first
     layer; inner faces of the decomposed axis are left to the exchange; functions are refused (they cannot run in the C loops)."""
@@ -657,6 +666,6 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
     assert proc.returncode == 0 and lines, proc.stderr[-3000:]
     report = json.loads(lines[-1][len("PYPDESLAB "):])
-    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 10 + FUZZ_CASES
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 13 + FUZZ_CASES
     if decomposition == "auto":     # blocks along more than one axis (`decomposition="auto"`, the reference's rule)
         assert sum(sum(d > 1 for d in c["decomposition"]) >= 2 for c in report["cases"].values()) >= 2, report

@@ -740,8 +740,9 @@ class DecomposedExpressionStepper:
         return add_noise
 
     def make_stepper(self, scheme: str = "euler", dt: float = 1e-3, *, adaptive: bool = False, tolerance: float = 1e-4, dt_min: float = 1e-10,
-                     dt_max: float = 1e10):
-        """``stepper(state_array, t_start, t_end) -> (state_array, t_last)`` on the box of this rank, plus its ``info`` dict."""
+                     dt_max: float = 1e10, post_step=None):
+        """``stepper(state_array, t_start, t_end) -> (state_array, t_last)`` on the box of this rank, plus its ``info`` dict.
+        ``post_step(array, t) -> array``: called after every (accepted) step, after the noise increment."""
         from types import SimpleNamespace
 
         from .backend import HipBackendMixin
@@ -752,7 +753,7 @@ class DecomposedExpressionStepper:
         solver = SimpleNamespace(pde=self.eq, adaptive=bool(adaptive), tolerance=float(tolerance), dt_min=float(dt_min), dt_max=float(dt_max),
                                  info={"dt": float(dt), "steps": 0})
         proxy = SimpleNamespace(grid=self.grid, dtype=self.dtype)
-        post_step = None
+        hook = post_step
         add_noise = self.make_noise_step(self.eq, float(dt))
         if add_noise is not None:
             # Euler-Maruyama (pde/solvers/euler.py:66-147): deterministic Euler step, then the noise increment
@@ -763,9 +764,9 @@ class DecomposedExpressionStepper:
                 msg = "decomposed stepping supports stochastic equations with the Euler scheme"
                 raise NotImplementedError(msg)
 
-            def post_step(arr, t):   # noqa: ARG001
+            def post_step(arr, t):
                 add_noise(arr)
-                return arr
+                return arr if hook is None else hook(arr, t)
 
         solver.info["stochastic"] = add_noise is not None
         step = HipBackendMixin._make_expression_stepper(self, solver, proxy, erhs=self.erhs, scheme=scheme, post_step=post_step,

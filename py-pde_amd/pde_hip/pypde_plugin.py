@@ -132,15 +132,13 @@ class HipSlabSolver(AdaptiveSolverBase):
             dt = self.dt_default
         self.info.update(dt=float(dt), steps=0, dt_adaptive=bool(self.adaptive), stochastic=False, scheme=self.scheme, post_step_data=None)
         self._select_backend(state)
-        # a post-step hook would have to run on the gathered state between the steps of the C loops: refused instead of being
-        # dropped silently (the single-GPU steppers run hooks, `solver="euler"`)
+        # a post-step hook runs between the steps, on the host, on the box of each rank - the semantics of the reference's MPI solver
+        # ("post_step_hook can only be used to do local modifications", pde/solvers/explicit_mpi.py:43-49): never inside the fused C loops
         try:
             self.pde.make_post_step_hook(state, backend="numpy")
+            has_hook = True
         except NotImplementedError:
-            pass                                   # no hook defined: the normal case (pde/pdes/base.py:160-208)
-        else:
-            msg = f"slab-parallel stepping does not support the post-step hook of {self.pde.__class__.__name__}"
-            raise NotImplementedError(msg)
+            has_hook = False                       # no hook defined: the normal case (pde/pdes/base.py:160-208)
         device = getattr(self.backend, "_device_request", None)
         # Diffusion / Cahn-Hilliard (classes or expressions of that form) on one scalar field: the fused loops (one C call per stepper
         # call); every other expression PDE - systems of scalar fields included -: its run-time compiled passes on the box of each
@@ -148,8 +146,8 @@ class HipSlabSolver(AdaptiveSolverBase):
         from .distributed import SlabStepper
 
         try:
-            if getattr(self.pde, "is_sde", False):
-                msg = "the fused slab loops are deterministic"     # (noise increments between the steps: the Python-level stepper)
+            if getattr(self.pde, "is_sde", False) or has_hook:
+                msg = "the fused slab loops are deterministic and run without hooks"     # (both act between the steps: the Python-level stepper)
                 raise NotImplementedError(msg)
             if state.__class__.__name__ != "ScalarField":
                 msg = "the fused slab loops take one ScalarField"
@@ -159,7 +157,7 @@ class HipSlabSolver(AdaptiveSolverBase):
                 raise NotImplementedError(msg)
             SlabStepper._describe(self.pde, state.grid)
         except NotImplementedError:
-            return self._make_expression_stepper(state, float(dt), device)
+            return self._make_expression_stepper(state, float(dt), device, has_hook)
         blocks = self.decomposition != "slab"
         if blocks:
             # a decomposition that only cuts axis 0 IS the slab decomposition (always the case for 1-D grids): the slab loops take it
@@ -215,7 +213,46 @@ class HipSlabSolver(AdaptiveSolverBase):
         return slab_stepper
 
 
-def _decomposed_expression_stepper(self, state, dt: float, device):
+def _local_post_step(self, stepper, state):
+    """The PDE's post-step hook on the BOX of this rank as ``post_step(array, t) -> array`` (host round trip of the box per step, like
+    the single-device ``_make_host_post_step``).  The hook is made for the sub-field of the box (py-pde classes on a sub-grid with
+    the box's bounds), its data stays local (``info["post_step_data"]``; all of them after every stepper call in
+    ``info["post_step_data_list"]``, pde/solvers/explicit_mpi.py:121-131, :219-223).  ``StopIteration`` on ANY rank ends the run on all
+    of them (agreed over the control plane after every step - a rank that stopped alone would leave the others in an exchange)."""
+    grid, mesh = state.grid, stepper.mesh
+    nd = grid.num_axes
+    lo = list(mesh.lo) if stepper.blocks else [mesh.lo] + [0] * (nd - 1)
+    hi = list(mesh.hi) if stepper.blocks else [mesh.hi] + [int(n) for n in grid.shape[1:]]
+    dx = grid.discretization
+    bounds = [(grid.axes_bounds[a][0] + lo[a] * dx[a], grid.axes_bounds[a][0] + hi[a] * dx[a]) for a in range(nd)]
+    periodic = [bool(grid.periodic[a]) and stepper.dims[a] == 1 for a in range(nd)]
+    subgrid = CartesianGrid(bounds, [h - l for l, h in zip(lo, hi)], periodic=periodic)
+    if state.__class__.__name__ == "FieldCollection":
+        sub_state = state.__class__([f.__class__(subgrid, data=np.ascontiguousarray(mesh.extract(f.data))) for f in state])
+    else:
+        sub_state = state.__class__(subgrid, data=np.ascontiguousarray(mesh.extract(state.data)))
+    hook, data = self.pde.make_post_step_hook(sub_state, backend="numpy")
+    self.info["post_step_data"] = data
+    control = stepper.control
+
+    def post_step(arr, t: float):
+        host = arr.get_valid(stream=stepper.stream)
+        stopped = False
+        try:
+            result = hook(host, t, self.info["post_step_data"])
+            if result is not None:
+                host, self.info["post_step_data"] = result
+        except StopIteration:
+            stopped = True        # (what the hook left in the array is the final state of this box)
+        arr.set_valid(np.asarray(host, dtype=arr.dtype), stepper.stream)
+        if any(control.allgather(stopped)):
+            raise StopIteration
+        return arr
+
+    return post_step
+
+
+def _decomposed_expression_stepper(self, state, dt: float, device, has_hook: bool = False):
     """``HipSlabSolver.make_stepper`` for PDEs without a fused decomposed loop."""
     from .distributed import DecomposedExpressionStepper
 
@@ -226,19 +263,25 @@ def _decomposed_expression_stepper(self, state, dt: float, device):
     dims = self.decomposition if isinstance(self.decomposition, str) else [int(d) for d in self.decomposition]    # (-1 entries: resolved there)
     stepper = DecomposedExpressionStepper(self.pde, state, dims=dims, device=device)
     self.info["decomposition"], self.info["world_size"] = list(stepper.dims), stepper.size
+    post_step = _local_post_step(self, stepper, state) if has_hook else None
     step, sinfo = stepper.make_stepper(self.scheme, dt, adaptive=bool(self.adaptive), tolerance=float(self.tolerance), dt_min=float(self.dt_min),
-                                       dt_max=float(self.dt_max))
+                                       dt_max=float(self.dt_max), post_step=post_step)
     self.info["stochastic"] = bool(sinfo.get("stochastic", False))
 
     def expression_stepper(state_field, t_start: float, t_end: float) -> float:
         arr = stepper.scatter(state_field.data)
         before = int(sinfo["steps"])
-        arr, t_last = step(arr, float(t_start), float(t_end))
-        self.info["steps"] += int(sinfo["steps"]) - before
+        try:
+            arr, t_last = step(arr, float(t_start), float(t_end))
+        finally:
+            # (also when a hook ended the run with StopIteration: every rank holds the whole field the hooks left behind)
+            self.info["steps"] += int(sinfo["steps"]) - before
+            state_field.data[...] = stepper.gather(arr)
+            if has_hook:
+                self.info["post_step_data_list"] = stepper.control.allgather(self.info["post_step_data"])
         self.info["dt"], self.info["stochastic"] = float(sinfo["dt"]), bool(sinfo.get("stochastic", False))
         if "dt_statistics" in sinfo:
             self.info["dt_statistics"] = sinfo["dt_statistics"]
-        state_field.data[...] = stepper.gather(arr)
         return t_last
 
     expression_stepper.slab = stepper  # type: ignore[attr-defined]

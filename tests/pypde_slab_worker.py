@@ -140,6 +140,42 @@ def main() -> int:
                 failures.append(f"{name}: relative difference {err:.3e}")
             if len(seen) != 3:
                 failures.append(f"{name}: {len(seen)} tracker interrupts")
+    # post-step hooks act on the box of each rank, like under the reference's MPI solver (pde/solvers/explicit_mpi.py:43-49: "local
+    # modifications"); a pointwise hook therefore equals its serial application.  StopIteration on one rank ends the run on all of them.
+    class Clipped(pde.DiffusionPDE):
+        def __init__(self, stop_at=None, **kw):
+            super().__init__(**kw)
+            self.stop_at = stop_at
+
+        def make_post_step_hook(self, state, backend="numpy"):
+            stop_at = self.stop_at
+
+            def hook(state_data, t, post_step_data):
+                np.minimum(state_data, 0.25, out=state_data)
+                if stop_at is not None and t > stop_at and state_data.max() > -1:
+                    raise StopIteration
+                post_step_data += 1
+                return state_data, post_step_data
+
+            return hook, 0
+
+    grid = pde.UnitGrid([12, 4, 6], periodic=[False, True, False])
+    state = pde.ScalarField.random_uniform(grid, -0.4, 0.4, rng=np.random.default_rng(3))
+    for label, stop_at in (("hook", None), ("hook_stop", 0.12)):
+        eq = Clipped(stop_at, diffusivity=0.6, bc={"x": {"value": 0.2}, "y": "periodic", "z": {"derivative": 0.1}})
+        kw = dict(t_range=0.3, dt=0.02, tracker=None, ret_info=True)
+        res, info = eq.solve(state, solver="hip_slab", backend="hip", decomposition=os.environ.get("PDEHIP_WORKER_DECOMPOSITION", "slab"), **kw)
+        ref, rinfo = eq.solve(state, solver="euler", backend="numpy", **kw)
+        report[label] = {"steps": info["solver"]["steps"], "world": world, "interrupts": 3, "decomposition": info["solver"]["decomposition"]}
+        err = np.abs(res.data - ref.data).max() / np.abs(ref.data).max()
+        # (a run ended by the hook: the reference's numpy loop leaves `steps` at 0 - it counts after the loop -, this backend counts the
+        # steps it took)
+        if not err < 1e-10 or (stop_at is None and info["solver"]["steps"] != rinfo["solver"]["steps"]):
+            failures.append(f"{label}: relative difference {err:.3e}, steps {info['solver']['steps']} / {rinfo['solver']['steps']}")
+        if info["solver"]["post_step_data"] != rinfo["solver"]["post_step_data"] or info["solver"]["post_step_data_list"] != [rinfo["solver"]["post_step_data"]] * world:
+            failures.append(f"{label}: hook data {info['solver']['post_step_data']} {info['solver'].get('post_step_data_list')} / {rinfo['solver']['post_step_data']}")
+        if info["controller"]["t_final"] != rinfo["controller"]["t_final"] or not res.data.max() <= 0.25:
+            failures.append(f"{label}: t_final {info['controller']['t_final']} / {rinfo['controller']['t_final']}")
     # noise (tests/solvers/test_explicit_mpi_solvers.py:56-82): a tiny variance leaves the deterministic result, `info` says stochastic
     field = pde.ScalarField.random_uniform(pde.UnitGrid([16]), -1, 1, rng=np.random.default_rng(5))
     runs = {}

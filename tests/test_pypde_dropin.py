@@ -398,9 +398,10 @@ def test_subclasses_that_change_the_equation_are_refused(hip1):
     ref = pde.DiffusionPDE().solve(state, t_range=0.1, dt=0.01, backend="hip", tracker=None)
     np.testing.assert_array_equal(res.data, ref.data)
     assert info["solver"]["post_step_data"] == 10
-    # the slab-parallel solver has no place to run a hook: refused instead of dropped
-    with pytest.raises(NotImplementedError, match="post-step hook"):
-        OnlyHook().solve(state, t_range=0.1, dt=0.01, solver="hip_slab", backend="hip", tracker=None)
+    # the slab-parallel solver runs the hook on the box of each rank (here: one rank, the whole grid), like the reference's MPI solver
+    res2, info2 = OnlyHook().solve(state, t_range=0.1, dt=0.01, solver="hip_slab", backend="hip", tracker=None, ret_info=True)
+    np.testing.assert_array_equal(res2.data, ref.data)
+    assert info2["solver"]["post_step_data"] == 10 and info2["solver"]["post_step_data_list"] == [10]
 
 
 def test_function_bcs_without_time_use_t0(hip1):

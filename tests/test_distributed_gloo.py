@@ -398,6 +398,76 @@ def test_any_expression_pde_on_decomposed_grids(size):
     assert size < 4 or multi_axis > 0
 
 
+# differential fuzz of the decomposed expression path: random right-hand sides (nested operators, vector operators, products, powers,
+# coordinates; one or two fields), ONE Euler step on slabs and blocks against the serial step
+def _random_rhs(rng, depth: int, fields: list[str]) -> str:
+    f = lambda: fields[rng.integers(len(fields))]  # noqa: E731
+    leaves = [lambda: f(), lambda: f"{rng.uniform(0.2, 1.5):.3f}", lambda: "x", lambda: "y", lambda: f"laplace({f()})", lambda: f"gradient_squared({f()})",
+              lambda: f"{f()}**3", lambda: f"d_dx({f()})", lambda: f"d_dy({f()})"]
+    if depth <= 0:
+        return leaves[rng.integers(len(leaves))]()
+    kind = rng.integers(10)
+    a, b = _random_rhs(rng, depth - 1, fields), _random_rhs(rng, depth - 1, fields)
+    return [f"({a} + {b})", f"({a} - {b})", f"({a} * {b})", f"laplace({a})", f"tanh({a})", f"dot(gradient({f()}), gradient({f()}))",
+            f"divergence(({a}) * gradient({f()}))", f"gradient_squared({a})", f"({a})**2", f"d_dx({a})"][kind]
+
+
+FUZZ_SEEDS = tuple(range(int(os.environ.get("PDEHIP_DECOMPOSED_FUZZ", "40"))))
+
+
+def _fuzz_case(seed: int):
+    rng = np.random.default_rng(7000 + seed)
+    grid = pde_hip.CartesianGrid([[0, 3], [-1, 1]], [12, 10], periodic=[bool(seed % 2), bool(seed % 3)])
+    bc = {"x": "periodic" if seed % 2 else {"value": 0.2}, "y": "periodic" if seed % 3 else {"derivative_expression": "0.1 * x - 0.2 * value"}}
+    fields = ["u", "v"] if seed % 3 == 0 else ["u"]
+    rhs = {name: _random_rhs(rng, 2 + seed % 2, fields) for name in fields}
+    data = rng.uniform(-0.4, 0.4, (len(fields), *grid.shape))
+    state = pde_hip.FieldCollection([pde_hip.ScalarField(grid, d) for d in data]) if len(fields) > 1 else pde_hip.ScalarField(grid, data[0])
+    return pde_hip.PDE(rhs, bc=bc), grid, (data if len(fields) > 1 else data[0]), state, rhs
+
+
+def solve_fuzz_cases(rank, size):
+    from pde_hip.distributed import DecomposedExpressionStepper
+
+    out = {}
+    for seed in FUZZ_SEEDS:
+        eq, grid, data, state, rhs = _fuzz_case(seed)
+        for dims in ("slab", "auto"):
+            try:
+                stepper = DecomposedExpressionStepper(eq, state, dims=dims)
+            except NotImplementedError as err:      # (forms the planner refuses: refused on one device as well - checked by the parent)
+                out[seed, dims] = ("refused", str(err))
+                continue
+            final, _ = stepper.solve(data, 1e-3, 1e-3, "euler")
+            stepper.close()
+            out[seed, dims] = ("ok", final)
+    return out
+
+
+def test_random_expressions_on_decomposed_grids():
+    """40 seeds by default (`PDEHIP_DECOMPOSED_FUZZ=n` for more; 300 ran green): every rank of a 4-rank run - slabs `[4, 1]` and blocks
+    `[2, 2]` - ends one Euler step of a random expression PDE with exactly the serial field."""
+    import shimlib
+
+    results = run_distributed("solve_fuzz_cases", 4)
+    compared = 0
+    with shimlib.use_shim():
+        for seed in FUZZ_SEEDS:
+            eq, grid, data, state, rhs = _fuzz_case(seed)
+            try:
+                expect = eq.solve(state, 1e-3, 1e-3, solver="euler").data
+            except NotImplementedError:
+                assert all(results[r][seed, d][0] == "refused" for r in range(4) for d in ("slab", "auto")), rhs
+                continue
+            for rank in range(4):
+                for dims in ("slab", "auto"):
+                    status, final = results[rank][seed, dims]
+                    assert status == "ok", (rhs, final)
+                    np.testing.assert_array_equal(final, expect, err_msg=f"seed {seed} {dims} rank {rank}: {rhs}")
+            compared += 1
+    assert compared >= len(FUZZ_SEEDS) * 2 // 3
+
+
 def solve_integral_case(rank, size):
     from pde_hip.distributed import DecomposedExpressionStepper
 

@@ -601,6 +601,7 @@ class ExpressionRhs:
         self._update_faces(t, state)
         if self._fused2(state, out, wrap, params):
             return
+        exchanged: set[str] = set()
         for i, p in enumerate(self.plan.passes):
             if p.reduce_slot is not None:
                 # integral over the grid -> run-time parameter of the passes that follow (8 bytes cross PCIe: a host sync)
@@ -615,8 +616,9 @@ class ExpressionRhs:
             for m, name in enumerate(extras):
                 ex[m] = arrays[name].ptr
             self._refresh_for_pass(i, arrays[p.src], t)
-            if self._exchange is not None and self.pass_faces[i] is not None:
-                self._exchange(arrays[p.src])
+            if self._exchange is not None and self.pass_faces[i] is not None and p.src not in exchanged:
+                self._exchange(arrays[p.src])      # (once per evaluation: no array is written after it has been read by a pass)
+                exchanged.add(p.src)
             self.lib.jit_apply(h, self.info.ref, arrays[p.src].ptr, ex, arrays[p.out].ptr, params, nparams, self._faces(i), self.backend.stream)
 
     def apply_stage(self, state, k_out, dt: float, t: float, kind: int, y, ks, coefs, c_new: float, out2, err=None) -> bool:

@@ -2,7 +2,9 @@
 
 Runs the slab-parallel solves of ``CASES`` with the PRODUCT stepper (``pde_hip.distributed.SlabStepper``: one process per
 device, libpdehip data plane, gloo control plane), gathers the global result on every rank and compares it on rank 0 with
-the serial CPU oracle — bit for bit, equal step counts.  Exit code 0 = all cases passed on all ranks.
+the serial CPU oracle — bit for bit, equal step counts; then ``MORE``: expression conditions in the slab / block loops, block
+decompositions, any expression PDE (``DecomposedExpressionStepper``) against the same library's single-device run.  Exit code
+0 = all cases passed on all ranks.
 
 Used by tests/test_hip_multirank.py (real GPUs, the real library) and by tests/test_distributed_gloo.py (the tests-only host
 shim selected with PDEHIP_LIB — same worker, same loops, no GPU).
@@ -40,6 +42,28 @@ CASES = {
     "diffusion_rkf45": (("diffusion", 1.0, {"x": {"value": 0.2}, "y": "periodic", "z": "periodic"}), (32, 8, 64), [False, True, True], 1.0, None, "runge-kutta"),
     "expression_rkf45": (("expression", 1.0, "auto_periodic_neumann"), (32, 16, 64), [True, True, True], 0.05, None, "runge-kutta"),
 }
+
+
+# Beyond the fused slab loops - compared on rank 0 with the SAME library's single-device run (the oracle has no expression conditions /
+# generic expressions; the single-device paths are pinned against the oracle and the reference elsewhere):
+# name: (stepper, equation, shape, periodic, t_range, dt, solver)
+_BC_EXPR = {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z - 0.3 * value**3"},
+            "y": "periodic", "z-": {"virtual_point": "value / (1 + value**2) + 0.05 * x"}, "z+": {"derivative_expression": "0.05 * x * sin(t)"}}
+MORE = {
+    # conditions of time / position / the field, refreshed by the device program inside the slab and block C loops
+    "slab_expression_bcs_rk4": ("slab", lambda: pde_hip.DiffusionPDE(0.05, bc=_BC_EXPR), (48, 8, 128), [False, True, False], 0.06, 0.01, "runge-kutta"),
+    "block_expression_bcs_rkf45": ("block", lambda: pde_hip.DiffusionPDE(0.05, bc=_BC_EXPR), (32, 16, 128), [False, True, False], 0.1, None, "runge-kutta"),
+    "block_cahn_hilliard_euler": ("block", lambda: pde_hip.CahnHilliardPDE(0.9), (32, 16, 128), [True, False, True], 0.005, 1e-3, "euler"),
+    # any expression PDE: compiled passes per rank + ghost exchange per operator operand (slabs and the blocks of the reference's rule)
+    "generic_nested_rk4": ("generic:slab", lambda: pde_hip.PDE({"c": "laplace(c**3 - c - 0.8 * laplace(c)) + 0.01 * x"}, bc={"x": {"derivative": 0}, "y": "periodic", "z": {"value": 0.1}}),
+                           (32, 8, 128), [False, True, False], 0.004, 1e-3, "runge-kutta"),
+    "generic_divgrad_rkf45": ("generic:auto", lambda: pde_hip.PDE({"c": "divergence((1.2 + tanh(y)) * gradient(c)) - 0.1 * c**3"}, bc={"x": "periodic", "y": {"derivative": 0.05}, "z": "periodic"}),
+                              (32, 16, 128), [True, False, True], 0.2, None, "runge-kutta"),
+}
+
+
+# cuts along more than one axis (the reference's rule would cut these elongated grids along z only); other world sizes: that rule
+BLOCKS = {2: [1, 2, 1], 4: [2, 1, 2], 8: [2, 2, 2]}
 
 
 def make_eq(spec):
@@ -87,6 +111,36 @@ def main() -> int:
             elif dt is None and abs(info["dt"] - dt_last) > 1e-12 * dt_last:
                 failures.append(f"{name}: next dt {info['dt']} vs oracle {dt_last}")
         # every rank holds the same gathered field
+        digests = control.allgather(hashlib.sha1(final.tobytes()).hexdigest())
+        if len(set(digests)) != 1:
+            failures.append(f"{name}: ranks gathered different fields")
+    from pde_hip.distributed import BlockStepper, DecomposedExpressionStepper
+
+    for name, (kind, mk_eq, shape, periodic, t_range, dt, solver) in MORE.items():
+        if (only and name not in only) or shape[0] < world:
+            continue
+        grid = pde_hip.UnitGrid(shape, periodic=periodic)
+        data = np.random.default_rng(7).uniform(-0.5, 0.5, shape)
+        eq = mk_eq()
+        state = pde_hip.ScalarField(grid, data)
+        if kind == "slab":
+            st = SlabStepper(eq, grid, control=control, device=local_rank)
+        elif kind == "block":
+            st = BlockStepper(eq, grid, dims=BLOCKS.get(world), control=control, device=local_rank)
+        else:
+            dims = kind.split(":")[1]
+            st = DecomposedExpressionStepper(eq, state, dims=BLOCKS.get(world, dims) if dims == "auto" else dims, control=control, device=local_rank)
+        final, info = st.solve(data, t_range, dt, solver)
+        st.close()
+        report[name] = {"steps": info["steps"], "decomposition": [int(d) for d in getattr(st, "dims", [world])]}
+        if rank == 0:
+            expect, sinfo = eq.solve(state, t_range, dt, solver=solver, ret_info=True)
+            if info["steps"] != sinfo["solver"]["steps"]:
+                failures.append(f"{name}: {info['steps']} steps, single device {sinfo['solver']['steps']}")
+            elif not np.array_equal(final, expect.data):
+                failures.append(f"{name}: max abs difference {np.abs(final - expect.data).max():.3e}")
+            elif not np.abs(expect.data - data).max() > 1e-4:
+                failures.append(f"{name}: nothing happened")
         digests = control.allgather(hashlib.sha1(final.tobytes()).hexdigest())
         if len(set(digests)) != 1:
             failures.append(f"{name}: ranks gathered different fields")

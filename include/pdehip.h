@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 4
+#define PDEHIP_ABI_VERSION 5
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -300,6 +300,12 @@ int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const vo
 int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew,
                          const void *const *k6_host, double *err_dev, void *stream);
 /* max |a - b| over the interior -> *out_dev (generic error estimate pde/solvers/base.py:416) */
+/* End of an adaptive Euler attempt, pde/backends/numba/_solvers.py:381-394 (numpy twin pde/solvers/euler.py:238-256):
+ *   out = half + k                       `step_small += 0.5 * dt * rate_midpoint`   (k = that product, half = state + dt/2 * rate)
+ *   *err_dev = max |(y + dt * rate) - out|      `np.abs(step_large - step_small).max()`, step_large is never stored
+ * The loops below compute the same inside the sweep that produces k (stage kind 4). */
+int pdehip_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y_full, const void *rate_full, double dt,
+                                  const void *half_full, const void *k_full, void *out_full, double *err_dev, void *stream);
 int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a_full, const void *b_full,
                         double *out_dev, void *stream);
 
@@ -444,6 +450,19 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
                           void *y_full, void *ynew_full, void *const *work7_host, double *err_dev, pdehip_adaptive_t *ctl,
                           void **result, void *stream);
 
+/* ADAPTIVE EULER from t_start to t_end - the reference's own loop `_make_adaptive_stepper_euler`, pde/backends/numba/_solvers.py:322-466
+ * (numpy twin pde/solvers/euler.py:181-283), NOT the generic one-step-versus-two-half-steps estimate: the rate of the current state
+ * is carried from attempt to attempt (a rejected attempt re-uses it), and after an accepted attempt the new rate is evaluated at the
+ * time BEFORE `t += dt` (:402-407) - with time-dependent conditions or explicit time in the equation results and step counts depend
+ * on that.  Control block and error handling as pdehip_slab_rkf45_run; work3 = rate, half step, slope scratch (slab arrays: the
+ * half step is a sweep input).  Two sweeps per accepted attempt where the stage epilogues cover the grid (kinds 0 and 4). */
+int pdehip_slab_euler_adaptive_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                                   void *y_full, void *ynew_full, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl,
+                                   void **result, void *stream);
+/* the same on one device (no communicator, flags decided here) */
+int pdehip_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *ynew_full, void *const *work3_host,
+                              double *err_dev, pdehip_adaptive_t *ctl, void **result, void *stream);
+
 /* ---- BLOCK decomposition: one process per GPU owns a box of the grid (e.g. 2 x 2 x 2 for 512^3 on 8 GPUs) -----------------------
  * Replaces GridMesh with a multi-axis decomposition (pde/grids/_mesh.py:59-93 `_get_optimal_decomposition`, :401-444 neighbours) and the
  * face exchange `_MPIBC` of every decomposed axis (pde/grids/boundaries/local.py:561-662).  nb6[2 * axis + side] = rank of the neighbour
@@ -455,7 +474,8 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
 int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *nb6, void *buf_full, void *stream);
 /* time loops on a block, ONE call per run: scheme 0 = `nsteps` explicit Euler steps (y_full / ynew_full ping-pong, *result names
  * the final one), 1 = `nsteps` RK4 steps in place (work: k1..k4, tmp), 2 = the adaptive RKF45 loop `ctl` incl. the MAX all-reduce
- * of the error (work: k1..k6, tmp).  Every right-hand side exchanges the faces of its input first (Cahn-Hilliard: c, then mu - the
+ * of the error (work: k1..k6, tmp), 3 = the reference's adaptive Euler loop `ctl` (pdehip_slab_euler_adaptive_run; work: rate, half
+ * step, slope scratch).  Every right-hand side exchanges the faces of its input first (Cahn-Hilliard: c, then mu - the
  * reference's sequence); fuse_stage != 0: diffusion stages carry their Runge-Kutta combination (decide it for ALL ranks alike).
  * The time of the first step is rhs->t. */
 int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme,
@@ -484,6 +504,8 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
  *   kind 1: out2 = y + (k_prev[0] + 2 k_prev[1] + 2 k_prev[2] + k) / 6        (RK4 update; k_out unused, out2 may be y)
  *   kind 2: out2 = y + c1 k1 + c3 k3 + c4 k4 + c5 k5 and *err_dev = max |error estimate| with k6 = k,
  *           k_prev = {k1, k3, k4, k5}                                         (end of an RKF45 attempt)
+ *   kind 4: out2 = k_prev[1] + k and *err_dev = max |(y + coef[0] * k_prev[0]) - out2| with k_prev = {carried rate, half step},
+ *           coef[0] = dt, k = dt/2 * F(half step)                             (end of an adaptive Euler attempt, pdehip_euler_adaptive_combine)
  * Same expressions in the same order as pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine: bit-identical to
  * pdehip_jit_apply followed by them.  *done = 0 (nothing launched) when only the generic kernel covers the grid. */
 int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host,
@@ -544,6 +566,14 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
 int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                       int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
                       pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream);
+
+/* The reference's adaptive Euler loop (pde/backends/numba/_solvers.py:322-466) for an expression PDE in ONE call: passes as in
+ * pdehip_jit_rk_run (the slope passes compute `p[0] * F`; the carried rate is obtained with p[0] = 1), work3 = rate, half step, slope
+ * scratch (ncomp components each).  stage_fuse != 0: single-component expressions take the stage epilogues (kinds 0 and 4 of
+ * pdehip_jit_apply_stage) where the vectorised kernel covers the grid. */
+int pdehip_jit_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                                  int ncomp, void *y, void *ynew, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl,
+                                  int stage_fuse, void *bc_program, void **result, void *stream);
 
 #ifdef __cplusplus
 }

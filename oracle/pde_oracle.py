@@ -218,6 +218,15 @@ def rkf45_combine(g, ncomp, y_full, ks):
     return ynew, err.value
 
 
+def euler_adaptive_combine(g, ncomp, y_full, rate_full, dt, half_full, k_full):
+    """End of an adaptive Euler attempt (pde/solvers/euler.py:238-256): returns (step_small, error)."""
+    out = np.zeros_like(y_full)
+    err = C.c_double(0)
+    _check(lib().oracle_euler_adaptive_combine(C.byref(g), ncomp, _p(y_full), _p(rate_full), float(dt), _p(half_full), _p(k_full), _p(out), C.byref(err)),
+           "euler_adaptive_combine")
+    return out, err.value
+
+
 def max_abs_diff(g, ncomp, a_full, b_full):
     err = C.c_double(0)
     _check(lib().oracle_max_abs_diff(C.byref(g), ncomp, _p(a_full), _p(b_full), C.addressof(err)), "max_abs_diff")

@@ -125,13 +125,18 @@ struct Eval {
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *st) { return ops.lincomb(g, out, y, n, c, k, st); }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return ops.rk4_combine(g, y, k1, k2, k3, k4, st); }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st) { return ops.rkf45_combine(g, y, ynew, k6, err, st); }
+    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *st)
+    {
+        return ops.euler_adaptive_combine(g, y, rate, dt, half, k, out, err, st);
+    }
     int zero(void *p, size_t bytes, void *st) { return ops.zero(p, bytes, st); }
     int reduce_error(double *err_dev, void *st) { return ops.allreduce_max(err_dev, st); }
     int read_scalar(double *host, const double *dev, void *st) { return ops.read_scalar(host, dev, st); }
     int fail_runtime(const char *fmt, double v) { return ops.fail_runtime(fmt, v); }
 };
 
-// scheme 0: `nsteps` Euler steps ping-ponging y / ynew; 1: `nsteps` RK4 steps in place on y; 2: the adaptive RKF45 loop `ctl`
+// scheme 0: `nsteps` Euler steps ping-ponging y / ynew; 1: `nsteps` RK4 steps in place on y; 2: the adaptive RKF45 loop `ctl`;
+// 3: the reference's adaptive Euler loop `ctl` (work: rate, step_half, slope scratch)
 template <class Ops>
 int run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, bool fuse, int scheme, void *y, void *ynew, void *const *work,
         double *err_dev, double dt, int64_t nsteps, pdehip_adaptive_t *ctl, void **result, void *st)
@@ -152,6 +157,7 @@ int run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs,
         *result = y;
         return 0;
     }
+    if (scheme == 3) return rk::euler_adaptive_run(ev, y, ynew, work, err_dev, ctl, result, st);
     return rk::rkf45_run(ev, y, ynew, work, err_dev, ctl, result, st);
 }
 

@@ -209,6 +209,7 @@ struct HipOps {
             const void *k6[6] = {sf.k[0], sf.k[0] /* k2 does not enter */, sf.k[1], sf.k[2], sf.k[3], k};
             return pdehip_rkf45_combine(g, 1, sf.y, sf.out2, k6, sf.err, st);
         }
+        if (sf.kind == 4) return pdehip_euler_adaptive_combine(g, 1, sf.y, sf.k[0], sf.c[0], sf.k[1], k, sf.out2, sf.err, st);
         PDEHIP_FAIL(E_NOTIMPL, "internal: unknown stage kind %d", sf.kind);
     }
     // in-place MAX over all ranks of one fp64 device scalar; NaN wins like numpy.max
@@ -268,6 +269,11 @@ struct HipOps {
     int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *st) { return pdehip_lincomb(g, 1, out, y, n, cf, k, st); }
     int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, 1, y, k1, k2, k3, k4, st); }
     int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, 1, y, ynew, k6, err, st); }
+    int euler_adaptive_combine(const pdehip_grid_t *g, const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err,
+                               void *st)
+    {
+        return pdehip_euler_adaptive_combine(g, 1, y, rate, dt, half, k, out, err, st);
+    }
 };
 
 // geometry of a block + its staging buffers; nb6[2 * axis + side] = neighbour rank or -1
@@ -588,6 +594,30 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
 }
 
+int pdehip_slab_euler_adaptive_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags,
+                                   void *y_full, void *ynew_full, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl,
+                                   void **result, void *stream)
+{
+    if (!y_full || !ynew_full || !work3_host || !err_dev || !ctl || !result) PDEHIP_FAIL(E_VALUE, "slab_euler_adaptive_run: NULL pointer");
+    if (!(ctl->tolerance > 0) || !(ctl->dt > 0)) PDEHIP_FAIL(E_VALUE, "slab_euler_adaptive_run: tolerance and dt must be positive");
+    PDEHIP_TRY(check_rhs(rhs));
+    Comm *c;
+    PDEHIP_TRY(context(comm, lower, upper, &c));
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    HipOps ops{c};
+    return slab::euler_adaptive_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work3_host, err_dev, ctl, result, stream);
+}
+
+int pdehip_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *ynew_full, void *const *work3_host,
+                              double *err_dev, pdehip_adaptive_t *ctl, void **result, void *stream)
+{
+    int flags = 0;
+    PDEHIP_TRY(pdehip_slab_flags_supported(g, rhs, -1, -1, &flags));
+    return pdehip_slab_euler_adaptive_run(nullptr, g, rhs, -1, -1, flags, y_full, ynew_full, work3_host, err_dev, ctl, result, stream);
+}
+
 // ---- block decomposition (pdehip_block_loops.h) ------------------------------------------------------------------------------
 static int block_context(void *comm, const pdehip_grid_t *g_local, const int *nb6, Comm **c, NGrid *n, block::Geo *q)
 {
@@ -621,10 +651,10 @@ int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_
                      void *stream)
 {
     if (!y_full || !result) PDEHIP_FAIL(E_VALUE, "block_run: NULL pointer");
-    if (scheme < 0 || scheme > 2) PDEHIP_FAIL(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4) or 2 (adaptive RKF45)");
-    if ((scheme == 0 || scheme == 2) && !ynew_full) PDEHIP_FAIL(E_VALUE, "block_run: the scheme needs a second state array");
-    if (scheme >= 1 && !work_host) PDEHIP_FAIL(E_VALUE, "block_run: the Runge-Kutta schemes need work arrays");
-    if (scheme == 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
+    if (scheme < 0 || scheme > 3) PDEHIP_FAIL(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4), 2 (adaptive RKF45) or 3 (adaptive Euler)");
+    if (scheme != 1 && !ynew_full) PDEHIP_FAIL(E_VALUE, "block_run: the scheme needs a second state array");
+    if (scheme >= 1 && !work_host) PDEHIP_FAIL(E_VALUE, "block_run: the scheme needs work arrays");
+    if (scheme >= 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
     if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "block_run: negative step count");
     PDEHIP_TRY(check_rhs(rhs));
     Comm *c;

@@ -294,7 +294,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
                    const StageFuse *stage, int *done)
 {
     if (done) *done = 0;
-    if (!handle || !in_full || (!out_full && !(stage && (stage->kind == 1 || stage->kind == 2)))) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
+    if (!handle || !in_full || (!out_full && !(stage && (stage->kind == 1 || stage->kind == 2 || stage->kind == 4)))) PDEHIP_FAIL(E_VALUE, "jit_apply: NULL pointer");
     if (nparams < 0 || nparams > 12) PDEHIP_FAIL(E_VALUE, "jit_apply: at most 12 scalar parameters");
     Jit *j = static_cast<Jit *>(handle);
     NGrid n;
@@ -322,7 +322,8 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2; a.st_err = stage->err;
         int nk = 0;
         for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
-        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || stage->kind < 0 || stage->kind > 2)
+        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || (stage->kind == 4 && (nk != 2 || !stage->err)) || stage->kind < 0 ||
+            stage->kind == 3 || stage->kind > 4)
             PDEHIP_FAIL(E_VALUE, "jit_apply_stage: malformed stage (kind %d with %d earlier slopes)", stage->kind, nk);
         a.st_c[5] = stage->c_new;
         uintptr_t bits = (uintptr_t)a.st_y | (uintptr_t)a.st_out;
@@ -445,6 +446,8 @@ int pdehip_jit_apply(void *handle, const pdehip_grid_t *g, void *in_full, const 
 //   kind 1: out2 = y + (k_prev[0] + 2 k_prev[1] + 2 k_prev[2] + k) / 6     (RK4 update; k_out unused, out2 may be y)
 //   kind 2: out2 = y + c1 k1 + c3 k3 + c4 k4 + c5 k5, *err_dev = max |error estimate| with k6 = k, k_prev = {k1, k3, k4, k5}
 //           (end of an RKF45 attempt; *err_dev is zeroed first)
+//   kind 4: out2 = k_prev[1] + k, *err_dev = max |(y + coef[0] * k_prev[0]) - out2|: end of an adaptive Euler attempt with k_prev = {carried
+//           rate, half step}, coef[0] = dt, k = dt/2 * F(half step)  (pde/backends/numba/_solvers.py:381-394; *err_dev is zeroed first)
 // The same expressions in the same order as pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine.
 // *done = 0 and nothing launched when only the generic kernel covers the grid (1-D, odd rows).
 int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, const void *const *extra3_host, void *k_out_full,
@@ -453,16 +456,16 @@ int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, 
                            void *out2_full, double *err_dev, int *done, void *stream)
 {
     if (!done) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL pointer");
-    if (nk < 0 || nk > 5 || (nk > 0 && !k_prev_host) || (kind == 0 && nk > 0 && !coef_host)) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: bad slope table");
+    if (nk < 0 || nk > 5 || (nk > 0 && !k_prev_host) || ((kind == 0 || kind == 4) && nk > 0 && !coef_host)) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: bad slope table");
     StageFuse sf;
     memset(&sf, 0, sizeof(sf));
     sf.kind = kind; sf.y = y_full; sf.out2 = out2_full; sf.err = err_dev; sf.c_new = c_new;
     for (int m = 0; m < nk; m++) {
         if (!k_prev_host[m]) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL slope array");
         sf.k[m] = k_prev_host[m];
-        sf.c[m] = (kind == 0) ? coef_host[m] : 0.0;
+        sf.c[m] = (kind == 0 || (kind == 4 && m == 0)) ? coef_host[m] : 0.0;
     }
-    if (kind == 2) {
+    if (kind == 2 || kind == 4) {
         if (!err_dev) PDEHIP_FAIL(E_VALUE, "jit_apply_stage: NULL error cell");
         PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
     }
@@ -961,6 +964,10 @@ struct JitEval {
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *st) { return pdehip_lincomb(g, ncomp, out, y, n, c, k, st); }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, ncomp, y, k1, k2, k3, k4, st); }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, ncomp, y, ynew, k6, err, st); }
+    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *st)
+    {
+        return pdehip_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err, st);
+    }
     int zero(void *ptr, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(st))); return 0; }
     int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *st)
@@ -973,13 +980,14 @@ struct JitEval {
 };
 }  // namespace
 
-int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
-                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
-                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
+// scheme 0: RK4 with fixed steps (ctl == NULL) / adaptive RKF45 (ctl), 1: the reference's adaptive Euler loop (ctl)
+static int jit_loop_run(const char *who, int scheme, const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                        int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                        pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
 {
-    if (!g || !passes || !y || !work_host || !result || (nfixed > 0 && !fixed)) PDEHIP_FAIL(E_VALUE, "jit_rk_run: NULL pointer");
-    if (npasses < 1 || ncomp < 1 || nsteps < 0) PDEHIP_FAIL(E_VALUE, "jit_rk_run: bad pass / component / step count");
-    if (ctl && (!ynew || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "jit_rk_run: the adaptive loop needs ynew, err_dev, tolerance > 0 and dt > 0");
+    if (!g || !passes || !y || !work_host || !result || (nfixed > 0 && !fixed)) PDEHIP_FAIL(E_VALUE, "%s: NULL pointer", who);
+    if (npasses < 1 || ncomp < 1 || nsteps < 0) PDEHIP_FAIL(E_VALUE, "%s: bad pass / component / step count", who);
+    if (ctl && (!ynew || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) PDEHIP_FAIL(E_VALUE, "%s: the adaptive loop needs ynew, err_dev, tolerance > 0 and dt > 0", who);
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
     for (int q = 0; q < npasses; q++) {
@@ -993,10 +1001,28 @@ int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, i
         }
     }
     JitEval ev{g, passes, npasses, fixed, ncomp, (size_t)n.pc * elem_size(n.dtype), stage_fuse ? 1 : 0, bc_program};
+    if (scheme == 1) return rk::euler_adaptive_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     for (int64_t s = 0; s < nsteps; s++) PDEHIP_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));
     *result = y;
     return 0;
+}
+
+int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    return jit_loop_run("jit_rk_run", 0, g, passes, npasses, fixed, nfixed, ncomp, y, ynew, work_host, err_dev, dt, t0, nsteps, ctl, stage_fuse,
+                        bc_program, result, stream);
+}
+
+int pdehip_jit_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                                  int ncomp, void *y, void *ynew, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl,
+                                  int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    if (!ctl) PDEHIP_FAIL(E_VALUE, "jit_euler_adaptive_run: NULL pointer");
+    return jit_loop_run("jit_euler_adaptive_run", 1, g, passes, npasses, fixed, nfixed, ncomp, y, ynew, work3_host, err_dev, 0.0, 0.0, 0, ctl,
+                        stage_fuse, bc_program, result, stream);
 }
 
 }  // extern "C"

@@ -324,7 +324,7 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
                    double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg, const StageFuse *stage)
 {
     if ((mode == LAP_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage epilogue without / with a stage descriptor");
-    if (!in || (!out && !(stage && (stage->kind == 1 || stage->kind == 2)))) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
+    if (!in || (!out && !(stage && (stage->kind == 1 || stage->kind == 2 || stage->kind == 4)))) PDEHIP_FAIL(E_VALUE, "laplace: NULL array pointer");
     if (mode == LAP_EULER && !y) PDEHIP_FAIL(E_VALUE, "laplace_euler: y is NULL");
     LapArgs a;
     memset(&a, 0, sizeof(a));
@@ -353,6 +353,7 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
         if (stage->kind == 1 && nk != 3) PDEHIP_FAIL(E_RUNTIME, "internal: the RK4 update needs three earlier slopes");
         if (stage->kind == 2 && (nk != 4 || !stage->err)) PDEHIP_FAIL(E_RUNTIME, "internal: the RKF45 update needs four earlier slopes and the error cell");
         if (stage->kind == 3 && nk != 1) PDEHIP_FAIL(E_RUNTIME, "internal: the Adams-Bashforth update needs the previous rate");
+        if (stage->kind == 4 && (nk != 2 || !stage->err || stage->k[1] != in)) PDEHIP_FAIL(E_RUNTIME, "internal: the adaptive Euler update needs the rate, the half step as the input of the sweep and the error cell");
         a.st_err = stage->err;
         a.st_c[5] = stage->c_new;
     }
@@ -786,7 +787,9 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
         a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2; a.st_err = stage->err;
         int nk = 0;
         for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
-        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || (stage->kind == 3 && nk != 1)) PDEHIP_FAIL(E_RUNTIME, "internal: malformed stage descriptor");
+        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || (stage->kind == 3 && nk != 1) ||
+            (stage->kind == 4 && (nk != 2 || !stage->err || stage->k[1] != in)))
+            PDEHIP_FAIL(E_RUNTIME, "internal: malformed stage descriptor");
         a.st_c[5] = stage->c_new;
         if (!stage_aligned(a)) return 0;
     }

@@ -554,6 +554,36 @@ __global__ void __launch_bounds__(256) rkf45_combine_kernel(Rkf45Args a)
     block_max_to(emax, a.err);
 }
 
+// end of an adaptive Euler attempt (pde/backends/numba/_solvers.py:381-394; StageFuse kind 4 is the same arithmetic inside a sweep):
+//   out = half + k   (`step_small += 0.5 * dt * rate_midpoint`, k = that product),   *err = max |(y + dt * rate) - out|
+struct EulerAdaptArgs {
+    DevGrid g;
+    int ncomp;
+    const void *y, *rate, *half, *k;
+    void *out;
+    double dt;
+    double *err;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) euler_adaptive_combine_kernel(EulerAdaptArgs a)
+{
+    typedef typename VecOf<T, VEC>::type V;
+    double emax = 0;
+    for_each_chunk<VEC>(a.g, a.ncomp, [&](int, long, long, long, long e) {
+        const V y = *(const V *)((const T *)a.y + e), r = *(const V *)((const T *)a.rate + e);
+        const V h = *(const V *)((const T *)a.half + e), k = *(const V *)((const T *)a.k + e);
+        V o;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            o[q] = (T)((double)h[q] + (double)k[q]);                       // :391
+            const double large = (double)(T)((double)y[q] + a.dt * (double)r[q]);   // :381 (an array of the state's type in the reference)
+            emax = max_nan(emax, abs_nan_canon(large - (double)o[q]));     // :394
+        }
+        *(V *)((T *)a.out + e) = o;
+    });
+    block_max_to(emax, a.err);
+}
+
 struct DiffArgs {
     DevGrid g;
     int ncomp;
@@ -686,7 +716,7 @@ int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, doubl
     *done = false;
     NGrid n;
     PDEHIP_TRY(norm_grid(g, &n));
-    if (!in || (!out && !(stage && (stage->kind == 1 || stage->kind == 2))) || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
+    if (!in || (!out && !(stage && (stage->kind == 1 || stage->kind == 2 || stage->kind == 4))) || !faces_c || !faces_mu) PDEHIP_FAIL(E_VALUE, "cahn_hilliard_fused: NULL pointer");
     if (stage && euler) PDEHIP_FAIL(E_RUNTIME, "internal: a Runge-Kutta stage sweep computes the scaled slope");
     if (n.ndim < 2) return 0;
     InputBCs fc, fm;
@@ -942,6 +972,21 @@ int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const vo
     a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.rc = rate_cur; a.rp = rate_prev; a.dt = dt;
     const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
     PDEHIP_VEC_LAUNCH(ab2_combine_kernel, a, items);
+    return 0;
+}
+
+int pdehip_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y_full, const void *rate_full, double dt, const void *half_full,
+                                  const void *k_full, void *out_full, double *err_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!y_full || !rate_full || !half_full || !k_full || !out_full || !err_dev) PDEHIP_FAIL(E_VALUE, "euler_adaptive_combine: NULL pointer");
+    if (ncomp < 1) PDEHIP_FAIL(E_VALUE, "ncomp must be >= 1");
+    PDEHIP_HIP(hipMemsetAsync(err_dev, 0, sizeof(double), as_stream(stream)));
+    EulerAdaptArgs a;
+    a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.rate = rate_full; a.half = half_full; a.k = k_full; a.out = out_full; a.dt = dt; a.err = err_dev;
+    const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
+    PDEHIP_VEC_LAUNCH(euler_adaptive_combine_kernel, a, items);
     return 0;
 }
 

@@ -36,6 +36,10 @@ struct StageFuse {
                          // 2: end of an RKF45 attempt  out2 = 4th-order state from y and k = {k1, k3, k4, k5}, *err = max-norm
                          //    of the error estimate with k6 = k  (k is not stored; *err must be zero before the launch)
                          // 3: Adams-Bashforth step  out2 = y + c_new * (1.5*k - 0.5*k[0])  with k = the rate (also stored), c_new = dt
+                         // 4: end of an adaptive Euler attempt (pde/backends/numba/_solvers.py:380-395): k = dt/2 * rhs(step_half) with
+                         //    step_half = k[1] (REQUIRED to be the input array of the sweep), out2 = step_half + k (the double step),
+                         //    *err = max |(y + c[0]*k[0]) - out2| with k[0] = the rate carried from the last accepted state and
+                         //    c[0] = dt (the single step; never stored)  (k is not stored; *err must be zero before the launch)
     const void *y;
     const void *k[5];    // earlier slopes, NULL-terminated
     double c[5], c_new;
@@ -274,9 +278,17 @@ int rhs_sweep(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t
     if (flags & F_FUSED_CH) {
         SLAB_TRY(exchange2(ops, q, layer(in, q, -1), lower, upper, st));
         bool done = false;
-        // a kind-1/2 stage does not store the slope: the kernel gets no `out`, the fallback below would need one
+        // a kind-1/2/4 stage does not store the slope: the kernel gets no `out`
         SLAB_TRY(ops.ch_fused(g, in, fuse_stage && sf->kind != 0 && sf->kind != 3 ? nullptr : out, rhs->param, dt, euler, fc, fm, st, &done,
                               xends(lower, upper), false, fuse_stage ? sf : nullptr));
+        if (!done && fuse_stage && out) {
+            // The sweep itself is covered, its stage epilogue is not: on grids that need overlapping tiles (an odd row count, rows
+            // that end inside a vector) cells are computed twice, so an epilogue that overwrites one of its own operands - the RK4
+            // update writes the new state over y - is refused (launch_euler2_tv).  Slope alone into `out` (every caller passes a
+            // free array, also for the kinds that do not store it), then the pointwise combination: what pdehip_rk4_step does.
+            SLAB_TRY(ops.ch_fused(g, in, out, rhs->param, dt, euler, fc, fm, st, &done, xends(lower, upper), false, nullptr));
+            if (done) return ops.combine(g, out, *sf, st);
+        }
         if (!done) return ops.fail("slab sweep: grid or faces are not covered by the two-level kernel (flags were decided wrongly)");
         return (sf && !fuse_stage) ? ops.combine(g, out, *sf, st) : 0;
     }

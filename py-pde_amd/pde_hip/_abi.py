@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -169,6 +169,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "rk4_combine": ([_pg, _i, _vp, _vp, _vp, _vp, _vp], True),
     "rkf45_combine": ([_pg, _i, _vp, _vp, _pvp, _vp], True),
     "ab2_combine": ([_pg, _i, _vp, _vp, _vp, _d], True),
+    "euler_adaptive_combine": ([_pg, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp], True),
     "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
     "integrate": ([_pg, _i, _vp, _d, _vp], True),
     "count_nonfinite": ([_pg, _i, _vp, _vp], True),
@@ -224,6 +225,9 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler_sweeps": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_rk4_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _pvp, _d, _i64, _vp],
     "slab_rkf45_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _pvp, _vp, _pa, _pvp, _vp],
+    # the reference's adaptive Euler loop (rate carried from attempt to attempt): slab / serial, one C call per run
+    "slab_euler_adaptive_run": [_vp, _pg, _pr, _i, _i, _i, _vp, _vp, _pvp, _vp, _pa, _pvp, _vp],
+    "euler_adaptive_run": [_pg, _pr, _vp, _vp, _pvp, _vp, _pa, _pvp, _vp],
     # block decomposition (csrc/pdehip_block_loops.h)
     "block_exchange": [_vp, _pg, C.POINTER(_i), _vp, _vp],
     "block_run": [_vp, _pg, _pr, C.POINTER(_i), _i, _i, _vp, _vp, _pvp, _vp, _d, _i64, _pa, _pvp, _vp],
@@ -247,6 +251,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "jit_fused2": [_vp, _pg, _vp, _vp, _pd, _i, _pf, _pf, C.POINTER(_i), _vp],
     "jit_euler_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _vp, _vp, _i, _d, _d, _i, _i64, _vp, _pvp, _vp],
     "jit_rk_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _i, _vp, _vp, _pvp, _vp, _d, _d, _i64, _pa, _i, _vp, _pvp, _vp],
+    "jit_euler_adaptive_run": [_pg, C.POINTER(JitPass), _i, _pvp, _i, _i, _vp, _vp, _pvp, _vp, _pa, _i, _vp, _pvp, _vp],
     # expression boundary conditions evaluated on the device
     "bcprog_create": [C.c_char_p, _i, C.POINTER(BcProgFace), _pg, _pvp],
     "bcprog_run": [_vp, _d, _vp, _vp],

@@ -933,7 +933,7 @@ class HipBackendMixin:
         # (`scheme`: "euler" / "runge-kutta" for callers without one of the solver classes, e.g. the decomposed steppers)
         is_rk = (scheme == "runge-kutta") if scheme is not None else solver.__class__.__name__ == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
-        nwork = (7 if adaptive else 5) if is_rk else (2 if adaptive else 1)
+        nwork = (7 if adaptive else 5) if is_rk else (3 if adaptive else 1)   # adaptive Euler: rate, half step, slope scratch
         work = [DeviceArray(info, comp_shape) for _ in range(nwork)]
         B = [[1 / 4], [3 / 32, 9 / 32], [1932 / 2197, -7200 / 2197, 7296 / 2197], [439 / 216, -8.0, 3680 / 513, -845 / 4104],
              [-8 / 27, 2.0, -3544 / 2565, 1859 / 4104, -11 / 40]]
@@ -1026,18 +1026,19 @@ class HipBackendMixin:
                 if not erhs.apply_stage(src, ks[5], dt_step, t + A[5] * dt_step, 2, y, [ks[0], ks[2], ks[3], ks[4]], [], 0.0, ynew, err_dev):
                     lib.rkf45_combine(info.ref, ncomp, y.ptr, ynew.ptr, ptr_array(ks), err_dev.ptr, stream)
             else:
-                k1, k2a = work[0], work[1]
-                erhs.apply(y, k1, "euler", dt_step, t)
-                if not erhs.euler2(y, ynew, 0.5 * dt_step):   # the two half steps in one sweep where covered
-                    erhs.apply(y, k2a, "euler", 0.5 * dt_step, t)
-                    erhs.apply(k2a, ynew, "euler", 0.5 * dt_step, t + 0.5 * dt_step)
-                lib.max_abs_diff(info.ref, ncomp, k1.ptr, ynew.ptr, err_dev.ptr, stream)
+                # second half of the reference's adaptive Euler attempt (pde/backends/numba/_solvers.py:385-394): `work[1]` holds
+                # step_small = y + dt/2 * rate; the sweep adds dt/2 * rhs(step_small, t + dt/2) and takes the error norm against
+                # step_large = y + dt * rate, which is never stored (stage kind 4)
+                rate, half, kmid = work[0], work[1], work[2]
+                h = 0.5 * dt_step
+                if not erhs.apply_stage(half, kmid, h, t + h, 4, y, [rate, half], [dt_step, 0.0], 0.0, ynew, err_dev):
+                    lib.euler_adaptive_combine(info.ref, ncomp, y.ptr, rate.ptr, dt_step, half.ptr, kmid.ptr, ynew.ptr, err_dev.ptr, stream)
             if reduce_error is not None:
                 reduce_error(err_dev)     # MAX over the ranks of a decomposed run, on the device, NaN wins (pde/backends/base.py:678-712)
             return err_dev.value(stream)
 
         ctl = None
-        if is_rk and post_step is None and hasattr(erhs, "rk_run") and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+        if post_step is None and hasattr(erhs, "rk_run") and reduce_error is None and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
             # the adaptive loop itself in C (pdehip_jit_rk_run: pde/backends/numba/_solvers.py:199-319 is jitted in the reference)
             from .solvers import AdaptiveStatistics
 
@@ -1050,7 +1051,10 @@ class HipBackendMixin:
                 ctl.t_start, ctl.t_end, ctl.dt = float(t_start), float(t_end), float(solver.info["dt"])
                 before = int(ctl.steps)
                 try:
-                    res = erhs.rk_run(state_data, ynew0, work[:7], err_dev, 0.0, 0.0, 0, ctl)
+                    if is_rk:
+                        res = erhs.rk_run(state_data, ynew0, work[:7], err_dev, 0.0, 0.0, 0, ctl)
+                    else:   # the reference's adaptive Euler loop in one C call (pdehip_jit_euler_adaptive_run)
+                        res = erhs.rk_run(state_data, ynew0, work[:3], err_dev, 0.0, 0.0, 0, ctl, euler_adaptive=True)
                 finally:
                     solver.info["steps"] += int(ctl.steps) - before
                 if res is not None:
@@ -1064,15 +1068,31 @@ class HipBackendMixin:
             t, steps = t_start, 0
             stats = solver.info["dt_statistics"]
             cur, nxt = state_data, ynew0   # an accepted attempt swaps the roles (no copy of the field per step)
+            # Adaptive Euler is the reference's own loop (pde/backends/numba/_solvers.py:374-433, pde/solvers/euler.py:222-280; C twin
+            # csrc/pdehip_rk_loops.h `euler_adaptive_run`): the rate of the current state is carried from attempt to attempt and,
+            # after an accepted attempt, evaluated at the time BEFORE `t += dt` - here lazily at the start of the next attempt, in
+            # the sweep that also writes the first half step; with a hook eagerly, before the hook sees (and may change) the state.
+            have_rate, t_rate = False, t_start
             try:
                 while True:
                     dt_step = max(min(dt_opt, t_end - t), dt_min)
+                    if not is_rk:
+                        rate, half = work[0], work[1]
+                        h = 0.5 * dt_step
+                        if have_rate or not erhs.apply_stage(cur, rate, 1.0, t_rate, 0, cur, [], [], h, half):
+                            lincomb(half, cur, [h], [rate])
+                        have_rate = True
                     error_rel = attempt(cur, nxt, t, dt_step) / tolerance
                     if error_rel <= 1:
                         steps += 1
+                        t_rate = t
                         t += dt_step
                         cur, nxt = nxt, cur
+                        have_rate = False
                         if post_step is not None:
+                            if not is_rk:
+                                erhs.apply(cur, work[0], "rate", 0.0, t_rate)   # `rate = rhs_pde(step_small, t)` precedes the hook (:402-411)
+                                have_rate = True
                             cur = post_step(cur, t)
                         stats.add(dt_step)
                     if t < t_end:
@@ -1383,7 +1403,7 @@ class HipBackendMixin:
         info, lib, stream = spec.info, self._lib, self.stream
         is_rk = solver_name == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
-        work = [DeviceArray(info) for _ in range((7 if adaptive else 5) if is_rk else (2 if adaptive else 1))]
+        work = [DeviceArray(info) for _ in range((7 if adaptive else 5) if is_rk else (3 if adaptive else 1))]   # adaptive Euler: rate, half step, scratch
         work_ptrs = ptr_array(work)
         if not adaptive:
             dt = float(solver.info["dt"])
@@ -1409,16 +1429,15 @@ class HipBackendMixin:
 
         solver.info["dt_adaptive"] = True
         solver.info.setdefault("dt_statistics", OnlineStatistics())
-        adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
         tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
         err_dev = DeviceScalar()
         ynew = DeviceArray(info)
-        sync_errors = getattr(solver, "_sync_errors", None) or (lambda e: e)
 
-        if is_rk and getattr(solver, "_sync_errors", None) is None and os.environ.get("PDEHIP_ADAPTIVE_LOOP", "1") != "0":
-            # The whole adaptive loop of pde/backends/numba/_solvers.py:249-281 in ONE C call (`pdehip_slab_rkf45_run` without a
-            # communicator and without neighbours = the serial use of the slab loop templates): stage sequence, error norm,
-            # accept / reject, controller and step statistics run in C; the host reads 8 bytes per attempt and nothing else.
+        if os.environ.get("PDEHIP_ADAPTIVE_LOOP", "1") != "0":
+            # The whole adaptive loop in ONE C call (the slab loop templates without a communicator and without neighbours = their
+            # serial use): RKF45 attempts inside the generic loop of pde/backends/numba/_solvers.py:249-281 (`pdehip_slab_rkf45_run`),
+            # or the reference's own adaptive Euler loop with the carried rate, :374-433 (`pdehip_slab_euler_adaptive_run`).  Stage
+            # sequence, error norm, accept / reject, controller and step statistics run in C; the host reads 8 bytes per attempt.
             from .solvers import AdaptiveStatistics
 
             flags = C.c_int(0)
@@ -1426,14 +1445,14 @@ class HipBackendMixin:
             ctl = _abi.Adaptive()
             ctl.tolerance, ctl.dt_min, ctl.dt_max = tolerance, dt_min, float(solver.dt_max)
             solver.info["dt_statistics"] = AdaptiveStatistics(ctl)
+            run = lib.slab_rkf45_run if is_rk else lib.slab_euler_adaptive_run
 
             def adaptive_loop(state_data: DeviceArray, t_start: float, t_end: float):
                 ctl.t_start, ctl.t_end, ctl.dt = float(t_start), float(t_end), float(solver.info["dt"])
                 before = int(ctl.steps)
                 res = C.c_void_p()
                 try:
-                    lib.slab_rkf45_run(None, info.ref, spec.ref, -1, -1, flags.value, state_data.ptr, ynew.ptr, work_ptrs, err_dev.ptr,
-                                       C.byref(ctl), C.byref(res), stream)
+                    run(None, info.ref, spec.ref, -1, -1, flags.value, state_data.ptr, ynew.ptr, work_ptrs, err_dev.ptr, C.byref(ctl), C.byref(res), stream)
                 finally:
                     solver.info["steps"] += int(ctl.steps) - before
                 if res.value != state_data.ptr:
@@ -1444,53 +1463,8 @@ class HipBackendMixin:
             adaptive_loop.keepalive = (work, ynew, err_dev, spec)   # type: ignore[attr-defined]  (work_ptrs holds raw pointers only)
             return adaptive_loop
 
-        two_half_steps = [spec.kind == _abi.RHS_DIFFUSION and not spec.time_dependent]
-
-        def attempt(state_data: DeviceArray, ynew: DeviceArray, dt_step: float, t: float = 0.0) -> float:
-            spec.c.t = float(t)      # faces with explicit time dependence: the C entry points evaluate them at t (+ a_s * dt per stage)
-            if is_rk:
-                lib.rkf45_attempt(info.ref, spec.ref, state_data.ptr, ynew.ptr, work_ptrs, dt_step, err_dev.ptr, stream)
-            else:
-                # generic estimate (solvers/base.py:409-423): one full step vs two half steps
-                res = C.c_void_p()
-                k1, k2a = work[0], work[1]
-                lib.euler_run(info.ref, spec.ref, state_data.ptr, k1.ptr, dt_step, 1, C.byref(res), stream)
-                done = C.c_int(0)
-                if two_half_steps[0]:
-                    # the two half steps in ONE sweep (two-level kernel, intermediate level in registers)
-                    lib.diffusion_euler2(info.ref, spec.bc_c.c, state_data.ptr, ynew.ptr, spec.param, 0.5 * dt_step, C.byref(done), stream)
-                    two_half_steps[0] = bool(done.value)
-                if not done.value:
-                    lib.euler_run(info.ref, spec.ref, state_data.ptr, k2a.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
-                    spec.c.t = float(t) + 0.5 * dt_step
-                    lib.euler_run(info.ref, spec.ref, k2a.ptr, ynew.ptr, 0.5 * dt_step, 1, C.byref(res), stream)
-                lib.max_abs_diff(info.ref, 1, k1.ptr, ynew.ptr, err_dev.ptr, stream)
-            return err_dev.value(stream)
-
-        def adaptive_stepper(state_data: DeviceArray, t_start: float, t_end: float):
-            dt_opt = float(solver.info["dt"])
-            t, steps = t_start, 0
-            stats = solver.info["dt_statistics"]
-            cur, nxt = state_data, ynew   # an accepted attempt swaps the roles (no copy of the field per step)
-            while True:
-                dt_step = max(min(dt_opt, t_end - t), dt_min)
-                error_rel = sync_errors(attempt(cur, nxt, dt_step, t) / tolerance)
-                if error_rel <= 1:
-                    steps += 1
-                    t += dt_step
-                    cur, nxt = nxt, cur
-                    stats.add(dt_step)
-                if t < t_end:
-                    dt_opt = adjust_dt(dt_step, error_rel)
-                else:
-                    break
-            if cur is not state_data:
-                lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
-            solver.info["dt"] = dt_opt
-            solver.info["steps"] += steps
-            return state_data, t
-
-        return adaptive_stepper
+        # the same loops driven from Python (PDEHIP_ADAPTIVE_LOOP=0: a debugging aid): `_make_expression_stepper` holds them
+        return self._make_expression_stepper(solver, state, SpecRhs(self, spec))
 
     def make_stepper(self, solver, state):
         """``stepper(state_field, t_start, t_end) -> t_last`` mutating ``state.data`` (base.py:728-755).

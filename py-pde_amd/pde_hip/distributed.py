@@ -314,6 +314,15 @@ class SlabStepper:
                                 self.err.ptr, C.byref(ctl), C.byref(res), self.stream)
         return cur if res.value == cur.ptr else nxt
 
+    def euler_adaptive_run(self, cur: SlabArray, nxt: SlabArray, ctl: _abi.Adaptive) -> SlabArray:
+        """The reference's adaptive Euler loop (rate carried between attempts, ``pde/backends/numba/_solvers.py:322-466``) from
+        ``ctl.t_start`` to ``ctl.t_end`` in one C call, incl. the halo exchanges and the MAX all-reduce of the error."""
+        work = self._work(["k1", "tmp", "k2"])   # rate, half step (a sweep input), slope scratch
+        res = C.c_void_p()
+        self.lib.slab_euler_adaptive_run(self.comm, C.byref(self.g), C.byref(self.rhs), self._lo, self._up, self.flags, cur.ptr, nxt.ptr, work,
+                                         self.err.ptr, C.byref(ctl), C.byref(res), self.stream)
+        return cur if res.value == cur.ptr else nxt
+
     # --- user level --------------------------------------------------------------------------------------
     def set_local(self, buf: SlabArray, local_valid: np.ndarray) -> None:
         host = np.ascontiguousarray(local_valid, dtype=self.dtype)
@@ -368,12 +377,12 @@ class SlabStepper:
                 raise NotImplementedError(msg)
             info.update(steps=steps, dt=dt, t_final=(steps - 1) * dt + dt)
         else:
-            if solver != "runge-kutta":
-                msg = "adaptive slab stepping is implemented for runge-kutta (RKF45)"
+            if solver not in ("runge-kutta", "euler"):
+                msg = "adaptive slab stepping is implemented for runge-kutta (RKF45) and euler"
                 raise NotImplementedError(msg)
             ctl = _abi.Adaptive()
             ctl.t_start, ctl.t_end, ctl.dt, ctl.tolerance, ctl.dt_min, ctl.dt_max = 0.0, float(t_range), 1e-3, tolerance, dt_min, dt_max
-            cur = self.rkf45_run(cur, nxt, ctl)
+            cur = self.rkf45_run(cur, nxt, ctl) if solver == "runge-kutta" else self.euler_adaptive_run(cur, nxt, ctl)
             info.update(steps=int(ctl.steps), attempts=int(ctl.attempts), dt=ctl.dt, t_final=ctl.t_last, dt_statistics=_abi.adaptive_statistics(ctl))
         self.synchronize()
         return self.gather(cur), info
@@ -493,6 +502,10 @@ class BlockStepper:
     def rkf45_run(self, cur, nxt, ctl: _abi.Adaptive):
         return self._run(2, cur, nxt, [self.buf(n) for n in ("k1", "k2", "k3", "k4", "k5", "k6", "tmp")], 0.0, 0, ctl)
 
+    def euler_adaptive_run(self, cur, nxt, ctl: _abi.Adaptive):
+        """The reference's adaptive Euler loop (``pde/backends/numba/_solvers.py:322-466``) on the block decomposition."""
+        return self._run(3, cur, nxt, [self.buf(n) for n in ("k1", "tmp", "k2")], 0.0, 0, ctl)
+
     # --- user level --------------------------------------------------------------------------------------
     def scatter(self, global_valid: np.ndarray):
         """Upload this rank's block of a (replicated) global initial state; returns the array."""
@@ -523,12 +536,12 @@ class BlockStepper:
                 raise NotImplementedError(msg)
             info.update(steps=steps, dt=dt, t_final=(steps - 1) * dt + dt)
         else:
-            if solver != "runge-kutta":
-                msg = "adaptive block stepping is implemented for runge-kutta (RKF45)"
+            if solver not in ("runge-kutta", "euler"):
+                msg = "adaptive block stepping is implemented for runge-kutta (RKF45) and euler"
                 raise NotImplementedError(msg)
             ctl = _abi.Adaptive()
             ctl.t_start, ctl.t_end, ctl.dt, ctl.tolerance, ctl.dt_min, ctl.dt_max = 0.0, float(t_range), 1e-3, tolerance, dt_min, dt_max
-            cur = self.rkf45_run(cur, nxt, ctl)
+            cur = self.rkf45_run(cur, nxt, ctl) if solver == "runge-kutta" else self.euler_adaptive_run(cur, nxt, ctl)
             info.update(steps=int(ctl.steps), attempts=int(ctl.attempts), dt=ctl.dt, t_final=ctl.t_last, dt_statistics=_abi.adaptive_statistics(ctl))
         self.synchronize()
         return self.gather(cur), info

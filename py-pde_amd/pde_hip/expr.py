@@ -477,13 +477,19 @@ def _run_loop(lib, info, loop, state, other, ncomp: int, dt: float, t0: float, n
     return state if result.value == state.ptr else other
 
 
-def _run_rk(lib, info, loop, ncomp: int, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl, stage_fuse: bool, stream, program=None):
+def _run_rk(lib, info, loop, ncomp: int, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl, stage_fuse: bool, stream, program=None,
+            euler_adaptive: bool = False):
     """``pdehip_jit_rk_run``: ``nsteps`` RK4 steps in place on ``y`` (``ctl`` None) or the adaptive RKF45 loop described by ``ctl``;
-    returns the array that holds the final state."""
+    ``euler_adaptive``: the reference's adaptive Euler loop instead (``pdehip_jit_euler_adaptive_run``, work = rate, half step, scratch).
+    Returns the array that holds the final state."""
     from .device import ptr_array
 
     passes, fixed, nfixed, _keep = loop
     result = C.c_void_p()
+    if euler_adaptive:
+        lib.jit_euler_adaptive_run(info.ref, passes, len(passes), fixed, nfixed, ncomp, y.ptr, ynew.ptr, ptr_array(work), err.ptr, C.byref(ctl),
+                                   int(bool(stage_fuse)), None if program is None else program.ptr, C.byref(result), stream)
+        return y if result.value == y.ptr else ynew
     lib.jit_rk_run(info.ref, passes, len(passes), fixed, nfixed, ncomp, y.ptr, None if ynew is None else ynew.ptr, ptr_array(work),
                    None if err is None else err.ptr, float(dt), float(t0), int(nsteps), None if ctl is None else C.byref(ctl),
                    int(bool(stage_fuse)), None if program is None else program.ptr, C.byref(result), stream)
@@ -645,7 +651,7 @@ class ExpressionRhs:
                 continue
             done = C.c_int(0)
             kp = (C.c_void_p * max(1, len(ks)))(*[k.ptr for k in ks])
-            cf = (C.c_double * max(1, len(ks)))(*(list(coefs) if kind == 0 else [0.0] * len(ks)))
+            cf = (C.c_double * max(1, len(ks)))(*(list(coefs) if kind in (0, 4) else [0.0] * len(ks)))
             self.lib.jit_apply_stage(h, self.info.ref, arrays[p.src].ptr, ex, k_out.ptr, params, 2, self._faces(i), kind, y.ptr, len(ks), kp,
                                      cf, c_new, out2.ptr, err.ptr if err is not None else None, C.byref(done), self.backend.stream)
             if not done.value:
@@ -724,11 +730,11 @@ class ExpressionRhs:
             cache[wrap] = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
         return cache[wrap]
 
-    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None):
+    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None, euler_adaptive: bool = False):
         """Runge-Kutta steps in ONE C call (``pdehip_jit_rk_run``): ``nsteps`` RK4 steps in place on ``y``, or - with ``ctl`` -
-        the adaptive RKF45 loop; returns the array holding the final state, or None when the loop is not available (integrals,
-        function-valued conditions; two-pass chains of LARGE grids keep the Python loop, whose steps run the chain as one
-        two-level sweep)."""
+        the adaptive RKF45 loop (``euler_adaptive``: the reference's adaptive Euler loop, ``pdehip_jit_euler_adaptive_run``);
+        returns the array holding the final state, or None when the loop is not available (integrals, function-valued
+        conditions; two-pass chains of LARGE grids keep the Python loop, whose steps run the chain as one two-level sweep)."""
         if not self.loop_ok():
             return None
         chain = self._fused_handle("scaled") is not None
@@ -736,7 +742,7 @@ class ExpressionRhs:
             return None
         stage_fuse = getattr(self, "_stage_ok", True) and not chain
         return _run_rk(self.lib, self.info, self._loop_desc("scaled"), 1, y, ynew, work, err, dt, t0, nsteps, ctl, stage_fuse, self.backend.stream,
-                       self.bc_program())
+                       self.bc_program(), euler_adaptive)
 
     def _fused_handle(self, wrap: str):
         if wrap not in self._fused:
@@ -865,11 +871,11 @@ class SystemRhs:
             self._bc_program = program_for(self.parts[0].lib, tables) if tables else None
         return self._bc_program
 
-    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None):
+    def rk_run(self, y, ynew, work, err, dt: float, t0: float, nsteps: int, ctl=None, euler_adaptive: bool = False):
         """Runge-Kutta steps of the whole system in one C call (see :meth:`ExpressionRhs.rk_run`): every equation evaluates its
         component of the slope from the stage input of all fields; the combinations run on all components at once."""
         if not all(p.loop_ok() for p in self.parts):
             return None
         part0 = self.parts[0]
         return _run_rk(part0.lib, self.info, self._loop_desc("scaled"), self.ncomp, y, ynew, work, err, dt, t0, nsteps, ctl, False,
-                       part0.backend.stream, self.bc_program())
+                       part0.backend.stream, self.bc_program(), euler_adaptive)

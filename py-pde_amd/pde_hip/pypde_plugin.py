@@ -152,9 +152,6 @@ class HipSlabSolver(AdaptiveSolverBase):
             if state.__class__.__name__ != "ScalarField":
                 msg = "the fused slab loops take one ScalarField"
                 raise NotImplementedError(msg)
-            if self.adaptive and self.scheme != "runge-kutta":
-                msg = "the fused adaptive loop is the Runge-Kutta-Fehlberg scheme"
-                raise NotImplementedError(msg)
             SlabStepper._describe(self.pde, state.grid)
         except NotImplementedError:
             return self._make_expression_stepper(state, float(dt), device, has_hook)
@@ -192,7 +189,7 @@ class HipSlabSolver(AdaptiveSolverBase):
             if self.adaptive:
                 ctl.t_start, ctl.t_end = float(t_start), float(t_end)
                 before = int(ctl.steps)
-                res = stepper.rkf45_run(a, b, ctl)
+                res = stepper.rkf45_run(a, b, ctl) if self.scheme == "runge-kutta" else stepper.euler_adaptive_run(a, b, ctl)
                 self.info["steps"] += int(ctl.steps) - before
                 self.info["dt"] = float(ctl.dt)
                 self.info["dt_statistics"] = _Statistics(_abi.adaptive_statistics(ctl))   # the controller calls .to_dict()

@@ -53,6 +53,15 @@ def main() -> int:
                                    dict(t_range=0.3, dt=1e-2, scheme="runge-kutta", adaptive=True)),
         "diffusion_adaptive_euler": (pde.DiffusionPDE(0.6, bc=wall), pde.UnitGrid([12, 4, 6], periodic=[False, True, False]),
                                      dict(t_range=0.5, dt=1e-2, adaptive=True)),
+        # the reference's adaptive Euler loop (rate carried between attempts, evaluated at the old time) with conditions that depend on time,
+        # on the decomposed and on an undecomposed axis: the fused slab / block loop (Diffusion, Cahn-Hilliard) and the decomposed passes
+        "diffusion_adaptive_euler_time_bcs": (pde.DiffusionPDE(0.6, bc={"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative": 0.1},
+                                                                        "y": "periodic", "z-": {"derivative_expression": "0.05 * x * sin(t)"}, "z+": {"value": 0.1}}),
+                                              pde.UnitGrid([12, 4, 6], periodic=[False, True, False]), dict(t_range=0.5, dt=0.2, adaptive=True)),
+        "cahn_hilliard_adaptive_euler_time_bcs": (pde.CahnHilliardPDE(0.9, bc_c={"x-": {"value_expression": "0.1 * cos(2 * t)"}, "x+": {"derivative": 0}, "y": "periodic"}),
+                                                  pde.UnitGrid([12, 8], periodic=[False, True]), dict(t_range=0.05, dt=1e-3, adaptive=True)),
+        "allen_cahn_adaptive_euler_time_bcs": (pde.AllenCahnPDE(0.9, bc={"x-": {"value_expression": "0.2 * sin(3 * t)"}, "x+": {"derivative": 0.1}, "y": "periodic"}),
+                                               pde.UnitGrid([12, 8], periodic=[False, True]), dict(t_range=0.3, dt=0.1, adaptive=True)),
         "swift_hohenberg_class_rk4": (pde.SwiftHohenbergPDE(rate=0.1, kc2=0.8, delta=0.3), pde.UnitGrid([10, 8], periodic=[True, False]),
                                       dict(t_range=0.008, dt=1e-3, scheme="runge-kutta")),
         "pde_nested_euler": (pde.PDE({"c": "laplace(c**3 - c - 0.7 * laplace(c)) + 0.01 * x * y"}, bc={"x": {"derivative": 0.05}, "y": "periodic"}),
@@ -109,6 +118,8 @@ def main() -> int:
             kw["scheme"] = "runge-kutta"
             if k % 3 == 0:
                 kw["adaptive"] = True
+        elif k % 3 == 1:
+            kw["adaptive"] = True      # the reference's adaptive Euler loop
         cases[f"fuzz{k}"] = (eq, grid, kw)
     pde.config["default_backend"] = "scipy"
     for name, (eq, grid, kw, *rest) in cases.items():

@@ -242,6 +242,11 @@ int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *r
 int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew, const void *const *k6_host, double *err_dev,
                          void *stream)
 { (void)stream; GRID(g); TRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6_host, err_dev)); return 0; }
+int oracle_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y, const void *rate, double dt, const void *half, const void *k,
+                                  void *out, double *err);
+int pdehip_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y, const void *rate, double dt, const void *half, const void *k,
+                                  void *out, double *err_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err_dev)); return 0; }
 int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a, const void *b, double *out_dev, void *stream)
 { (void)stream; GRID(g); TRY(oracle_max_abs_diff(g, ncomp, a, b, out_dev)); return 0; }
 
@@ -672,6 +677,10 @@ int pdehip_jit_apply_stage(void *handle, const pdehip_grid_t *g, void *in_full, 
         /* k2 does not enter the RKF45 tail: any valid array stands in for it */
         const void *k6[6] = {k_prev_host[0], k_prev_host[0], k_prev_host[1], k_prev_host[2], k_prev_host[3], k};
         rc = oracle_rkf45_combine(g, 1, y_full, out2_full, k6, err_dev);
+    } else if (!rc && kind == 4) {
+        rc = oracle_euler_adaptive_combine(g, 1, y_full, k_prev_host[0], coef_host[0], k_prev_host[1], k, out2_full, err_dev);
+    } else if (!rc) {
+        rc = 1;
     }
     if (kind != 0) free(k);
     if (rc > 99) return rc;

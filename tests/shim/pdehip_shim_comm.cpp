@@ -43,6 +43,8 @@ int oracle_cahn_hilliard_mu(const pdehip_grid_t *g, const void *c_full, void *mu
 int oracle_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void *y_full, int nk, const double *coef, const void *const *k);
 int oracle_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *k1, const void *k2, const void *k3, const void *k4);
 int oracle_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew, const void *const *k6, double *err);
+int oracle_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y, const void *rate, double dt, const void *half, const void *k,
+                                  void *out, double *err);
 int oracle_rhs_scaled(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *k_out_full, double dt);
 // the rest of the shim
 int pdehip_layout(const pdehip_grid_t *g, int64_t *out8);
@@ -175,9 +177,9 @@ struct HostOps {
         if (kind == slab::K_EULER) { OTRY(oracle_laplace_euler(gs, in, y, out, s1, s2)); return 0; }
         if (kind == slab::K_SCALED) { OTRY(oracle_laplace_scaled(gs, in, out, s1, s2)); return 0; }
         if (kind == slab::K_CH_MU) { OTRY(oracle_cahn_hilliard_mu(gs, in, out, gamma)); return 0; }
-        // K_STAGE: slope, then the combination (kinds 1 and 2 do not store the slope)
+        // K_STAGE: slope, then the combination (kinds 1, 2 and 4 do not store the slope)
         void *k = out, *tmp = nullptr;
-        if (sf->kind == 1 || sf->kind == 2) k = tmp = calloc(1, full_bytes(gs));
+        if (sf->kind == 1 || sf->kind == 2 || sf->kind == 4) k = tmp = calloc(1, full_bytes(gs));
         int rc = oracle_laplace_scaled(gs, in, k, s1, s2);
         if (!rc) rc = combine(gs, k, *sf, st);
         free(tmp);
@@ -204,6 +206,12 @@ struct HostOps {
             double err = 0;
             OTRY(oracle_rkf45_combine(g, 1, sf.y, sf.out2, k6, &err));
             // like the device kernel: atomic max onto the (zeroed) scalar, NaN wins
+            if (err != err || *sf.err != *sf.err) *sf.err = NAN; else if (err > *sf.err) *sf.err = err;
+            return 0;
+        }
+        if (sf.kind == 4) {
+            double err = 0;
+            OTRY(oracle_euler_adaptive_combine(g, 1, sf.y, sf.k[0], sf.c[0], sf.k[1], k, sf.out2, &err));
             if (err != err || *sf.err != *sf.err) *sf.err = NAN; else if (err > *sf.err) *sf.err = err;
             return 0;
         }
@@ -269,7 +277,7 @@ struct HostOps {
                              if (euler) { OTRY(oracle_laplace_euler(g2, mu, static_cast<const char *>(in) + off, static_cast<char *>(out) + off, 1.0, dt)); return 0; }
                              if (!sf) { OTRY(oracle_laplace_scaled(g2, mu, static_cast<char *>(out) + off, 1.0, dt)); return 0; }
                              void *k = out, *tmp = nullptr;
-                             if (sf->kind == 1 || sf->kind == 2) k = tmp = calloc(1, full_bytes(g2));
+                             if (sf->kind == 1 || sf->kind == 2 || sf->kind == 4) k = tmp = calloc(1, full_bytes(g2));
                              int rc = oracle_laplace_scaled(g2, mu, k, 1.0, dt);
                              if (!rc) rc = combine(g2, k, *sf, st);
                              free(tmp);
@@ -320,6 +328,11 @@ struct HostOps {
     int lincomb(const pdehip_grid_t *g, void *out, const void *y, int n, const double *cf, const void *const *k, void *) { OTRY(oracle_lincomb(g, 1, out, y, n, cf, k)); return 0; }
     int rk4_combine(const pdehip_grid_t *g, void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const pdehip_grid_t *g, const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }
+    int euler_adaptive_combine(const pdehip_grid_t *g, const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *)
+    {
+        OTRY(oracle_euler_adaptive_combine(g, 1, y, rate, dt, half, k, out, err));
+        return 0;
+    }
 };
 
 int make_block(Comm *c, const pdehip_grid_t *g, const int *nb6, block::Geo *q)
@@ -542,6 +555,22 @@ int pdehip_slab_rkf45_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     return slab::rkf45_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work7_host, err_dev, ctl, result, stream);
 }
 
+int pdehip_slab_euler_adaptive_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, int flags, void *y_full,
+                                   void *ynew_full, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl, void **result, void *stream)
+{
+    if (!(ctl->tolerance > 0) || !(ctl->dt > 0)) return failf(E_VALUE, "slab_euler_adaptive_run: tolerance and dt must be positive");
+    SLAB_ENTRY_PROLOGUE(euler_adaptive_run)
+    return slab::euler_adaptive_run(ops, g_local, q, rhs, lower, upper, flags, y_full, ynew_full, work3_host, err_dev, ctl, result, stream);
+}
+
+int pdehip_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *y_full, void *ynew_full, void *const *work3_host,
+                              double *err_dev, pdehip_adaptive_t *ctl, void **result, void *stream)
+{
+    int flags = 0;
+    SLAB_TRY(pdehip_slab_flags_supported(g, rhs, -1, -1, &flags));
+    return pdehip_slab_euler_adaptive_run(nullptr, g, rhs, -1, -1, flags, y_full, ynew_full, work3_host, err_dev, ctl, result, stream);
+}
+
 }  // extern "C"
 
 // ---- the generic Runge-Kutta loops of csrc/pdehip_rk_loops.h on the host ------------------------------------------------------
@@ -562,6 +591,11 @@ struct SpecEval {
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, 1, out, y, n, c, k)); return 0; }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, 1, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, 1, y, ynew, k6, err)); return 0; }
+    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *)
+    {
+        OTRY(oracle_euler_adaptive_combine(g, 1, y, rate, dt, half, k, out, err));
+        return 0;
+    }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
     int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
@@ -618,6 +652,11 @@ struct JitEval {
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, ncomp, out, y, n, c, k)); return 0; }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, ncomp, y, k1, k2, k3, k4)); return 0; }
     int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6, err)); return 0; }
+    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *)
+    {
+        OTRY(oracle_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err));
+        return 0;
+    }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
     int reduce_error(double *, void *) { return 0; }
     int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
@@ -639,7 +678,7 @@ int shim_timed_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, vo
     return rk::rkf45_attempt(ev, y, ynew, w, dt, t, err, nullptr);
 }
 
-int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+static int jit_loop_run(int scheme, const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                       int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
                       pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
 {
@@ -655,10 +694,26 @@ int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, i
         }
     }
     JitEval ev{g, passes, npasses, fixed, ncomp, full_bytes(g), stage_fuse ? 1 : 0, bc_program};
+    if (scheme == 1) return rk::euler_adaptive_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));
     *result = y;
     return 0;
+}
+
+int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                      int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,
+                      pdehip_adaptive_t *ctl, int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    return jit_loop_run(0, g, passes, npasses, fixed, nfixed, ncomp, y, ynew, work_host, err_dev, dt, t0, nsteps, ctl, stage_fuse, bc_program, result, stream);
+}
+
+int pdehip_jit_euler_adaptive_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
+                                  int ncomp, void *y, void *ynew, void *const *work3_host, double *err_dev, pdehip_adaptive_t *ctl,
+                                  int stage_fuse, void *bc_program, void **result, void *stream)
+{
+    if (!ctl) return failf(E_VALUE, "jit_euler_adaptive_run: NULL pointer");
+    return jit_loop_run(1, g, passes, npasses, fixed, nfixed, ncomp, y, ynew, work3_host, err_dev, 0.0, 0.0, 0, ctl, stage_fuse, bc_program, result, stream);
 }
 
 
@@ -679,10 +734,10 @@ int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_
                      void *stream)
 {
     if (!g_local || !nb6 || !rhs || !y_full || !result) return failf(E_VALUE, "block_run: NULL pointer");
-    if (scheme < 0 || scheme > 2) return failf(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4) or 2 (adaptive RKF45)");
-    if ((scheme == 0 || scheme == 2) && !ynew_full) return failf(E_VALUE, "block_run: the scheme needs a second state array");
-    if (scheme >= 1 && !work_host) return failf(E_VALUE, "block_run: the Runge-Kutta schemes need work arrays");
-    if (scheme == 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) return failf(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
+    if (scheme < 0 || scheme > 3) return failf(E_VALUE, "block_run: scheme 0 (Euler), 1 (RK4), 2 (adaptive RKF45) or 3 (adaptive Euler)");
+    if (scheme != 1 && !ynew_full) return failf(E_VALUE, "block_run: the scheme needs a second state array");
+    if (scheme >= 1 && !work_host) return failf(E_VALUE, "block_run: the scheme needs work arrays");
+    if (scheme >= 2 && (!ctl || !err_dev || !(ctl->tolerance > 0) || !(ctl->dt > 0))) return failf(E_VALUE, "block_run: the adaptive loop needs ctl, err_dev, tolerance > 0, dt > 0");
     Comm *c = static_cast<Comm *>(comm);
     if (!c) c = serial_context();
     block::Geo q;

@@ -68,7 +68,7 @@ def test_random_class_pde_runs_match_the_reference(seed, monkeypatch):
         eq = pde.SwiftHohenbergPDE(rate=0.1, kc2=float(rng.uniform(0.2, 1.0)), delta=float(rng.uniform(0, 1)), bc=_random_bc(rng, grid),
                                    bc_lap=_random_bc(rng, grid))
     solver = ["euler", "runge-kutta"][int(rng.integers(2))]
-    adaptive = bool(seed % 5 == 0) and solver == "runge-kutta"
+    adaptive = (bool(seed % 5 == 0) and solver == "runge-kutta") or (bool(seed % 3 == 1) and solver == "euler")   # RKF45 / the reference's adaptive Euler
     dt = 1e-3 * dx**4
     kw = dict(t_range=12 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
     if adaptive:
@@ -129,7 +129,7 @@ def test_random_runs_with_conditions_that_read_the_field(seed, monkeypatch):
     else:
         eq = pde.CahnHilliardPDE(interface_width=float(rng.uniform(0.5, 1.5)), bc_c=bc_nonlinear(), bc_mu=_random_bc(rng, grid))
     solver = ["euler", "runge-kutta"][int(rng.integers(2))]
-    adaptive = bool(seed % 4 == 0) and solver == "runge-kutta"
+    adaptive = (bool(seed % 4 == 0) and solver == "runge-kutta") or (bool(seed % 3 == 1) and solver == "euler")
     dt = 1e-3 * dx**4
     kw = dict(t_range=6 * dt, dt=dt, solver=solver, tracker=None, ret_info=True)
     if adaptive:

@@ -736,6 +736,6 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("PYPDESLAB ")]
     assert proc.returncode == 0 and lines, proc.stderr[-3000:]
     report = json.loads(lines[-1][len("PYPDESLAB "):])
-    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 15 + FUZZ_CASES
+    assert report["world"] == world and not report["failures"] and len(report["cases"]) == 18 + FUZZ_CASES
     if decomposition == "auto":     # blocks along more than one axis (`decomposition="auto"`, the reference's rule)
         assert sum(sum(d > 1 for d in c["decomposition"]) >= 2 for c in report["cases"].values()) >= 2, report

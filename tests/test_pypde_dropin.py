@@ -716,8 +716,8 @@ def test_nine_point_laplacian_through_pypde(hip1):
         np.testing.assert_array_equal(field2.laplace("auto_periodic_neumann", backend="hip").data, lap9.data)
 
 
-@pytest.mark.parametrize("adaptive", [False, True])
-def test_post_step_hook_runs_on_the_host(hip1, adaptive):
+@pytest.mark.parametrize("solver,adaptive", [("euler", False), ("runge-kutta", True), ("euler", True)])
+def test_post_step_hook_runs_on_the_host(hip1, solver, adaptive):
     """`pde.PDE(..., post_step_hook=...)` (pde/pdes/pde.py:99-118, base.py:160-208): the hook clips the state and counts the
     correction; the run equals the reference's numpy backend incl. `post_step_data`."""
     def hook(state_data, t, post_step_data):
@@ -733,9 +733,9 @@ def test_post_step_hook_runs_on_the_host(hip1, adaptive):
         def make_post_step_hook(self, state, backend="numpy"):
             return hook, 0.0
 
-    # (adaptive runs use Runge-Kutta: the reference's adaptive EULER stepper evaluates the rate of the next step on the state
-    # BEFORE the hook modified it, pde/solvers/euler.py:262-274 — a quirk this backend does not reproduce)
-    kw = {"t_range": 0.5, "dt": 0.01, "solver": "runge-kutta" if adaptive else "euler", "tracker": None, "ret_info": True, "adaptive": adaptive}
+    # (the reference's adaptive EULER stepper evaluates the rate of the next step on the state BEFORE the hook modified it,
+    # pde/solvers/euler.py:262-274 — reproduced since round 4: the carried rate precedes the hook)
+    kw = {"t_range": 0.5, "dt": 0.01, "solver": solver, "tracker": None, "ret_info": True, "adaptive": adaptive}
     r_hip, i_hip = HookedDiffusion(0.7).solve(state, backend="hip", **kw)
     old = pde.config["default_backend"]
     pde.config["default_backend"] = "scipy"

@@ -625,27 +625,54 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
         if (!grid) PDEHIP_FAIL(E_VALUE, "bcprog_create: a face reads the field but no grid is given");
         PDEHIP_TRY(norm_grid(grid, &ng));
     }
-    PDEHIP_TRY(load_rtc());
-    std::string src = "#define PDEHIP_BC_FN __device__ __forceinline__\n";
-    src += source;
-    src += kBcKernel;
-    hiprtcProgram prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src.c_str(), "bc_program.hip", 0, nullptr, nullptr) != 0) PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    if (g_rtc.CompileProgram(prog, 4, opts) != 0) {
-        size_t n = 0;
-        g_rtc.GetProgramLogSize(prog, &n);
-        std::string log(n + 1, '\0');
-        if (n) g_rtc.GetProgramLog(prog, &log[0]);
-        g_rtc.DestroyProgram(&prog);
-        PDEHIP_FAIL(E_VALUE, "boundary-condition program does not compile: %.400s", log.c_str());
+    // One compiled + loaded module per SOURCE STRING for the life of the process: a program is built per face table, per
+    // right-hand side and per loop, mostly from identical sources; modules are never unloaded (see pdehip_bcprog_destroy), so without
+    // the cache every solver leaked a code object and paid the hiprtc compile again.  The per-handle state is the face table only.
+    static std::mutex bc_mu;
+    static std::map<std::string, std::pair<hipModule_t, hipFunction_t>> bc_modules;
+    const std::string key(source);
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(bc_mu);
+        auto it = bc_modules.find(key);
+        if (it != bc_modules.end()) { module = it->second.first; fn = it->second.second; }
     }
-    size_t n = 0;
-    g_rtc.GetCodeSize(prog, &n);
-    std::vector<char> code(n);
-    g_rtc.GetCode(prog, code.data());
-    g_rtc.DestroyProgram(&prog);
+    if (!module) {
+        PDEHIP_TRY(load_rtc());
+        // (no host headers in a hiprtc source: constants arrive as literals, pde_hip/expr.py `c_printer`)
+        std::string src = "#define PDEHIP_BC_FN __device__ __forceinline__\n";
+        src += source;
+        src += kBcKernel;
+        hiprtcProgram prog = nullptr;
+        if (g_rtc.CreateProgram(&prog, src.c_str(), "bc_program.hip", 0, nullptr, nullptr) != 0) PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
+        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+        if (g_rtc.CompileProgram(prog, 4, opts) != 0) {
+            size_t n = 0;
+            g_rtc.GetProgramLogSize(prog, &n);
+            std::string log(n + 1, '\0');
+            if (n) g_rtc.GetProgramLog(prog, &log[0]);
+            g_rtc.DestroyProgram(&prog);
+            PDEHIP_FAIL(E_VALUE, "boundary-condition program does not compile: %.400s", log.c_str());
+        }
+        size_t n = 0;
+        g_rtc.GetCodeSize(prog, &n);
+        std::vector<char> code(n);
+        g_rtc.GetCode(prog, code.data());
+        g_rtc.DestroyProgram(&prog);
+        hipError_t e = hipModuleLoadData(&module, code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&fn, module, "bc_refresh");
+        if (e != hipSuccess) {
+            if (module) (void)hipModuleUnload(module);
+            PDEHIP_FAIL(E_RUNTIME, "bcprog_create: %s", hipGetErrorString(e));
+        }
+        std::lock_guard<std::mutex> lock(bc_mu);
+        auto ins = bc_modules.emplace(key, std::make_pair(module, fn));
+        if (!ins.second) { module = ins.first->second.first; fn = ins.first->second.second; }   // (another thread was first: its module serves)
+    }
     BcProg *b = new BcProg();
+    b->module = module;
+    b->fn = fn;
     std::vector<BcFaceDev> host((size_t)nfaces);
     long start = 0;
     for (int f = 0; f < nfaces; f++) {
@@ -672,14 +699,11 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     b->reads = reads ? 1 : 0;
     b->esz = reads ? (int)elem_size(ng.dtype) : 8;
     b->total = start;
-    hipError_t e = hipModuleLoadData(&b->module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&b->fn, b->module, "bc_refresh");
-    if (e == hipSuccess) e = hipMalloc(&b->faces_dev, sizeof(BcFaceDev) * host.size());
+    hipError_t e = hipMalloc(&b->faces_dev, sizeof(BcFaceDev) * host.size());
     if (e == hipSuccess) e = hipMemcpy(b->faces_dev, host.data(), sizeof(BcFaceDev) * host.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // the program runs on the callers' non-blocking streams (see pdehip_malloc)
     if (e != hipSuccess) {
         if (b->faces_dev) (void)hipFree(b->faces_dev);
-        if (b->module) (void)hipModuleUnload(b->module);
         delete b;
         PDEHIP_FAIL(E_RUNTIME, "bcprog_create: %s", hipGetErrorString(e));
     }
@@ -705,8 +729,8 @@ int pdehip_bcprog_destroy(void *handle)
 {
     BcProg *b = static_cast<BcProg *>(handle);
     if (!b) return 0;
-    // (the module stays loaded: unloading code objects in the middle of a run was the trigger of the lazy-load fault noted in
-    // pdehip_kernels.hip; a program is a few KB)
+    // (the module belongs to the per-source cache of pdehip_bcprog_create and stays loaded: unloading code objects in the middle of a
+    // run was the trigger of the lazy-load fault noted in pdehip_kernels.hip)
     if (b->faces_dev) (void)hipFree(b->faces_dev);
     delete b;
     return 0;

@@ -271,14 +271,14 @@ class RhsSpec:
         """... and some of them are Python functions: refreshed from the host, which keeps the steps out of the C loops."""
         return any(getattr(tb, "host_only", False) for tb in (self.bc_c, self.bc_mu) if tb is not None)
 
-    def update(self, t: float) -> None:
+    def update(self, t: float, stream=None) -> None:
         """Time of the next evaluation: the C entry points refresh the device-evaluated faces themselves (``self.c.t``); faces
-        given as Python functions get their coefficient arrays from the host here."""
+        given as Python functions get their coefficient arrays from the host here (copied on ``stream``, the consumers' stream)."""
         self.c.t = float(t)
         if self.program is None:
             for tb in (self.bc_c, self.bc_mu):
                 if tb is not None and getattr(tb, "time_dependent", False):
-                    tb.update({"t": t})
+                    tb.update({"t": t}, stream=stream)
 
     @property
     def ref(self):
@@ -373,7 +373,7 @@ class SpecRhs:
 
     def apply(self, state, out, wrap: str = "rate", dt: float = 0.0, t: float = 0.0) -> None:
         spec, st = self.spec, self.backend.stream
-        spec.update(t)
+        spec.update(t, st)
         if wrap == "euler":
             res = C.c_void_p()
             self.lib.euler_run(self.info.ref, spec.ref, state.ptr, out.ptr, dt, 1, C.byref(res), st)
@@ -399,7 +399,7 @@ def make_face_setter(backend, bcs, comp_shape: tuple[int, ...] = ()):
     lib = backend._lib
 
     def set_faces(data_full: DeviceArray, args=None) -> None:
-        table.update(args, state=data_full)   # (conditions that are not affine in the adjacent value read it from `data_full`)
+        table.update(args, state=data_full, stream=backend.stream)   # (conditions that are not affine in the adjacent value read it from `data_full`)
         lib.set_ghost_cells(data_full.info.ref, data_full.ncomp, table.c, data_full.ptr, backend.stream)
 
     set_faces.table = table   # type: ignore[attr-defined]
@@ -772,7 +772,7 @@ class HipBackendMixin:
         def pde_rhs(state_data, t: float = 0) -> DeviceArray:
             state_data = to_device(state_data)
             out = state_data.empty_like()
-            spec.update(float(t))
+            spec.update(float(t), self.stream)
             # 1.0 * (D * lap) == D * lap exactly
             lib.rhs_scaled(spec.info.ref, spec.ref, state_data.ptr, out.ptr, 1.0, self.stream)
             return out

@@ -93,6 +93,15 @@ class _AffineFace:
         self._offset = sp.lambdify([value, *args], offset, modules="numpy")
         self._slope = sp.lambdify(args, slope, modules="numpy")
         self._symbolic = (offset, slope, {n: by_name.get(n, sp.Symbol(n)) for n in names[1:]}, value)   # for the device program
+        try:
+            _c_code(offset), _c_code(slope)
+            self._printable = True
+        except NotImplementedError:
+            # no C form (a function the printer does not know): the coefficient arrays come from the host, like those of a Python
+            # function - unless the condition reads the field, which only the device holds
+            if self.reads_value:
+                raise
+            self._printable = False
         self.axis, self.upper, self.grid = int(bc.axis), bool(bc.upper), grid
         self.time_dependent = "t" in by_name or self.reads_value     # i.e. "has to be refreshed"
         self.needs_time = "t" in by_name
@@ -105,6 +114,11 @@ class _AffineFace:
             self.coords = [np.asarray(c, dtype=np.float64) for c in np.moveaxis(coords, -1, 0)]
             index = int(bc._get_value_cell_index(with_ghost_cells=False))
         self._set_window(window, index)
+
+    @property
+    def host_only(self) -> bool:
+        """The coefficient arrays of this face are evaluated on the host (a Python function, or an expression without a C form)."""
+        return self._callable is not None or not getattr(self, "_printable", True)
 
     def _set_window(self, window, index: int) -> None:
         """Cut the face to the box ``window`` (None: the whole grid); ``index``: value cell along the face's axis (whole grid)."""
@@ -160,17 +174,16 @@ class _AffineFace:
 
 
 def _c_code(expr) -> str:
-    from sympy.printing.c import C99CodePrinter
+    """C source of a sympy expression for the device programs.  Constants such as ``pi`` are printed as their 17-digit values (hiprtc
+    sources have no <math.h> macros: ``M_PI`` would not compile); a function the C printer does not know raises
+    ``NotImplementedError`` (its fallback is a comment line inside the statement)."""
+    from .expr import c_printer
 
-    class Printer(C99CodePrinter):
-        def _print_Pow(self, e):   # small integer powers as repeated multiplication, like the right-hand-side epilogues (expr.py)
-            b, ex = e.as_base_exp()
-            if ex.is_Integer and 1 <= abs(int(ex)) <= 8:
-                prod = "*".join([f"({self._print(b)})"] * abs(int(ex)))
-                return f"({prod})" if ex > 0 else f"(1.0/({prod}))"
-            return super()._print_Pow(e)
-
-    return Printer({"precision": 17}).doprint(expr)
+    code = c_printer().doprint(expr)
+    if "Not supported in C" in code:
+        msg = f"hip backend: `{expr}` has no C form"
+        raise NotImplementedError(msg)
+    return code
 
 
 def build_program(lib, entries, info=None) -> Any:
@@ -182,7 +195,7 @@ def build_program(lib, entries, info=None) -> Any:
 
     import sympy as sp
 
-    if not entries or any(face._callable is not None for face, _, _ in entries):
+    if not entries or any(face.host_only for face, _, _ in entries):
         return None
     reads = any(face.reads_value for face, _, _ in entries)
     if reads and info is None:
@@ -293,9 +306,10 @@ class ExprFaceTable:
         arr = np.asarray(getattr(state, "arr", state))
         return np.take(arr, face.index + 1, axis=face.axis)[(slice(1, -1),) * (arr.ndim - 1)]
 
-    def update(self, args=None, state=None) -> None:
+    def update(self, args=None, state=None, stream=None) -> None:
         """Re-evaluate the coefficient arrays of the faces that depend on time / on the field ``state`` - the full array the
-        conditions are about to be applied to - for ``args["t"]`` (no-op when there are none)."""
+        conditions are about to be applied to - for ``args["t"]`` (no-op when there are none).  ``stream``: the stream of the
+        kernels that consume the arrays (the device program is enqueued there; host-evaluated arrays are copied on it)."""
         if not self._dynamic:
             return
         if args is None or "t" not in args:
@@ -317,7 +331,7 @@ class ExprFaceTable:
         if self._program is None:
             # faces given as expressions are refreshed on the device (one launch); Python functions and the host-side tables of
             # the test harness (numpy buffers) are evaluated here
-            device = all(face._callable is None and getattr(buf, "arr", None) is None for face, buf, _ in self._dynamic)
+            device = all(not face.host_only and getattr(buf, "arr", None) is None for face, buf, _ in self._dynamic)
             self._program = False
             if device:
                 from ._lib import require_device
@@ -326,29 +340,29 @@ class ExprFaceTable:
                 if prog.handle is not None:
                     self._program = prog
         if self._program is not False:
-            self._program.run(t, state=state if reads else None)
+            self._program.run(t, stream=stream, state=state if reads else None)
             self._t = t
             return
         for face, buf_a, buf_b in self._dynamic:
             a, b = face.evaluate(t, self._host_values(face, state) if face.reads_value else None)
-            self._write(buf_a, a)
-            self._write(buf_b, b)
+            self._write(buf_a, a, stream)
+            self._write(buf_b, b, stream)
         self._t = t
 
     @property
     def host_only(self) -> bool:
         """Some time-dependent face is a Python function: coefficient arrays come from the host before every evaluation."""
-        return any(face._callable is not None for face, _, _ in self._dynamic)
+        return any(face.host_only for face, _, _ in self._dynamic)
 
 
-def _write_buffer(buf, arr: np.ndarray) -> None:
+def _write_buffer(buf, arr: np.ndarray, stream=None) -> None:
     host = getattr(buf, "arr", None)
     if host is not None:                      # host-side tables of the test harness
         host[...] = arr.reshape(host.shape)
     else:
         from ._lib import require_device
 
-        require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, None)
+        require_device().memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, stream)   # (synchronous for pageable memory: `arr` may go)
 
 
 def expression_faces(bcs, skip=None) -> dict[tuple[int, bool], Any]:

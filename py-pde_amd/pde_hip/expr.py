@@ -32,6 +32,29 @@ P_DT, P_T = 0, 1  # slots of the run-time parameter vector
 P_FIRST_REDUCTION, MAX_REDUCTIONS = 2, 8   # p[2..9]: integrals over the grid (reduction passes)
 
 
+
+def c_printer():
+    """The C printer of the generated device code (right-hand-side epilogues here, boundary programs in bc_expr.py): small integer powers
+    as repeated multiplication (numba does the same), constants such as ``pi`` / ``E`` as 17-digit literals - the run-time compiled
+    sources include no <math.h>, so ``M_PI`` would not compile; numpy, which the reference evaluates with, uses the same
+    double values."""
+    from sympy.printing.c import C99CodePrinter
+
+    class Printer(C99CodePrinter):
+        def _print_Pow(self, e):
+            b, ex = e.as_base_exp()
+            if ex.is_Integer and 1 <= abs(int(ex)) <= 8:
+                prod = "*".join([f"({self._print(b)})"] * abs(int(ex)))
+                return f"({prod})" if ex > 0 else f"(1.0/({prod}))"
+            return super()._print_Pow(e)
+
+        def _print_NumberSymbol(self, e):
+            return repr(float(e.evalf(17)))
+
+        _print_Pi = _print_Exp1 = _print_EulerGamma = _print_GoldenRatio = _print_Catalan = _print_TribonacciConstant = _print_NumberSymbol
+
+    return Printer({"precision": 17})
+
 class _Pass:
     """One kernel launch: stencil array `src`, centre-only arrays `extras`, result array `out`."""
 
@@ -414,16 +437,6 @@ class ExpressionPlan:
         ``wrap`` in {"rate", "scaled", "euler"} selects what the LAST pass returns: F, dt*F, state + dt*F.
         """
         sp = _sympy()
-        from sympy.printing.c import C99CodePrinter
-
-        class Printer(C99CodePrinter):
-            def _print_Pow(self, e):  # small integer powers as repeated multiplication (numba does the same)
-                b, ex = e.as_base_exp()
-                if ex.is_Integer and 1 <= abs(int(ex)) <= 8:
-                    prod = "*".join([f"({self._print(b)})"] * abs(int(ex)))
-                    return f"({prod})" if ex > 0 else f"(1.0/({prod}))"
-                return super()._print_Pow(e)
-
         c, lap, gsq = sp.symbols("c lap gsq", real=True)
         e_syms = sp.symbols("e0 e1 e2", real=True)
         sub: dict[Any, Any] = {}
@@ -442,7 +455,10 @@ class ExpressionPlan:
             sub2[self._arrays[name]] = e_syms[i]
         expr = p.expr.subs(sub2, simultaneous=True)
         extras = list(p.extras)
-        code = Printer({"precision": 17}).doprint(expr)
+        code = c_printer().doprint(expr)
+        if "Not supported in C" in code:
+            msg = f"hip backend: `{expr}` has no C form"
+            raise NotImplementedError(msg)
         lines = [f"const double t = p[{P_T}]; (void)t;", f"const double F = {code};"]
         if p.out != "out" or wrap == "rate":
             lines.append("return F;")
@@ -561,7 +577,7 @@ class ExpressionRhs:
     def _update_faces(self, t: float, state=None) -> None:
         """Coefficient arrays of faces that depend on the time or on the field ``state`` (expression BCs, ``pde_hip/bc_expr.py``)."""
         for tb in self._dynamic:
-            tb.update({"t": t}, state=state)
+            tb.update({"t": t}, state=state, stream=self.backend.stream)
 
     def _faces(self, index: int):
         t = self.pass_faces[index]
@@ -571,7 +587,7 @@ class ExpressionRhs:
         """Conditions that read the field, applied to an intermediate field: rewritten from the input of THIS pass."""
         tb = self.pass_faces[index]
         if self._reads_intermediate and tb is not None and getattr(tb, "reads_value", False):
-            tb.update({"t": t}, state=src)     # (also for passes on the state itself: an earlier pass may have rewritten a shared table)
+            tb.update({"t": t}, state=src, stream=self.backend.stream)     # (also for passes on the state itself: an earlier pass may have rewritten a shared table)
 
     def _kernel(self, index: int, wrap: str):
         key = (index, wrap if self.plan.passes[index].out == "out" else "rate")

@@ -532,3 +532,20 @@ def test_finite_check_on_the_device(rng):
                                        tracker=lambda s, t: seen.append(is_finite(s)), interval=0.2, backend="hip")
     link = res.__dict__["_hip_link"]
     assert all(seen) and len(seen) >= 5 and link.downloads == 0
+
+
+def test_constants_reach_the_runtime_compiler_as_literals(rng):
+    """`sin(2*pi*t)` in a condition or in the equation used to be printed as `sin(2*M_PI*t)`; hiprtc sources include no
+    <math.h>.  Written with `pi` and with the literal 3.141592653589793 the runs are the same, bit for bit."""
+    grid = pde_hip.UnitGrid([10, 12, 64], periodic=[False, True, True])
+    y0 = rng.uniform(0, 1, grid.shape)
+    runs = []
+    for const in ("pi", "3.141592653589793"):
+        eq = pde_hip.DiffusionPDE(0.4, bc={"x-": {"value_expression": f"0.3*sin(2*{const}*t) + E*0"}, "x+": {"derivative": 0.1}, "y": "periodic", "z": "periodic"})
+        a = eq.solve(pde_hip.ScalarField(grid, y0), t_range=0.2, dt=0.01, solver="runge-kutta", backend="hip")
+        eq2 = pde_hip.PDE({"c": f"0.4*laplace(c) + 0.1*cos({const}*t)"}, bc={"x": {"derivative": 0.1}, "y": "periodic", "z": "periodic"})
+        b = eq2.solve(pde_hip.ScalarField(grid, y0), t_range=0.2, dt=0.01, solver="euler", backend="hip")
+        runs.append((np.array(a.data), np.array(b.data)))
+    assert np.isfinite(runs[0][0]).all() and np.abs(runs[0][0] - y0).max() > 1e-3
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])

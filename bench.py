@@ -45,7 +45,7 @@ def parse_args():
                     help="run the slab/RCCL path even on one rank (periodic halo sent to self) - overhead probe")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the operator roofline, the cfg2/cfg3/cfg5 timings and the parity bit")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=9,
                     help="the timed region (EXACTLY --steps steps between two synchronisations) is run this many times; value / ms_per_step "
                          "are the MEDIAN, the line carries every repetition and the minimum (SURVEY.md 8d: min / median of >= 5)")
     return ap.parse_args()

@@ -718,7 +718,7 @@ def _check_distributed_bench_line(out, world, size, env):
     import json
     import subprocess
 
-    assert out["repeats"]["n"] == 5 and len(out["repeats"]["samples"]) == 5 and out["repeats"]["min"] <= out["repeats"]["median"]
+    assert out["repeats"]["n"] == 9 and len(out["repeats"]["samples"]) == 9 and out["repeats"]["min"] <= out["repeats"]["median"]
     assert out["ms_per_step"] == pytest.approx(out["repeats"]["median"], rel=1e-3) and out["value_best"] >= out["value"]
     assert [r["rank"] for r in out["per_rank"]] == list(range(world))
     assert all({"ms_per_step", "compute_only_ms_per_step", "exchange_exposed_ms_per_step", "layers"} <= set(r) for r in out["per_rank"])

@@ -681,7 +681,7 @@ static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, In
 }
 
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain, bool dry_run, int ends)
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain, bool dry_run, int ends, unsigned long long *const *sig3)
 {
     *done = false;
     NGrid n;
@@ -690,7 +690,7 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     if (n.ndim < 2) return 0;
     InputBCs fg;
     if (!faces_to_input_bcs(n, faces, &fg, xplain ? 1 : 0, xplain)) return 0;
-    return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
+    return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends, E2_DIFFUSION, nullptr, 0.0, nullptr, nullptr, sig3);
 }
 
 int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,

@@ -300,6 +300,10 @@ int pdehip_ab2_combine(const pdehip_grid_t *g, int ncomp, void *y_full, const vo
 int pdehip_rkf45_combine(const pdehip_grid_t *g, int ncomp, const void *y, void *ynew,
                          const void *const *k6_host, double *err_dev, void *stream);
 /* max |a - b| over the interior -> *out_dev (generic error estimate pde/solvers/base.py:416) */
+/* *out_dev = max |z| over complex data held as pairs of real components of the full array (component 2p = real part, 2p + 1 =
+ * imaginary part): the error norm `np.abs(error).max()` of the adaptive schemes when the state is complex
+ * (pde/solvers/runge_kutta.py:147-148, pde/solvers/euler.py:253; complex states: pde/solvers/controller.py:430-432).  NaN wins. */
+int pdehip_max_abs_pairs(const pdehip_grid_t *g, int npairs, const void *arr_full, double *out_dev, void *stream);
 /* End of an adaptive Euler attempt, pde/backends/numba/_solvers.py:381-394 (numpy twin pde/solvers/euler.py:238-256):
  *   out = half + k                       `step_small += 0.5 * dt * rate_midpoint`   (k = that product, half = state + dt/2 * rate)
  *   *err_dev = max |(y + dt * rate) - out|      `np.abs(step_large - step_small).max()`, step_large is never stored

@@ -227,6 +227,13 @@ def euler_adaptive_combine(g, ncomp, y_full, rate_full, dt, half_full, k_full):
     return out, err.value
 
 
+def max_abs_pairs(g, npairs, arr_full):
+    """max |z| of complex data held as pairs of real components (2p: real part, 2p + 1: imaginary part)."""
+    out = C.c_double(0)
+    _check(lib().oracle_max_abs_pairs(C.byref(g), npairs, _p(arr_full), C.byref(out)), "max_abs_pairs")
+    return out.value
+
+
 def max_abs_diff(g, ncomp, a_full, b_full):
     err = C.c_double(0)
     _check(lib().oracle_max_abs_diff(C.byref(g), ncomp, _p(a_full), _p(b_full), C.addressof(err)), "max_abs_diff")

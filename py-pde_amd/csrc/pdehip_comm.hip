@@ -77,11 +77,6 @@ struct Comm {
     // block decomposition: contiguous staging buffers of the packed faces, [axis][side][0 send / 1 receive]
     void *stg[3][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
     size_t stg_bytes[3] = {0, 0, 0};
-    // merged slab sweep (slab::euler2_run): the boundary waves of a sweep count themselves in *sig (signal memory); the halo stream waits
-    // for `sig_target` with hipStreamWaitValue64 before it starts the exchange.  sig_ok: -1 not probed, 0 unavailable, 1 available
-    unsigned long long *sig = nullptr, *cnt = nullptr;   // signal memory (host-coherent) / device memory
-    unsigned long long sig_target = 0;
-    int sig_ok = -1;
 };
 
 // serial use of the slab loops (comm == NULL, no neighbours): streams / events of a process-wide context without RCCL
@@ -188,50 +183,7 @@ struct HipOps {
     int euler2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *st, bool *done,
                int xplain, bool dry, int ends)
     {
-        if (ends >= 0) return euler2_with_input_bcs(gs, in, out, D, dt, faces, st, done, xplain, dry, ends);
-        // merged sweep: the launch that follows brings the device counter to sig_target + (its boundary waves); the dry run plans them
-        unsigned long long *sig3[3] = {dry ? (unsigned long long *)8 : c->sig, dry ? (unsigned long long *)8 : c->cnt,
-                                       (unsigned long long *)(uintptr_t)(c->sig_target + (unsigned long long)euler2_merged_waves())};
-        return euler2_with_input_bcs(gs, in, out, D, dt, faces, st, done, xplain, dry, ends, sig3);
-    }
-    // --- merged slab sweep: the boundary layers come out of the launch that sweeps the interior, the exchange is released from inside it ---
-    // available: signal memory + hipStreamWaitValue64 on this device (PDEHIP_SLAB_MERGED=0 switches the path off: A/B aid)
-    bool merged_available()
-    {
-        if (c->sig_ok < 0) {
-            c->sig_ok = 0;
-            static const bool off = getenv("PDEHIP_SLAB_MERGED") && atoi(getenv("PDEHIP_SLAB_MERGED")) == 0;
-            int dev = 0, can = 0;
-            if (!off && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) == hipSuccess && can) {
-                void *p = nullptr;
-                void *d = nullptr;
-                if (hipExtMallocWithFlags(&p, sizeof(unsigned long long), hipMallocSignalMemory) == hipSuccess && hipMalloc(&d, sizeof(unsigned long long)) == hipSuccess) {
-                    c->sig = static_cast<unsigned long long *>(p);
-                    c->cnt = static_cast<unsigned long long *>(d);
-                    c->sig_ok = 1;
-                } else {
-                    (void)hipGetLastError();
-                }
-            }
-        }
-        return c->sig_ok == 1;
-    }
-    long merged_boundary_waves(const pdehip_grid_t *) { return euler2_merged_waves(); }   // (of the dry run just made)
-    int signal_skip(long waves) { c->sig_target += (unsigned long long)waves; return 0; }
-    // start of a run: the counter back to zero, ordered on `st` before the first sweep (the halo stream is ordered behind `st` by the caller)
-    int signal_reset(void *st)
-    {
-        c->sig_target = 0;
-        PDEHIP_HIP(hipMemsetAsync(c->cnt, 0, sizeof(unsigned long long), as_stream(st)));
-        PDEHIP_HIP(hipStreamWriteValue64(as_stream(st), c->sig, 0, 0));
-        return 0;
-    }
-    // `waves` more boundary waves will count themselves: `st` continues when all of them (and all earlier ones) have
-    int signal_wait(void *st, long waves)
-    {
-        c->sig_target += (unsigned long long)waves;
-        PDEHIP_HIP(hipStreamWaitValue64(as_stream(st), c->sig, c->sig_target, hipStreamWaitValueGte, ~0ull));
-        return 0;
+        return euler2_with_input_bcs(gs, in, out, D, dt, faces, st, done, xplain, dry, ends);
     }
     int ch_fused(const pdehip_grid_t *gs, const void *in, void *out, double gamma, double dt, bool euler, const pdehip_bc_face_t *fc,
                  const pdehip_bc_face_t *fm, void *st, bool *done, int xplain, bool dry, const StageFuse *sf)

@@ -127,9 +127,7 @@ struct Euler2Plan {
 };
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, int xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
-                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr,
-                  unsigned long long *const *sig3 = nullptr);   // ends < 0: merged slab sweep; {signal cell, device counter, (goal as a
-                                                                // value)}: LapArgs::sig / cnt / mrg_goal
+                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr);
 // K Euler steps of a 2-D grid per launch, time levels in LDS (pdehip_tile2d.inc): diffusion (rhs->kind 0) or Cahn-Hilliard
 int tile2d_max_steps(int mode);
 int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
@@ -140,10 +138,8 @@ int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *
                    bool *done);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
-long euler2_merged_waves();   // boundary waves of the merged slab sweep planned last on this thread (launch_euler2 with ends < 0)
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain = 0, bool dry_run = false, int ends = 0,
-                          unsigned long long *const *sig3 = nullptr);
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain = 0, bool dry_run = false, int ends = 0);
 // one Cahn-Hilliard sweep: mu = c^3 - c - gamma*lap(c) with the faces of c, then (euler) out = c + dt*lap(mu) or
 // (!euler) out = dt*lap(mu) with the faces of mu — mu never leaves the registers; *done as above
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,

@@ -136,17 +136,6 @@ struct LapArgs {
     // d2 = (r - 2c + l) * dd2 with dd2 = 1 / dx^2 (:150-190).  (At the end: the kernarg offsets of everything else stay.)
     double dd1[3], dd2[3];
     double dg[3];   // LAP_CUSTOM: 0.5 / dx, the scale of the components of `gradient` / `divergence` (cartesian.py:451-454, :876-879)
-    // euler2_kernel, MERGED slab sweep (mrg_e > 0): ONE launch sweeps the whole slab; x-chunk 0 = the first mrg_e planes, x-chunk 1 = the
-    // last mrg_e planes - the layers the neighbours are waiting for -, x-chunks 2.. = the planes between them in pieces of `lx`.  The
-    // mrg_nb workgroups of the two boundary chunks have the lowest block indices (dispatched first, spread over all XCDs); every wave of
-    // them adds 1 to the DEVICE counter *cnt behind its stores, and the wave that brings it to mrg_goal writes mrg_goal into the SIGNAL
-    // cell *sig: the halo stream waits for that value (hipStreamWaitValue64) and starts the exchange while the same launch is still
-    // sweeping the interior (csrc/pdehip_slab_loops.h `euler2_run`).  (Signal memory is host-coherent: 1024 waves counting in it
-    // directly serialised over PCIe - 1.05 ms per sweep instead of 0.055, profiles/r04_probe_slab.md.)
-    int mrg_e;
-    long mrg_nb;
-    unsigned long long *sig, *cnt;
-    unsigned long long mrg_goal;
 };
 
 // per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)

@@ -407,10 +407,6 @@ static const TuneF32 &tune_f32()
     return t;
 }
 
-// boundary waves of the merged slab sweep planned last on this thread (dry runs included): what the halo stream has to wait for
-static thread_local long g_merged_waves = 0;
-long euler2_merged_waves() { return g_merged_waves; }
-
 template <typename T, int VEC>
 static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
                             Euler2Plan *plan, int ry_f32)
@@ -458,23 +454,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     a.nty = (a.n1 + ry - 1) / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
-    if (ends < 0) {
-        // MERGED slab sweep (LapArgs::mrg_e): the first and the last -ends planes as x-chunks 0 and 1 of the launch that also sweeps the
-        // planes between them; their workgroups are dispatched first and signal the halo stream when they are stored.  Interior
-        // chunks: what fills the chip together with the boundary chunks (PDEHIP_MERGED_WAVES overrides the 2048 wave slots)
-        const long e = -ends, ni = a.n0 - 2 * e;
-        if (!has_y || xplain != 1 || ni < 0 || plan || m2 != E2_DIFFUSION) return 0;
-        static const long cap_env = getenv("PDEHIP_MERGED_WAVES") ? atol(getenv("PDEHIP_MERGED_WAVES")) : 0;
-        const long cap = cap_env > 0 ? cap_env : 2048;
-        long nxi = ni > 0 ? (cap - 2 * tiles) / tiles : 0;
-        if (ni > 0 && nxi < 1) nxi = 1;
-        if (nxi > ni / 4 && ni >= 4) nxi = ni / 4;     // (chunks of at least 4 planes: every chunk recomputes two)
-        if (ni > 0 && nxi < 1) nxi = 1;
-        const long lx = ni > 0 ? (ni + nxi - 1) / nxi : 1;
-        a.lx = (int)lx; a.xstride = lx;
-        a.nxc = 2 + (ni > 0 ? (ni + lx - 1) / lx : 0);
-        a.mrg_e = (int)e;
-    } else if (ends > 0) {
+    if (ends > 0) {
         // boundary sweep of a slab: the first and the last `ends` planes in ONE launch
         a.lx = ends; a.nxc = 2; a.xstride = a.n0 - ends;
     } else if (!has_y) {
@@ -544,11 +524,6 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     a.nwy = nwy;
     a.nblocks = a.nxc * tiles / (nwz * nwy);
     a.no_swizzle = 0;
-    if (a.mrg_e > 0) {
-        if (!a.sig || !a.cnt) PDEHIP_FAIL(E_RUNTIME, "internal: merged slab sweep without a signal cell");
-        a.mrg_nb = 2 * tiles / (nwz * nwy);   // workgroups of the two boundary chunks
-        g_merged_waves = 2 * tiles;           // ... every wave of them counts itself in *sig
-    }
     const dim3 grid((unsigned)a.nblocks), block(64 * nwz * nwy);
     // real halo planes instead of BCs on the slowest axis: both sides (1), upper side only (2), lower side only (3)
     if (xplain) a.per[0] = xplain == 1 ? 2 : (xplain == 2 ? 3 : 4);
@@ -761,7 +736,7 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
                   int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
-                  Euler2Plan *plan, const StageFuse *stage, unsigned long long *const *sig3)
+                  Euler2Plan *plan, const StageFuse *stage)
 {
     *done = false;
     if ((m2 == E2_CH_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage sweep without / with a stage descriptor");
@@ -776,7 +751,6 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[am] % vec || n.p[1] % vec) return 0;
     LapArgs a;
     memset(&a, 0, sizeof(a));
-    if (sig3) { a.sig = sig3[0]; a.cnt = sig3[1]; a.mrg_goal = (unsigned long long)(uintptr_t)sig3[2]; }
     for (int k = 0; k < 3; k++) {   // k = kernel axis
         if (k == 0 && xplain == 1) continue;
         if (k == 0 && xplain > 1) {

@@ -603,6 +603,21 @@ __global__ void __launch_bounds__(256) max_abs_diff_kernel(DiffArgs a)
     block_max_to(emax, a.err);
 }
 
+// max |z| over the cells of complex data held as pairs of real components (2p = real part, 2p + 1 = imaginary part): the error norm
+// `np.abs(err).max()` of the adaptive schemes for complex states (pde/solvers/runge_kutta.py:147-148, pde/solvers/euler.py:253);
+// hypot like numpy's absolute value of a complex number
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) max_abs_pairs_kernel(DiffArgs a)
+{
+    double emax = 0;
+    for_each_chunk<1>(a.g, a.ncomp, [&](int comp, long, long, long, long e) {
+        const T *p = (const T *)a.a + e + (long)comp * a.g.pc;   // (e already carries comp * pc: component 2 * comp)
+        const double re = (double)p[0], im = (double)p[a.g.pc];
+        emax = max_nan(emax, abs_nan_canon(hypot(re, im)));   // (hypot: inf wins over nan, like numpy's |z|)
+    });
+    block_max_to(emax, a.err);
+}
+
 template <typename T> static constexpr int vec_of() { return 16 / sizeof(T); }
 
 #define PDEHIP_VEC_LAUNCH(KERNEL, ARGS, ITEMS)                                                         \
@@ -681,7 +696,7 @@ static bool faces_to_input_bcs(const NGrid &n, const pdehip_bc_face_t *faces, In
 }
 
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
-                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain, bool dry_run, int ends, unsigned long long *const *sig3)
+                          const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain, bool dry_run, int ends)
 {
     *done = false;
     NGrid n;
@@ -690,7 +705,7 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     if (n.ndim < 2) return 0;
     InputBCs fg;
     if (!faces_to_input_bcs(n, faces, &fg, xplain ? 1 : 0, xplain)) return 0;
-    return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends, E2_DIFFUSION, nullptr, 0.0, nullptr, nullptr, sig3);
+    return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
 
 int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,
@@ -987,6 +1002,22 @@ int pdehip_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void 
     a.g = dev_grid(n); a.ncomp = ncomp; a.y = y_full; a.rate = rate_full; a.half = half_full; a.k = k_full; a.out = out_full; a.dt = dt; a.err = err_dev;
     const long items = (long)ncomp * n.n[0] * n.n[1] * n.n[2];
     PDEHIP_VEC_LAUNCH(euler_adaptive_combine_kernel, a, items);
+    return 0;
+}
+
+int pdehip_max_abs_pairs(const pdehip_grid_t *g, int npairs, const void *arr_full, double *out_dev, void *stream)
+{
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    if (!arr_full || !out_dev || npairs < 1) PDEHIP_FAIL(E_VALUE, "max_abs_pairs: NULL pointer or no pairs");
+    PDEHIP_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), as_stream(stream)));
+    DiffArgs a;
+    a.g = dev_grid(n); a.ncomp = npairs; a.a = arr_full; a.b = nullptr; a.err = out_dev;
+    const long items = (long)npairs * n.n[0] * n.n[1] * n.n[2];
+    hipStream_t st = as_stream(stream);
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((max_abs_pairs_kernel<double, 1>), dim3(grid_blocks(items)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((max_abs_pairs_kernel<float, 1>), dim3(grid_blocks(items)), dim3(256), 0, st, a);
+    PDEHIP_HIP(hipGetLastError());
     return 0;
 }
 

@@ -216,57 +216,11 @@ int euler2_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_
         if (!done) return ops.fail("internal: two-step kernel refused a sub-slab");
         return 0;
     };
-    int64_t s = 0;
-    int pair = 0;
-    // MERGED sweeps (a slab between two neighbours, HIP: signal memory + hipStreamWaitValue64): ONE launch per pair sweeps the whole slab, its
-    // first workgroups produce the layers the neighbours wait for and count themselves in a signal cell; the halo stream waits for that
-    // count and runs the exchange while the same launch sweeps the interior.  Against the two launches below this removes the second
-    // set of waves - boundary sweep (1024 waves) + interior sweep (1536) exceeded the chip's 2048 wave slots, the boundary sweep took 41
-    // us next to the interior sweep and 16 us alone (profiles/r03_probe_slab.md) -, one launch and two event hand-overs per pair.
-    //   comp stream : [wait exchange(p-1)] sweep(p): boundary chunks first, then the interior .................. | sweep(p+1)
-    //   halo stream :      wait for the count of sweep(p)'s boundary waves - exchange(p) of the new boundary layers
-    if (xe == 1 && q.nloc >= 4 && ops.merged_available()) {
-        bool probe = false;
-        pdehip_grid_t gs = *g;
-        gs.shape[0] = q.nloc;
-        long waves = 0;
-        SLAB_TRY(ops.euler2(&gs, layer(cur, q, 1), layer(nxt, q, 1), rhs->param, dt, faces, comp, &probe, 1, true, -2));
-        if (probe && (waves = ops.merged_boundary_waves(&gs)) > 0) {
-            SLAB_TRY(ops.signal_reset(comp));
-            SLAB_TRY(ops.record(EV_COMP, comp));
-            SLAB_TRY(ops.wait(halo, EV_COMP));
-            SLAB_TRY(exchange2(ops, q, cur, lower, upper, halo));
-            SLAB_TRY(ops.record(EV_HALO, halo));
-            for (; s + 2 <= nsteps; s += 2, pair++) {
-                bool done = false;
-                SLAB_TRY(ops.wait(comp, EV_HALO));   // the halo layers of `cur` are in place (and the last exchange has read what this sweep overwrites)
-                SLAB_TRY(ops.euler2(&gs, layer(cur, q, 1), layer(nxt, q, 1), rhs->param, dt, faces, comp, &done, 1, false, -2));
-                if (!done) return ops.fail("internal: merged two-step sweep refused a slab it accepted in the dry run");
-                if (s + 2 < nsteps) {
-                    SLAB_TRY(ops.signal_wait(halo, waves));
-                    SLAB_TRY(exchange2(ops, q, nxt, lower, upper, halo));
-                } else {
-                    SLAB_TRY(ops.signal_skip(waves));   // the last sweep's boundary waves count as well: keep the target in step
-                }
-                SLAB_TRY(ops.record(EV_HALO, halo));
-                char *t = cur; cur = nxt; nxt = t;
-            }
-            SLAB_TRY(ops.record(EV_COMP, comp));
-            SLAB_TRY(ops.wait(halo, EV_COMP));
-            SLAB_TRY(ops.record(EV_HALO, halo));
-            SLAB_TRY(ops.wait(comp, EV_HALO));
-            if (s < nsteps) {
-                SLAB_TRY(ops.lap(g, layer(cur, q, 1), layer(cur, q, 1), layer(nxt, q, 1), K_EULER, rhs->param, dt, 0.0, faces, comp, nullptr));
-                char *t = cur; cur = nxt; nxt = t;
-            }
-            SLAB_TRY(ops.copy(layer(buf_a, q, 1), layer(cur, q, 2), (size_t)q.nloc * q.lp, comp));
-            *result = buf_a;
-            return 0;
-        }
-    }
     SLAB_TRY(ops.record(EV_COMP, comp));
     SLAB_TRY(ops.wait(halo, EV_COMP));
     SLAB_TRY(exchange2(ops, q, cur, lower, upper, halo));
+    int64_t s = 0;
+    int pair = 0;
     for (; s + 2 <= nsteps; s += 2, pair++) {
         // The boundary sweep and the exchange are ENQUEUED FIRST, on the (high-priority) halo stream: their few workgroups are
         // dispatched before the interior sweep fills the chip with workgroups that live for the whole sweep - enqueued behind it

@@ -171,6 +171,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "ab2_combine": ([_pg, _i, _vp, _vp, _vp, _d], True),
     "euler_adaptive_combine": ([_pg, _i, _vp, _vp, _d, _vp, _vp, _vp, _vp], True),
     "max_abs_diff": ([_pg, _i, _vp, _vp, _vp], True),
+    "max_abs_pairs": ([_pg, _i, _vp, _vp], True),
     "integrate": ([_pg, _i, _vp, _d, _vp], True),
     "count_nonfinite": ([_pg, _i, _vp, _vp], True),
     "add_gaussian_noise": ([_pg, _i, _vp, _d, C.c_uint64, C.c_uint64, C.c_uint64], True),

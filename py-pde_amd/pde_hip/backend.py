@@ -34,6 +34,10 @@ from .device import DeviceArray, DeviceBuffer, DeviceScalar, GridInfo, ptr_array
 _logger = logging.getLogger("pde_hip.backend")
 
 
+# operators that are not linear in their argument: real and imaginary part of a complex field cannot go through them separately
+_NONLINEAR_OPERATORS = frozenset({"gradient_squared"})
+
+
 class OperatorInfo(NamedTuple):
     """Stores information about an operator (same fields as ``pde.grids.base.OperatorInfo``)."""
 
@@ -70,14 +74,25 @@ def _upload_f64(arr: np.ndarray) -> DeviceBuffer:
     return buf
 
 
+def real_dtype_of(dtype) -> np.dtype:
+    """The real type that carries ``dtype`` on the device (complex data: planar real and imaginary part, pde_hip/complex_expr.py)."""
+    dt = np.dtype(dtype if dtype is not None else np.float64)
+    if dt.kind == "c":
+        return np.dtype(np.float64 if dt == np.complex128 else np.float32)
+    return dt
+
+
 def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, bool]] | None = None, upload=None,
-                component: int | tuple[int, ...] | None = None) -> FaceTable:
+                component: int | tuple[int, ...] | None = None, part: str | None = None) -> FaceTable:
     """Reduce a ``BoundariesList`` (mirror or real py-pde) to the C face table.
 
     ``skip`` lists (axis, upper) faces that are filled by a halo exchange instead.  ``upload``
     turns an fp64 host array into an object with a ``.ptr`` (default: copy to the device).
     ``component``: the table of ONE component of a vector field's conditions (``comp_shape == (dim,)``) as a table for a
     scalar array - the terms of ``divergence`` inside expression PDEs are evaluated component by component.
+    ``part``: "re" / "im" - the table for the real / imaginary part of a COMPLEX field: the virtual point ``const + factor * value``
+    splits into the parts as long as the factors are real (value, derivative and curvature conditions with complex values; a mixed
+    condition with a complex coefficient would couple the parts and is refused).
     """
     if upload is None:
         upload = _upload_f64
@@ -113,6 +128,15 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
                 msg = "hip backend: `normal_*` conditions of a vector inside an expression are not supported"
                 raise NotImplementedError(msg)
             face.flags = _abi.BCF_NORMAL if normal else 0
+            if part is not None or any(np.iscomplexobj(v) for v in (const, f1, f2)):
+                if part is None:
+                    msg = "hip backend: complex-valued boundary conditions need a complex field"
+                    raise NotImplementedError(msg)
+                if np.any(np.imag(f1) != 0) or np.any(np.imag(f2) != 0):
+                    msg = "hip backend: boundary conditions with complex coefficients of the field value couple real and imaginary part"
+                    raise NotImplementedError(msg)
+                const = np.real(const) if part == "re" else np.imag(const)
+                f1, f2 = np.real(f1), np.real(f2)
             const, f1, f2 = np.asarray(const, dtype=np.float64), np.asarray(f1, dtype=np.float64), np.asarray(f2, dtype=np.float64)
             if const.ndim == 0 and f1.ndim == 0 and f2.ndim == 0:
                 face.const_v, face.factor1, face.factor2 = float(const), float(f1), float(f2)
@@ -657,6 +681,22 @@ class HipBackendMixin:
             msg = "hip backend: operator does not know its grid"
             raise TypeError(msg)
         nd = len(grid.shape)
+        if any(np.iscomplexobj(v) for v in values):
+            # complex fields: the stencils have real coefficients - real and imaginary part separately (ghost cells are set already)
+            if getattr(func, "__name__", "") in _NONLINEAR_OPERATORS:
+                msg = f"hip backend: operator `{func.__name__}` on complex fields is not supported"
+                raise NotImplementedError(msg)
+            parts = []
+            for take in (np.real, np.imag):
+                natives = []
+                for v in values:
+                    info = self.grid_info(grid, real_dtype_of(v.dtype))
+                    natives.append(DeviceArray(info, v.shape[: v.ndim - nd]).set_hostfull(np.ascontiguousarray(take(v)), self.stream))
+                res = DeviceArray(natives[0].info, out.shape[: out.ndim - nd])
+                func(*natives, res, **kwargs)
+                parts.append(res.get_valid(stream=self.stream))
+            out[...] = parts[0] + 1j * parts[1]
+            return
         natives = []
         for v in values:
             info = self.grid_info(grid, v.dtype)
@@ -675,10 +715,12 @@ class HipBackendMixin:
         """
         info = self.get_operator_info(grid, operator)
         op_no_bc = info.factory(grid, backend=self, **kwargs)
-        set_ghosts = self.make_ghost_cell_setter(bcs)
         nd = len(grid.shape)
         shape_in = (grid.dim,) * info.rank_in + tuple(grid.shape)
         shape_out = (grid.dim,) * info.rank_out + tuple(grid.shape)
+        if dtype is not None and np.dtype(dtype).kind == "c":
+            return self._make_complex_operator(grid, operator, info, op_no_bc, bcs, dtype, shape_in, shape_out)
+        set_ghosts = self.make_ghost_cell_setter(bcs)
 
         def apply_op(arr, out=None, args=None):
             host = not isinstance(arr, DeviceArray)
@@ -698,6 +740,51 @@ class HipBackendMixin:
             if host:
                 return res.get_valid(out=out, stream=self.stream)
             return res
+
+        apply_op.grid = grid  # type: ignore[attr-defined]
+        return apply_op
+
+    def _make_complex_operator(self, grid, operator, info, op_no_bc, bcs, dtype, shape_in, shape_out):
+        """``make_operator`` for complex data (the reference specialises its kernels for complex arrays, numba/operators/cartesian.py;
+        here: real coefficients, so real and imaginary part go through the real kernels one after the other, each with its part of the
+        boundary values).  Host arrays in, host arrays out: complex data lives as planar pairs on the device only inside the steppers."""
+        from .bc_expr import expression_faces
+
+        operator = getattr(info, "name", operator)       # (py-pde hands over the OperatorInfo itself, pde/grids/base.py:1254-1261)
+        if info.rank_in != 0 or operator in _NONLINEAR_OPERATORS:
+            msg = f"hip backend: operator `{operator}` on complex fields is not supported"
+            raise NotImplementedError(msg)
+        if expression_faces(bcs):
+            msg = "hip backend: expression boundary conditions on complex fields are not supported"
+            raise NotImplementedError(msg)
+        real = real_dtype_of(dtype)
+        ginfo = self.grid_info(grid, real)
+        tables = {part: convert_bcs(bcs, part=part) for part in ("re", "im")}
+        lib, nd = self._lib, len(grid.shape)
+
+        def apply_op(arr, out=None, args=None):
+            if isinstance(arr, DeviceArray):
+                msg = "hip backend: operators on complex data take host arrays"
+                raise NotImplementedError(msg)
+            arr = np.asarray(arr)
+            if tuple(arr.shape) != shape_in:
+                msg = f"Incompatible shapes {tuple(arr.shape)} != {shape_in}"
+                raise ValueError(msg)
+            if out is not None and tuple(out.shape) != shape_out:
+                msg = f"Incompatible shapes {tuple(out.shape)} != {shape_out}"
+                raise ValueError(msg)
+            parts = []
+            for part, take in (("re", np.real), ("im", np.imag)):
+                native = DeviceArray(ginfo).set_valid(np.ascontiguousarray(take(arr), dtype=real), self.stream)
+                lib.set_ghost_cells(ginfo.ref, 1, tables[part].c, native.ptr, self.stream)
+                res = DeviceArray(ginfo, shape_out[: len(shape_out) - nd])
+                op_no_bc(native, res)
+                parts.append(res.get_valid(stream=self.stream))
+            result = parts[0] + 1j * parts[1]
+            if out is not None:
+                out[...] = result
+                return out
+            return result.astype(dtype, copy=False)
 
         apply_op.grid = grid  # type: ignore[attr-defined]
         return apply_op
@@ -746,15 +833,23 @@ class HipBackendMixin:
         ``state_native`` is a :class:`DeviceArray`; host valid data (what ``numpy_to_native`` passes through when it is
         called without a grid, e.g. by ``ScipySolver``) is uploaded here, where the grid is known."""
         grid = state.grid
-        info = self.grid_info(grid, state.dtype)
+        is_complex = np.dtype(state.dtype).kind == "c"
+        info = self.grid_info(grid, real_dtype_of(state.dtype))
         comp_shape = tuple(np.shape(state.data))[: np.ndim(state.data) - len(info.shape)]   # (n,) for a FieldCollection
+        if is_complex:
+            comp_shape += (2,)       # planar (re, im) pairs
 
         def to_device(state_data):
             if isinstance(state_data, DeviceArray):
                 return state_data
+            if is_complex:
+                return DeviceArray(info, comp_shape, complex_pairs=True).set_valid(np.asarray(state_data), self.stream)
             return DeviceArray(info, comp_shape).set_valid(np.asarray(state_data, dtype=info.dtype), self.stream)
 
         try:
+            if is_complex:
+                msg = "complex state"
+                raise NotImplementedError(msg)
             spec = self.make_rhs_spec(eq, state)
         except NotImplementedError:
             erhs = self.make_expression_rhs(eq, state)   # raises NotImplementedError itself if unsupported
@@ -787,9 +882,15 @@ class HipBackendMixin:
 
     def _expression_faces(self, grid, bc, comp):
         """Face table of one operator: scalar conditions (``comp`` None), or those of component ``comp`` (k / (i, j)) of a vector /
-        tensor operand."""
-        from .bc_expr import convert_bcs_with_expressions
+        tensor operand; ``comp`` "re" / "im": the conditions of the real / imaginary part of a complex scalar field."""
+        from .bc_expr import convert_bcs_with_expressions, expression_faces
 
+        if comp in ("re", "im"):
+            bcs = grid.get_boundary_conditions(bc, rank=0)
+            if expression_faces(bcs):
+                msg = "hip backend: expression boundary conditions on complex fields are not supported"
+                raise NotImplementedError(msg)
+            return convert_bcs(bcs, part=comp)
         if comp is None:
             return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
         rank = 2 if isinstance(comp, tuple) else 1
@@ -810,9 +911,13 @@ class HipBackendMixin:
         rhs = dict(builtin[0]) if builtin else dict(eq.rhs)
         variables = list(rhs)
         grid = state.grid
-        info = self._expression_info(grid, state.dtype)
+        is_complex = np.dtype(state.dtype).kind == "c"
+        info = self._expression_info(grid, real_dtype_of(state.dtype))
         consts = dict(builtin[1]) if builtin else dict(getattr(eq, "consts", {}) or {})
         aliases = builtin[3] if builtin else {}
+        if not is_complex and any(np.iscomplexobj(v) for v in consts.values()) or (not is_complex and bool(getattr(eq, "complex_valued", False))):
+            msg = "hip backend: a complex-valued equation needs a complex state (py-pde's controller converts it, pde/solvers/controller.py:430-432)"
+            raise NotImplementedError(msg)
         kind = state.__class__.__name__
         fields = list(state) if kind == "FieldCollection" else [state]
         kinds = [f.__class__.__name__ for f in fields]
@@ -826,8 +931,30 @@ class HipBackendMixin:
         flat: list[tuple[str, str, Any]] = []     # (flat name, variable, component: None / k / (i, j))
         vectors: dict[str, tuple[str, ...]] = {}
         tensors: dict[str, tuple[tuple[str, ...], ...]] = {}
+        # complex fields: the real system of the parts (pde_hip/complex_expr.py); every field of the state is complex then, a scalar
+        # field `u` contributes `u_re_`, `u_im_` - the planar pair of `DeviceArray(complex_pairs=True)`
+        part_exprs: dict[str, str] = {}
+        if is_complex:
+            from .complex_expr import part_names, split_expression
+
+            if any(k != "ScalarField" for k in kinds):
+                msg = "hip backend: complex states are scalar fields (or collections of scalar fields)"
+                raise NotImplementedError(msg)
+            if getattr(eq, "user_funcs", None):
+                msg = "hip backend: user functions in complex-valued expressions are not supported"
+                raise NotImplementedError(msg)
+            real_consts: dict[str, Any] = {}
+            for var in variables:
+                expr_src = rhs[var] if builtin else pde_expression(eq, var)
+                re_s, im_s, keep, more = split_expression(str(expr_src), variables, consts, tuple(grid.axes), aliases)
+                real_consts.update(keep)
+                aliases = {**aliases, **more}
+                part_exprs[part_names(var)[0]], part_exprs[part_names(var)[1]] = re_s, im_s
+            consts = real_consts
         for var, k in zip(variables, kinds):
-            if k == "VectorField":
+            if is_complex:
+                flat += [(part_names(var)[0], var, "re"), (part_names(var)[1], var, "im")]
+            elif k == "VectorField":
                 vectors[var] = tuple(f"{var}#{c}" for c in range(dim))
                 flat += [(f"{var}#{c}", var, c) for c in range(dim)]
             elif k == "Tensor2Field":
@@ -839,8 +966,9 @@ class HipBackendMixin:
             msg = f"hip backend: {eq.__class__.__name__} takes scalar fields"
             raise NotImplementedError(msg)
 
-        def tables_for(var, plan):
+        def tables_for(var, plan, part=None):
             # one face table per operator NAME in the equation of `var`, like the reference (pde/pdes/pde.py:329-343)
+            # (`part` not None: the equation of one part of a complex field; its operators are tagged with the part of THEIR operand)
             tables: dict[str, Any] = {}
             specs: list[tuple[Any, Any, Any]] = []
             for op in plan.operators_used:
@@ -851,6 +979,15 @@ class HipBackendMixin:
                     idx = [int(x) for x in op.split("_")[1:]]
                     base, comp = {"grad": ("gradient", None), "div": ("divergence", idx[0]), "vlap": ("vector_laplace", idx[0]),
                                   "vgrad": ("vector_gradient", idx[0]), "tdiv": ("tensor_divergence", tuple(idx))}[op.split("_")[0]]
+                if part is not None:
+                    # complex fields: the operand of `<op>_imop` is the imaginary part of the operator's complex argument (complex_expr.py)
+                    from .complex_expr import IM_OPERAND
+
+                    if comp is not None:
+                        msg = f"hip backend: operator `{base}` on complex fields inside an expression is not supported"
+                        raise NotImplementedError(msg)
+                    comp = "im" if op.endswith(IM_OPERAND) else "re"
+                    base = base[: -len(IM_OPERAND)] if base.endswith(IM_OPERAND) else base
                 bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
                 for other, other_comp, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:
@@ -898,21 +1035,24 @@ class HipBackendMixin:
         names = [name for name, _, _ in flat]
         for name, var, comp in flat:
             try:
-                plan = ExpressionPlan(rhs[var] if builtin else pde_expression(eq, var), name, consts, others=tuple(n for n in names if n != name),
+                source = part_exprs[name] if is_complex else (rhs[var] if builtin else pde_expression(eq, var))
+                plan = ExpressionPlan(source, name, consts, others=tuple(n for n in names if n != name),
                                       axes=tuple(grid.axes), aliases=aliases, aux=tuple(a for a in aux_host if a not in vectors and a not in tensors),
-                                      vectors=vectors, component=comp, user_funcs=user_funcs, tensors=tensors)
+                                      vectors=vectors, component=None if is_complex else comp, user_funcs=user_funcs, tensors=tensors)
             except ValueError as err:
                 if "unknown symbol" in str(err):   # the reference's error for this case (pde/pdes/pde.py:455-459)
                     msg = f"Undefined variable in expression for rhs of `{var}`: {err}"
                     raise RuntimeError(msg) from err
                 raise
-            parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan), aux_for(plan)))
+            parts.append(ExpressionRhs(self, plan, info, tables_for(var, plan, comp if is_complex else None), aux_for(plan)))
         variables = names
         if len(parts) == 1:
             return parts[0]
         from .expr import SystemRhs
 
-        return SystemRhs(variables, parts, info)
+        system = SystemRhs(variables, parts, info)
+        system.complex_pairs = is_complex          # the state is complex: planar (re, im) pairs, modulus error norm
+        return system
 
     def _make_expression_stepper(self, solver, state, erhs=None, post_step=None, reduce_error=None, scheme=None):
         """Python-level twin of the C steppers for expression right-hand sides: the same update rules
@@ -934,7 +1074,13 @@ class HipBackendMixin:
         is_rk = (scheme == "runge-kutta") if scheme is not None else solver.__class__.__name__ == "RungeKuttaSolver"
         adaptive = bool(getattr(solver, "adaptive", False))
         nwork = (7 if adaptive else 5) if is_rk else (3 if adaptive else 1)   # adaptive Euler: rate, half step, slope scratch
-        work = [DeviceArray(info, comp_shape) for _ in range(nwork)]
+        # complex states (planar (re, im) pairs, SystemRhs.complex_pairs): arrays that may hold the state hand out complex host data
+        # (hooks); the error norm of the adaptive schemes is the modulus `np.abs(complex)` - taken from an explicit error field
+        is_complex = bool(getattr(erhs, "complex_pairs", False))
+        if is_complex:
+            comp_shape = (ncomp // 2, 2)
+            nwork += 1 if adaptive else 0      # the error field
+        work = [DeviceArray(info, comp_shape, complex_pairs=is_complex) for _ in range(nwork)]
         B = [[1 / 4], [3 / 32, 9 / 32], [1932 / 2197, -7200 / 2197, 7296 / 2197], [439 / 216, -8.0, 3680 / 513, -845 / 4104],
              [-8 / 27, 2.0, -3544 / 2565, 1859 / 4104, -11 / 40]]
         A = [0.0, 1 / 4, 3 / 8, 12 / 13, 1.0, 1 / 2]
@@ -1011,9 +1157,38 @@ class HipBackendMixin:
         solver.info.setdefault("dt_statistics", OnlineStatistics())
         adjust_dt = make_dt_adjuster(solver.dt_min, solver.dt_max)
         tolerance, dt_min = float(solver.tolerance), float(solver.dt_min)
-        err_dev, ynew0 = DeviceScalar(), DeviceArray(info, comp_shape)
+        err_dev, ynew0 = DeviceScalar(), DeviceArray(info, comp_shape, complex_pairs=is_complex)
+
+        def attempt_complex(y, ynew, t, dt_step) -> float:
+            """The attempts below for complex states: new state and error FIELD with the pointwise kernels, then max |error| as the
+            modulus over the (re, im) pairs (pdehip_max_abs_pairs) - `np.abs(...).max()` of a complex array in the reference."""
+            efield = work[-1]
+            if is_rk:
+                ks, tmp = work[:6], work[6]
+                src = y
+                for s_, b in enumerate(B):
+                    erhs.apply(src, ks[s_], "scaled", dt_step, t + A[s_] * dt_step)
+                    lincomb(tmp, y, b, ks[: s_ + 1])
+                    src = tmp
+                erhs.apply(src, ks[5], "scaled", dt_step, t + A[5] * dt_step)
+                lincomb(ynew, y, [25 / 216, 1408 / 2565, 2197 / 4104, -1 / 5], [ks[0], ks[2], ks[3], ks[4]])          # runge_kutta.py:150
+                cf = (C.c_double * 5)(1 / 360, -128 / 4275, -2197 / 75240, 1 / 50, 2 / 55)                                # runge_kutta.py:147
+                lib.lincomb(info.ref, ncomp, efield.ptr, None, 5, cf, ptr_array([ks[0], ks[2], ks[3], ks[4], ks[5]]), stream)
+            else:
+                rate, half, kmid = work[0], work[1], work[2]
+                h = 0.5 * dt_step
+                erhs.apply(half, kmid, "scaled", h, t + h)
+                lincomb(ynew, half, [1.0], [kmid])              # step_small += 0.5 * dt * rate_midpoint
+                lincomb(efield, y, [dt_step], [rate])            # step_large
+                lincomb(efield, efield, [-1.0], [ynew])          # step_large - step_small
+            lib.max_abs_pairs(info.ref, ncomp // 2, efield.ptr, err_dev.ptr, stream)
+            if reduce_error is not None:
+                reduce_error(err_dev)
+            return err_dev.value(stream)
 
         def attempt(y, ynew, t, dt_step) -> float:
+            if is_complex:
+                return attempt_complex(y, ynew, t, dt_step)
             if is_rk:
                 # stages 1-5: slope + next stage input in one sweep (inputs alternate between tmp and ynew, which is free
                 # until the last sweep); stage 6: new state + error norm with k6 in registers (like pdehip_rkf45_attempt)
@@ -1038,7 +1213,7 @@ class HipBackendMixin:
             return err_dev.value(stream)
 
         ctl = None
-        if post_step is None and hasattr(erhs, "rk_run") and reduce_error is None and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+        if post_step is None and hasattr(erhs, "rk_run") and reduce_error is None and not is_complex and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
             # the adaptive loop itself in C (pdehip_jit_rk_run: pde/backends/numba/_solvers.py:199-319 is jitted in the reference)
             from .solvers import AdaptiveStatistics
 
@@ -1079,6 +1254,9 @@ class HipBackendMixin:
                     if not is_rk:
                         rate, half = work[0], work[1]
                         h = 0.5 * dt_step
+                        if is_complex and not have_rate:
+                            erhs.apply(cur, rate, "rate", 0.0, t_rate)
+                            have_rate = True
                         if have_rate or not erhs.apply_stage(cur, rate, 1.0, t_rate, 0, cur, [], [], h, half):
                             lincomb(half, cur, [h], [rate])
                         have_rate = True
@@ -1148,6 +1326,37 @@ class HipBackendMixin:
                 rates.reverse()
             if cur is not state_data:
                 lib.memcpy_d2d(state_data.ptr, cur.ptr, state_data.nbytes, stream)
+            solver.info["steps"] += steps
+            return state_data, t_start + (steps - 1) * dt + dt
+
+        return fixed_stepper
+
+    def _make_adams_bashforth_expression_stepper(self, solver, erhs):
+        """Two-step Adams-Bashforth (pde/solvers/adams_bashforth.py:31-70, pde/backends/numba/_solvers.py:121-196) around any evaluator
+        with the interface of :class:`~pde_hip.expr.ExpressionRhs` (expression PDEs, systems, complex states as real systems).  Like
+        the class version above, ``rhs(state_prev, t - dt)`` is the rate of the step before, kept instead of being evaluated again."""
+        info, lib, stream = erhs.info, self._lib, self.stream
+        ncomp = int(getattr(erhs, "ncomp", 1))
+        is_complex = bool(getattr(erhs, "complex_pairs", False))
+        comp_shape = ((ncomp // 2, 2) if is_complex else (ncomp,)) if ncomp > 1 else ()
+        dt = float(solver.info["dt"])
+        rates = [DeviceArray(info, comp_shape, complex_pairs=is_complex) for _ in range(2)]   # [current, previous], roles swap every step
+        tmp = DeviceArray(info, comp_shape, complex_pairs=is_complex)
+        minus_dt = (C.c_double * 1)(-dt)
+        first = [True]
+
+        def fixed_stepper(state_data: DeviceArray, t_start: float, t_end: float):
+            steps = max(1, round((t_end - t_start) / dt))
+            if first[0]:
+                # state_prev = state - dt * rhs(state, t)  ->  rate_prev = rhs(state_prev, t - dt)   (adams_bashforth.py:62-66)
+                erhs.apply(state_data, rates[0], "rate", 0.0, float(t_start))
+                lib.lincomb(info.ref, ncomp, tmp.ptr, state_data.ptr, 1, minus_dt, ptr_array([rates[0]]), stream)
+                erhs.apply(tmp, rates[1], "rate", 0.0, float(t_start) - dt)
+                first[0] = False
+            for i in range(steps):
+                erhs.apply(state_data, rates[0], "rate", 0.0, t_start + i * dt)
+                lib.ab2_combine(info.ref, ncomp, state_data.ptr, rates[0].ptr, rates[1].ptr, dt, stream)
+                rates.reverse()
             solver.info["steps"] += steps
             return state_data, t_start + (steps - 1) * dt + dt
 
@@ -1378,10 +1587,18 @@ class HipBackendMixin:
             msg = f"Backend `{self.name}` does not support post-step hooks with {solver_name}"
             raise NotImplementedError(msg)
         try:
+            if np.dtype(state.dtype).kind == "c":
+                # complex states: the equation as a real system of the parts through the run-time compiled passes (pde_hip/complex_expr.py)
+                if add_noise is not None:
+                    msg = f"Backend `{self.name}` does not support noise on complex fields"
+                    raise RuntimeError(msg)
+                msg = "complex state"
+                raise NotImplementedError(msg)
             spec = self.make_rhs_spec(solver.pde, state)
         except NotImplementedError as err:
             if solver_name == "AdamsBashforthSolver":
-                raise
+                # expression PDEs (and complex states): the same two-step scheme around the run-time compiled right-hand side
+                return self._make_adams_bashforth_expression_stepper(solver, self.make_expression_rhs(solver.pde, state))
             try:
                 return self._make_expression_stepper(solver, state, post_step=post_step)   # generic expression PDE
             except NotImplementedError as err2:
@@ -1477,12 +1694,13 @@ class HipBackendMixin:
         or progress-only trackers uploads once and downloads once.  See :class:`ResidentState`.
         """
         inner = self.make_inner_stepper(solver, state)
-        info = self.grid_info(state.grid, state.dtype)
-        comp_shape = tuple(np.shape(state.data))[: np.ndim(state.data) - len(info.shape)]
+        is_complex = np.dtype(state.dtype).kind == "c"     # complex states: planar (re, im) pairs of the real type on the device
+        info = self.grid_info(state.grid, real_dtype_of(state.dtype))
+        comp_shape = tuple(np.shape(state.data))[: np.ndim(state.data) - len(info.shape)] + ((2,) if is_complex else ())
         # a FieldCollection hands out its sub-fields as separate objects viewing the same memory: reads of `state[0].data`
         # cannot be intercepted, so collections take the plain upload / download per call
         resident = bool(_config_get(getattr(self, "config", None), "resident_state", True)) and state.__class__.__name__ != "FieldCollection"
-        dev_state = DeviceArray(info, comp_shape)
+        dev_state = DeviceArray(info, comp_shape, complex_pairs=is_complex)
         if not resident:
 
             def stepper(state_field, t_start: float, t_end: float) -> float:

@@ -76,7 +76,8 @@ class BCBase:
             mesh = np.meshgrid(*coords, indexing="ij") if coords else []
             arr = np.broadcast_to(np.asarray(func(*mesh), dtype=np.double), shape_t + shape_f)
             return np.array(arr), False
-        arr = np.asarray(value, dtype=np.double)
+        arr = np.asarray(value)
+        arr = arr.astype(np.complex128 if np.iscomplexobj(arr) and np.any(np.imag(arr) != 0) else np.double)   # (complex values: complex fields only)
         if arr.ndim <= len(shape_t):
             try:
                 return np.array(np.broadcast_to(arr, shape_t)), True

@@ -1,0 +1,133 @@
+"""Complex-valued expression PDEs as real systems ("fp64 / fp32 / complex").
+
+The reference specialises its operators and right-hand sides for complex arrays (numba type specialisation,
+``pde/backends/numba/operators/cartesian.py``; the controller turns the state complex when ``pde.complex_valued``,
+``pde/solvers/controller.py:430-432``; expressions may contain ``I``, ``pde/pdes/pde.py:299-399``).  Every stencil of this path has
+REAL coefficients, so a complex field ``u = a + i b`` is carried on the device as the two real components ``(a, b)`` - planar, like the
+components of a vector field - and an equation ``du/dt = F(u)`` becomes the real system ``da/dt = Re F``, ``db/dt = Im F``:
+
+* linear operators act on the parts separately, ``laplace(a + i b) = laplace(a) + i laplace(b)`` (the same for ``d_dx`` ... and the
+  components of ``gradient``); ``gradient_squared(w) = sum (d w)^2`` gives ``gs(a) - gs(b) + 2 i dot(gradient(a), gradient(b))``;
+* everything pointwise (``I``, products, integer powers, ``conjugate``, ``Abs``, ``re``, ``im``, ``exp``) is split by sympy's
+  ``as_real_imag`` after the operator applications have been replaced by real place-holders.
+
+The split is symbolic and happens once per equation; the kernels then see ordinary real expressions (``pde_hip/expr.py``).  Steppers act
+componentwise, which is exactly complex arithmetic with real step sizes; only the error norm of the adaptive schemes is the complex
+modulus (``np.abs`` of a complex array, ``pde/solvers/runge_kutta.py:147-148``): ``pdehip_max_abs_pairs``.
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+IM_OPERAND = "_imop"     # suffix of an operator name whose operand is the IMAGINARY part of the operator's complex argument
+
+
+def part_names(var: str) -> tuple[str, str]:
+    """Names of the real and the imaginary part of ``var`` inside the real system."""
+    return f"{var}_re_", f"{var}_im_"
+
+
+def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any], axes: tuple[str, ...], aliases: dict[str, str] | None = None,
+                     user_funcs: dict[str, Any] | None = None) -> tuple[str, str, dict[str, float], dict[str, str]]:
+    """Real and imaginary part of the right-hand side ``expr_str`` as expression strings over the parts ``part_names(v)`` of the
+    (complex) fields ``variables``; complex scalar constants are folded in, real ones stay symbols.  Returns ``(re, im, consts, aliases)``:
+    the constants the new expressions still need and the operator aliases they use - ``laplace(w)`` of a complex argument ``w`` becomes
+    ``laplace(Re w) + I * laplace_imop(Im w)``: the same stencil, but the conditions of the second operand are the IMAGINARY parts of the
+    operator's boundary values (``convert_bcs(part="im")``), whatever equation the term ends up in."""
+    import sympy as sp
+
+    aliases = aliases or {}
+    expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
+    local: dict[str, Any] = {"I": sp.I}
+    fields = {v: sp.Symbol(v) for v in variables}
+    local.update(fields)
+    real_syms: dict[str, Any] = {}
+    keep: dict[str, float] = {}
+    folded: dict[Any, Any] = {}
+    for name, value in consts.items():
+        if name in fields:
+            continue
+        sym = sp.Symbol(name, real=True)
+        real_syms[name] = sym
+        local[name] = sym
+        try:
+            scalar = complex(value)
+        except (TypeError, ValueError):
+            keep[name] = value          # an array / field on the grid: stays a (real) symbol of the plan
+            continue
+        if scalar.imag != 0:
+            folded[sym] = sp.Float(scalar.real, 17) + sp.I * sp.Float(scalar.imag, 17)
+        else:
+            keep[name] = scalar.real
+    for name in (*axes, "t"):
+        if name not in local:
+            local[name] = sp.Symbol(name, real=True)
+    if user_funcs:
+        msg = "hip backend: user functions inside complex-valued expressions are not supported"
+        raise NotImplementedError(msg)
+    # every other name followed by "(" is an operator: an undefined function
+    import re as _re
+
+    for name in set(_re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*\(", expr_str)):
+        if name not in local and not hasattr(sp, name):
+            local[name] = sp.Function(name)
+    for name in ("laplace", "gradient_squared", *aliases):
+        local.setdefault(name, sp.Function(name))
+    expr = sp.sympify(expr_str, locals=local)
+    parts = {fields[v]: tuple(sp.Symbol(n, real=True) for n in part_names(v)) for v in variables}
+    holders: dict[Any, Any] = {}
+    new_aliases: dict[str, str] = dict(aliases)
+
+    def hold(call) -> Any:
+        sym = sp.Symbol(f"_op{len(holders)}_", real=True)
+        holders[sym] = call
+        return sym
+
+    def split(e) -> tuple[Any, Any]:
+        """(real part, imaginary part) of ``e`` as expressions over the real symbols and the place-holders."""
+        undefined = [a for a in e.atoms(sp.core.function.AppliedUndef)]
+        # innermost first: replace operator applications by (holder_re + I holder_im)
+        sub: dict[Any, Any] = {}
+        for call in sorted(undefined, key=lambda c: len(str(c))):
+            if call in sub:
+                continue
+            name = call.func.__name__
+            base = aliases.get(name, name)
+            if len(call.args) != 1:
+                msg = f"hip backend: operator `{name}` with {len(call.args)} arguments inside a complex-valued expression"
+                raise NotImplementedError(msg)
+            ar, ai = split(call.args[0].xreplace(sub))
+            fn = call.func
+            if base == "laplace":
+                # linear with real coefficients: acts on the parts separately; the imaginary operand takes the imaginary parts of the
+                # operator's boundary values
+                re_part = hold(fn(ar)) if ar != 0 else sp.Integer(0)
+                im_part = sp.Integer(0)
+                if ai != 0:
+                    new_aliases[name + IM_OPERAND] = base
+                    im_part = hold(sp.Function(name + IM_OPERAND)(ai))
+            elif base == "gradient_squared" and ai == 0:
+                re_part, im_part = hold(fn(ar)), sp.Integer(0)
+            else:
+                # (gradient_squared of a complex argument is gs(Re) - gs(Im) + 2 i grad(Re) . grad(Im); the per-axis derivatives and the
+                # vector operators would split like laplace: not built)
+                msg = f"hip backend: operator `{name}` of a complex argument inside an expression is not supported"
+                raise NotImplementedError(msg)
+            sub[call] = re_part + sp.I * im_part
+        e = e.xreplace(sub).xreplace(folded)
+        e = e.xreplace({f: p[0] + sp.I * p[1] for f, p in parts.items()})
+        re_part, im_part = sp.expand(e).as_real_imag()
+        leftovers = (re_part.atoms(sp.re, sp.im, sp.arg) | im_part.atoms(sp.re, sp.im, sp.arg))
+        if leftovers:
+            msg = f"hip backend: cannot split `{e}` into real and imaginary part ({sorted(map(str, leftovers))[:3]})"
+            raise NotImplementedError(msg)
+        return re_part, im_part
+
+    re_part, im_part = split(expr)
+    # put the operator applications back (outermost holders contain inner ones)
+    for _ in range(len(holders) + 1):
+        if not (re_part.free_symbols | im_part.free_symbols) & set(holders):
+            break
+        re_part, im_part = re_part.xreplace(holders), im_part.xreplace(holders)
+    return sp.sstr(re_part), sp.sstr(im_part), keep, new_aliases

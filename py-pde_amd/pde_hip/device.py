@@ -70,9 +70,16 @@ class GridInfo:
 class DeviceArray:
     """A field in the device "full" layout; ``comp_shape`` = leading tensor dimensions."""
 
-    def __init__(self, info: GridInfo, comp_shape=(), *, buffer: DeviceBuffer | None = None, ptr: int | None = None):
+    def __init__(self, info: GridInfo, comp_shape=(), *, buffer: DeviceBuffer | None = None, ptr: int | None = None, complex_pairs: bool = False):
+        """``complex_pairs``: the array holds COMPLEX data as planar real components - the last tensor axis (length 2) is (real part,
+        imaginary part), ``info.dtype`` the real type; ``set_valid`` / ``get_valid`` then take / hand out complex host arrays of shape
+        ``comp_shape[:-1] + grid`` (pde_hip/complex_expr.py: every stencil of this path has real coefficients)."""
         self.info = info
         self.comp_shape = tuple(int(c) for c in comp_shape)
+        self.complex_pairs = bool(complex_pairs)
+        if self.complex_pairs and (not self.comp_shape or self.comp_shape[-1] != 2):
+            msg = "complex data needs a last tensor axis of length 2 (real part, imaginary part)"
+            raise ValueError(msg)
         self.ncomp = int(np.prod(self.comp_shape)) if self.comp_shape else 1
         self.itemsize = info.dtype.itemsize
         self.nbytes = (self.ncomp * info.comp_elems + info.slack) * self.itemsize
@@ -100,7 +107,24 @@ class DeviceArray:
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr:x})"
 
     def empty_like(self) -> "DeviceArray":
-        return DeviceArray(self.info, self.comp_shape)
+        return DeviceArray(self.info, self.comp_shape, complex_pairs=self.complex_pairs)
+
+    # --- complex host data <-> planar real components ---------------------------------------------------------------
+    @property
+    def host_dtype(self):
+        """dtype of the host arrays ``set_valid`` takes / ``get_valid`` returns."""
+        if not self.complex_pairs:
+            return self.info.dtype
+        return np.dtype(np.complex128 if self.info.dtype == np.float64 else np.complex64)
+
+    @property
+    def host_shape(self) -> tuple[int, ...]:
+        return (self.comp_shape[:-1] if self.complex_pairs else self.comp_shape) + self.info.shape
+
+    def _to_planar(self, host: np.ndarray) -> np.ndarray:
+        axis = len(self.comp_shape) - 1
+        host = np.asarray(host)
+        return np.ascontiguousarray(np.stack([host.real, host.imag if np.iscomplexobj(host) else np.zeros_like(host.real)], axis=axis), dtype=self.info.dtype)
 
     def component(self, index: int) -> "DeviceArray":
         """View of ``arr[index]`` (first tensor axis), sharing memory with ``self``."""
@@ -109,7 +133,7 @@ class DeviceArray:
             raise IndexError(msg)
         sub = self.comp_shape[1:]
         stride = (int(np.prod(sub)) if sub else 1) * self.info.comp_elems * self.itemsize
-        return DeviceArray(self.info, sub, buffer=self._buffer, ptr=self.ptr + int(index) * stride)
+        return DeviceArray(self.info, sub, buffer=self._buffer, ptr=self.ptr + int(index) * stride, complex_pairs=self.complex_pairs and len(sub) >= 1)
 
     def flat(self) -> "DeviceArray":
         """The same memory with ONE tensor axis: all components in C order (a rank-2 field as ``dim * dim`` scalar components)."""
@@ -149,6 +173,11 @@ class DeviceArray:
         as ``field.data`` of the reference, a window of the ghost-padded host array - is read in place."""
         lib = require_device()
         host = np.asarray(data)
+        if self.complex_pairs:
+            if host.shape != self.host_shape:
+                msg = f"Incompatible shapes {host.shape} != {self.host_shape}"
+                raise ValueError(msg)
+            host = self._to_planar(host)
         if host.shape != self.shape:
             msg = f"Incompatible shapes {host.shape} != {self.shape}"
             raise ValueError(msg)
@@ -178,6 +207,15 @@ class DeviceArray:
         """Download the interior as a host numpy array (written into ``out`` if given: in place when ``out`` has this
         array's dtype and a contiguous fastest axis, e.g. ``field.data`` of the reference)."""
         lib = require_device()
+        if self.complex_pairs:
+            planar = np.empty(self.shape, dtype=self.dtype)
+            lib.download_valid(self.info.ref, self.ncomp, self.ptr, planar.ctypes.data, self._host_strides(planar), stream)
+            axis = len(self.comp_shape) - 1
+            res = np.take(planar, 0, axis=axis) + 1j * np.take(planar, 1, axis=axis)
+            if out is not None:
+                out[...] = res
+                return out
+            return res.astype(self.host_dtype, copy=False)
         strides = None
         if out is not None and out.flags.writeable:
             strides = self._host_strides(out)

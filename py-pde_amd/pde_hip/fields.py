@@ -34,7 +34,7 @@ class DataFieldBase:
             self._data_full = np.ascontiguousarray(arr)
         else:
             arr = np.asarray(data, dtype=dtype)
-            if not np.issubdtype(arr.dtype, np.floating):
+            if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.complexfloating)):
                 arr = arr.astype(np.double)
             self._data_full = np.zeros(shape_full, arr.dtype)
             self.data = np.broadcast_to(arr, (grid.dim,) * self.rank + grid.shape)

@@ -212,6 +212,18 @@ class PDE(PDEBase):
         return bool((self.noise != 0).any())
 
     @property
+    def complex_valued(self) -> bool:
+        """The right-hand side contains the imaginary unit or a complex constant (pde/pdes/pde.py:206-216): the controller then
+        evolves a complex state (pde/solvers/controller.py:430-432)."""
+        import re
+
+        import numpy as np
+
+        if any(np.iscomplexobj(v) for v in self.consts.values()):
+            return True
+        return any(re.search(r"(?<![A-Za-z0-9_])I(?![A-Za-z0-9_])", str(e)) for e in self.rhs.values())
+
+    @property
     def expressions(self) -> dict[str, str]:
         """Expressions after the shorthand replacement of the reference (pde/pdes/pde.py:47-53)."""
         return {var: str(e).replace("∇²", "laplace") for var, e in self.rhs.items()}

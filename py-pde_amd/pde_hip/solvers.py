@@ -185,6 +185,8 @@ class Controller:
 
     def run(self, initial_state, dt: float | None = None):
         state = initial_state.copy()
+        if bool(getattr(self.solver.pde, "complex_valued", False)) and state.dtype.kind != "c":
+            state = state.copy(dtype=complex)        # pde/solvers/controller.py:430-432
         t_start, t_end = self.t_range
         t0 = time.perf_counter()
         stepper = self.solver.make_stepper(state, dt)

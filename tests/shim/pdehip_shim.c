@@ -247,6 +247,9 @@ int oracle_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void 
 int pdehip_euler_adaptive_combine(const pdehip_grid_t *g, int ncomp, const void *y, const void *rate, double dt, const void *half, const void *k,
                                   void *out, double *err_dev, void *stream)
 { (void)stream; GRID(g); TRY(oracle_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err_dev)); return 0; }
+int oracle_max_abs_pairs(const pdehip_grid_t *g, int npairs, const void *a, double *out);
+int pdehip_max_abs_pairs(const pdehip_grid_t *g, int npairs, const void *arr_full, double *out_dev, void *stream)
+{ (void)stream; GRID(g); TRY(oracle_max_abs_pairs(g, npairs, arr_full, out_dev)); return 0; }
 int pdehip_max_abs_diff(const pdehip_grid_t *g, int ncomp, const void *a, const void *b, double *out_dev, void *stream)
 { (void)stream; GRID(g); TRY(oracle_max_abs_diff(g, ncomp, a, b, out_dev)); return 0; }
 

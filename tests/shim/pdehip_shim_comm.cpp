@@ -254,18 +254,11 @@ struct HostOps {
         SLAB_TRY(range(1, ends));
         return range(count - ends + 1, ends);
     }
-    // merged slab sweep (ends < 0): on the host simply the whole slab in one go; the signal / wait pair is a no-op (everything is synchronous)
-    bool merged_available() { const char *e = getenv("PDEHIP_SLAB_MERGED"); return !(e && atoi(e) == 0); }
-    long merged_boundary_waves(const pdehip_grid_t *) { return 1; }
-    int signal_reset(void *) { return 0; }
-    int signal_wait(void *, long) { return 0; }
-    int signal_skip(long) { return 0; }
     int euler2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *, bool *done,
                int xplain, bool dry, int ends)
     {
         *done = gs->ndim >= 2;
         if (dry || !*done) return 0;
-        if (ends < 0) ends = 0;
         return two_level(gs, in, faces, faces, xplain, ends,
                          [&](const pdehip_grid_t *gw, void *src, void *l1) -> int { OTRY(oracle_laplace_euler(gw, src, src, l1, D, dt)); return 0; },
                          [&](const pdehip_grid_t *g2, void *v, long off) -> int {

@@ -1,0 +1,176 @@
+"""Complex fields (SURVEY 8 row a1 "fp64 / fp32 / complex"; VERDICT r3 "missing #2"): ``pde.complex_valued`` equations - expressions with
+``I``, complex constants, complex boundary values - and operators on complex data.
+
+Every stencil of the path has real coefficients: a complex field travels as planar (re, im) pairs of the real type and its equation as the
+real system of the parts (``pde_hip/complex_expr.py``).  CPU part: the symbolic split against sympy / numpy directly, the oracle's modulus
+norm, and the product's host side through the REAL py-pde (host shim) against the reference's numpy solver (with the right-hand side
+written with its field operators: ``pde.PDE`` needs numba there) and its torch backend.  GPU part: tests/test_hip_complex.py.
+"""
+
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+import pytest
+from refpath import REF  # noqa: E402
+
+
+def test_symbolic_split_against_complex_arithmetic():
+    """Re / Im of pointwise expressions == numpy's complex arithmetic on random data."""
+    import sympy as sp
+
+    from pde_hip.complex_expr import split_expression
+
+    rng = np.random.default_rng(0)
+    a, b = rng.uniform(-1, 1, 50), rng.uniform(-1, 1, 50)
+    u = a + 1j * b
+    for expr, ref in (("(1 + 2*I) * u * Abs(u)**2 - I * u**3", (1 + 2j) * u * np.abs(u) ** 2 - 1j * u**3),
+                      ("conjugate(u) * u + g * u", np.conj(u) * u + (0.5 - 0.25j) * u),
+                      ("exp(I * t) * u + re(u) - 2 * im(u)", np.exp(0.3j) * u + u.real - 2 * u.imag)):
+        re_s, im_s, consts, aliases = split_expression(expr, ["u"], {"g": 0.5 - 0.25j}, ("x",))
+        syms = {"u_re_": a, "u_im_": b, "t": 0.3, **consts}
+        f = [sp.lambdify(list(map(sp.Symbol, syms)), sp.sympify(s), modules="numpy")(*syms.values()) for s in (re_s, im_s)]
+        np.testing.assert_allclose(f[0] + 1j * f[1], ref, rtol=1e-13, atol=1e-14)
+    re_s, im_s, _, aliases = split_expression("I * laplace(u**2) + laplace(laplace(u))", ["u"], {}, ("x",))
+    assert "laplace_imop" in aliases and aliases["laplace_imop"] == "laplace"
+    # Re [i lap(u^2)] = -lap(Im u^2) = -lap(2ab) through the IMAGINARY-operand operator; Re lap lap u = lap lap a
+    assert "laplace_imop(2*u_im_*u_re_)" in re_s.replace(" ", "").replace("2*u_re_*u_im_", "2*u_im_*u_re_") and "laplace(laplace(u_re_))" in re_s
+    with pytest.raises(NotImplementedError):
+        split_expression("gradient_squared(u)", ["u"], {}, ("x",))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_oracle_modulus_norm(dtype):
+    from helpers import oracle_grid, to_full
+
+    import pde_hip
+    from oracle import pde_oracle as O
+
+    rng = np.random.default_rng(1)
+    grid = pde_hip.UnitGrid([5, 6, 7])
+    z = (rng.normal(size=(2, *grid.shape)) + 1j * rng.normal(size=(2, *grid.shape))).astype(np.complex128 if dtype == np.float64 else np.complex64)
+    planar = np.stack([z.real, z.imag], axis=1).reshape(4, *grid.shape).astype(dtype)
+    got = O.max_abs_pairs(oracle_grid(grid, dtype), 2, to_full(grid, planar))
+    assert got == pytest.approx(float(np.abs(z).max()), rel=1e-15 if dtype == np.float64 else 1e-6)
+    planar[3, 1, 2, 3] = np.nan
+    assert np.isnan(O.max_abs_pairs(oracle_grid(grid, dtype), 2, to_full(grid, planar)))
+
+
+if not (REF / "pde").exists():
+    pytest.skip("py-pde (reference) not available", allow_module_level=True)
+if str(REF) not in sys.path:
+    sys.path.append(str(REF))
+
+import pde  # noqa: E402
+import shimlib  # noqa: E402
+from helpers import max_rel  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _scipy_operators(monkeypatch):
+    monkeypatch.setitem(pde.config, "default_backend", "scipy")
+    monkeypatch.setitem(pde.config, "backend.torch.compile", False)
+
+
+@pytest.fixture(params=[False, True], ids=["unfused", "fused"])
+def hip(request):
+    with shimlib.use_shim(fused=request.param):
+        import pde_hip.pypde_plugin  # noqa: F401
+
+        yield pde.backends.get_backend("hip")
+
+
+_BC = {"x": {"value": 1 + 2j}, "y": "periodic"}
+
+
+class _Schroedinger(pde.PDEBase):
+    """`PDE({'p': 'I * laplace(p)'})` for the reference's numpy solver (pde.PDE takes its operators from numba there)."""
+
+    complex_valued = True
+
+    def evolution_rate(self, state, t=0):
+        return 1j * state.laplace(_BC)
+
+
+@pytest.mark.parametrize("solver,adaptive", [("euler", False), ("runge-kutta", False), ("runge-kutta", True), ("euler", True), ("adams-bashforth", False)])
+def test_schroedinger_against_the_reference(hip, solver, adaptive):
+    """VERDICT r3 "next #5": `PDE({'u': 'I*laplace(u)'})` with a complex boundary value, Euler / RK4 / RKF45 / adaptive Euler / AB2:
+    equal step counts, <= 1e-10 of the reference's numpy backend; a REAL initial field is turned complex by the controller."""
+    grid = pde.UnitGrid([8, 6], periodic=[False, True])
+    rng = np.random.default_rng(0)
+    for field in (pde.ScalarField(grid, rng.uniform(-1, 1, grid.shape) + 1j * rng.uniform(-1, 1, grid.shape)), pde.ScalarField.random_uniform(grid, rng=rng)):
+        kw = dict(t_range=0.05, dt=1e-3, solver=solver, tracker=None, ret_info=True)
+        if adaptive:
+            kw["adaptive"] = True
+        ref, iref = _Schroedinger().solve(field, backend="numpy", **kw)
+        res, info = pde.PDE({"p": "I * laplace(p)"}, bc=_BC).solve(field, backend="hip", **kw)
+        got = np.array(res.data)
+        assert got.dtype == np.complex128 and res.is_complex
+        assert info["solver"]["steps"] == iref["solver"]["steps"]
+        assert max_rel(got, ref.data) < 1e-10
+
+
+@pytest.mark.parametrize("solver,adaptive", [("euler", False), ("runge-kutta", True)])
+def test_nonlinear_complex_equation(hip, solver, adaptive):
+    """Gross-Pitaevskii-like right-hand side with a complex coefficient, `Abs`, `conjugate` and a complex Neumann value; yardstick: the
+    reference's numpy solver around the same right-hand side written with its field operators."""
+    grid = pde.CartesianGrid([[0, 10], [0, 8]], [10, 8], periodic=[True, False])
+    rng = np.random.default_rng(2)
+    field = pde.ScalarField(grid, rng.uniform(-0.5, 0.5, grid.shape) + 1j * rng.uniform(-0.5, 0.5, grid.shape))
+    bc = {"x": "periodic", "y": {"derivative": 0.1 - 0.2j}}
+    g = 0.3 - 0.8j
+
+    class Restated(pde.PDEBase):
+        complex_valued = True
+
+        def evolution_rate(self, state, t=0):
+            c = state.data
+            return pde.ScalarField(state.grid, -1j * state.laplace(bc).data + g * c * np.abs(c) ** 2 - 0.1 * np.conjugate(c))
+
+    eq = pde.PDE({"c": "-I * laplace(c) + g * c * Abs(c)**2 - 0.1 * conjugate(c)"}, consts={"g": g}, bc=bc)
+    kw = dict(t_range=0.05, dt=1e-3, solver=solver, tracker=None, ret_info=True, adaptive=adaptive)
+    ref, iref = Restated().solve(field, backend="numpy", **kw)
+    res, info = eq.solve(field, backend="hip", **kw)
+    assert info["solver"]["steps"] == iref["solver"]["steps"]
+    assert max_rel(np.array(res.data), ref.data) < 1e-10
+
+
+def test_two_complex_fields_and_a_class_pde(hip):
+    """A collection of two complex scalar fields (coupled), and DiffusionPDE on a complex state (linear: acts on the parts)."""
+    grid = pde.UnitGrid([9, 7], periodic=[True, False])
+    rng = np.random.default_rng(3)
+    fields = [pde.ScalarField(grid, rng.uniform(-1, 1, grid.shape) + 1j * rng.uniform(-1, 1, grid.shape), label=n) for n in "ab"]
+    state = pde.FieldCollection(fields)
+    eq = pde.PDE({"a": "I * laplace(a) - b", "b": "laplace(b) + I * a"}, bc={"x": "periodic", "y": {"value": 0.5j}})
+    ref = eq.solve(state, t_range=0.02, dt=1e-3, backend="torch", tracker=None)
+    res = eq.solve(state, t_range=0.02, dt=1e-3, backend="hip", tracker=None)
+    assert max_rel(np.array(res.data), ref.data) < 1e-10
+    diff = pde.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 1 - 1j}})
+    for solver in ("euler", "runge-kutta"):
+        ref = diff.solve(fields[0], t_range=0.1, dt=0.01, solver=solver, backend="numpy", tracker=None)
+        res = diff.solve(fields[0], t_range=0.1, dt=0.01, solver=solver, backend="hip", tracker=None)
+        assert max_rel(np.array(res.data), ref.data) < 1e-10
+
+
+def test_operators_on_complex_fields(hip):
+    """`field.laplace(bc, backend="hip")`, `gradient`, `grid.make_operator(...)` on complex data: the parts through the real kernels."""
+    grid = pde.CartesianGrid([[0, 4], [0, 4.5]], [8, 9], periodic=[False, True])   # (dx = 0.5: the scipy yardstick wants one spacing)
+    rng = np.random.default_rng(4)
+    field = pde.ScalarField(grid, rng.uniform(-1, 1, grid.shape) + 1j * rng.uniform(-1, 1, grid.shape))
+    bc = {"x": {"value": 0.3 - 0.7j}, "y": "periodic"}
+    np.testing.assert_allclose(field.laplace(bc, backend="hip").data, field.laplace(bc, backend="scipy").data, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(field.gradient(bc, backend="hip").data, field.gradient(bc, backend="scipy").data, rtol=1e-12, atol=1e-12)
+    op = grid.make_operator("laplace", bc=bc, backend="hip", dtype=complex)
+    np.testing.assert_allclose(op(field.data), field.laplace(bc, backend="scipy").data, rtol=1e-12, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        grid.make_operator("gradient_squared", bc=bc, backend="hip", dtype=complex)
+
+
+def test_what_is_refused(hip):
+    grid = pde.UnitGrid([6, 6])
+    field = pde.ScalarField(grid, 1.0 + 1j)
+    with pytest.raises((NotImplementedError, RuntimeError)):   # mixed condition with a complex coefficient couples the parts
+        pde.PDE({"c": "I * laplace(c)"}, bc={"type": "mixed", "value": 1j, "const": 1}).solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        pde.PDE({"c": "gradient_squared(c) + I * c"}).solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)

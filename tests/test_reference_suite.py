@@ -34,8 +34,10 @@ SUITES: dict[str, dict[str, str]] = {
     "backends/generic/test_boundaries.py": {},
     # solver x backend matrix, erf known answer (tests/solvers/test_generic_solvers.py:123-230)
     # ... incl. Euler-Maruyama with the device generator (additive noise; Milstein / implicit solvers are refused)
+    # ... and complex fields (`test_solvers_complex`: `-I * laplace(c)` against the real system of its parts) with every EXPLICIT solver
     "solvers/test_generic_solvers.py": {
-        "test_solvers_complex": "complex-valued fields (real fp64 / fp32 only)",
+        "test_solvers_complex[hip-CrankNicolsonSolver]": "implicit solvers are out of scope (SURVEY 8: explicit steppers)",
+        "test_solvers_complex[hip-ImplicitSolver]": "implicit solvers are out of scope (SURVEY 8: explicit steppers)",
     },
     # noise scaling: Kolmogorov-Smirnov test of the final field against the analytical normal distribution
     "pdes/test_diffusion_pdes.py": {},

@@ -58,9 +58,13 @@ def test_complex_equation_equals_the_real_system_of_its_parts(rng, solver):
     tests/solvers/test_generic_solvers.py:80-97): the same kernels on the same planar components - identical bits."""
     grid = pde_hip.UnitGrid([12, 10, 130], periodic=[True, False, True])
     a, b = rng.uniform(-1, 1, grid.shape), rng.uniform(-1, 1, grid.shape)
-    bc = {"x": "periodic", "y": {"derivative": 0.1}, "z": "periodic"}
-    res_c = pde_hip.PDE({"c": "-I * laplace(c)"}, bc=bc).solve(pde_hip.ScalarField(grid, a + 1j * b), t_range=0.02, dt=1e-3, solver=solver, backend="hip")
-    res_r = pde_hip.PDE({"a": "laplace(b)", "b": "-laplace(a)"}, bc=bc).solve(
+    def bc(value):
+        return {"x": "periodic", "y": {"derivative": value}, "z": "periodic"}
+
+    # the complex condition d_n c = 0.1 - 0.3 i: the real part belongs to the operand a, the imaginary part to the operand b - in the real
+    # system the conditions are named after the EQUATION an operator stands in (pde/pdes/pde.py:232-264): laplace(b) is in a's equation
+    res_c = pde_hip.PDE({"c": "-I * laplace(c)"}, bc=bc(0.1 - 0.3j)).solve(pde_hip.ScalarField(grid, a + 1j * b), t_range=0.02, dt=1e-3, solver=solver, backend="hip")
+    res_r = pde_hip.PDE({"a": "laplace(b)", "b": "-laplace(a)"}, bc_ops={"a:laplace": bc(-0.3), "b:laplace": bc(0.1)}).solve(
         pde_hip.FieldCollection([pde_hip.ScalarField(grid, a), pde_hip.ScalarField(grid, b)]), t_range=0.02, dt=1e-3, solver=solver, backend="hip")
     got = np.array(res_c.data)
     np.testing.assert_array_equal(got.real, np.array(res_r.data)[0])

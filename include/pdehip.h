@@ -209,6 +209,11 @@ int pdehip_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_fa
  * array is written, its ghost cells are left untouched). */
 int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout,
                    void *stream);
+/* The SPECTRAL Laplacian of periodic 1-D / 2-D grids: out = ifft(factor * fft(in)).real with factor = -(2 pi fftfreq)^2 summed over the
+ * axes - `_make_laplace_numba_spectral_1d` / `_2d`, pde/backends/numba/operators/cartesian.py:232-330, chosen by `spectral=True` /
+ * `use_spectral` (:359-372).  The transform is hipFFT's (loaded at run time); ghost cells of in_full are not read (every axis is
+ * periodic: the caller checks).  3-D: error "not implemented", like the reference (:369-370). */
+int pdehip_laplace_spectral(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream);
 int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out,
                     int out_layout, void *stream);
 int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, void *out,
@@ -546,12 +551,25 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
  * p[1] = t).  state_a holds the state on entry; *result is the buffer that holds it afterwards.  uses_time = 0 allows replaying a
  * captured hipGraph for long runs (PDEHIP_JIT_GRAPH=1; measured slower than the plain launches of this loop, so off by default). */
 #define PDEHIP_JIT_NONE INT32_MIN
+/* DECOMPOSED grids (one box per GPU): a pass whose `exchange` is set fills the ghost layers of its `src` from the neighbours before it
+ * runs - pdehip_halo_exchange (slab: lower / upper) or pdehip_block_exchange (blocks: nb6) on the loop's stream - like `_MPIBC` inside
+ * every operator of the reference's MPI path (pde/grids/boundaries/local.py:561-662, pde/solvers/explicit_mpi.py:133-226).  The caller
+ * sets it on the FIRST pass of an evaluation that applies operators to an array (the operand of a nested operator is an intermediate
+ * field: exchanged like the state); the faces towards neighbours are PDEHIP_BC_SKIP in `faces`.  The adaptive loops reduce their
+ * error norm over all ranks of `comm` (MAX, NaN wins: pde/backends/base.py:678-712). */
+typedef struct {
+    void *comm;
+    int32_t blocks;          /* 0: axis-0 slab (lower / upper), 1: block decomposition (nb6) */
+    int32_t lower, upper;
+    int32_t nb6[6];
+} pdehip_exchange_t;
 typedef struct {
     void *handle;
     int32_t src;
     int32_t extras[3];
     int32_t out;
     const pdehip_bc_face_t *faces;   /* conditions applied to src before the pass (NULL: none) */
+    const pdehip_exchange_t *exchange;   /* decomposed grids: exchange the ghost layers of src first (NULL: nothing) */
 } pdehip_jit_pass_t;
 int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                          void *state_a, void *state_b, int ncomp, double dt, double t0, int uses_time, int64_t nsteps,

@@ -119,6 +119,13 @@ def laplace(g, arr_full, layout=_abi.OUT_VALID):
     return out
 
 
+def laplace_spectral(g, arr_full, layout=_abi.OUT_VALID):
+    """FFT-based Laplacian of periodic 1-D / 2-D grids (pde/backends/numba/operators/cartesian.py:232-330)."""
+    out = _out_array(g, (), layout, arr_full.dtype)
+    _check(lib().oracle_laplace_spectral(C.byref(g), _p(arr_full), _p(out), layout), "laplace_spectral")
+    return out
+
+
 def set_corner_points_2d(g, periodic, arr_full) -> None:
     per = (C.c_int * 2)(*[int(bool(p)) for p in periodic])
     _check(lib().oracle_set_corner_points_2d(C.byref(g), per, _p(arr_full)), "set_corner_points_2d")

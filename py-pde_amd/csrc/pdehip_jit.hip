@@ -751,6 +751,22 @@ hipStream_t g_loop_cap = nullptr;
 hipEvent_t g_loop_ev = nullptr;
 
 // all passes of one evaluation: `src` / `extras` index -1 - k = component k of `cur`, `out` index -1 - k = component k of `nxt`
+// decomposed grids: the ghost layers of a pass's operand travel before the pass (pdehip_exchange_t, include/pdehip.h)
+int exchange_operand(const pdehip_grid_t *g, const pdehip_jit_pass_t &p, void *src, void *stream)
+{
+    const pdehip_exchange_t *x = p.exchange;
+    if (!x) return 0;
+    int nb6[6];
+    for (int i = 0; i < 6; i++) nb6[i] = x->nb6[i];
+    return x->blocks ? pdehip_block_exchange(x->comm, g, nb6, src, stream) : pdehip_halo_exchange(x->comm, g, src, x->lower, x->upper, stream);
+}
+void *exchange_comm(const pdehip_jit_pass_t *passes, int npasses)
+{
+    for (int q = 0; q < npasses; q++)
+        if (passes[q].exchange && passes[q].exchange->comm) return passes[q].exchange->comm;
+    return nullptr;
+}
+
 int run_passes(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, char *cur, char *nxt,
                size_t comp_bytes, const double *params, void *stream, int skip_last = 0)
 {
@@ -762,6 +778,7 @@ int run_passes(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npas
         };
         void *out = p.out >= 0 ? fixed[p.out] : (void *)(nxt + (size_t)(-1 - p.out) * comp_bytes);
         const void *ex[3] = {in(p.extras[0]), in(p.extras[1]), in(p.extras[2])};
+        PDEHIP_TRY(exchange_operand(g, p, in(p.src), stream));
         PDEHIP_TRY(jit_apply_impl(p.handle, g, in(p.src), ex, out, params, 2, p.faces, stream, nullptr, nullptr));
     }
     return 0;
@@ -781,6 +798,7 @@ int loop_steps(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npas
             };
             void *out = p.out >= 0 ? fixed[p.out] : (void *)(nxt + (size_t)(-1 - p.out) * comp_bytes);
             const void *ex[3] = {in(p.extras[0]), in(p.extras[1]), in(p.extras[2])};
+            PDEHIP_TRY(exchange_operand(g, p, in(p.src), stream));
             PDEHIP_TRY(jit_apply_impl(p.handle, g, in(p.src), ex, out, params, 2, p.faces, stream, nullptr, nullptr));
         }
         char *t = cur; cur = nxt; nxt = t;
@@ -905,7 +923,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
     // loop 3.68 us - the run-time built kernels carry 1.3 KB of arguments per node; the graph stays an option (PDEHIP_JIT_GRAPH=1)
     static int graphs = -1;
     if (graphs < 0) { const char *e = getenv("PDEHIP_JIT_GRAPH"); graphs = (e && e[0] == '1') ? 1 : 0; }
-    if (graphs && !uses_time && nsteps - s >= 4 * kBlock) {
+    if (graphs && !uses_time && nsteps - s >= 4 * kBlock && !exchange_comm(passes, npasses)) {   // (no RCCL groups inside a captured graph)
         // launch-bound regime: replay a captured block (cached per passes / arrays / dt)
         std::vector<char> key;
         auto put = [&](const void *ptr, size_t len) { key.insert(key.end(), (const char *)ptr, (const char *)ptr + len); };
@@ -979,11 +997,14 @@ struct JitEval {
         int nk = 0;
         while (nk < 5 && sf->k[nk]) nk++;
         int done = 0;
+        PDEHIP_TRY(exchange_operand(g, last, arr(last.src), st));
         PDEHIP_TRY(pdehip_jit_apply_stage(last.handle, g, arr(last.src), ex, k_out, params, 2, last.faces, sf->kind, sf->y, nk, sf->k, sf->c,
                                           sf->c_new, sf->out2, sf->err, &done, st));
         if (done) { *fused = true; return 0; }
         stage_fuse = -1;   // only the generic kernel covers this grid: plain pass + pointwise combination from now on
-        return run_passes(g, passes + npasses - 1, 1, fixed, (char *)in, (char *)k_out, comp_bytes, params, st);
+        pdehip_jit_pass_t again = last;
+        again.exchange = nullptr;   // (its operand has just been exchanged)
+        return run_passes(g, &again, 1, fixed, (char *)in, (char *)k_out, comp_bytes, params, st);
     }
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *st) { return pdehip_lincomb(g, ncomp, out, y, n, c, k, st); }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, ncomp, y, k1, k2, k3, k4, st); }
@@ -993,7 +1014,12 @@ struct JitEval {
         return pdehip_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err, st);
     }
     int zero(void *ptr, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(st))); return 0; }
-    int reduce_error(double *, void *) { return 0; }
+    // decomposed grids: MAX over the ranks of the communicator the passes exchange through (NaN wins); nothing on one device
+    int reduce_error(double *err_dev, void *st)
+    {
+        void *comm = exchange_comm(passes, npasses);
+        return comm ? pdehip_allreduce_max(comm, err_dev, st) : 0;
+    }
     int read_scalar(double *host, const double *dev, void *st)
     {
         PDEHIP_HIP(hipMemcpyAsync(host, dev, sizeof(double), hipMemcpyDeviceToHost, as_stream(st)));

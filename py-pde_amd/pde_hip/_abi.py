@@ -87,10 +87,17 @@ class BcProgFace(C.Structure):
 JIT_NONE = -(2**31)   # PDEHIP_JIT_NONE
 
 
+class Exchange(C.Structure):
+    """``pdehip_exchange_t``: where the ghost layers of a pass's operand come from on a decomposed grid."""
+
+    _fields_ = [("comm", C.c_void_p), ("blocks", C.c_int32), ("lower", C.c_int32), ("upper", C.c_int32), ("nb6", C.c_int32 * 6)]
+
+
 class JitPass(C.Structure):
     """``pdehip_jit_pass_t``: one pass of the Euler loop of an expression PDE (``pdehip_jit_euler_run``)."""
 
-    _fields_ = [("handle", C.c_void_p), ("src", C.c_int32), ("extras", C.c_int32 * 3), ("out", C.c_int32), ("faces", C.c_void_p)]
+    _fields_ = [("handle", C.c_void_p), ("src", C.c_int32), ("extras", C.c_int32 * 3), ("out", C.c_int32), ("faces", C.c_void_p),
+                ("exchange", C.c_void_p)]
 
 
 class Adaptive(C.Structure):
@@ -157,6 +164,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
     "full_to_hostfull": ([_pg, _i, _vp, _vp], True),
     "set_ghost_cells": ([_pg, _i, _pf, _vp], True),
     "laplace": ([_pg, _vp, _vp, _i], True),
+    "laplace_spectral": ([_pg, _vp, _vp, _i], True),
     "gradient": ([_pg, _i, _vp, _vp, _i], True),
     "divergence": ([_pg, _i, _vp, _vp, _i], True),
     "gradient_squared": ([_pg, _i, _vp, _vp, _i], True),

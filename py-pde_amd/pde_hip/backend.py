@@ -1213,7 +1213,9 @@ class HipBackendMixin:
             return err_dev.value(stream)
 
         ctl = None
-        if post_step is None and hasattr(erhs, "rk_run") and reduce_error is None and not is_complex and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+        # (decomposed grids: the C loops reduce the error over the ranks themselves when the passes carry their exchange descriptor)
+        reduces_in_c = reduce_error is None or bool(getattr(erhs, "reduces_error_in_loops", False))
+        if post_step is None and hasattr(erhs, "rk_run") and reduces_in_c and not is_complex and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
             # the adaptive loop itself in C (pdehip_jit_rk_run: pde/backends/numba/_solvers.py:199-319 is jitted in the reference)
             from .solvers import AdaptiveStatistics
 
@@ -1540,6 +1542,9 @@ class HipBackendMixin:
             solver.info["post_step_data"] = None   # no hook defined: the normal case
             return None
         solver.info["post_step_data"] = data
+        device_hook = self._make_device_post_step(solver, state, hook, data)
+        if device_hook is not None:
+            return device_hook
         _logger.warning("post-step hook of %s runs on the host: the state crosses PCIe twice per step", solver.pde.__class__.__name__)
 
         def post_step(arr: DeviceArray, t: float) -> DeviceArray:
@@ -1556,6 +1561,40 @@ class HipBackendMixin:
             arr.set_valid(np.asarray(host, dtype=arr.dtype), self.stream)
             return arr
 
+        return post_step
+
+    def _make_device_post_step(self, solver, state, hook, data):
+        """The hook as ONE run-time compiled pointwise pass on the device (``pde_hip/hooks.py``: the hook is traced once with a symbolic
+        array - masked assignment, ``np.clip`` / ``np.where`` / ``np.minimum`` ..., arithmetic with ``t``), or None when it cannot be
+        traced (reductions, control flow on values, hook data that changes, states that are not one real scalar field): then the host
+        round trip below.  The reference compiles hooks into its jitted loops (``pde/backends/numba/_solvers.py:22-64``).
+        ``PDEHIP_DEVICE_HOOKS=0`` switches the tracing off."""
+        if os.environ.get("PDEHIP_DEVICE_HOOKS", "1") == "0" or state.__class__.__name__ != "ScalarField" or np.dtype(state.dtype).kind != "f":
+            return None
+        from .expr import ExpressionPlan, ExpressionRhs
+        from .hooks import trace_hook
+
+        expr = trace_hook(hook, data, tuple(state.grid.shape), state.dtype)
+        if expr is None:
+            return None
+        try:
+            plan = ExpressionPlan(expr, "c", {}, axes=tuple(state.grid.axes))
+            if plan.operators_used or plan.aux_used or len(plan.passes) != 1:
+                return None
+            erhs = ExpressionRhs(self, plan, self.grid_info(state.grid, state.dtype), {}, {})
+        except Exception:  # noqa: BLE001 - an expression the planner / printer cannot take: host path
+            return None
+        spare: list[DeviceArray | None] = [None]
+        _logger.info("post-step hook of %s runs on the device as `c <- %s`", solver.pde.__class__.__name__, expr)
+
+        def post_step(arr: DeviceArray, t: float) -> DeviceArray:
+            out = spare[0] if spare[0] is not None and spare[0] is not arr else arr.empty_like()
+            erhs.apply(arr, out, "rate", 0.0, float(t))
+            spare[0] = arr          # (the array the state just left serves the next call)
+            return out
+
+        post_step.on_device = True  # type: ignore[attr-defined]
+        post_step.expression = expr  # type: ignore[attr-defined]
         return post_step
 
     def make_inner_stepper(self, solver, state):

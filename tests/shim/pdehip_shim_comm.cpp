@@ -612,6 +612,17 @@ struct JitEval {
     size_t comp_bytes;
     int stage_fuse;
     void *bc_program;
+    bool skip_exchange_once = false;
+    // decomposed grids: the ghost layers of a pass's operand travel before the pass (pdehip_exchange_t, include/pdehip.h)
+    int exchange_operand(const pdehip_grid_t *gg, const pdehip_jit_pass_t &p, void *src, void *st)
+    {
+        const pdehip_exchange_t *x = p.exchange;
+        if (!x) return 0;
+        if (skip_exchange_once) { skip_exchange_once = false; return 0; }
+        int nb6[6];
+        for (int i = 0; i < 6; i++) nb6[i] = x->nb6[i];
+        return x->blocks ? pdehip_block_exchange(x->comm, gg, nb6, src, st) : pdehip_halo_exchange(x->comm, gg, src, x->lower, x->upper, st);
+    }
     int run(int first, int count, char *in, char *k_out, const double *params, void *st)
     {
         for (int q = first; q < first + count; q++) {
@@ -622,6 +633,7 @@ struct JitEval {
             };
             void *out = p.out >= 0 ? fixed[p.out] : (void *)(k_out + (size_t)(-1 - p.out) * comp_bytes);
             const void *ex[3] = {arr(p.extras[0]), arr(p.extras[1]), arr(p.extras[2])};
+            SLAB_TRY(exchange_operand(g, p, arr(p.src), st));
             SLAB_TRY(pdehip_jit_apply(p.handle, g, arr(p.src), ex, out, params, 2, p.faces, st));
         }
         return 0;
@@ -643,10 +655,12 @@ struct JitEval {
         int nk = 0;
         while (nk < 5 && sf->k[nk]) nk++;
         int done = 0;
+        SLAB_TRY(exchange_operand(g, last, arr(last.src), st));
         SLAB_TRY(pdehip_jit_apply_stage(last.handle, g, arr(last.src), ex, k_out, params, 2, last.faces, sf->kind, sf->y, nk, sf->k, sf->c, sf->c_new,
                                         sf->out2, sf->err, &done, st));
         if (done) { *fused = true; return 0; }
         stage_fuse = -1;
+        skip_exchange_once = true;     // (the operand of the last pass has just been exchanged)
         return run(npasses - 1, 1, (char *)in, (char *)k_out, params, st);
     }
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, ncomp, out, y, n, c, k)); return 0; }
@@ -658,7 +672,12 @@ struct JitEval {
         return 0;
     }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
-    int reduce_error(double *, void *) { return 0; }
+    int reduce_error(double *err_dev, void *st)
+    {
+        for (int q = 0; q < npasses; q++)
+            if (passes[q].exchange && passes[q].exchange->comm) return pdehip_allreduce_max(passes[q].exchange->comm, err_dev, st);
+        return 0;
+    }
     int read_scalar(double *host, const double *dev, void *) { return shim_read(host, dev); }
     int fail_runtime(const char *fmt, double v) { return failf(E_RUNTIME, fmt, v); }
 };

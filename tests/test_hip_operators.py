@@ -286,3 +286,26 @@ def test_full_size_properties_512cubed(backend):
     setter(dv)
     backend._lib.laplace(info.ref, dv.ptr, out.ptr, _abi.OUT_FULL, None)
     assert max_rel(lap_c, 2.5 * lap_u + out.get_valid()) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape,bounds", [((64,), [[0, 6.0]]), ((48, 40), [[0, 4.0], [0, 3.0]]), ((33, 27), [[0, 3.3], [0, 2.7]]), ((512, 512), [[0, 512.0]] * 2)])
+def test_spectral_laplace_against_numpy_fft(rng, shape, bounds, dtype):
+    """`spectral=True` (pde/backends/numba/operators/cartesian.py:232-330): hipFFT + the factor table against the reference's formula
+    evaluated with numpy's FFT in double, and - small grids - against the oracle's plain DFT."""
+    backend = pde_hip.get_backend("hip")
+    grid = pde_hip.CartesianGrid(bounds, list(shape), periodic=True)
+    data = rng.uniform(-1, 1, shape).astype(dtype)
+    got = pde_hip.ScalarField(grid, data, dtype=dtype).laplace("periodic", backend=backend, spectral=True).data
+    ks = [np.fft.fftfreq(n, d) for n, d in zip(grid.shape, grid.discretization)]
+    d64 = data.astype(np.float64)
+    if len(shape) == 1:
+        expect = np.fft.ifft(-((2 * np.pi * ks[0]) ** 2) * np.fft.fft(d64)).real
+    else:
+        expect = np.fft.ifft2(-4 * np.pi**2 * (ks[0][:, None] ** 2 + ks[1][None, :] ** 2) * np.fft.fft2(d64)).real
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    assert got.dtype == dtype and max_rel(got, expect) < tol
+    if np.prod(shape) <= 4096:
+        assert max_rel(O.laplace_spectral(oracle_grid(grid, dtype), to_full(grid, data)), expect) < tol
+    with pytest.raises(NotImplementedError):
+        pde_hip.ScalarField(pde_hip.UnitGrid([8, 8, 8], periodic=True), 1.0).laplace("periodic", backend=backend, spectral=True)

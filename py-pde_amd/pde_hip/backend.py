@@ -1568,9 +1568,19 @@ class HipBackendMixin:
         array - masked assignment, ``np.clip`` / ``np.where`` / ``np.minimum`` ..., arithmetic with ``t``), or None when it cannot be
         traced (reductions, control flow on values, hook data that changes, states that are not one real scalar field): then the host
         round trip below.  The reference compiles hooks into its jitted loops (``pde/backends/numba/_solvers.py:22-64``).
-        ``PDEHIP_DEVICE_HOOKS=0`` switches the tracing off."""
-        if os.environ.get("PDEHIP_DEVICE_HOOKS", "1") == "0" or state.__class__.__name__ != "ScalarField" or np.dtype(state.dtype).kind != "f":
+        The trace CALLS the hook once with a symbolic array.  By default only hooks given as ``PDE(..., post_step_hook=f)`` are traced - the
+        form the reference hands to its backend's compiler (``pde/pdes/pde.py:691-706``: compiled code has no Python side effects); a
+        class that overrides ``make_post_step_hook`` may count calls or collect data in Python and keeps the host path unless
+        ``PDEHIP_DEVICE_HOOKS=1`` asks for the trace (``=0``: never)."""
+        mode = os.environ.get("PDEHIP_DEVICE_HOOKS", "auto")
+        if mode == "0" or state.__class__.__name__ != "ScalarField" or np.dtype(state.dtype).kind != "f":
             return None
+        if mode != "1":
+            eq = solver.pde
+            plain = getattr(eq, "post_step_hook", None) is not None and not any(
+                "make_post_step_hook" in vars(c) for c in type(eq).__mro__ if c.__name__ not in ("PDE", "PDEBase", "object") and c.__module__ != "pde.pdes.pde")
+            if not plain:
+                return None
         from .expr import ExpressionPlan, ExpressionRhs
         from .hooks import trace_hook
 

@@ -177,8 +177,10 @@ class PDE(PDEBase):
     use_noise_variance = True
     use_noise_realization = False
 
-    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None, noise=0, rng=None, user_funcs=None):
+    def __init__(self, rhs: dict[str, str], *, bc="auto_periodic_neumann", bc_ops=None, consts=None, noise=0, rng=None, user_funcs=None,
+                 post_step_hook=None):
         super().__init__()
+        self.post_step_hook = post_step_hook          # `f(state_data, t) -> state_data` after every step (pde/pdes/pde.py:99-118, :671-706)
         self.user_funcs = dict(user_funcs or {})      # Python functions the expressions may call (traced symbolically by the backend)
         self.rhs = {k: str(v) for k, v in rhs.items()}
         self.variables = tuple(self.rhs)
@@ -210,6 +212,18 @@ class PDE(PDEBase):
     @property
     def is_sde(self) -> bool:
         return bool((self.noise != 0).any())
+
+    def make_post_step_hook(self, state, backend="numpy"):
+        """``(hook(state_data, t, data) -> (state_data, data), initial data)`` around ``post_step_hook`` (pde/pdes/pde.py:671-706)."""
+        if self.post_step_hook is None:
+            msg = "`post_step_hook` not set"
+            raise NotImplementedError(msg)
+        user = self.post_step_hook
+
+        def post_step_hook_impl(state_data, t, post_step_data):
+            return user(state_data, t), None
+
+        return post_step_hook_impl, None
 
     @property
     def complex_valued(self) -> bool:

@@ -582,9 +582,21 @@ def test_traced_post_step_hook_runs_on_the_device(rng, shape, solver, adaptive, 
         return orig(self, *a, **k)
 
     monkeypatch.setattr(device.DeviceArray, "get_valid", counting)
+    monkeypatch.setenv("PDEHIP_DEVICE_HOOKS", "1")      # (a class with its own make_post_step_hook is traced on request only)
     res, info = eq.solve(pde_hip.ScalarField(grid, y0), **kw)
     on_device = np.array(res.data)
     downloads_device = counts["down"]
+    # ... a hook given as PDE(..., post_step_hook=f) is traced by default
+    monkeypatch.delenv("PDEHIP_DEVICE_HOOKS")
+    counts["down"] = 0
+
+    def clip(state_data, t):
+        state_data[state_data > 0.6] = 0.6
+        return state_data
+
+    plain = pde_hip.PDE({"c": "0.8 * laplace(c)"}, post_step_hook=clip)
+    res_plain = plain.solve(pde_hip.ScalarField(grid, y0), **kw)[0]
+    assert counts["down"] <= 2 and np.array(res_plain.data).max() <= 0.6
     monkeypatch.setenv("PDEHIP_DEVICE_HOOKS", "0")
     counts["down"] = 0
     res_host, info_host = eq.solve(pde_hip.ScalarField(grid, y0), **kw)

@@ -301,10 +301,14 @@ def extra_configs(backend) -> dict:
     rng = np.random.default_rng(0)
     out = {}
 
-    def run(name, eq, grid, dtype, t_range, dt, solver, lo=0.0, hi=1.0, **kw):
+    def run(name, eq, grid, dtype, t_range, dt, solver, lo=0.0, hi=1.0, moved_values_per_attempt=0, **kw):
         state = pde_hip.ScalarField(grid, rng.uniform(lo, hi, grid.shape), dtype=dtype)
         eq.solve(state, t_range=t_range / 50, dt=dt, solver=solver, backend=backend, **kw)   # warm-up: allocations, run-time builds
         backend.synchronize()
+        t0 = time.perf_counter()
+        _, short = eq.solve(state, t_range=t_range / 50, dt=dt, solver=solver, backend=backend, ret_info=True, **kw)   # the same again, timed: the
+        backend.synchronize()                                                                                       # fixed cost of a solve
+        wall_short = time.perf_counter() - t0
         t0 = time.perf_counter()
         _, info = eq.solve(state, t_range=t_range, dt=dt, solver=solver, backend=backend, ret_info=True, **kw)
         backend.synchronize()
@@ -313,6 +317,19 @@ def extra_configs(backend) -> dict:
         cells = int(np.prod(grid.shape))
         out[name] = {"steps": steps, "wall_ms": round(wall * 1e3, 2), "us_per_step": round(wall / steps * 1e6, 2),
                      "mcell_steps_per_s": round(cells * steps / wall / 1e6, 1)}
+        attempts = info["solver"].get("attempts")
+        if attempts and moved_values_per_attempt:
+            # an RKF45 attempt of the fused stage sweeps moves, per cell: stages 1-5 read the stage input, y and the earlier slopes and write
+            # the slope and the next input (4 + 5 + 6 + 7 + 8 values), the last stage reads input, y, k1, k3, k4, k5 and writes the new state
+            # (7): 37 values - SURVEY 8d's schedule with separate combination kernels counts 56 (224 B in fp32)
+            # differential timing: (long run - short run) / (attempts of the long run - attempts of the short one) takes the fixed cost of a
+            # solve (stepper construction, upload, download) out of the attempt
+            a_short = int(short["solver"].get("attempts") or 0)
+            t_attempt = (wall - wall_short) / max(1, attempts - a_short) if attempts > a_short else wall / attempts
+            moved = cells * moved_values_per_attempt * np.dtype(dtype).itemsize
+            out[name].update(attempts=int(attempts), us_per_attempt=round(t_attempt * 1e6, 2), moved_bytes_per_attempt=int(moved),
+                             frac_of_peak_on_moved_bytes=round(moved / t_attempt / 1e9 / HBM_PEAK_GBS, 4),
+                             frac_of_peak_on_survey_bytes=round(cells * 56 * np.dtype(dtype).itemsize / t_attempt / 1e9 / HBM_PEAK_GBS, 4))
 
     run("cfg2_diffusion_1024sq_f64_euler", pde_hip.DiffusionPDE(), pde_hip.CartesianGrid([[0, 1024]] * 2, 1024, periodic=True), np.float64, 100.0, 0.1, "euler")
     run("cfg3_cahn_hilliard_512sq_f64_euler_1e4_steps", pde_hip.CahnHilliardPDE(), pde_hip.UnitGrid([512, 512]), np.float64, 10.0, 1e-3, "euler")
@@ -320,7 +337,7 @@ def extra_configs(backend) -> dict:
     # sweeps of that class, NOT the generic expression compiler; the line next to it is a two-pass expression of the same cost that is
     # not of that form (one more term) and goes through the run-time compiled passes (pdehip_jit_rk_run)
     run("cfg5_expression_256cube_f32_rkf45_fused_CH_form", pde_hip.PDE({"c": "laplace(c**3 - c - laplace(c))"}), pde_hip.UnitGrid([256] * 3, periodic=True),
-        np.float32, 1.0, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, adaptive=True)
+        np.float32, 1.0, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, moved_values_per_attempt=37, adaptive=True)
     run("generic_two_pass_expression_256cube_f32_rkf45", pde_hip.PDE({"c": "laplace(c**3 - c - laplace(c)) - 0.01 * c"}), pde_hip.UnitGrid([256] * 3, periodic=True),
         np.float32, 0.3, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, adaptive=True)
     return out

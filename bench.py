@@ -228,13 +228,14 @@ def bench_single(args) -> dict:
     }
     if not args.no_extra:
         out["roofline_operator"] = operator_roofline(backend, lib, spec, cur, nxt, stream, ev, cells, max(1, args.repeats))
-        del a, b
-        try:
-            out["parity"] = parity_bit(backend, n)
+    del a, b
+    try:
+        out["parity"] = parity_bit(backend, n)      # (always: the digest of the state is what makes the N > 1 lines checkable)
+        if not args.no_extra:
             out["extra"] = extra_configs(backend)
-        except Exception as err:   # the metric line must survive a failure of the side measurements; it says so
-            out.setdefault("parity", None)
-            out["extra_error"] = f"{type(err).__name__}: {err}"
+    except Exception as err:   # the metric line must survive a failure of the side measurements; it says so
+        out.setdefault("parity", None)
+        out["extra_error"] = f"{type(err).__name__}: {err}"
     return out
 
 

@@ -150,7 +150,7 @@ def test_the_three_probes_of_the_round3_review(fused):
     assert n == nref and max_rel(got, ref) < 1e-10
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(16))
 def test_fuzz_with_explicit_time_dependence(seed):
     """Random class PDEs whose conditions depend on time and position, random expression PDEs with `t` in the equation, initial step
     sizes that force rejections, tracker interrupts: adaptive Euler, hip (host shim) vs the reference's numpy backend."""
@@ -197,6 +197,8 @@ def test_fuzz_with_explicit_time_dependence(seed):
 
         eq_ref = Restated()
     kw = dict(t_range=float(rng.choice([0.05, 0.2])), dt=float(rng.choice([1e-3, 0.05, 0.3])), solver="euler", adaptive=True, ret_info=True)
+    if which == 1:
+        kw["t_range"] = 0.02      # (the fourth-order equation takes ~1e-4 steps on these grids: keep the reference's runs short)
     interrupts = [None, 0.03][int(rng.integers(2))]
 
     def run(backend):

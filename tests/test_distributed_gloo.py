@@ -759,7 +759,7 @@ def _check_distributed_bench_line(out, world, size, env):
     assert all({"ms_per_step", "compute_only_ms_per_step", "exchange_exposed_ms_per_step", "layers"} <= set(r) for r in out["per_rank"])
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0
     if size not in _SERIAL_DIGEST:
-        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--size", str(size), "--no-cpu-baseline", "--repeats", "1"]
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--size", str(size), "--no-cpu-baseline", "--no-extra", "--repeats", "1"]
         proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={**os.environ, **env}, cwd=str(ROOT))
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
         assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-3000:]
@@ -787,10 +787,10 @@ def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     _check_distributed_bench_line(out, 8, 32, env)
 
 
-FUZZ_CASES = 18    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
+FUZZ_CASES = 10    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
 
 
-@pytest.mark.parametrize("world,decomposition", [(2, "slab"), (3, "slab"), (4, "auto")])
+@pytest.mark.parametrize("world,decomposition", [(3, "slab"), (4, "auto")])
 def test_real_pypde_drives_the_slab_path(world, decomposition):
     """`eq.solve(state, solver="hip_slab", backend="hip")` of the REAL py-pde (pde_hip.pypde_plugin.HipSlabSolver, the
     counterpart of the reference's ExplicitMPISolver) on N ranks under torch.distributed.run: Euler, RK4 and adaptive RKF45

@@ -158,6 +158,35 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
                         (((uintptr_t)a.out) % 16 == 0) && (((uintptr_t)a.in) % 16 == 0) &&
                         (a.y == nullptr || ((uintptr_t)a.y) % 16 == 0) && stage_aligned(a);
     if (n.ndim >= 2 && vec_ok && !tn.force_generic) {
+        // A row that is a few cells longer than a whole number of 64-lane chunks (513 = 4 x 128 + 1): the extra chunk would march every
+        // plane for those few cells AND take the whole-row tile away from the rest (measured at 513^3: 0.48 of the peak against 0.65-0.71
+        // at 512^3, profiles/r03_time_sizes.md).  Split: the aligned part of every row through the vectorised kernel - its last halo
+        // column is the first cell of the remainder, real data in memory - and the remaining columns through the one-cell-per-thread
+        // kernel (same expressions, cartesian.py:147-151 / :220-227).  Ghost cells from memory only (operators on a field whose faces are
+        // set; the sweeps with on-the-fly faces of odd rows are the two-step kernel's, which has no such cliff).
+        static const long split_max = getenv("PDEHIP_ROW_SPLIT") ? atol(getenv("PDEHIP_ROW_SPLIT")) : 8;
+        // The same for a row that ends inside a lane's vector (511 cells of fp64, 2 per lane): without its last n2 % VEC columns the
+        // row takes the instance without the element-wise tail bookkeeping (0.55 -> the rate of 510^3).
+        const long cw = 64L * VEC;
+        long tail = n.n[2] % cw;
+        if (tail == 0 || tail > split_max) tail = n.n[2] % VEC;
+        // (3-D only: on a 2-D grid the second launch costs more than the narrow tiles - 4095 x 4097: 0.046 against 0.039 ms)
+        if (n.ndim == 3 && MODE <= LAP_CH_MU && !a.any_ibc && tail > 0 && split_max > 0 && n.n[2] - tail >= cw && !tn.ry) {
+            NGrid nm = n;
+            nm.n[2] -= tail;
+            LapArgs am = a;
+            am.n2 = nm.n[2];
+            PDEHIP_TRY((launch_laplace_t<T, MODE>(nm, am, o, st)));
+            LapArgs as = a;
+            as.n2 = tail;
+            as.off += nm.n[2];
+            as.o_off += nm.n[2];
+            const long total = as.n0 * as.n1 * as.n2;
+            const long blocks = (total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192;
+            hipLaunchKernelGGL((lap_generic_kernel<T, MODE>), dim3((unsigned)blocks), dim3(256), 0, st, as);
+            PDEHIP_HIP(hipGetLastError());
+            return 0;
+        }
         const bool y_is_in = (a.y == a.in) || a.y == nullptr;
         // chunks per row: cover the whole fastest axis with one wave where possible (contiguous
         // RY x row bytes per wave and plane is what the HBM write path likes) ...

@@ -138,6 +138,13 @@ int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *
                    bool *done);
 // two Euler steps of the diffusion equation in one sweep, BCs of both levels on the fly; *done = false
 // (nothing launched) when the grid / faces are not covered by the kernel (see pdehip_march2.inc)
+// two Euler steps per sweep with faces given as coefficient arrays (pdehip_shell.hip) and the two coefficient sets of a program of
+// expression conditions (pdehip_jit.hip)
+int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2, const pdehip_bc_face_t *faces,
+                       void *bc_program, void *stream, bool *done);
+bool bcprog_reads(void *handle);
+bool bcprog_second_set(void *handle, const double *const_arr, const double **c2, const double **f2);
+int bcprog_run_pair(void *handle, double t0, double t1, void *stream);
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
                           const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain = 0, bool dry_run = false, int ends = 0);
 // one Cahn-Hilliard sweep: mu = c^3 - c - gamma*lap(c) with the faces of c, then (euler) out = c + dt*lap(mu) or

@@ -136,6 +136,10 @@ struct LapArgs {
     // d2 = (r - 2c + l) * dd2 with dd2 = 1 / dx^2 (:150-190).  (At the end: the kernarg offsets of everything else stay.)
     double dd1[3], dd2[3];
     double dg[3];   // LAP_CUSTOM: 0.5 / dx, the scale of the components of `gradient` / `divergence` (cartesian.py:451-454, :876-879)
+    // lap_march_kernel, split rows (launch_laplace_t): the first `strip_blocks` workgroups compute the `strip_n2` columns behind the n2
+    // columns of the vectorised part, one cell per thread and 8 rows per thread (lap_strip)
+    long strip_blocks;
+    int strip_n2;
 };
 
 // per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)

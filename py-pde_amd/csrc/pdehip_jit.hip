@@ -578,6 +578,10 @@ struct BcProg {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     BcFaceDev *faces_dev = nullptr;
+    // the second coefficient set (bcprog_run_pair: the faces of the second level of a two-step sweep), allocated on first use
+    std::vector<BcFaceDev> host;
+    BcFaceDev *faces_dev2 = nullptr;
+    double *second = nullptr;   // 2 * total doubles: per face A then B
     int nfaces = 0;
     long total = 0;
     int reads = 0;     // some face reads the field
@@ -585,7 +589,8 @@ struct BcProg {
 };
 const char *kBcKernel = R"SRC(
 struct BcFaceDev { double *A, *B; long m1, m2; double origin[3], step[3]; int index[3]; long first[3]; int reads; double dx; long start; long soff, sp1, sp2; };
-extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t, const void *state, int esz)
+extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *faces, int nfaces, long total, double t, const void *state, int esz,
+                                                              const BcFaceDev *faces2, double t2)
 {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         int f = 0;
@@ -608,6 +613,11 @@ extern "C" __global__ void __launch_bounds__(256) bc_refresh(const BcFaceDev *fa
         bc_face(f, value, F.dx, c[0], c[1], c[2], t, &a, &b);
         F.A[loc] = a;
         F.B[loc] = b;
+        if (faces2) {   // the second coefficient set: the same faces at time t2 (the second level of a two-step sweep)
+            bc_face(f, value, F.dx, c[0], c[1], c[2], t2, &a, &b);
+            faces2[f].A[loc] = a;
+            faces2[f].B[loc] = b;
+        }
     }
 }
 )SRC";
@@ -695,6 +705,7 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
         }
         start += s.m1 * s.m2;
     }
+    b->host = host;
     b->nfaces = nfaces;
     b->reads = reads ? 1 : 0;
     b->esz = reads ? (int)elem_size(ng.dtype) : 8;
@@ -719,7 +730,9 @@ int pdehip_bcprog_run(void *handle, double t, const void *state_full, void *stre
     const BcFaceDev *faces = b->faces_dev;
     int nfaces = b->nfaces, esz = b->esz;
     long total = b->total;
-    void *kargs[] = {&faces, &nfaces, &total, &t, &state_full, &esz};
+    const BcFaceDev *faces2 = nullptr;
+    double t2 = 0;
+    void *kargs[] = {&faces, &nfaces, &total, &t, &state_full, &esz, &faces2, &t2};
     const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     PDEHIP_HIP(hipModuleLaunchKernel(b->fn, blocks, 1, 1, 256, 1, 1, 0, as_stream(stream), kargs, nullptr));
     return 0;
@@ -732,11 +745,66 @@ int pdehip_bcprog_destroy(void *handle)
     // (the module belongs to the per-source cache of pdehip_bcprog_create and stays loaded: unloading code objects in the middle of a
     // run was the trigger of the lazy-load fault noted in pdehip_kernels.hip)
     if (b->faces_dev) (void)hipFree(b->faces_dev);
+    if (b->faces_dev2) (void)hipFree(b->faces_dev2);
+    if (b->second) (void)hipFree(b->second);
     delete b;
     return 0;
 }
 
 }  // extern "C"
+
+// ---- two coefficient sets per launch pair: the faces of BOTH levels of a two-step sweep (pdehip_shell.hip) ------------------------
+extern "C++" {   // (this part of the file sits inside an extern "C" region)
+namespace pdehip {
+bool bcprog_reads(void *handle) { return handle && static_cast<BcProg *>(handle)->reads != 0; }
+
+static int bcprog_second_alloc(BcProg *b)
+{
+    if (b->second) return 0;
+    PDEHIP_HIP(hipMalloc(&b->second, sizeof(double) * 2 * (size_t)b->total));
+    std::vector<BcFaceDev> h2 = b->host;
+    for (auto &d : h2) {
+        d.A = b->second + 2 * d.start;
+        d.B = d.A + d.m1 * d.m2;
+    }
+    hipError_t e = hipMalloc(&b->faces_dev2, sizeof(BcFaceDev) * h2.size());
+    if (e == hipSuccess) e = hipMemcpy(b->faces_dev2, h2.data(), sizeof(BcFaceDev) * h2.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) PDEHIP_FAIL(E_RUNTIME, "bcprog (second set): %s", hipGetErrorString(e));
+    return 0;
+}
+
+// the coefficient arrays of the second set that belong to the face whose first-set constants are `const_arr`
+bool bcprog_second_set(void *handle, const double *const_arr, const double **c2, const double **f2)
+{
+    BcProg *b = static_cast<BcProg *>(handle);
+    if (!b || bcprog_second_alloc(b) != 0) return false;
+    for (const auto &d : b->host)
+        if (d.A == const_arr) {
+            *c2 = b->second + 2 * d.start;
+            *f2 = *c2 + d.m1 * d.m2;
+            return true;
+        }
+    return false;
+}
+
+// first set for time t0 (the arrays of the face tables), second set for t1; programs that read the field have no second set
+int bcprog_run_pair(void *handle, double t0, double t1, void *stream)
+{
+    BcProg *b = static_cast<BcProg *>(handle);
+    if (!b || b->reads) PDEHIP_FAIL(E_RUNTIME, "internal: two coefficient sets of a program that reads the field");
+    PDEHIP_TRY(bcprog_second_alloc(b));
+    const BcFaceDev *faces = b->faces_dev, *faces2 = b->faces_dev2;   // both sets in ONE launch
+    int nfaces = b->nfaces, esz = b->esz;
+    long total = b->total;
+    const void *state = nullptr;
+    void *kargs[] = {&faces, &nfaces, &total, &t0, &state, &esz, &faces2, &t1};
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    PDEHIP_HIP(hipModuleLaunchKernel(b->fn, blocks, 1, 1, 256, 1, 1, 0, as_stream(stream), kargs, nullptr));
+    return 0;
+}
+}  // namespace pdehip
+}  // extern "C++"
 
 // ---- fixed-step Euler loop over the passes of an expression PDE (include/pdehip.h) ---------------------------------------------
 namespace {

@@ -112,7 +112,14 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     // only the Euler epilogue reads a second array; on-the-fly BCs exist for the four laplace epilogues
     constexpr bool kHasY = (MODE == LAP_EULER);
     constexpr bool kIbc = (MODE <= LAP_CH_MU) || MODE == LAP_STAGE;
-    const dim3 grid((unsigned)a.nblocks), block(64 * WY);
+    // split rows (launch_laplace_t): the workgroups of the strip in front of those of the main part, a multiple of 8 (XCD mapping)
+    a.strip_blocks = 0;
+    if (a.strip_n2 > 0) {
+        if (!(HAS_X && MODE <= LAP_CH_MU && !a.any_ibc)) PDEHIP_FAIL(E_RUNTIME, "internal: split rows reached a sweep without the strip");
+        const long threads = a.n0 * ((a.n1 + 7) / 8) * a.strip_n2;
+        a.strip_blocks = ((threads + 64 * WY - 1) / (64 * WY) + 7) / 8 * 8;
+    }
+    const dim3 grid((unsigned)(a.nblocks + a.strip_blocks)), block(64 * WY);
     if (a.any_ibc && !kIbc) PDEHIP_FAIL(E_RUNTIME, "internal: on-the-fly BCs are not built for the derivative epilogues");
     // rows that end inside a lane's vector, or tiles with whole chunks beyond the row, take the TAILS instance
     const bool tails = (a.n2 % VEC != 0) || (((a.n2 + 64L * VEC - 1) / (64L * VEC)) % CZ != 0);
@@ -169,13 +176,21 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // row takes the instance without the element-wise tail bookkeeping (0.55 -> the rate of 510^3).
         const long cw = 64L * VEC;
         long tail = n.n[2] % cw;
-        if (tail == 0 || tail > split_max) tail = n.n[2] % VEC;
+        // (fp64 only: 511^3 0.584 -> 0.667 of the peak; the three columns an fp32 row of 511 ends with cost more than the bookkeeping: 0.465 -> 0.417)
+        if (tail == 0 || tail > split_max) tail = sizeof(T) == 8 ? n.n[2] % VEC : 0;
         // (3-D only: on a 2-D grid the second launch costs more than the narrow tiles - 4095 x 4097: 0.046 against 0.039 ms)
         if (n.ndim == 3 && MODE <= LAP_CH_MU && !a.any_ibc && tail > 0 && split_max > 0 && n.n[2] - tail >= cw && !tn.ry) {
             NGrid nm = n;
             nm.n[2] -= tail;
             LapArgs am = a;
             am.n2 = nm.n[2];
+            // the strip inside the launch of the main part (its workgroups first: lap_strip) - or, PDEHIP_ROW_SPLIT_SEPARATE=1 (A/B), as
+            // a launch of its own behind it (44 us at 513^3 fp64 against ~10 us inside)
+            static const bool separate = getenv("PDEHIP_ROW_SPLIT_SEPARATE") != nullptr;
+            if (!separate) {
+                am.strip_n2 = (int)tail;
+                return launch_laplace_t<T, MODE>(nm, am, o, st);
+            }
             PDEHIP_TRY((launch_laplace_t<T, MODE>(nm, am, o, st)));
             LapArgs as = a;
             as.n2 = tail;

@@ -180,6 +180,15 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     // Two steps per sweep where the temporal-blocking kernel covers the grid and its BCs (the intermediate
     // level never touches HBM: 16 B per cell for two steps), else one step per sweep.
     bool two_ok = rhs->kind == PDEHIP_RHS_DIFFUSION && !timed;   // (the second level would need the faces at t + dt)
+    // ... which a program of conditions that depend on time and position (not on the field) writes as a second coefficient set: two
+    // steps per sweep with stand-in faces, then the two layers of cells next to those faces again with the true coefficients of both
+    // levels (pdehip_shell.hip).  The same for faces given as arrays that nothing rewrites (conditions that depend on the position).
+    // PDEHIP_TIMED_TWO_STEP=0: one step per sweep (A/B, tests).
+    bool array_faces = false;
+    for (int q = 0; q < 2 * g->ndim; q++) array_faces = array_faces || (rhs->bc_c[q].flags & PDEHIP_BCF_ARRAYS) != 0;
+    const char *two_env = getenv("PDEHIP_TIMED_TWO_STEP");
+    bool two_arr = rhs->kind == PDEHIP_RHS_DIFFUSION && (timed || array_faces) && !(timed && bcprog_reads(rhs->bc_program)) &&
+                   !(two_env && two_env[0] == '0');
     // 2-D grids of a few MB: K steps per launch with the time levels in LDS (pdehip_tile2d.inc) — such grids are bound by
     // launch / cache latency per step, not by HBM.  PDEHIP_TILE2D=off disables it, PDEHIP_TILE2D=<k> caps K,
     // PDEHIP_TILE2D_CELLS=<n> moves the size limit (default 2^21 cells).
@@ -195,6 +204,13 @@ int pdehip_euler_run(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *buf_
     for (int q = 0; q < g->ndim; q++) ncells *= g->shape[q];
     bool tile_ok = g->ndim == 2 && tile_k > 0 && ncells <= tile_cells && !timed;
     auto advance = [&](void *c, void *n, void *st, int64_t left, int *took, int64_t step = 0) -> int {
+        if (two_arr && left >= 2) {
+            if (timed) PDEHIP_TRY(bcprog_run_pair(rhs->bc_program, rhs->t + (double)step * dt, rhs->t + (double)(step + 1) * dt, st));
+            bool done = false;
+            PDEHIP_TRY(euler2_timed_faces(g, c, n, rhs->param, dt, rhs->bc_c, rhs->bc_program, st, &done));
+            if (done) { *took = 2; return 0; }
+            two_arr = false;
+        }
         if (timed) PDEHIP_TRY(refresh_bcs(rhs, rhs->t + (double)step * dt, c, st));   // _solvers.py:100: t = t_start + i * dt
         if (tile_ok) {
             int k = tile2d_max_steps(rhs->kind == PDEHIP_RHS_DIFFUSION ? 0 : 1);

@@ -262,6 +262,70 @@ def test_time_dependent_bcs_in_the_steppers(rng, shape, scheme, nonlinear, expre
     assert np.abs(res.data - y0).max() > 1e-3          # the run did something
 
 
+TWO_STEP_CASES = {
+    # name: (bounds, shape, periodic, bc) - conditions of time and position on some faces, constants / periodic axes on others
+    "2d-all-faces": ([[0, 2], [0, 3]], (37, 70), False, {"x-": {"value_expression": "0.3 * sin(2 * t) + 0.1 * y"}, "x+": {"derivative_expression": "0.2 * cos(t) * y"},
+                                                        "y-": {"type": "mixed_expression", "value": "0.5 + 0.1 * x + 0.2 * t", "const": "0.3 * sin(t + x)"},
+                                                        "y+": {"value_expression": "0.1 * x * cos(2 * t)"}}),
+    "2d-mixed-with-constants": ([[0, 1], [0, 1]], (64, 128), False, {"x-": {"value": 0.2}, "x+": {"derivative_expression": "0.1 * t * y"}, "y": {"derivative": -0.1}}),
+    "2d-periodic-axis": ([[0, 1], [0, 2]], (20, 256), [True, False], {"x": "periodic", "y-": {"value_expression": "sin(3 * t) * x"}, "y+": {"value": 0.3}}),
+    "3d-all-faces": ([[0, 1]] * 3, (12, 10, 130), False, {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z"},
+                                                       "y-": {"value_expression": "x * z * (1 + t)"}, "y+": {"derivative_expression": "0.05 * x * sin(t)"},
+                                                       "z-": {"value_expression": "tanh(x - y) * t"}, "z+": {"derivative_expression": "0.1 * y * cos(2 * t)"}}),
+    "3d-periodic-rows": ([[0, 1], [0, 1], [0, 8]], (9, 8, 128), [False, True, False], {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative": 0.1},
+                                                                                    "y": "periodic", "z-": {"value_expression": "0.1 * t"}, "z+": {"derivative_expression": "0.05 * x * sin(t)"}}),
+    "3d-position-only": ([[0, 1]] * 3, (8, 12, 64), False, {"x": {"value": 0.1}, "y-": {"value_expression": "sin(3 * x) * z"}, "y+": {"derivative": 0.0}, "z": {"derivative_expression": "0.2 * x - y"}}),
+}
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("case", sorted(TWO_STEP_CASES))
+def test_two_steps_per_sweep_with_conditions_of_time_and_position(rng, case, dtype, monkeypatch):
+    """Conditions that depend on time and position ride the two-step sweep (second coefficient set for t + dt, the two layers of cells
+    next to such faces recomputed: pdehip_shell.hip): bit-identical to one step per sweep with a refresh and a ghost pass per step
+    (PDEHIP_TIMED_TWO_STEP=0), odd and even step counts; and the same against the host loop over the oracle's operators."""
+    bounds, shape, periodic, bc = TWO_STEP_CASES[case]
+    grid = pde_hip.CartesianGrid(bounds, shape, periodic=periodic)
+    D = 0.3 * float(min(grid.discretization)) ** 2 / 2e-3      # dt * D / dx^2 = 0.3
+    y0 = rng.uniform(-0.5, 0.5, shape).astype(dtype)
+    dt = 2e-3
+    for nsteps in (8, 7):
+        runs = []
+        for env in ("1", "0"):
+            monkeypatch.setenv("PDEHIP_TIMED_TWO_STEP", env)
+            eq = pde_hip.DiffusionPDE(D, bc=bc)
+            res = eq.solve(pde_hip.ScalarField(grid, y0, dtype=dtype), t_range=nsteps * dt, dt=dt, solver="euler", backend="hip", tracker=None)
+            runs.append(res.data.copy())
+        assert np.array_equal(runs[0], runs[1]), f"{case} {nsteps} steps: max diff {np.abs(runs[0] - runs[1]).max()}"
+        assert np.isfinite(runs[0]).all() and np.abs(runs[0] - y0).max() > 1e-4
+    if dtype == np.float64:
+        rhs = _HostRhs(grid, bc, D)
+        y = y0.astype(np.float64)
+        for i in range(7):
+            y = y + dt * rhs(y, i * dt)
+        assert np.abs(runs[0] - y).max() <= 1e-12 * max(1.0, np.abs(y).max())
+
+
+def test_two_steps_per_sweep_with_position_dependent_faces_in_a_replayed_graph(rng, monkeypatch):
+    """Faces given as arrays that nothing rewrites (conditions of the position only), a run long enough for the captured block of steps
+    (pdehip_euler_run replays a hipGraph on small grids): the two-step sweep + the cells next to the faces inside the graph."""
+    grid = pde_hip.CartesianGrid([[0, 1], [0, 2]], (48, 96))
+    bc = {"x-": {"value_expression": "sin(3 * y)"}, "x+": {"derivative": 0.1}, "y-": {"derivative_expression": "0.2 * x"}, "y+": {"value_expression": "x * (1 - x)"}}
+    y0 = rng.uniform(-0.5, 0.5, grid.shape)
+    D, dt, nsteps = 0.02, 2e-3, 203
+    runs = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("PDEHIP_TIMED_TWO_STEP", env)
+        res = pde_hip.DiffusionPDE(D, bc=bc).solve(pde_hip.ScalarField(grid, y0), t_range=nsteps * dt, dt=dt, solver="euler", backend="hip", tracker=None)
+        runs.append(res.data.copy())
+    assert np.array_equal(runs[0], runs[1]), np.abs(runs[0] - runs[1]).max()
+    rhs = _HostRhs(grid, bc, D)
+    y = y0.copy()
+    for i in range(nsteps):
+        y = y + dt * rhs(y, 0.0)
+    assert np.abs(runs[0] - y).max() <= 1e-12
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # f3: post-step hooks
 # ----------------------------------------------------------------------------------------------------------------------

@@ -140,6 +140,9 @@ struct LapArgs {
     // columns of the vectorised part, one cell per thread and 8 rows per thread (lap_strip)
     long strip_blocks;
     int strip_n2;
+    // euler2_kernel, "open" rows (launch_euler2_tv): the tiles cover whole chunks only, the row goes on for one or two cells that another
+    // kernel computes (pdehip_shell.hip) - the last tile is not moved back to the end of the row
+    int z_open;
 };
 
 // per-axis central first and second derivatives at a cell, by normalised axis (a 2-D grid uses entries 1 and 2)

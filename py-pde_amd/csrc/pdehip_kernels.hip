@@ -469,6 +469,15 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
     // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
     // of non-periodic rows has no exactly fitting tile at all.
+    // "Open" rows: a row one or two cells longer than a whole number of chunks (513 = 4 x 128 + 1) gave the moved last chunk a wave of
+    // its own that marched every plane for one vector - 25 % more waves (fp64 513^3 0.281 against 0.228 ms per step at 512^3, fp32 0.268
+    // against 0.167).  Instead the tiles cover the whole chunks - the halo columns right of the last one are real cells, or the virtual
+    // column through the `zhi2` code of the ragged instances - and the remaining columns are recomputed from the input by the LDS-tiled
+    // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
+    static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
+    long open_tail = 0;
+    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 2) open_tail = a.n2 % CW;
+    const long n2t = a.n2 - open_tail;   // the columns the tiles cover
     const int ry_want = ry;
     while (ry > 1 && a.n1 % ry) ry /= 2;
     if (has_y && ry < ry_want) {
@@ -478,12 +487,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         else if (ry == 1) ry = 2;   // (1-row tiles exist for periodic rows of fp32 grids only and recompute 3 x)
     }
     // the stage epilogue (six more streams) does not fit the ragged 4-row fp64 tile without spilling: 2-row tiles there
-    const long n2v = (a.n2 + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
+    const long n2v = (n2t + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
     if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
     if (tall) ry = 8;
-    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != a.n2 && a.n2 < CW)) return 0;
-    const bool overlap = n2v != a.n2 || a.n1 % ry != 0;
+    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
+    const bool overlap = n2v != n2t || a.n1 % ry != 0;
     // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
     // with local faces): the narrow tile takes those grids (launch_euler2_t)
     if (sizeof(T) == 4 && VEC == 4 && ((has_y && a.n1 % ry != 0 && !a.per[1]) || (a.n2 % CW == 1 && !a.per[2]))) return 0;
@@ -494,7 +503,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         for (int m = 0; m < 5; m++) alias = alias || (a.st_k[m] && (a.st_k[m] == a.st_out || a.st_k[m] == a.out));
         if (alias) return 0;
     }
-    a.ntz = (a.n2 + CW - 1) / CW;   // the row may end inside the last chunk
+    a.ntz = (n2t + CW - 1) / CW;   // the row may end inside the last chunk
+    a.z_open = open_tail > 0;
     a.nty = (a.n1 + ry - 1) / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
@@ -615,7 +625,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // ragged-row code): compiled into the hot instances they cost 5-9 % through register allocation alone
     const bool xs = xplain > 1;
     // (the virtual rows next to a moved last tile - pdehip_march2.inc: ylo2 / yhi2 - are part of the ragged-row code)
-    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && a.n1 % ry != 0 && !a.per[1]);
+    // (... and so is the virtual FAR column right of the last chunk of an open row with one more cell: zhi2)
+    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && a.n1 % ry != 0 && !a.per[1]) || (open_tail == 1 && !a.per[2]);
     // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
 #if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
     const bool nt = false;   // A/B variant: non-temporal loads, plain stores
@@ -659,6 +670,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
 #undef PDEHIP_E2
     if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
     PDEHIP_HIP(hipGetLastError());
+    if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, st));   // the last one or two columns of every row
     *done = true;
     return 0;
 }
@@ -683,7 +695,12 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
             else {
                 // rows that fill the 128-cell chunks of the narrow tile much better than the 256-cell chunks of the wide one
                 // (300 cells: 78 % against 59 % of the lanes own cells; 513: 80 % against 67 %)
-                const double wide = (double)a.n2 / (double)((a.n2 + 255) / 256 * 256), narrow = (double)a.n2 / (double)((a.n2 + 127) / 128 * 128);
+                // (rows one or two cells beyond whole chunks leave those cells to another kernel: launch_euler2_tv, "open" rows)
+                auto fill = [&](long cw) {
+                    const long t = a.n2 % cw;
+                    return (a.n2 > cw && t >= 1 && t <= 2) ? 1.0 : (double)a.n2 / (double)((a.n2 + cw - 1) / cw * cw);
+                };
+                const double wide = fill(256), narrow = fill(128);
                 if (narrow > 1.15 * wide) { vec = 2; ry = 4; }
             }
         }

@@ -299,4 +299,37 @@ int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double
     return 0;
 }
 
+// The last one or two columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
+// the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
+int shell_open_rows(const NGrid &n, const LapArgs &la, hipStream_t st)
+{
+    ShellArgs a;
+    memset(&a, 0, sizeof(a));
+    a.first_axis = 3 - n.ndim;
+    for (int ax = a.first_axis; ax < 3; ax++) {
+        const int k = n.ndim == 3 ? ax : (ax == 1 ? 0 : 2);   // kernel axis of the normalised axis (2-D: the march axis is the first grid axis)
+        for (int side = 0; side < 2; side++) {
+            ShellFace &F = a.face[ax][side];
+            F.mode = la.per[k] == 1 ? 1 : 2;
+            if (la.per[k] != 0 && la.per[k] != 1) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of a slab sweep");
+            F.c[0] = F.c[1] = la.ibc[k][side].c;
+            F.f[0] = F.f[1] = la.ibc[k][side].f;
+        }
+    }
+    ShellJob &J = a.job[a.njobs++];
+    J.ax = 2; J.side = 1; J.first = 0;
+    J.nb0 = (n.n[0] + 7) / 8; J.nb1 = (n.n[1] + 15) / 16; J.nb2 = 1;   // TileDims<2>
+    const long total = J.nb0 * J.nb1;
+    a.in = la.in; a.out = la.out; a.off = n.off;
+    for (int k = 0; k < 3; k++) { a.n[k] = n.n[k]; a.p[k] = n.p[k]; a.sc[k] = n.lap_scale[k]; a.ni[k] = (int)n.n[k]; }
+    a.pi[0] = (int)n.p[0]; a.pi[1] = (int)n.p[1];
+    for (int k = 0; k < 3; k++) a.per[k] = a.face[k][0].mode == 1 && a.face[k][1].mode == 1;
+    a.s1 = la.s1; a.s2 = la.s2;
+    if (total >= (1L << 31) || n.p[0] >= (1L << 31) || n.p[2] != 1) PDEHIP_FAIL(E_RUNTIME, "internal: grid beyond the index range of the shell kernel");
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((shell_kernel<double>), dim3((unsigned)total), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((shell_kernel<float>), dim3((unsigned)total), dim3(256), 0, st, a);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace pdehip

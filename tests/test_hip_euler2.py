@@ -85,6 +85,12 @@ PERIODIC = list(itertools.product([True, False], repeat=3))
     (np.float32, (7, 9, 257)),
     (np.float32, (4, 35, 518)),
     (np.float32, (5, 6, 130)),      # row shorter than the wide chunk: the narrow tile takes it
+    # "open" rows (one or two cells beyond whole chunks): the tiles cover the chunks, pdehip_shell.hip the remaining columns
+    (np.float64, (12, 20, 257)),
+    (np.float64, (10, 8, 258)),
+    (np.float32, (9, 16, 513)),     # wide fp32 tile when the fastest axis is periodic, the narrow one (virtual far column) otherwise
+    (np.float32, (6, 10, 514)),
+    (np.float32, (6, 8, 385)),      # 3 x 128 + 1: the narrow tile
 ])
 def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
     grid, bc, bcs, data = _setup(shape, list(periodic), dtype)
@@ -213,6 +219,9 @@ PERIODIC2 = list(itertools.product([True, False], repeat=2))
     (np.float32, (7, 100)),
     (np.float64, (11, 131)),     # the last chunk moved back by one cell
     (np.float32, (9, 262)),
+    (np.float64, (11, 129)),     # open rows in 2-D
+    (np.float32, (9, 258)),
+    (np.float32, (12, 514)),     # (one cell beyond the chunks with a local face there: the wide fp32 tile - the only 2-D fp32 one - declines)
 ])
 def test_two_dimensional_grids(backend, periodic, dtype, shape):
     """2-D: the same two-level kernel marching along the first axis (no rows): two diffusion steps per sweep and the

@@ -341,6 +341,32 @@ def extra_configs(backend) -> dict:
         np.float32, 1.0, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, moved_values_per_attempt=37, adaptive=True)
     run("generic_two_pass_expression_256cube_f32_rkf45", pde_hip.PDE({"c": "laplace(c**3 - c - laplace(c)) - 0.01 * c"}), pde_hip.UnitGrid([256] * 3, periodic=True),
         np.float32, 0.3, 1e-3, "runge-kutta", lo=-0.1, hi=0.1, adaptive=True)
+    # the headline grid with walls whose conditions depend on time and position on all six faces (tools/time_bc_program.py): two
+    # steps per sweep with a second coefficient set + the cells next to the faces recomputed (csrc/pdehip_shell.hip); differential timing of two
+    # run lengths (upload, download and run-time builds cancel)
+    n = 512
+    grid = pde_hip.CartesianGrid([[0, 1]] * 3, [n] * 3, periodic=False)
+    dt = 0.1 * float(grid.discretization[0]) ** 2
+    bc = {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z"},
+          "y-": {"value_expression": "x * z * (1 + t)"}, "y+": {"derivative_expression": "0.05 * x * sin(t)"},
+          "z-": {"value_expression": "tanh(x - y) * t"}, "z+": {"derivative_expression": "0.1 * y * cos(2 * t)"}}
+    eq = pde_hip.DiffusionPDE(1.0, bc=bc)
+    state = pde_hip.ScalarField(grid, rng.uniform(-1, 1, grid.shape))
+    eq.solve(state, 4 * dt, dt, solver="euler", backend=backend)
+
+    def timed(count):
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = eq.solve(state, count * dt, dt, solver="euler", backend=backend)
+            float(res.data[0, 0, 0])
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+        return best
+
+    t1, t2 = timed(100), timed(300)
+    out["diffusion_512cube_f64_euler_walls_of_time_and_position"] = {"us_per_step": round((t2 - t1) / 200 * 1e6, 2),
+                                                                     "mcell_steps_per_s": round(n**3 * 200 / (t2 - t1) / 1e6, 1)}
     return out
 
 

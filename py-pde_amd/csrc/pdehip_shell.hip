@@ -25,7 +25,7 @@ struct ShellFace {
     const double *ca[2], *fa[2];
 };
 // one face given as arrays: its two layers of cells as a list of workgroup tiles
-struct ShellJob { int ax, side; long first, nb0, nb1, nb2; };   // first workgroup; workgroups per (normalised) axis
+struct ShellJob { int ax, side; long first, nb0, nb1, nb2; int origin; };   // first workgroup; workgroups per (normalised) axis; first of the two layers
 struct ShellArgs {
     const void *in;
     void *out;
@@ -153,14 +153,14 @@ __device__ __forceinline__ T euler_at(const ShellArgs &a, const Boxes<T> &bx, co
 
 // the tile (b0, b1, b2) of the two layers next to face (AX, side)
 template <typename T, int AX>
-__device__ __forceinline__ void shell_tile(const ShellArgs &a, int side, int b0, int b1, int b2, T *lds0, T *lds1)
+__device__ __forceinline__ void shell_tile(const ShellArgs &a, int origin, int b0, int b1, int b2, T *lds0, T *lds1)
 {
     typedef TileDims<AX> D;
     constexpr int S[3] = {D::S0, D::S1, D::S2};
     constexpr int G0 = S[0] + 4, G1 = S[1] + 4, G2 = S[2] + 4, H0 = S[0] + 2, H1 = S[1] + 2, H2 = S[2] + 2;
     static_assert(G0 * G1 * G2 <= kBox0 && H0 * H1 * H2 <= kBox1, "LDS boxes");
     int o[3] = {b0 * S[0], b1 * S[1], b2 * S[2]};
-    o[AX] = side ? a.ni[AX] - 2 : 0;   // (n >= 4 along every axis: launch_euler2)
+    o[AX] = origin;   // (n >= 4 along every axis: launch_euler2)
     Boxes<T> bx;
     bx.u0 = lds0; bx.u1 = lds1;
     bx.g0 = o[0] - 2; bx.g1 = o[1] - 2; bx.g2 = o[2] - 2;
@@ -215,17 +215,17 @@ __global__ void __launch_bounds__(256) shell_kernel(ShellArgs a)
     for (int m = 1; m < 6; m++)
         if (m < a.njobs && (long)blockIdx.x >= a.job[m].first) q = m;
     long first = a.job[0].first, nb1 = a.job[0].nb1, nb2 = a.job[0].nb2;
-    int ax = a.job[0].ax, side = a.job[0].side;
+    int ax = a.job[0].ax, origin = a.job[0].origin;
 #pragma unroll
     for (int m = 1; m < 6; m++)
-        if (q == m) { first = a.job[m].first; nb1 = a.job[m].nb1; nb2 = a.job[m].nb2; ax = a.job[m].ax; side = a.job[m].side; }
+        if (q == m) { first = a.job[m].first; nb1 = a.job[m].nb1; nb2 = a.job[m].nb2; ax = a.job[m].ax; origin = a.job[m].origin; }
     long b = (long)blockIdx.x - first;
     const long b2 = b % nb2;
     b /= nb2;
     const long b1 = b % nb1, b0 = b / nb1;
-    if (ax == 0) shell_tile<T, 0>(a, side, (int)b0, (int)b1, (int)b2, lds0, lds1);
-    else if (ax == 1) shell_tile<T, 1>(a, side, (int)b0, (int)b1, (int)b2, lds0, lds1);
-    else shell_tile<T, 2>(a, side, (int)b0, (int)b1, (int)b2, lds0, lds1);
+    if (ax == 0) shell_tile<T, 0>(a, origin, (int)b0, (int)b1, (int)b2, lds0, lds1);
+    else if (ax == 1) shell_tile<T, 1>(a, origin, (int)b0, (int)b1, (int)b2, lds0, lds1);
+    else shell_tile<T, 2>(a, origin, (int)b0, (int)b1, (int)b2, lds0, lds1);
 }
 
 }  // namespace
@@ -274,7 +274,7 @@ int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double
                 if (!bc_program || !bcprog_second_set(bc_program, r.const_arr, &F.ca[1], &F.fa[1])) { F.ca[1] = F.ca[0]; F.fa[1] = F.fa[0]; }
                 ShellJob &J = a.job[a.njobs++];
                 const long s0 = ax == 0 ? 2 : (ax == 1 ? 4 : 8), s1 = ax == 0 ? 4 : (ax == 1 ? 2 : 16), s2 = ax == 2 ? 2 : 32;   // TileDims
-                J.ax = ax; J.side = side; J.first = total;
+                J.ax = ax; J.side = side; J.first = total; J.origin = side ? (int)n.n[ax] - 2 : 0;
                 J.nb0 = ax == 0 ? 1 : (n.n[0] + s0 - 1) / s0;
                 J.nb1 = ax == 1 ? 1 : (n.n[1] + s1 - 1) / s1;
                 J.nb2 = ax == 2 ? 1 : (n.n[2] + s2 - 1) / s2;
@@ -299,9 +299,9 @@ int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double
     return 0;
 }
 
-// The last one or two columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
+// The last one to four columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
 // the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
-int shell_open_rows(const NGrid &n, const LapArgs &la, hipStream_t st)
+int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t st)
 {
     ShellArgs a;
     memset(&a, 0, sizeof(a));
@@ -316,10 +316,14 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, hipStream_t st)
             F.f[0] = F.f[1] = la.ibc[k][side].f;
         }
     }
-    ShellJob &J = a.job[a.njobs++];
-    J.ax = 2; J.side = 1; J.first = 0;
-    J.nb0 = (n.n[0] + 7) / 8; J.nb1 = (n.n[1] + 15) / 16; J.nb2 = 1;   // TileDims<2>
-    const long total = J.nb0 * J.nb1;
+    long total = 0;
+    for (int c = 0; c < columns; c += 2) {   // two layers per job, from the end of the row inwards
+        ShellJob &J = a.job[a.njobs++];
+        J.ax = 2; J.side = 1; J.first = total; J.origin = (int)n.n[2] - 2 - c;
+        J.nb0 = (n.n[0] + 7) / 8; J.nb1 = (n.n[1] + 15) / 16; J.nb2 = 1;   // TileDims<2>
+        total += J.nb0 * J.nb1;
+    }
+    if (columns < 1 || columns > 4 || n.n[2] < 8) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns", columns);
     a.in = la.in; a.out = la.out; a.off = n.off;
     for (int k = 0; k < 3; k++) { a.n[k] = n.n[k]; a.p[k] = n.p[k]; a.sc[k] = n.lap_scale[k]; a.ni[k] = (int)n.n[k]; }
     a.pi[0] = (int)n.p[0]; a.pi[1] = (int)n.p[1];

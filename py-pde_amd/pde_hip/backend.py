@@ -988,6 +988,8 @@ class HipBackendMixin:
                         raise NotImplementedError(msg)
                     comp = "im" if op.endswith(IM_OPERAND) else "re"
                     base = base[: -len(IM_OPERAND)] if base.endswith(IM_OPERAND) else base
+                    if base.startswith("gradient_squared_d"):   # the central differences inside gradient_squared of a complex argument
+                        base = "gradient_squared"
                 bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
                 for other, other_comp, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:

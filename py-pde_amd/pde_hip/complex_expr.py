@@ -6,8 +6,8 @@ The reference specialises its operators and right-hand sides for complex arrays 
 REAL coefficients, so a complex field ``u = a + i b`` is carried on the device as the two real components ``(a, b)`` - planar, like the
 components of a vector field - and an equation ``du/dt = F(u)`` becomes the real system ``da/dt = Re F``, ``db/dt = Im F``:
 
-* linear operators act on the parts separately, ``laplace(a + i b) = laplace(a) + i laplace(b)`` (the same for ``d_dx`` ... and the
-  components of ``gradient``); ``gradient_squared(w) = sum (d w)^2`` gives ``gs(a) - gs(b) + 2 i dot(gradient(a), gradient(b))``;
+* linear operators act on the parts separately, ``laplace(a + i b) = laplace(a) + i laplace(b)`` (the same for ``d_dx``, ``d2_dx2`` ...);
+  ``gradient_squared(w) = sum (d w)^2`` gives ``gs(a) - gs(b) + 2 i sum d(a) d(b)``; the vector operators are not built;
 * everything pointwise (``I``, products, integer powers, ``conjugate``, ``Abs``, ``re``, ``im``, ``exp``) is split by sympy's
   ``as_real_imag`` after the operator applications have been replaced by real place-holders.
 
@@ -38,6 +38,7 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
     import sympy as sp
 
     aliases = aliases or {}
+    linear_axis_ops = {f"d_d{ax}" for ax in axes} | {f"d2_d{ax}2" for ax in axes}
     expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
     local: dict[str, Any] = {"I": sp.I}
     fields = {v: sp.Symbol(v) for v in variables}
@@ -72,7 +73,7 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
     for name in set(_re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*\(", expr_str)):
         if name not in local and not hasattr(sp, name):
             local[name] = sp.Function(name)
-    for name in ("laplace", "gradient_squared", *aliases):
+    for name in ("laplace", "gradient_squared", *linear_axis_ops, *aliases):
         local.setdefault(name, sp.Function(name))
     expr = sp.sympify(expr_str, locals=local)
     parts = {fields[v]: tuple(sp.Symbol(n, real=True) for n in part_names(v)) for v in variables}
@@ -99,9 +100,9 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
                 raise NotImplementedError(msg)
             ar, ai = split(call.args[0].xreplace(sub))
             fn = call.func
-            if base == "laplace":
-                # linear with real coefficients: acts on the parts separately; the imaginary operand takes the imaginary parts of the
-                # operator's boundary values
+            if base == "laplace" or base in linear_axis_ops:
+                # linear with real coefficients (the Laplacian, d_dx, d2_dx2 ...): acts on the parts separately; the imaginary operand takes
+                # the imaginary parts of the operator's boundary values
                 re_part = hold(fn(ar)) if ar != 0 else sp.Integer(0)
                 im_part = sp.Integer(0)
                 if ai != 0:
@@ -109,9 +110,20 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
                     im_part = hold(sp.Function(name + IM_OPERAND)(ai))
             elif base == "gradient_squared" and ai == 0:
                 re_part, im_part = hold(fn(ar)), sp.Integer(0)
+            elif base == "gradient_squared" and name == base:
+                # sum_axes (d w)^2 of w = a + i b (no conjugate: cartesian.py:661-668 squares the complex central differences) is
+                # gs(a) - gs(b) + 2 i sum_axes d(a) d(b); the per-axis central differences read the ghost cells of THIS operator's
+                # conditions: aliases of d_d<ax> named after it (`gradient_squared_d<ax>`, `..._imop` for the imaginary operand)
+                re_part = (hold(fn(ar)) if ar != 0 else sp.Integer(0)) - hold(sp.Function(name + IM_OPERAND)(ai))
+                new_aliases[name + IM_OPERAND] = base
+                im_part = sp.Integer(0)
+                if ar != 0:
+                    for ax in axes:
+                        d_re, d_im = f"{name}_d{ax}", f"{name}_d{ax}{IM_OPERAND}"
+                        new_aliases[d_re] = new_aliases[d_im] = f"d_d{ax}"
+                        im_part = im_part + 2 * hold(sp.Function(d_re)(ar)) * hold(sp.Function(d_im)(ai))
             else:
-                # (gradient_squared of a complex argument is gs(Re) - gs(Im) + 2 i grad(Re) . grad(Im); the per-axis derivatives and the
-                # vector operators would split like laplace: not built)
+                # (the vector operators would split like laplace: not built)
                 msg = f"hip backend: operator `{name}` of a complex argument inside an expression is not supported"
                 raise NotImplementedError(msg)
             sub[call] = re_part + sp.I * im_part

@@ -104,9 +104,12 @@ class ExpressionPlan:
             self.axis_ops[f"d_d{ax}"] = ("d1", 3 - len(axes) + k)
             self.axis_ops[f"d2_d{ax}2"] = ("d2", 3 - len(axes) + k)
         self.aliases = dict(aliases or {})
-        for alias, base in self.aliases.items():
-            if base not in OPERATORS:
-                msg = f"operator alias `{alias}` must stand for one of {OPERATORS}"
+        for alias, base in list(self.aliases.items()):
+            if base in self.axis_ops:      # another name of a per-axis derivative (its own conditions: complex_expr.py)
+                self.axis_ops[alias] = self.axis_ops[base]
+                del self.aliases[alias]
+            elif base not in OPERATORS:
+                msg = f"operator alias `{alias}` must stand for one of {OPERATORS} or a per-axis derivative"
                 raise ValueError(msg)
         # components of the vector operators `gradient` / `divergence` (central), lowered to per-axis atoms by `_lower_vectors`
         nd = len(axes)
@@ -374,7 +377,8 @@ class ExpressionPlan:
             def cost(name):
                 return sum(1 for other, lst in by_array.items() if other != name for a in lst if a not in self._memo)
 
-            src = min(reversed(names), key=cost)
+            # (ties in the pass that writes the result: the equation's own variable - the Euler update reads it anyway, as stencil array it costs no slot)
+            src = min(reversed(names), key=lambda name: (cost(name), 0 if (out == "out" and name == "state") else 1))
         else:
             used = [n for n, s in self._arrays.items() if s in expr.free_symbols]
             src = used[0] if used else "state"

@@ -72,6 +72,30 @@ def test_complex_equation_equals_the_real_system_of_its_parts(rng, solver):
     assert np.abs(got - (a + 1j * b)).max() > 1e-3
 
 
+def test_axis_derivatives_and_gradient_squared_of_a_complex_field(rng):
+    """`d_dx`, `d2_dy2`, `gradient_squared` of c = a + i b inside an expression (round 4): the split written out by hand as a real system
+    of a and b - gs(c) = gs(a) - gs(b) + 2 i (d_x a d_x b + d_y a d_y b) - to rounding (another pass order), and against numpy central differences
+    of the complex field."""
+    grid = pde_hip.CartesianGrid([[0, 6], [0, 5]], [24, 40], periodic=True)
+    a, b = rng.uniform(-1, 1, grid.shape), rng.uniform(-1, 1, grid.shape)
+    eq_c = pde_hip.PDE({"c": "(0.5 + 0.2*I) * gradient_squared(c) - I * d_dx(c) + 0.3 * d2_dy2(c)"})
+    eq_r = pde_hip.PDE({"a": "0.5 * (gradient_squared(a) - gradient_squared(b)) - 0.4 * (d_dx(a) * d_dx(b) + d_dy(a) * d_dy(b)) + d_dx(b) + 0.3 * d2_dy2(a)",
+                        "b": "0.2 * (gradient_squared(a) - gradient_squared(b)) + 1.0 * (d_dx(a) * d_dx(b) + d_dy(a) * d_dy(b)) - d_dx(a) + 0.3 * d2_dy2(b)"})
+    c0 = a + 1j * b
+    res_c = eq_c.solve(pde_hip.ScalarField(grid, c0), t_range=0.01, dt=1e-3, solver="euler", backend="hip")
+    res_r = eq_r.solve(pde_hip.FieldCollection([pde_hip.ScalarField(grid, a), pde_hip.ScalarField(grid, b)]), t_range=0.01, dt=1e-3, solver="euler", backend="hip")
+    got = np.array(res_c.data)
+    assert max_rel(got.real, np.array(res_r.data)[0]) < 1e-13 and max_rel(got.imag, np.array(res_r.data)[1]) < 1e-13
+    dx, dy = (float(d) for d in grid.discretization)
+    c = c0.copy()
+    for _ in range(10):
+        gx = (np.roll(c, -1, 0) - np.roll(c, 1, 0)) / (2 * dx)
+        gy = (np.roll(c, -1, 1) - np.roll(c, 1, 1)) / (2 * dy)
+        d2y = (np.roll(c, -1, 1) - 2 * c + np.roll(c, 1, 1)) / dy**2
+        c = c + 1e-3 * ((0.5 + 0.2j) * (gx * gx + gy * gy) - 1j * gx + 0.3 * d2y)
+    assert max_rel(got, c) < 1e-12
+
+
 def test_a_real_state_turns_complex_and_complex64_stays_single(rng):
     grid = pde_hip.UnitGrid([16, 64], periodic=True)
     eq = pde_hip.PDE({"p": "I * laplace(p)"})

@@ -91,6 +91,10 @@ PERIODIC = list(itertools.product([True, False], repeat=3))
     (np.float32, (9, 16, 513)),     # wide fp32 tile when the fastest axis is periodic, the narrow one (virtual far column) otherwise
     (np.float32, (6, 10, 514)),
     (np.float32, (6, 8, 385)),      # 3 x 128 + 1: the narrow tile
+    (np.float64, (6, 8, 131)),      # three and four columns: two jobs of the shell kernel
+    (np.float64, (5, 12, 260)),
+    (np.float32, (7, 8, 515)),
+    (np.float32, (6, 6, 388)),
 ])
 def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
     grid, bc, bcs, data = _setup(shape, list(periodic), dtype)

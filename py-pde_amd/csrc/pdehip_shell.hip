@@ -75,10 +75,13 @@ template <int AX> __device__ __forceinline__ int phys(const ShellArgs &a, int q)
 {
     return q < 0 ? q + a.ni[AX] : (q >= a.ni[AX] ? q - a.ni[AX] : q);
 }
-__device__ __forceinline__ bool exists(const ShellArgs &a, const Cell &x)   // inside the grid, or an image across a periodic axis
+// inside the grid, or an image across a periodic axis - the two layers of images a tile of the last cells can need, not more: a box may reach
+// further out than that when the axis is shorter than the tile (6 rows under a 16-row tile), and `phys` wraps once
+__device__ __forceinline__ bool exists(const ShellArgs &a, const Cell &x)
 {
-    return ((unsigned)x.x0 < (unsigned)a.ni[0] || a.per[0]) && ((unsigned)x.x1 < (unsigned)a.ni[1] || a.per[1]) &&
-           ((unsigned)x.x2 < (unsigned)a.ni[2] || a.per[2]);
+    return ((unsigned)x.x0 < (unsigned)a.ni[0] || (a.per[0] && (unsigned)(x.x0 + 2) < (unsigned)(a.ni[0] + 4))) &&
+           ((unsigned)x.x1 < (unsigned)a.ni[1] || (a.per[1] && (unsigned)(x.x1 + 2) < (unsigned)(a.ni[1] + 4))) &&
+           ((unsigned)x.x2 < (unsigned)a.ni[2] || (a.per[2] && (unsigned)(x.x2 + 2) < (unsigned)(a.ni[2] + 4)));
 }
 
 template <typename T> struct Boxes {

@@ -787,7 +787,7 @@ def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     _check_distributed_bench_line(out, 8, 32, env)
 
 
-FUZZ_CASES = 10    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
+FUZZ_CASES = 7    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
 
 
 @pytest.mark.parametrize("world,decomposition", [(3, "slab"), (4, "auto")])

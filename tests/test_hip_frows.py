@@ -274,6 +274,9 @@ TWO_STEP_CASES = {
                                                        "z-": {"value_expression": "tanh(x - y) * t"}, "z+": {"derivative_expression": "0.1 * y * cos(2 * t)"}}),
     "3d-periodic-rows": ([[0, 1], [0, 1], [0, 8]], (9, 8, 128), [False, True, False], {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative": 0.1},
                                                                                     "y": "periodic", "z-": {"value_expression": "0.1 * t"}, "z+": {"derivative_expression": "0.05 * x * sin(t)"}}),
+    # (a periodic axis shorter than the tile of the recomputing kernel: its boxes reach beyond the images they may read)
+    "3d-short-periodic-rows": ([[0, 1], [0, 1], [0, 8]], (8, 6, 128), [False, True, False], {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z"},
+                                                                                          "y": "periodic", "z-": {"value_expression": "0.1 * t"}, "z+": {"derivative_expression": "0.05 * x * sin(t)"}}),
     "3d-position-only": ([[0, 1]] * 3, (8, 12, 64), False, {"x": {"value": 0.1}, "y-": {"value_expression": "sin(3 * x) * z"}, "y+": {"derivative": 0.0}, "z": {"derivative_expression": "0.2 * x - y"}}),
 }
 

@@ -116,7 +116,8 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     a.strip_blocks = 0;
     if (a.strip_n2 > 0) {
         if (!(HAS_X && MODE <= LAP_CH_MU && !a.any_ibc)) PDEHIP_FAIL(E_RUNTIME, "internal: split rows reached a sweep without the strip");
-        const long threads = a.n0 * ((a.n1 + 7) / 8) * a.strip_n2;
+        const long rs = 8L * a.strip_n2;   // rows per thread (lap_strip)
+        const long threads = a.n0 * ((a.n1 + rs - 1) / rs) * a.strip_n2;
         a.strip_blocks = ((threads + 64 * WY - 1) / (64 * WY) + 7) / 8 * 8;
     }
     const dim3 grid((unsigned)(a.nblocks + a.strip_blocks)), block(64 * WY);
@@ -171,15 +172,16 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // column is the first cell of the remainder, real data in memory - and the remaining columns through the one-cell-per-thread
         // kernel (same expressions, cartesian.py:147-151 / :220-227).  Ghost cells from memory only (operators on a field whose faces are
         // set; the sweeps with on-the-fly faces of odd rows are the two-step kernel's, which has no such cliff).
-        // (one or two columns: 513 0.56 -> 0.44-0.46 ms, 514 0.487 -> 0.472; four or eight columns LOSE - 516: 0.47 -> 0.67 ms -, the strip's
-        // scattered accesses grow with its width while the extra chunk's cost does not: profiles/r04_time_sizes.md)
-        static const long split_max = getenv("PDEHIP_ROW_SPLIT") ? atol(getenv("PDEHIP_ROW_SPLIT")) : 2;
+        // (up to eight columns, measured: 512 x 512 x 514 / 516 / 520 fp64 0.512 / 0.522 / 0.536 -> 0.408 / 0.416 / 0.434 ms next to 0.409 for 512^3 -
+        // with a CONSTANT number of strip workgroups, lap_strip; with one workgroup per 64 x 8 cells four columns took 0.67 ms:
+        // profiles/r04_time_sizes.md)
+        static const long split_max = getenv("PDEHIP_ROW_SPLIT") ? atol(getenv("PDEHIP_ROW_SPLIT")) : 8;
         // The same for a row that ends inside a lane's vector (511 cells of fp64, 2 per lane): without its last n2 % VEC columns the
         // row takes the instance without the element-wise tail bookkeeping (0.55 -> the rate of 510^3).
         const long cw = 64L * VEC;
         long tail = n.n[2] % cw;
-        // (fp64 only: 511^3 0.584 -> 0.667 of the peak; the three columns an fp32 row of 511 ends with cost more than the bookkeeping: 0.465 -> 0.417)
-        if (tail == 0 || tail > split_max) tail = sizeof(T) == 8 ? n.n[2] % VEC : 0;
+        // (fp64 511^3: 0.584 -> 0.667 of the peak)
+        if (tail == 0 || tail > split_max) tail = n.n[2] % VEC;
         // (3-D only: on a 2-D grid the second launch costs more than the narrow tiles - 4095 x 4097: 0.046 against 0.039 ms)
         // (a.strip_n2: this IS the aligned part of a split row - 131 = 130 + 1 by the vector rule must not split its 130 = 128 + 2 again)
         if (n.ndim == 3 && MODE <= LAP_CH_MU && !a.any_ibc && tail > 0 && split_max > 0 && n.n[2] - tail >= cw && !tn.ry && a.strip_n2 == 0) {

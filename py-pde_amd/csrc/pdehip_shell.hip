@@ -42,7 +42,7 @@ struct ShellArgs {
 // A workgroup recomputes a box of S0 x S1 x S2 cells (two layers along the face's axis): it stages the input it needs (the box widened by
 // two cells) in LDS, computes level 1 ONCE per cell of the box widened by one cell into LDS, and takes level 2 from there.  One cell per
 // thread straight from memory - seven evaluations of level 1 per output, ~60 operands - took 0.97 ms at 512^3, 0.8 of it at the faces of
-// the fastest axis, where every operand of a thread is a cache line of its own; with the input staged 0.19 ms; this form 0.126 ms
+// the fastest axis, where every operand of a thread is a cache line of its own; with the input staged 0.19 ms; level 1 shared through LDS 0.126 ms
 // (profiles/r04_time_bc_program.md).
 template <int AX> struct TileDims {
     static constexpr int S0 = AX == 0 ? 2 : (AX == 1 ? 4 : 8);
@@ -57,11 +57,6 @@ constexpr int kBox1 = 816;    // max (S0 + 2) * (S1 + 2) * (S2 + 2): 4 x 6 x 34
 // offsets - with run-time axis indices the coordinates lived in scratch memory)
 struct Cell { int x0, x1, x2; };
 template <int AX> __device__ __forceinline__ int coord(const Cell &x) { return AX == 0 ? x.x0 : (AX == 1 ? x.x1 : x.x2); }
-template <int AX> __device__ __forceinline__ Cell with_coord(Cell x, int q)
-{
-    if (AX == 0) x.x0 = q; else if (AX == 1) x.x1 = q; else x.x2 = q;
-    return x;
-}
 __device__ __forceinline__ long elem(const ShellArgs &a, const Cell &x) { return a.off + (long)x.x0 * a.pi[0] + (long)x.x1 * a.pi[1] + x.x2; }   // (p[2] == 1)
 __device__ __forceinline__ bool inside(const ShellArgs &a, const Cell &x)
 {
@@ -69,37 +64,29 @@ __device__ __forceinline__ bool inside(const ShellArgs &a, const Cell &x)
 }
 // A tile works in UNWRAPPED coordinates: next to the end of a periodic axis its boxes reach one or two cells beyond the grid, and those
 // entries hold the cells of the far side (staged from there, level 1 computed like for any other cell).  So every operand of a cell of the
-// level-1 box is in the input box and every operand of an output is in the level-1 box: plain LDS reads, no range checks, no second code
-// path (with them inlined the kernel was 317 KB of code for a 64 KB instruction cache and took 0.145 ms).
+// level-1 box is in the input box and every operand of an output is in the level-1 box: plain LDS reads at the centre's index +- the
+// compile-time stride of the axis - no range checks, no second code path, no index arithmetic per operand.  (With a fallback path inlined
+// the kernel was 317 KB of code for a 64 KB instruction cache: 0.145 ms; with coordinates -> index per operand it issued ~1090 lane
+// operations per output and was bound by them: 0.126 ms, VALU busy 66 %, profiles/r04_shell_kernel_counters.md.)
 template <int AX> __device__ __forceinline__ int phys(const ShellArgs &a, int q)   // the cell of the grid behind an unwrapped coordinate
 {
     return q < 0 ? q + a.ni[AX] : (q >= a.ni[AX] ? q - a.ni[AX] : q);
 }
 // inside the grid, or an image across a periodic axis - the two layers of images a tile of the last cells can need, not more: a box may reach
 // further out than that when the axis is shorter than the tile (6 rows under a 16-row tile), and `phys` wraps once
-__device__ __forceinline__ bool exists(const ShellArgs &a, const Cell &x)
+template <int AX> __device__ __forceinline__ bool exists1(const ShellArgs &a, int q)
 {
-    return ((unsigned)x.x0 < (unsigned)a.ni[0] || (a.per[0] && (unsigned)(x.x0 + 2) < (unsigned)(a.ni[0] + 4))) &&
-           ((unsigned)x.x1 < (unsigned)a.ni[1] || (a.per[1] && (unsigned)(x.x1 + 2) < (unsigned)(a.ni[1] + 4))) &&
-           ((unsigned)x.x2 < (unsigned)a.ni[2] || (a.per[2] && (unsigned)(x.x2 + 2) < (unsigned)(a.ni[2] + 4)));
+    return (unsigned)q < (unsigned)a.ni[AX] || (a.per[AX] && (unsigned)(q + 2) < (unsigned)(a.ni[AX] + 4));
 }
+__device__ __forceinline__ bool exists(const ShellArgs &a, const Cell &x) { return exists1<0>(a, x.x0) && exists1<1>(a, x.x1) && exists1<2>(a, x.x2); }
 
-template <typename T> struct Boxes {
-    const T *u0, *u1;
-    int g0, g1, g2;       // origin of the input box; the level-1 box starts one cell further in
-    int G1, G2, H1, H2;   // extents along the last two axes
+// extents of the two boxes of a tile next to a face of axis JAX: the input box (level 0) and the level-1 box
+template <int JAX, int LV> struct BoxDims {
+    typedef TileDims<JAX> D;
+    static constexpr int W = LV == 0 ? 4 : 2;
+    static constexpr int B0 = D::S0 + W, B1 = D::S1 + W, B2 = D::S2 + W;
+    template <int AX> static constexpr int stride() { return AX == 0 ? B1 * B2 : (AX == 1 ? B2 : 1); }
 };
-
-template <typename T>
-__device__ __forceinline__ double real_at(const Boxes<T> &bx, const Cell &x)
-{
-    return (double)bx.u0[((x.x0 - bx.g0) * bx.G1 + (x.x1 - bx.g1)) * bx.G2 + (x.x2 - bx.g2)];
-}
-template <typename T>
-__device__ __forceinline__ double level1_at(const Boxes<T> &bx, const Cell &x)
-{
-    return (double)bx.u1[((x.x0 - bx.g0 - 1) * bx.H1 + (x.x1 - bx.g1 - 1)) * bx.H2 + (x.x2 - bx.g2 - 1)];
-}
 
 // coefficients of face (AX, SIDE) at the face cell of `x`, level lv
 template <int AX, int SIDE>
@@ -117,67 +104,64 @@ __device__ __forceinline__ void face_coef(const ShellArgs &a, int lv, const Cell
     }
 }
 
-// level LV at the neighbour of the cell x on side SIDE of axis AX: a cell (of the grid, or its image across a periodic axis) or the
-// virtual point `c + f * (adjacent cell = x)` (local.py:1636)
-template <typename T, int LV, int AX, int SIDE>
-__device__ __forceinline__ double neighbour(const ShellArgs &a, const Boxes<T> &bx, const Cell &x, double cen)
+// level LV at the neighbour of the cell x (box entry ci) on side SIDE of axis AX: a cell (of the grid, or its image across a periodic axis)
+// or the virtual point `c + f * (adjacent cell = x)` (local.py:1636)
+template <typename T, int JAX, int LV, int AX, int SIDE>
+__device__ __forceinline__ double neighbour(const ShellArgs &a, const T *box, const Cell &x, int ci, double cen)
 {
     const int q = coord<AX>(x) + (SIDE ? 1 : -1);
     // (x itself may be an image: then q is further out still - a cell as well)
-    if ((unsigned)q < (unsigned)a.ni[AX] || a.per[AX]) return LV == 0 ? real_at<T>(bx, with_coord<AX>(x, q)) : level1_at<T>(bx, with_coord<AX>(x, q));
+    if ((unsigned)q < (unsigned)a.ni[AX] || a.per[AX]) return (double)box[ci + (SIDE ? 1 : -1) * BoxDims<JAX, LV>::template stride<AX>()];
     double c, f;
     face_coef<AX, SIDE>(a, LV, x, &c, &f);
     return (double)(T)(c + f * cen);
 }
 
-template <typename T, int LV, int AX>
-__device__ __forceinline__ void add_axis(const ShellArgs &a, const Boxes<T> &bx, const Cell &x, double cen, double vm, double &lap, bool &first)
+template <typename T, int JAX, int LV, int AX>
+__device__ __forceinline__ void add_axis(const ShellArgs &a, const T *box, const Cell &x, int ci, double cen, double vm, double &lap, bool &first)
 {
     if (AX < a.first_axis) return;
-    const double lm = neighbour<T, LV, AX, 0>(a, bx, x, cen), lp = neighbour<T, LV, AX, 1>(a, bx, x, cen);
+    const double lm = neighbour<T, JAX, LV, AX, 0>(a, box, x, ci, cen), lp = neighbour<T, JAX, LV, AX, 1>(a, box, x, ci, cen);
     const double l = (lm - vm + lp) * a.sc[AX];
     lap = first ? l : lap + l;
     first = false;
 }
 
-// one Euler step at the cell x from level LV, rounded to the storage type like a stored field
-template <typename T, int LV>
-__device__ __forceinline__ T euler_at(const ShellArgs &a, const Boxes<T> &bx, const Cell &x)
+// one Euler step at the cell x (entry ci of the box of level LV), rounded to the storage type like a stored field
+template <typename T, int JAX, int LV>
+__device__ __forceinline__ T euler_at(const ShellArgs &a, const T *box, const Cell &x, int ci)
 {
-    const double cen = LV == 0 ? real_at<T>(bx, x) : level1_at<T>(bx, x);
+    const double cen = (double)box[ci];
     const double vm = 2 * cen;
     double lap = 0;
     bool first = true;
-    add_axis<T, LV, 0>(a, bx, x, cen, vm, lap, first);
-    add_axis<T, LV, 1>(a, bx, x, cen, vm, lap, first);
-    add_axis<T, LV, 2>(a, bx, x, cen, vm, lap, first);
+    add_axis<T, JAX, LV, 0>(a, box, x, ci, cen, vm, lap, first);
+    add_axis<T, JAX, LV, 1>(a, box, x, ci, cen, vm, lap, first);
+    add_axis<T, JAX, LV, 2>(a, box, x, ci, cen, vm, lap, first);
     return (T)(cen + a.s2 * (a.s1 * lap));
 }
 
-// the tile (b0, b1, b2) of the two layers next to face (AX, side)
+// the tile (b0, b1, b2) of the two layers next to a face of axis AX (first layer: `origin`)
 template <typename T, int AX>
 __device__ __forceinline__ void shell_tile(const ShellArgs &a, int origin, int b0, int b1, int b2, T *lds0, T *lds1)
 {
     typedef TileDims<AX> D;
+    typedef BoxDims<AX, 0> G;
+    typedef BoxDims<AX, 1> H;
     constexpr int S[3] = {D::S0, D::S1, D::S2};
-    constexpr int G0 = S[0] + 4, G1 = S[1] + 4, G2 = S[2] + 4, H0 = S[0] + 2, H1 = S[1] + 2, H2 = S[2] + 2;
-    static_assert(G0 * G1 * G2 <= kBox0 && H0 * H1 * H2 <= kBox1, "LDS boxes");
+    static_assert(G::B0 * G::B1 * G::B2 <= kBox0 && H::B0 * H::B1 * H::B2 <= kBox1, "LDS boxes");
     int o[3] = {b0 * S[0], b1 * S[1], b2 * S[2]};
     o[AX] = origin;   // (n >= 4 along every axis: launch_euler2)
-    Boxes<T> bx;
-    bx.u0 = lds0; bx.u1 = lds1;
-    bx.g0 = o[0] - 2; bx.g1 = o[1] - 2; bx.g2 = o[2] - 2;
-    bx.G1 = G1; bx.G2 = G2; bx.H1 = H1; bx.H2 = H2;
-    {   // all loads of the thread first, then the stores: one memory round trip per workgroup instead of one per pass of the loop
-        constexpr int NA = (G0 * G1 * G2 + 255) / 256;
+    {   // the input box; all loads of the thread first, then the stores: one memory round trip per workgroup instead of one per pass
+        constexpr int NG = G::B0 * G::B1 * G::B2, NA = (NG + 255) / 256;
         T v[NA];
 #pragma unroll
         for (int m = 0; m < NA; m++) {
             const int e = threadIdx.x + m * 256;
-            const int c2 = e % G2, c1 = (e / G2) % G1, c0 = e / (G2 * G1);
-            const Cell x = {bx.g0 + c0, bx.g1 + c1, bx.g2 + c2};
+            const int c2 = e % G::B2, c1 = (e / G::B2) % G::B1, c0 = e / (G::B2 * G::B1);
+            const Cell x = {o[0] - 2 + c0, o[1] - 2 + c1, o[2] - 2 + c2};
             v[m] = 0;
-            if (e < G0 * G1 * G2 && exists(a, x)) {
+            if (e < NG && exists(a, x)) {
                 const Cell y = {phys<0>(a, x.x0), phys<1>(a, x.x1), phys<2>(a, x.x2)};
                 v[m] = ((const T *)a.in)[elem(a, y)];
             }
@@ -185,34 +169,45 @@ __device__ __forceinline__ void shell_tile(const ShellArgs &a, int origin, int b
 #pragma unroll
         for (int m = 0; m < NA; m++) {
             const int e = threadIdx.x + m * 256;
-            if (e < G0 * G1 * G2) lds0[e] = v[m];
+            if (e < NG) lds0[e] = v[m];
         }
     }
     __syncthreads();
-    {
-        constexpr int NE = (H0 * H1 * H2 + 255) / 256;
+    {   // level 1, once per cell of the box widened by one
+        constexpr int NH = H::B0 * H::B1 * H::B2, NE = (NH + 255) / 256;
 #pragma unroll
         for (int m = 0; m < NE; m++) {   // (unrolled: the coefficient loads of the passes overlap)
             const int e = threadIdx.x + m * 256;
-            const int c2 = e % H2, c1 = (e / H2) % H1, c0 = e / (H2 * H1);
-            const Cell x = {bx.g0 + 1 + c0, bx.g1 + 1 + c1, bx.g2 + 1 + c2};
+            const int c2 = e % H::B2, c1 = (e / H::B2) % H::B1, c0 = e / (H::B2 * H::B1);
+            const Cell x = {o[0] - 1 + c0, o[1] - 1 + c1, o[2] - 1 + c2};
             T v = 0;
-            if (e < H0 * H1 * H2 && exists(a, x)) v = euler_at<T, 0>(a, bx, x);
-            if (e < H0 * H1 * H2) lds1[e] = v;
+            if (e < NH && exists(a, x)) v = euler_at<T, AX, 0>(a, lds0, x, ((c0 + 1) * G::B1 + (c1 + 1)) * G::B2 + (c2 + 1));
+            if (e < NH) lds1[e] = v;
         }
     }
     __syncthreads();
     const int t2 = threadIdx.x % S[2], t1 = (threadIdx.x / S[2]) % S[1], t0 = threadIdx.x / (S[2] * S[1]);
     const Cell x = {o[0] + t0, o[1] + t1, o[2] + t2};
     if (!inside(a, x)) return;
-    ((T *)a.out)[elem(a, x)] = euler_at<T, 1>(a, bx, x);
+    ((T *)a.out)[elem(a, x)] = euler_at<T, AX, 1>(a, lds1, x, ((t0 + 1) * H::B1 + (t1 + 1)) * H::B2 + (t2 + 1));
 }
 
+// The arguments - six face descriptors among them - are read from LDS: as scalar registers they did not fit (106 SGPRs and ~3000 `v_readlane`
+// in the code: values spilled into lanes of vector registers, half of the instructions a wave issued).  The first lanes copy the kernel
+// argument segment word by word.
 template <typename T>
-__global__ void __launch_bounds__(256) shell_kernel(ShellArgs a)
+__global__ void __launch_bounds__(256) shell_kernel(ShellArgs by_value)
 {
     __shared__ T lds0[kBox0];
     __shared__ T lds1[kBox1];
+    __shared__ ShellArgs a;
+    {
+        const int *src = (const int *)__builtin_amdgcn_kernarg_segment_ptr();   // (`by_value` sits at offset 0 of the segment)
+        int *dst = (int *)&a;
+        for (int w = threadIdx.x; w < (int)(sizeof(ShellArgs) / sizeof(int)); w += 256) dst[w] = src[w];
+        (void)by_value;
+    }
+    __syncthreads();
     int q = 0;
 #pragma unroll
     for (int m = 1; m < 6; m++)

@@ -172,10 +172,12 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // column is the first cell of the remainder, real data in memory - and the remaining columns through the one-cell-per-thread
         // kernel (same expressions, cartesian.py:147-151 / :220-227).  Ghost cells from memory only (operators on a field whose faces are
         // set; the sweeps with on-the-fly faces of odd rows are the two-step kernel's, which has no such cliff).
-        // (up to eight columns, measured: 512 x 512 x 514 / 516 / 520 fp64 0.512 / 0.522 / 0.536 -> 0.408 / 0.416 / 0.434 ms next to 0.409 for 512^3 -
+        // (measured: 512 x 512 x 514 / 516 / 520 fp64 0.512 / 0.522 / 0.536 -> 0.408 / 0.416 / 0.434 ms next to 0.409 for 512^3 -
         // with a CONSTANT number of strip workgroups, lap_strip; with one workgroup per 64 x 8 cells four columns took 0.67 ms:
         // profiles/r04_time_sizes.md)
-        static const long split_max = getenv("PDEHIP_ROW_SPLIT") ? atol(getenv("PDEHIP_ROW_SPLIT")) : 8;
+        // (wider: 512 x 512 x 524 / 528 / 536 / 544 fp64 0.48-0.50 -> 0.41-0.44 ms, fp32 0.28-0.29 -> 0.22-0.24; 48 and 64 columns still win for
+        // fp64 but lose for fp32, 44 of 300 lose for both: 32)
+        static const long split_max = getenv("PDEHIP_ROW_SPLIT") ? atol(getenv("PDEHIP_ROW_SPLIT")) : 32;
         // The same for a row that ends inside a lane's vector (511 cells of fp64, 2 per lane): without its last n2 % VEC columns the
         // row takes the instance without the element-wise tail bookkeeping (0.55 -> the rate of 510^3).
         const long cw = 64L * VEC;

@@ -20,8 +20,9 @@ from pde_hip import _abi
 
 pytestmark = pytest.mark.gpu
 
-SHAPES64 = [(9, 7, 129), (5, 6, 131), (4, 9, 257), (11, 127), (8, 1025), (3, 5, 1)]
-SHAPES32 = [(6, 5, 130), (3, 4, 133), (4, 6, 259), (7, 135), (5, 1027)]
+# (3-D rows 1..32 cells beyond whole 64-lane chunks are split into the aligned part and a strip: 129, 131, 145, 160, 257 / 130, 133, 259, 281, 288)
+SHAPES64 = [(9, 7, 129), (5, 6, 131), (4, 9, 257), (11, 127), (8, 1025), (3, 5, 1), (6, 21, 145), (5, 40, 160)]
+SHAPES32 = [(6, 5, 130), (3, 4, 133), (4, 6, 259), (7, 135), (5, 1027), (5, 19, 281), (4, 33, 288)]
 BCS = {
     "periodic": lambda nd: "auto_periodic_neumann",
     "walls": lambda nd: {"x": {"value": 0.4}, "y": {"derivative": -0.3}, "z": {"type": "mixed", "value": 0.5, "const": 0.2}} if nd == 3

@@ -117,6 +117,7 @@ int launch_deriv_march(const NGrid &n, const void *in, void *out, const OutStr &
 int launch_div_march(const NGrid &n, int method, const void *in, void *out, const OutStr &o, hipStream_t st, bool *done);
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
+int preload_shell_kernels();     // pdehip_shell.hip: the same for its code object
 int preload_stencil_kernels();   // pdehip_kernels.hip: load the code object of the stencil kernels now (see pdehip_set_device)
 // launch configuration of the two-level kernel handed to a caller that launches a run-time compiled instance itself
 struct Euler2Plan {

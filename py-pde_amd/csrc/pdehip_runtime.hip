@@ -183,6 +183,7 @@ int pdehip_set_device(int device)
     std::lock_guard<std::mutex> guard(m);
     if (!loaded) {
         PDEHIP_TRY(preload_stencil_kernels());
+        PDEHIP_TRY(preload_shell_kernels());
         loaded = true;
     }
     return 0;

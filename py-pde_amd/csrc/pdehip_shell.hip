@@ -297,6 +297,14 @@ int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double
     return 0;
 }
 
+// (see preload_stencil_kernels: the code object of this translation unit is loaded when the device is selected as well, not in the middle of a run)
+int preload_shell_kernels()
+{
+    hipFuncAttributes attr;
+    PDEHIP_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&shell_kernel<double>)));
+    return 0;
+}
+
 // The last one to four columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
 // the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
 int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t st)

@@ -476,14 +476,14 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
     // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
     // of non-periodic rows has no exactly fitting tile at all.
-    // "Open" rows: a row one to four cells longer than a whole number of chunks (513 = 4 x 128 + 1) gave the moved last chunk a wave of
+    // "Open" rows: a row one to eight cells longer than a whole number of chunks (513 = 4 x 128 + 1) gave the moved last chunk a wave of
     // its own that marched every plane for one vector - 25 % more waves (fp64 513^3 0.281 against 0.228 ms per step at 512^3, fp32 0.268
     // against 0.167).  Instead the tiles cover the whole chunks - the halo columns right of the last one are real cells, or the virtual
     // column through the `zhi2` code of the ragged instances - and the remaining columns are recomputed from the input by the LDS-tiled
     // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
     static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
     long open_tail = 0;
-    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 4) open_tail = a.n2 % CW;
+    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8) open_tail = a.n2 % CW;
     const long n2t = a.n2 - open_tail;   // the columns the tiles cover
     const int ry_want = ry;
     while (ry > 1 && a.n1 % ry) ry /= 2;
@@ -705,7 +705,7 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
                 // (rows one or two cells beyond whole chunks leave those cells to another kernel: launch_euler2_tv, "open" rows)
                 auto fill = [&](long cw) {
                     const long t = a.n2 % cw;
-                    return (a.n2 > cw && t >= 1 && t <= 4) ? 1.0 : (double)a.n2 / (double)((a.n2 + cw - 1) / cw * cw);
+                    return (a.n2 > cw && t >= 1 && t <= 8) ? 1.0 : (double)a.n2 / (double)((a.n2 + cw - 1) / cw * cw);
                 };
                 const double wide = fill(256), narrow = fill(128);
                 if (narrow > 1.15 * wide) { vec = 2; ry = 4; }

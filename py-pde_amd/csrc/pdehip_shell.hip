@@ -305,7 +305,7 @@ int preload_shell_kernels()
     return 0;
 }
 
-// The last one to four columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
+// The last one to eight columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
 // the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
 int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t st)
 {
@@ -329,7 +329,7 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t 
         J.nb0 = (n.n[0] + 7) / 8; J.nb1 = (n.n[1] + 15) / 16; J.nb2 = 1;   // TileDims<2>
         total += J.nb0 * J.nb1;
     }
-    if (columns < 1 || columns > 4 || n.n[2] < 8) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns", columns);
+    if (columns < 1 || columns > 8 || n.n[2] < 16) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns", columns);
     a.in = la.in; a.out = la.out; a.off = n.off;
     for (int k = 0; k < 3; k++) { a.n[k] = n.n[k]; a.p[k] = n.p[k]; a.sc[k] = n.lap_scale[k]; a.ni[k] = (int)n.n[k]; }
     a.pi[0] = (int)n.p[0]; a.pi[1] = (int)n.p[1];

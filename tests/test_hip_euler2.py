@@ -95,6 +95,9 @@ PERIODIC = list(itertools.product([True, False], repeat=3))
     (np.float64, (5, 12, 260)),
     (np.float32, (7, 8, 515)),
     (np.float32, (6, 6, 388)),
+    (np.float32, (5, 8, 263)),      # seven and eight columns: four jobs
+    (np.float64, (7, 9, 135)),
+    (np.float32, (6, 10, 520)),
 ])
 def test_two_steps_per_sweep_equal_two_single_steps(backend, periodic, dtype, shape):
     grid, bc, bcs, data = _setup(shape, list(periodic), dtype)

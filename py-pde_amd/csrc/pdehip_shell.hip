@@ -271,11 +271,11 @@ int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double
                 // (arrays no program rewrites - conditions that depend on the position only - serve both levels)
                 if (!bc_program || !bcprog_second_set(bc_program, r.const_arr, &F.ca[1], &F.fa[1])) { F.ca[1] = F.ca[0]; F.fa[1] = F.fa[0]; }
                 ShellJob &J = a.job[a.njobs++];
-                const long s0 = ax == 0 ? 2 : (ax == 1 ? 4 : 8), s1 = ax == 0 ? 4 : (ax == 1 ? 2 : 16), s2 = ax == 2 ? 2 : 32;   // TileDims
+                const long tile0 = ax == 0 ? 2 : (ax == 1 ? 4 : 8), tile1 = ax == 0 ? 4 : (ax == 1 ? 2 : 16), tile2 = ax == 2 ? 2 : 32;   // TileDims
                 J.ax = ax; J.side = side; J.first = total; J.origin = side ? (int)n.n[ax] - 2 : 0;
-                J.nb0 = ax == 0 ? 1 : (n.n[0] + s0 - 1) / s0;
-                J.nb1 = ax == 1 ? 1 : (n.n[1] + s1 - 1) / s1;
-                J.nb2 = ax == 2 ? 1 : (n.n[2] + s2 - 1) / s2;
+                J.nb0 = ax == 0 ? 1 : (n.n[0] + tile0 - 1) / tile0;
+                J.nb1 = ax == 1 ? 1 : (n.n[1] + tile1 - 1) / tile1;
+                J.nb2 = ax == 2 ? 1 : (n.n[2] + tile2 - 1) / tile2;
                 total += J.nb0 * J.nb1 * J.nb2;
             } else {
                 return 0;

@@ -149,6 +149,7 @@ SHAPES = [
     ((64, 64), np.float64), ((1024, 1024), np.float64), ((130, 258), np.float64), ((33, 77), np.float64),
     ((32, 32, 128), np.float64), ((48, 40, 256), np.float64), ((17, 9, 130), np.float64), ((8, 8, 12), np.float64), ((5, 7, 9), np.float64),
     ((64, 64, 64), np.float32), ((16, 24, 256), np.float32), ((256, 512), np.float32), ((4097,), np.float64), ((1000,), np.float32),
+    ((9, 12, 150), np.float64), ((6, 10, 280), np.float32),      # split rows: 22 / 24 columns beyond whole chunks as a strip of the same launch
 ]
 
 

@@ -1597,14 +1597,15 @@ class HipBackendMixin:
             erhs = ExpressionRhs(self, plan, self.grid_info(state.grid, state.dtype), {}, {})
         except Exception:  # noqa: BLE001 - an expression the planner / printer cannot take: host path
             return None
-        spare: list[DeviceArray | None] = [None]
         _logger.info("post-step hook of %s runs on the device as `c <- %s`", solver.pde.__class__.__name__, expr)
 
         def post_step(arr: DeviceArray, t: float) -> DeviceArray:
-            out = spare[0] if spare[0] is not None and spare[0] is not arr else arr.empty_like()
-            erhs.apply(arr, out, "rate", 0.0, float(t))
-            spare[0] = arr          # (the array the state just left serves the next call)
-            return out
+            # IN PLACE: the pass is pointwise (no operators: checked above), every cell is read as the centre value only by the
+            # thread that then writes it.  (Round 4 wrote into a recycled "spare" array and returned that: across stepper calls the
+            # spare could be the caller's own `state_data`, i.e. the stepper's next output buffer - `cur is nxt`, an in-place
+            # stencil sweep; ADVICE r4 high.  The hook now never hands out an array the stepper does not already hold as `cur`.)
+            erhs.apply(arr, arr, "rate", 0.0, float(t))
+            return arr
 
         post_step.on_device = True  # type: ignore[attr-defined]
         post_step.expression = expr  # type: ignore[attr-defined]

@@ -664,15 +664,21 @@ class DecomposedExpressionStepper:
             d.upper = 0 if self._force else (-1 if getattr(self.mesh, "upper", None) is None else int(self.mesh.upper))
             for i in range(6):
                 d.nb6[i] = int(self.mesh.nb6[i]) if self.blocks else -1
+        # The C loops find the communicator for the MAX all-reduce of the adaptive error through a pass that carries the exchange
+        # descriptor - only passes with operators do.  An equation WITHOUT differential operators on a decomposed grid has none: its
+        # adaptive loop then runs from Python with `reduce_error` (each rank would otherwise pick its own step sizes, unlike the
+        # reference's `sync_errors`, pde/solvers/base.py:577-590).
+        desc = self._exchange_desc if os.environ.get("PDEHIP_DECOMP_LOOPS", "1") != "0" else None
+        in_loops = desc is not None and any(tb is not None for part in parts for tb in part.pass_faces)
         if hasattr(self.erhs, "parts"):
-            self.erhs.reduces_error_in_loops = True
+            self.erhs.reduces_error_in_loops = in_loops
         for part in parts:
             part._reduce = self._sum_over_ranks if self.size > 1 else None
             part._pass_by_pass = True
             part._two_ok = False
             part._exchange = self.exchange if exchanging else None
-            part._exchange_desc = self._exchange_desc if os.environ.get("PDEHIP_DECOMP_LOOPS", "1") != "0" else None
-            part.reduces_error_in_loops = True
+            part._exchange_desc = desc
+            part.reduces_error_in_loops = in_loops
         # every rank must run the same passes in the same order (the exchanges pair up by issue order): checked, not assumed
         plans = ["\n".join(part.plan.describe()) for part in parts]
         if any(other != plans for other in self.control.allgather(plans)):

@@ -442,7 +442,7 @@ int pdehip_bcprog_create(const char *source, int nfaces, const pdehip_bcprog_fac
     snprintf(so, sizeof(so), "%s/b%d.so", dir, counter++);
     FILE *f = fopen(src, "w");
     if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
-    fprintf(f, "#include <math.h>\n#define PDEHIP_BC_FN static inline\n%s\n"
+    fprintf(f, "#include <math.h>\n#include <stdbool.h>\n#define PDEHIP_BC_FN static inline\n%s\n"
                "void bc_face_entry(int face, double value, double dx, double c0, double c1, double c2, double t, double *A, double *B)\n"
                "{ bc_face(face, value, dx, c0, c1, c2, t, A, B); }\n", source);
     fclose(f);
@@ -547,7 +547,7 @@ static int compile_epilogue(const char *body, void **dl, epilogue_fn *fn)
     snprintf(so, sizeof(so), "%s/e%d.so", dir, counter++);
     FILE *f = fopen(src, "w");
     if (!f) return fail(E_RUNTIME, "shim: cannot write %s", src);
-    fprintf(f, "#include <math.h>\ntypedef struct { double d1[3], d2[3], gr[3]; } PdeDer;\n"
+    fprintf(f, "#include <math.h>\n#include <stdbool.h>\ntypedef struct { double d1[3], d2[3], gr[3]; } PdeDer;\n"
                "double pde_epilogue(double c, double lap, double gsq, double e0, double e1, double e2, const double *p, PdeDer d)\n{\n"
                "(void)c; (void)lap; (void)gsq; (void)e0; (void)e1; (void)e2; (void)p; (void)d;\n%s\n}\n", body);
     fclose(f);

@@ -138,6 +138,63 @@ def test_traced_hook_runs_on_the_device(monkeypatch, solver, adaptive):
     assert counts["down"] <= 2, counts      # the final read(s) only - with the host path: one per step
 
 
+@pytest.mark.parametrize("solver,adaptive", [("euler", False), ("runge-kutta", False), ("runge-kutta", True), ("euler", True)])
+@pytest.mark.parametrize("interval", [0.02, 0.05])
+def test_traced_hook_with_a_tracker_that_splits_the_run(monkeypatch, solver, adaptive, interval):
+    """with a tracker the stepper is called once per interval of 2-5 steps; the hook of round 4 recycled the array the
+    state had left in the PREVIOUS call - which can be the caller's `state_data`, the next call's output buffer (`cur is nxt`: an
+    in-place stencil sweep, 1e-2 off for adaptive RK).  Every stored frame equals the reference's numpy run, and no right-hand side
+    is ever applied to its own output array."""
+    monkeypatch.setitem(pde.config, "default_backend", "scipy")
+
+    def post_step_hook(state_data, t):
+        state_data[state_data > 0.8] = 0.8
+        state_data[state_data < 0.05] = 0.05
+        return state_data
+
+    grid = pde.UnitGrid([12, 10], periodic=[True, False])
+    state = pde.ScalarField.random_uniform(grid, 0.0, 1.0, rng=np.random.default_rng(11))
+    bc = {"x": "periodic", "y": {"derivative": 0.1}}
+
+    class Restated(pde.PDEBase):
+        def evolution_rate(self, state, t=0):
+            return 0.6 * state.laplace(bc) - 0.1 * state
+
+        def make_post_step_hook(self, state, backend="numpy"):
+            def hook(state_data, t, data):
+                return post_step_hook(state_data, t), None
+
+            return hook, None
+
+    kw = dict(t_range=0.3, dt=0.01, solver=solver, adaptive=adaptive, ret_info=True)
+    sref = pde.MemoryStorage()
+    ref, iref = Restated().solve(state, backend="numpy", tracker=sref.tracker(interval), **kw)
+    with shimlib.use_shim():
+        import pde_hip.pypde_plugin  # noqa: F401
+        from pde_hip import expr
+
+        aliased = []
+        orig = expr.ExpressionRhs.apply
+
+        def watching(self, state_, out, wrap="rate", *a, **k):
+            if wrap != "rate" and state_.ptr == out.ptr:      # (the pointwise hook pass itself runs in place, wrap "rate")
+                aliased.append(wrap)
+            return orig(self, state_, out, wrap, *a, **k)
+
+        monkeypatch.setattr(expr.ExpressionRhs, "apply", watching)
+        shim_store = pde.MemoryStorage()
+        eq = pde.PDE({"c": "0.6 * laplace(c) - 0.1 * c"}, bc=bc, post_step_hook=post_step_hook)
+        res, info = eq.solve(state, backend="hip", tracker=shim_store.tracker(interval), **kw)
+        got = np.array(res.data)
+        frames = [np.array(f) for f in shim_store.data]
+    assert not aliased, aliased
+    assert info["solver"]["steps"] == iref["solver"]["steps"] > 3
+    assert len(frames) == len(sref.data) >= 6
+    for a, b in zip(frames, sref.data):
+        assert max_rel(a, b) < 1e-10
+    assert max_rel(got, ref.data) < 1e-10 and got.max() <= 0.8
+
+
 def test_untraceable_hook_keeps_the_host_path(monkeypatch):
     monkeypatch.setitem(pde.config, "default_backend", "scipy")
     calls = []

@@ -343,6 +343,10 @@ GENERIC_CASES = {
     "vector3d": (lambda: pde_hip.PDE({"u": "vector_laplace(u) - tensor_divergence(outer(u, u)) + 0.1 * gradient(dot(u, u))"},
                                      bc={"x": {"derivative": 0}, "y": "periodic", "z": {"value": 0}}),
                  lambda: pde_hip.UnitGrid([8, 4, 6], periodic=[False, True, False]), 0.02, 0.005, "runge-kutta", "vector"),
+    # NO differential operator: no pass carries the exchange descriptor through which the C loops find the communicator, so the
+    # adaptive error must be MAX-reduced from Python (each rank used to pick its own step sizes)
+    "reaction_only_adaptive": (lambda: pde_hip.PDE({"c": "-(1 + 6 * x) * c**3 + 0.2 * y - 3 * x * c"}),
+                               lambda: pde_hip.CartesianGrid([[0, 6], [0, 4]], [12, 8], periodic=[True, False]), 1.5, None, "runge-kutta", 1),
     "swift_hohenberg_adaptive_euler": (lambda: pde_hip.PDE({"c": "-0.54 * c - 1.6 * laplace(c) - laplace(laplace(c)) + 0.3 * c**2 - c**3"}),
                                        lambda: pde_hip.UnitGrid([10, 8], periodic=[True, False]), 0.01, None, "euler", 1),
 }

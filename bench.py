@@ -1,7 +1,8 @@
 """Benchmark of the hot path: 3-D DiffusionPDE 512^3 fp64, explicit Euler, on N MI355X GPUs.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver launches one rank per GPU through torch.distributed.run.  One "step" = one explicit Euler
+driver launches one rank per GPU through torch.distributed.run - started WITHOUT a launcher, `--gpus N`
+spawns its N ranks itself (`spawn_ranks`), and a world size that differs from `--gpus` is an error, never a line.  One "step" = one explicit Euler
 step of the whole 512^3 grid (BCs on the fly + fused Laplacian + D*, dt*, +=; two steps per kernel sweep), state
 resident in HBM (ping-pong buffers), i.e. 16 algorithmic bytes per cell-step.
 N > 1 slab-decomposes the SAME grid along axis 0 (strong scaling) with RCCL halo exchange
@@ -493,9 +494,58 @@ def bench_distributed(args) -> dict:
             "state_sha256": digest, "per_rank": per_rank, "roofline": roofline}
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher - one child
+    per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what `torch.distributed.run` sets), the children's output passed through
+    (rank 0 prints the JSON line), non-zero exit if any rank fails.  The reference's MPI entry is launcher-driven as well
+    (pde/solvers/explicit_mpi.py:133-226: `mpiexec -n N`); the bench contract is `--gpus N`, so a bare invocation fans out itself."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "PDEHIP_BENCH_SPAWNED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for rank in range(n):
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]],
+                                      env={**env, "RANK": str(rank), "LOCAL_RANK": str(rank), "LOCAL_WORLD_SIZE": str(n)}))
+    rc = 0
+    try:
+        while procs:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in procs:      # one rank failed: the others would wait in a collective for ever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            pr.kill()
+    return rc
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # never print a line whose n_gpus differs from what was asked for
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     n = args.size
     cells = n**3
     if args.gpus > 1 or world > 1 or args.force_distributed:

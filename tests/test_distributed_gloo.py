@@ -791,6 +791,31 @@ def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     _check_distributed_bench_line(out, 8, 32, env)
 
 
+def test_bare_bench_spawns_its_own_ranks_and_refuses_a_mismatch():
+    """VERDICT r4 "missing #2": `python bench.py --gpus 8` WITHOUT torch.distributed.run around it fans out into 8 ranks itself (one
+    process per device) and prints ONE line with n_gpus == 8 and the parity digest of the single-device run; under a launcher whose
+    world size differs from --gpus it prints NO line and fails."""
+    import json
+    import subprocess
+
+    import shimlib
+
+    so = shimlib.build()
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**clean, **env}, cwd=str(ROOT))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["finite"] and out["slab"]["layers_per_rank"] == [4] * 8
+    _check_distributed_bench_line(out, 8, 32, env)
+    # a launcher that started 2 ranks for `--gpus 4`: no line, non-zero exit
+    bad = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "0", "--size", "16"], capture_output=True, text=True,
+                         timeout=120, env={**clean, **env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, cwd=str(ROOT))
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")] and "WORLD_SIZE=2" in bad.stderr
+
+
 FUZZ_CASES = 7    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
 
 

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -45,8 +46,13 @@ enum { E_OK = 0, E_VALUE = 1, E_NOTIMPL = 2, E_RUNTIME = 3 };
 // A grid is normalised to three axes (an n-D grid occupies the trailing n axes; padded axes
 // have n = 1 and no ghost layer).  The device layout differs from the reference's host layout
 // (shape + 2, compact) in ONE respect: every row of the fastest axis is shifted and padded so
-// that the first interior cell of each row is 16-byte aligned and the pitch is a multiple of
-// 16 bytes.  This makes every interior vector (double2 / float4) an aligned dwordx4 access.
+// that the first interior cell of each row sits on a 128-byte line and the pitch is a multiple of
+// 128 bytes.  Every interior vector (double2 / float4) is an aligned dwordx4 access, and - round 5 - the
+// 1 KiB a wave moves per row piece covers exactly 8 cache lines: with the 16-byte alignment of rounds 1-4
+// (pitch n2 + 4) every such piece straddled 9 lines and the pieces of neighbouring waves / rows shared a
+// line, i.e. partial-line writes and double fetches at every seam.  Measured in tools/microbench6.hip
+// (profiles/r05_microbench6_row_alignment.md): copies of the interior rows 5.0 -> 5.9-6.0 TB/s, chunk-tiled
+// stencil marches +10-25 %.  PDEHIP_ROW_ALIGN=<bytes> (16 ... 256, A/B aid) selects the alignment.
 //   row:  [pad .. pad, ghost, interior(n2) ..., ghost, pad ..]     interior starts at `lpad`
 struct NGrid {
     int ndim;
@@ -62,6 +68,16 @@ struct NGrid {
 };
 
 inline long elem_size(int dtype) { return dtype == PDEHIP_F64 ? 8 : 4; }
+
+inline long row_align_bytes()
+{
+    static const long bytes = [] {
+        const char *e = getenv("PDEHIP_ROW_ALIGN");
+        const long v = e ? atol(e) : 128;
+        return (v == 16 || v == 32 || v == 64 || v == 128 || v == 256) ? v : 128L;
+    }();
+    return bytes;
+}
 
 inline int norm_grid(const pdehip_grid_t *g, NGrid *n)
 {
@@ -79,7 +95,7 @@ inline int norm_grid(const pdehip_grid_t *g, NGrid *n)
         n->dx[ax] = g->dx[a];
         n->lap_scale[ax] = std::pow(g->dx[a], -2.0);
     }
-    n->lpad = 16 / elem_size(g->dtype);
+    n->lpad = row_align_bytes() / elem_size(g->dtype);
     n->p[2] = 1;
     n->p[1] = ((n->lpad + n->n[2] + 1 + n->lpad - 1) / n->lpad) * n->lpad;
     n->p[0] = n->p[1] * (n->n[1] + 2 * n->gh[1]);

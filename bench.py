@@ -44,6 +44,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the slab/RCCL path even on one rank (periodic halo sent to self) - overhead probe")
+    ap.add_argument("--decomposition", default="slab",
+                    help="N > 1: `slab` (axis-0 slabs, two steps per sweep: the default), `auto` (the reference's rule, pde/grids/_mesh.py:59-93: "
+                         "2 x 2 x 2 for 512^3 on 8 ranks) or blocks per axis, e.g. `2,4,1` (decompositions that do not cut the fastest axis run the "
+                         "fast block loop, csrc/pdehip_block2_loops.h; the others the exact one-step loop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the operator roofline, the cfg2/cfg3/cfg5 timings and the parity bit")
     ap.add_argument("--repeats", type=int, default=9,
@@ -405,7 +409,15 @@ def bench_distributed(args) -> dict:
     n = args.size
     grid = pde_hip.UnitGrid([n, n, n], periodic=True)
     eq = pde_hip.DiffusionPDE(1.0)
-    stepper = SlabStepper(eq, grid, control=control, device=local_rank, force_exchange=args.force_distributed)
+    blocks = args.decomposition != "slab"
+    if blocks:
+        from pde_hip.distributed import BlockStepper
+        from pde_hip.mesh import block_decomposition
+
+        dims = block_decomposition(grid.shape, world) if args.decomposition == "auto" else [int(v) for v in args.decomposition.split(",")]
+        stepper = BlockStepper(eq, grid, dims=dims, control=control, device=local_rank, force_exchange=args.force_distributed)
+    else:
+        stepper = SlabStepper(eq, grid, control=control, device=local_rank, force_exchange=args.force_distributed)
     control = stepper.control
     # synthetic data: the seeded global field of the N = 1 line; every rank keeps its slab only
     local0 = np.ascontiguousarray(stepper.mesh.extract(pde_hip.ScalarField.random_uniform(grid, rng=np.random.default_rng(0)).data))
@@ -420,7 +432,13 @@ def bench_distributed(args) -> dict:
 
         parts = [None] * world if rank == 0 else None
         dist.gather_object(local, parts, dst=0)
-        return np.concatenate(parts, axis=0) if rank == 0 else None
+        if rank != 0:
+            return None
+        if blocks:
+            from pde_hip.mesh import combine_blocks
+
+            return combine_blocks(parts, stepper.dims, 3)
+        return np.concatenate(parts, axis=0)
 
     # parity: 6 steps (three two-step sweeps with their exchanges) from the seeded state, whole field hashed on rank 0
     stepper.set_local(a, local0)
@@ -456,7 +474,11 @@ def bench_distributed(args) -> dict:
         if out is not cur:
             cur, nxt = nxt, cur
     ok = all(control.allgather(bool(np.isfinite(stepper.gather_local(cur)).all())))
-    info = {"two_steps_per_sweep": stepper._euler2, "layers_per_rank": [int(c) for c in stepper.mesh.counts]}
+    if blocks:
+        info = {"decomposition": [int(d) for d in stepper.dims], "two_steps_per_sweep": bool(stepper.block2), "fast_block_loop": bool(stepper.block2),
+                "cells_per_rank": [int(v) for v in stepper.mesh.local_shape]}
+    else:
+        info = {"two_steps_per_sweep": stepper._euler2, "layers_per_rank": [int(c) for c in stepper.mesh.counts]}
     # the same steps on this rank's slab WITHOUT neighbours: the serial loop (two steps per sweep) on a periodic grid of the slab's shape
     local_shape = [int(v) for v in stepper.mesh.local_shape]
     serial = SlabStepper(eq, pde_hip.UnitGrid(local_shape, periodic=True), control=SerialControl(), device=local_rank)
@@ -556,7 +578,11 @@ def main():
         wall = r["wall"]
         line = {"roofline": r["roofline"], "cpu_baseline": None, "slab": r["info"], "finite": r["finite"], "parity": r["parity"],
                 "state_sha256_after_6_steps": r["state_sha256"], "per_rank": r["per_rank"]}
-        parallelism = f"slab{ngpu} (axis-0 slabs, RCCL send/recv halo exchange overlapped with interior kernel)"
+        if "decomposition" in r["info"]:
+            parallelism = (f"blocks{'x'.join(str(d) for d in r['info']['decomposition'])} (boxes with two-layer halos incl. edges, one RCCL message per "
+                           "neighbouring rank, rim kernel + interior sweep)")
+        else:
+            parallelism = f"slab{ngpu} (axis-0 slabs, RCCL send/recv halo exchange overlapped with interior kernel)"
     else:
         r = bench_single(args)
         ngpu = 1

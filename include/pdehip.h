@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 5
+#define PDEHIP_ABI_VERSION 6
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -490,6 +490,20 @@ int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *n
 int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme,
                      void *y_full, void *ynew_full, void *const *work_host, double *err_dev, double dt, int64_t nsteps,
                      pdehip_adaptive_t *ctl, void **result, void *stream);
+
+/* ---- the FAST block decomposition: two Euler steps per sweep on a box, halos two layers deep incl. the edges, ONE message per
+ * neighbouring rank, the exchange hidden behind the next sweep (csrc/pdehip_block2_loops.h; ABI version 6) -------------------------
+ * Replaces the same reference code as pdehip_block_run (GridMesh pde/grids/_mesh.py:59-93, :401-444; the blocking face exchange inside
+ * every right-hand side pde/backends/numba_mpi/backend.py:163-194, pde/grids/boundaries/local.py:561-662) for the case the benchmark
+ * runs: DiffusionPDE, fixed-step Euler, a 3-D grid that is periodic on every axis.  dims3 / coords3: blocks per axis and the block of
+ * this rank (ranks in C order of the block indices, like GridMesh); cut3[a] != 0: axis a is exchanged (several blocks - or one block
+ * that sends its halo to itself: the probe of the exchange path on one device), else it wraps inside the kernels.  The fastest axis
+ * cannot be cut (pdehip_block2_supported answers 0; the caller then takes pdehip_block_run).  buf_a: the state (full array of
+ * g_local), advanced in place by `nsteps` (EVEN) steps; buf_b is not touched (kept for the signature of the other loops).
+ * Bit-identical to single steps. */
+int pdehip_block2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, int *ok);
+int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *dims3, const int *coords3,
+                            const int *cut3, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream);
 
 /* ---- run-time specialised right-hand sides (generic `PDE({...})` expressions) ----------------------
  * Replaces the sympy -> numba code generation of pde/pdes/pde.py:401-499 / pde/tools/expressions.py:

@@ -1,0 +1,274 @@
+// pdehip_block2_loops.h — the FAST block decomposition: TWO Euler steps of the diffusion equation per sweep on a box of the grid,
+// halos of two layers incl. the edges in ONE message per neighbouring rank, and the exchange hidden behind the next sweep.
+// Written once against an `Ops` policy like pdehip_slab_loops.h / pdehip_block_loops.h (HipOps: csrc/pdehip_comm.hip; HostOps of the
+// tests-only shim: tests/shim/pdehip_shim_comm.cpp).
+//
+// Reference: GridMesh (pde/grids/_mesh.py:168-806; `_get_optimal_decomposition` :59-93, neighbours incl. the periodic wrap :401-444)
+// and the face exchange inside every right-hand side (pde/backends/numba_mpi/backend.py:163-194, pde/grids/boundaries/local.py:561-662):
+// blocking, one layer per face, one step per exchange.  Here (VERDICT r4 "next" #1b):
+//
+//   * the box lives in a private array `ext` with TWO halo layers on every CUT axis (planes / rows: the full array of a grid two
+//     cells larger per cut axis; fastest axis: two cells of the row padding on either side).  An axis with ONE block keeps its
+//     periodic wrap inside the kernels and travels nowhere;
+//   * two steps per sweep need |dx| + |dy| + |dz| <= 2 of the input: faces two layers deep AND the (+-1, +-1) edges - 6 + 12
+//     directions.  Everything a rank sends to ONE peer is packed into ONE message (one pack launch for all regions, one RCCL group
+//     with one send + one receive per distinct peer, one unpack launch); with two blocks along a periodic axis the lower and the upper
+//     neighbour are the same rank and four regions ride in its message.  Order of the regions inside a message: the sender's directions
+//     in lexicographic order - the receiver walks the SENDER's directions (every rank knows the topology);
+//   * three schedules of a pair of steps (`mode` of euler2_run; measured in profiles/r05_probe_block.md).  Common to all: the RIM - own
+//     cells less than two layers from a cut face, the only cells whose two-step domain of dependence reaches a halo cell - is computed
+//     by a kernel of its own (`rim`: no march, every operand of a 2 x 2 x 120-cell tile requested at once: 15 us where the two-ended
+//     boundary sweep of the slab loop takes 41), and its results are what the next exchange sends.
+//       0: the sweep runs over the whole box at once from halos that may still be in flight and the rim is recomputed behind it;
+//       1: boundary first - rim, then the interior box (it reads own cells only) while the rim travels;
+//       2 (default): like 1 with the rim on the halo stream.
+//     What the kernel timelines show: the waves of a sweep live for the whole sweep and hold every vector register of the chip (2 x 248
+//     per SIMD), so a small kernel enqueued next to it is dispatched when the sweep ENDS (a 7 us pack took 57 us), and the other way
+//     round the sweep's workgroups lose the arbitration against small kernels of the other queue.  A pair therefore costs about
+//     interior + rim + pack (~100 us for 16.7 M cells against 63 us without neighbours) whatever the order; giving the halo stream
+//     compute units of its own (PDEHIP_BLOCK2_CUS, hipExtStreamCreateWithCUMask) overlaps everything but takes them from the sweep.
+//
+// Scope: 3-D grids, DiffusionPDE, fixed-step Euler, every axis periodic (cut axes exchange, uncut axes wrap); anything else takes
+// the exact one-step loops of pdehip_block_loops.h.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+#include "pdehip_slab_loops.h"
+
+namespace pdehip {
+namespace block2 {
+
+constexpr int kMaxPeers = 18;     // 6 face + 12 edge directions, each possibly a rank of its own
+constexpr int kMaxRegions = 18;
+
+struct Box { long lo[3], n[3]; };   // own-cell coordinates: 0 .. n-1 own, -2 / -1 and n / n+1 halo layers
+
+struct Region {
+    Box box;
+    size_t offset;   // elements from the start of the send / receive buffer
+};
+
+struct Peer {
+    int rank;
+    size_t send_off, send_elems, recv_off, recv_elems;
+};
+
+struct Plan {
+    long n[3];          // own cells
+    int cut[3];         // the axis is exchanged (else: periodic wrap inside the kernels)
+    int dims[3], coords[3];
+    int nsend, nrecv, npeers;
+    Region send[kMaxRegions], recv[kMaxRegions];
+    Peer peers[kMaxPeers];
+    size_t send_total, recv_total;   // elements
+    int nrim;
+    Box rim[6];         // boxes of own cells whose two-step domain of dependence reaches a halo cell
+};
+
+inline int rank_of(const int *dims, const int *c) { return (c[0] * dims[1] + c[1]) * dims[2] + c[2]; }
+
+// neighbour of the block `coords` in direction d (periodic wrap on every axis: the caller checked that)
+inline int neighbour(const int *dims, const int *coords, const int *d)
+{
+    int c[3];
+    for (int a = 0; a < 3; a++) c[a] = ((coords[a] + d[a]) % dims[a] + dims[a]) % dims[a];
+    return rank_of(dims, c);
+}
+
+inline size_t box_elems(const Box &b) { return (size_t)b.n[0] * (size_t)b.n[1] * (size_t)b.n[2]; }
+
+// directions that travel: non-zero on cut axes only, one or two non-zero components (faces and edges; corners never enter a
+// two-step 7-point stencil), in lexicographic order
+inline int directions(const int *cut, int (*dirs)[3])
+{
+    int n = 0;
+    for (int d0 = -1; d0 <= 1; d0++)
+        for (int d1 = -1; d1 <= 1; d1++)
+            for (int d2 = -1; d2 <= 1; d2++) {
+                const int d[3] = {d0, d1, d2};
+                int nz = 0;
+                bool ok = true;
+                for (int a = 0; a < 3; a++) {
+                    nz += d[a] != 0;
+                    if (d[a] != 0 && !cut[a]) ok = false;
+                }
+                if (!ok || nz < 1 || nz > 2) continue;
+                for (int a = 0; a < 3; a++) dirs[n][a] = d[a];
+                n++;
+            }
+    return n;
+}
+
+// own cells next to the face / edge in direction d (what the neighbour there needs) and the halo cells beyond it
+inline Box send_box(const long *n, const int *d)
+{
+    Box b;
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = d[a] < 0 ? 0 : (d[a] > 0 ? n[a] - 2 : 0);
+        b.n[a] = d[a] != 0 ? 2 : n[a];
+    }
+    return b;
+}
+inline Box halo_box(const long *n, const int *d)
+{
+    Box b;
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = d[a] < 0 ? -2 : (d[a] > 0 ? n[a] : 0);
+        b.n[a] = d[a] != 0 ? 2 : n[a];
+    }
+    return b;
+}
+
+// Build the plan of one rank.  Returns 0, or -1 when the box is too small for two-layer halos.
+inline int make_plan(const long *n, const int *dims, const int *coords, const int *cut, Plan *p)
+{
+    memset(p, 0, sizeof(*p));
+    for (int a = 0; a < 3; a++) {
+        p->n[a] = n[a]; p->dims[a] = dims[a]; p->coords[a] = coords[a]; p->cut[a] = cut[a];
+        if (cut[a] && n[a] < 4) return -1;
+    }
+    const int me = rank_of(dims, coords);
+    int dirs[kMaxRegions][3];
+    const int nd = directions(cut, dirs);
+    // distinct peers in order of first appearance
+    int peer_of_dir[kMaxRegions];
+    for (int k = 0; k < nd; k++) {
+        const int r = neighbour(dims, coords, dirs[k]);
+        int idx = -1;
+        for (int q = 0; q < p->npeers; q++)
+            if (p->peers[q].rank == r) idx = q;
+        if (idx < 0) { idx = p->npeers++; p->peers[idx].rank = r; }
+        peer_of_dir[k] = idx;
+    }
+    // send regions: peer by peer, inside a peer's message my directions in order
+    size_t off = 0;
+    for (int q = 0; q < p->npeers; q++) {
+        p->peers[q].send_off = off;
+        for (int k = 0; k < nd; k++) {
+            if (peer_of_dir[k] != q) continue;
+            Region &r = p->send[p->nsend++];
+            r.box = send_box(n, dirs[k]);
+            r.offset = off;
+            off += box_elems(r.box);
+        }
+        p->peers[q].send_elems = off - p->peers[q].send_off;
+    }
+    p->send_total = off;
+    // receive regions: the message of peer q holds ITS directions d (in order) with neighbour(q, d) == me; its own cells next to its
+    // face d are my halo in direction -d.  (Every block has the extents of mine along the axes a message spans only if the grid
+    // divides evenly; the caller checks that all ranks agree on the region sizes through the message lengths.)
+    off = 0;
+    for (int q = 0; q < p->npeers; q++) {
+        p->peers[q].recv_off = off;
+        int pc[3];
+        const int pr = p->peers[q].rank;
+        pc[2] = pr % dims[2]; pc[1] = (pr / dims[2]) % dims[1]; pc[0] = pr / (dims[2] * dims[1]);
+        for (int k = 0; k < nd; k++) {
+            if (neighbour(dims, pc, dirs[k]) != me) continue;
+            // several directions of the peer may lead to me (two blocks along a periodic axis): each one is a region of its own
+            const int back[3] = {-dirs[k][0], -dirs[k][1], -dirs[k][2]};
+            Region &r = p->recv[p->nrecv++];
+            r.box = halo_box(n, back);
+            r.offset = off;
+            off += box_elems(r.box);
+        }
+        p->peers[q].recv_elems = off - p->peers[q].recv_off;
+    }
+    p->recv_total = off;
+    // rim: two layers behind every cut face, full extent of the other axes (the boxes overlap along the edges: the same values twice)
+    for (int a = 0; a < 3; a++) {
+        if (!cut[a]) continue;
+        for (int side = 0; side < 2; side++) {
+            Box &b = p->rim[p->nrim++];
+            for (int c = 0; c < 3; c++) { b.lo[c] = 0; b.n[c] = n[c]; }
+            b.lo[a] = side ? n[a] - 2 : 0;
+            b.n[a] = 2;
+        }
+    }
+    return 0;
+}
+
+enum { EV_RIM = 0, EV_HALO = 1, EV_INT = 2 };
+
+// One exchange of the halos of `ext` (pack -> one group -> unpack) on stream `st`.
+template <class Ops>
+int exchange(Ops &ops, const Plan &p, void *ext, void *st)
+{
+    if (!p.npeers) return 0;
+    SLAB_TRY(ops.pack(p, ext, true, st));
+    SLAB_TRY(ops.group_start());
+    for (int q = 0; q < p.npeers; q++) {
+        const Peer &pe = p.peers[q];
+        SLAB_TRY(ops.send(ops.msg(true, pe.send_off), pe.send_elems * ops.esz(), pe.rank, st));
+        SLAB_TRY(ops.recv(ops.msg(false, pe.recv_off), pe.recv_elems * ops.esz(), pe.rank, st));
+    }
+    SLAB_TRY(ops.group_end());
+    return ops.pack(p, ext, false, st);
+}
+
+// nsteps (even) Euler steps: `ext0` holds the state (own cells; halos arbitrary), `ext1` is the second buffer; *result = the one
+// holding the final state.  comp / halo: the two streams (Ops::halo()); three events belong to Ops.  `mode` - the SAME for all ranks:
+//   0  the sweep of a pair runs over the WHOLE box at once, from halos that may still be in flight; the rim (wrong then) is recomputed
+//      behind it when they have landed:          comp: sweep | wait halos | rim | sweep ...      halo: pack -> send/recv -> unpack
+//   1  boundary first: the rim from the landed halos, then the interior box (cells two layers from every cut face: it reads own cells
+//      only) while the rim travels:              comp: wait halos | rim | interior ...            halo: pack -> send/recv -> unpack
+//   2  like 1 with the rim on the halo stream, concurrent with the interior sweep of the same pair (pays when the two streams own
+//      disjoint sets of compute units):          comp: interior | interior ...                    halo: rim | pack -> send/recv -> unpack
+template <class Ops>
+int euler2_run(Ops &ops, const Plan &p, void *ext0, void *ext1, int64_t nsteps, void **result, void *comp, int mode = 0)
+{
+    void *halo = ops.halo();
+    void *cur = ext0, *nxt = ext1;
+    // halos of the initial state
+    SLAB_TRY(ops.record2(EV_INT, comp));
+    SLAB_TRY(ops.wait2(halo, EV_INT));
+    SLAB_TRY(exchange(ops, p, cur, halo));
+    SLAB_TRY(ops.record2(EV_HALO, halo));
+    SLAB_TRY(ops.record2(EV_RIM, halo));   // (mode 2: "the rim of the pair before" of the first pair)
+    for (int64_t s = 0; s + 2 <= nsteps; s += 2) {
+        const bool more = s + 4 <= nsteps;   // the result of this pair is the input of another one: its rim travels
+        if (mode == 0) {
+            SLAB_TRY(ops.sweep2(p, cur, nxt, false, comp));   // the whole box; the rim from stale halos (rewritten below)
+            SLAB_TRY(ops.wait2(comp, EV_HALO));               // halos of `cur` have landed
+            SLAB_TRY(ops.rim2(p, cur, nxt, comp));
+            SLAB_TRY(ops.record2(EV_RIM, comp));
+            if (more) {
+                SLAB_TRY(ops.wait2(halo, EV_RIM));
+                SLAB_TRY(exchange(ops, p, nxt, halo));        // overlaps the next sweep
+                SLAB_TRY(ops.record2(EV_HALO, halo));
+            }
+        } else if (mode == 1) {
+            SLAB_TRY(ops.wait2(comp, EV_HALO));
+            SLAB_TRY(ops.rim2(p, cur, nxt, comp));
+            SLAB_TRY(ops.record2(EV_RIM, comp));
+            if (more) {
+                SLAB_TRY(ops.wait2(halo, EV_RIM));
+                SLAB_TRY(exchange(ops, p, nxt, halo));        // overlaps the interior sweep
+                SLAB_TRY(ops.record2(EV_HALO, halo));
+            }
+            SLAB_TRY(ops.sweep2(p, cur, nxt, true, comp));    // interior box: reads own cells only
+        } else {
+            // halo stream: rim(p) needs the interior of the pair before (EV_INT) and - stream order - its own exchange before
+            SLAB_TRY(ops.wait2(halo, EV_INT));
+            SLAB_TRY(ops.rim2(p, cur, nxt, halo));
+            // comp stream: interior(p) reads the rim cells of `cur`: the rim of the pair before (EV_RIM, recorded before this pair's)
+            SLAB_TRY(ops.wait2(comp, EV_RIM));
+            SLAB_TRY(ops.sweep2(p, cur, nxt, true, comp));
+            SLAB_TRY(ops.record2(EV_INT, comp));
+            SLAB_TRY(ops.record2(EV_RIM, halo));
+            if (more) SLAB_TRY(exchange(ops, p, nxt, halo));
+        }
+        void *t = cur; cur = nxt; nxt = t;
+    }
+    // everything the halo stream still does is ordered before the caller's next use of the arrays
+    SLAB_TRY(ops.record2(EV_HALO, halo));
+    SLAB_TRY(ops.wait2(comp, EV_HALO));
+    *result = cur;
+    return 0;
+}
+
+}  // namespace block2
+}  // namespace pdehip

@@ -14,6 +14,8 @@
 // 64x512x512 slab needs on the GPU; the loop below enqueues a step in a few tens of us and never
 // synchronises with the host.
 #include <dlfcn.h>
+
+#include <map>
 #include <rccl/rccl.h>
 
 #include "pdehip_common.h"
@@ -664,6 +666,424 @@ int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_
     HipOps ops{c};
     ops.bn = &n;
     return block::run(ops, g_local, q, rhs, fuse_stage != 0, scheme, y_full, ynew_full, work_host, err_dev, dt, nsteps, ctl, result, stream);
+}
+
+}  // extern "C"
+
+// ======================================================================================================================================
+// The FAST block decomposition (pdehip_block2_loops.h): two Euler steps per sweep on a box, one message per neighbouring rank, the
+// exchange hidden behind the next sweep, the rim recomputed when the halos have landed.
+// ======================================================================================================================================
+#include "pdehip_block2_loops.h"
+
+namespace {
+
+// ---- box copies: pack / unpack of all regions of an exchange in ONE launch, and the own cells between the state array and `ext` ----
+struct BoxJob {
+    const void *src;
+    void *dst;
+    long sbase, s0, s1;   // element offset of the box's first cell and the pitches of its two slow axes (source)
+    long dbase, d0, d1;   // ... destination
+    long n1, nv;          // rows per plane, VECTORS per row
+    long start;           // first work item of this job
+};
+struct BoxJobs {
+    int n;
+    long total;
+    BoxJob j[block2::kMaxRegions];
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) box_copy_kernel(BoxJobs a)
+{
+    typedef T V __attribute__((ext_vector_type(VEC)));
+    for (long t = blockIdx.x * 256L + threadIdx.x; t < a.total; t += (long)gridDim.x * 256L) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < block2::kMaxRegions; q++)
+            if (q < a.n && t >= a.j[q].start) k = q;
+        const BoxJob &b = a.j[k];
+        const long loc = t - b.start;
+        const long v = loc % b.nv, r = loc / b.nv;
+        const long j = r % b.n1, i = r / b.n1;
+        const T *s = (const T *)b.src + b.sbase + i * b.s0 + j * b.s1 + v * VEC;
+        T *d = (T *)b.dst + b.dbase + i * b.d0 + j * b.d1 + v * VEC;
+        *(V *)d = *(const V *)s;
+    }
+}
+
+// ---- the rim: two Euler steps for the cells less than two layers from a cut face, recomputed from the sweep's input ------------------
+// No march: a wave owns an output tile of 2 planes x 2 rows x 60 lanes and requests every operand of it at once (24 row vectors of the
+// input: the tile widened by two cells, without the corners a 7-point stencil never reaches).  Neighbours along the fastest axis are the
+// neighbouring lanes (DPP wave shifts); lanes 0, 1, 62, 63 only feed their neighbours (level 1 is valid on lanes 1 .. 62, level 2 on
+// 2 .. 61).  Same expressions in the same order as the two-level sweep (pdehip_march2.inc: `laplace`, `update`; cartesian.py:220-227,
+// euler.py:172-175), the intermediate level rounded to the storage type: bit-identical to it and to two single steps.
+struct Rim2Args {
+    const void *in;
+    void *out;
+    long n0, n1, n2;
+    long p0, p1, off;       // pitches of `ext`, element offset of own cell (0, 0, 0)
+    int wrap[3];            // the axis wraps (one block along a periodic axis); else two real halo layers on either side
+    double sx, sy, sz, s1, s2;
+    int njobs;
+    struct Job { long i0, j0, ni, nj; long start; } job[6];   // box of own cells, tiles of 2 x 2 (the last one moved back)
+    long nzseg;             // lane segments per row
+    long total;             // wave tiles
+};
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) rim2_kernel(Rim2Args a)
+{
+    typedef typename VecT<T, VEC>::type V;
+    const int lane = threadIdx.x & 63;
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (w >= a.total) return;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 6; q++)
+        if (q < a.njobs && w >= a.job[q].start) k = q;
+    const long loc = w - a.job[k].start;
+    const long zseg = loc % a.nzseg;
+    const long ti = (loc / a.nzseg) % ((a.job[k].ni + 1) / 2), tj = (loc / a.nzseg) / ((a.job[k].ni + 1) / 2);
+    long i0 = a.job[k].i0 + 2 * ti, j0 = a.job[k].j0 + 2 * tj;
+    if (i0 + 2 > a.job[k].i0 + a.job[k].ni) i0 = a.job[k].i0 + a.job[k].ni - 2;
+    if (j0 + 2 > a.job[k].j0 + a.job[k].nj) j0 = a.job[k].j0 + a.job[k].nj - 2;
+    const long nv = a.n2 / VEC;
+    const long vi = zseg * 60 - 2 + lane;     // the lane's vector of the row
+    long vs = vi;
+    if (a.wrap[2]) vs = ((vi % nv) + nv) % nv;
+    else vs = vi < -1 ? -1 : (vi > nv ? nv : vi);   // one vector of halo on either side; lanes further out only feed lanes that store nothing
+    auto xs = [&](long i) { return a.wrap[0] ? ((i % a.n0) + a.n0) % a.n0 : i; };
+    auto ys = [&](long j) { return a.wrap[1] ? ((j % a.n1) + a.n1) % a.n1 : j; };
+    const T *base = (const T *)a.in + a.off + vs * VEC;
+
+    V u0[6][6];
+#pragma unroll
+    for (int pp = 0; pp < 6; pp++)
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+            const int dp = pp < 2 ? 2 - pp : (pp > 3 ? pp - 3 : 0), dr = rr < 2 ? 2 - rr : (rr > 3 ? rr - 3 : 0);
+            if (dp + dr > 2) continue;
+            u0[pp][rr] = *(const V *)(base + xs(i0 - 2 + pp) * a.p0 + ys(j0 - 2 + rr) * a.p1);
+        }
+    auto step = [&](double xm, double xp, double up, double dn, double left, double right, double cen) {
+        const double vm = 2 * cen;
+        const double lx = (xm - vm + xp) * a.sx;
+        const double ly = (up - vm + dn) * a.sy;
+        const double lz = (left - vm + right) * a.sz;
+        const double lap = lx + ly + lz;
+        return cen + a.s2 * (a.s1 * lap);
+    };
+    V u1[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (((q == 0 || q == 3) ? 1 : 0) + ((s == 0 || s == 3) ? 1 : 0) > 1) continue;
+            const V cc = u0[q + 1][s + 1];
+            const double zl = wave_shr1(0.0, (double)cc[VEC - 1]), zr = wave_shl1(0.0, (double)cc[0]);
+            V res;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const double left = (e == 0) ? zl : (double)cc[e > 0 ? e - 1 : 0];
+                const double right = (e == VEC - 1) ? zr : (double)cc[e < VEC - 1 ? e + 1 : e];
+                res[e] = (T)step((double)u0[q][s + 1][e], (double)u0[q + 2][s + 1][e], (double)u0[q + 1][s][e], (double)u0[q + 1][s + 2][e], left, right, (double)cc[e]);
+            }
+            u1[q][s] = res;
+        }
+    T *ob = (T *)a.out + a.off + vi * VEC;
+    const bool store = lane >= 2 && lane <= 61 && vi >= 0 && vi < nv;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const V cc = u1[q + 1][s + 1];
+            const double zl = wave_shr1(0.0, (double)cc[VEC - 1]), zr = wave_shl1(0.0, (double)cc[0]);
+            V res;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const double left = (e == 0) ? zl : (double)cc[e > 0 ? e - 1 : 0];
+                const double right = (e == VEC - 1) ? zr : (double)cc[e < VEC - 1 ? e + 1 : e];
+                res[e] = (T)step((double)u1[q][s + 1][e], (double)u1[q + 2][s + 1][e], (double)u1[q + 1][s][e], (double)u1[q + 1][s + 2][e], left, right, (double)cc[e]);
+            }
+            if (store) *(V *)(ob + (i0 + q) * a.p0 + (j0 + s) * a.p1) = res;
+        }
+}
+
+struct Block2Ctx {
+    void *ext[2] = {nullptr, nullptr};
+    size_t ext_bytes = 0;
+    void *msg[2] = {nullptr, nullptr};   // send / receive buffer (all peers, contiguous)
+    size_t msg_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // block2::EV_*, [3]: hand-over between the caller's stream and the masked one
+    // PDEHIP_BLOCK2_CUS=<R>: the halo stream (rim / pack / RCCL / unpack) owns R compute units, the sweeps the other 256 - R.  The waves
+    // of a sweep live for the whole sweep and hold every register of the chip: a small kernel enqueued next to it waits for its END
+    // (kernel timeline in profiles/r05_probe_block.md: the 7 us pack took 57 us), so without the partition nothing overlaps.
+    hipStream_t comp_masked = nullptr, halo_masked = nullptr;
+    int reserved = -1;
+};
+// (one context per communicator; the serial context of a process without neighbours has its own)
+Block2Ctx *block2_ctx(Comm *c)
+{
+    static std::map<Comm *, Block2Ctx> table;
+    return &table[c];
+}
+
+struct HipOps2 {
+    Comm *c;
+    Block2Ctx *x;
+    const pdehip_grid_t *g_box;
+    NGrid ne;              // the grid of `ext`
+    long own_off;          // element offset of own cell (0, 0, 0) in `ext`
+    const pdehip_bc_face_t *faces;
+    double D, dt;
+    size_t es;
+    void *halo_st = nullptr;
+    void *halo() { return halo_st; }
+    size_t esz() const { return es; }
+    void *msg(bool send, size_t elem_off) { return static_cast<char *>(x->msg[send ? 0 : 1]) + elem_off * es; }
+    int record2(int ev, void *st) { PDEHIP_HIP(hipEventRecord(x->ev[ev], as_stream(st))); return 0; }
+    int wait2(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), x->ev[ev], 0)); return 0; }
+    int group_start() { PDEHIP_NCCL(g_rccl.GroupStart()); return 0; }
+    int group_end() { PDEHIP_NCCL(g_rccl.GroupEnd()); return 0; }
+    int send(const void *p, size_t bytes, int peer, void *st) { PDEHIP_NCCL(g_rccl.Send(p, bytes, ncclInt8, peer, c->comm, as_stream(st))); return 0; }
+    int recv(void *p, size_t bytes, int peer, void *st) { PDEHIP_NCCL(g_rccl.Recv(p, bytes, ncclInt8, peer, c->comm, as_stream(st))); return 0; }
+
+    long elem_of(const long *lo) const { return own_off + lo[0] * ne.p[0] + lo[1] * ne.p[1] + lo[2]; }
+    int launch_copy(BoxJobs &jobs, int vec, void *st)
+    {
+        if (!jobs.total) return 0;
+        const unsigned blocks = (unsigned)((jobs.total + 255) / 256 < 4096 ? (jobs.total + 255) / 256 : 4096);
+        hipStream_t s = as_stream(st);
+        if (es == 8) {
+            if (vec == 2) hipLaunchKernelGGL((box_copy_kernel<double, 2>), dim3(blocks), dim3(256), 0, s, jobs);
+            else hipLaunchKernelGGL((box_copy_kernel<double, 1>), dim3(blocks), dim3(256), 0, s, jobs);
+        } else {
+            if (vec == 4) hipLaunchKernelGGL((box_copy_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, jobs);
+            else if (vec == 2) hipLaunchKernelGGL((box_copy_kernel<float, 2>), dim3(blocks), dim3(256), 0, s, jobs);
+            else hipLaunchKernelGGL((box_copy_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, jobs);
+        }
+        PDEHIP_HIP(hipGetLastError());
+        return 0;
+    }
+    // widest vector (elements) that every box of the list allows on both sides
+    static int common_vec(const BoxJobs &jobs, const long *n2s, int maxvec)
+    {
+        int vec = maxvec;
+        for (int k = 0; k < jobs.n; k++) {
+            const BoxJob &b = jobs.j[k];
+            while (vec > 1 && (n2s[k] % vec || b.sbase % vec || b.dbase % vec || b.s0 % vec || b.s1 % vec || b.d0 % vec || b.d1 % vec)) vec /= 2;
+        }
+        return vec;
+    }
+    // all regions of an exchange: own cells -> send buffer (is_pack) / receive buffer -> halo cells
+    int pack(const block2::Plan &p, void *ext, bool is_pack, void *st)
+    {
+        BoxJobs jobs;
+        long n2s[block2::kMaxRegions];
+        const int nreg = is_pack ? p.nsend : p.nrecv;
+        jobs.n = nreg;
+        for (int k = 0; k < nreg; k++) {
+            const block2::Region &r = is_pack ? p.send[k] : p.recv[k];
+            BoxJob &b = jobs.j[k];
+            const long e = elem_of(r.box.lo);
+            const long m0 = r.box.n[1] * r.box.n[2], m1 = r.box.n[2];
+            if (is_pack) { b.src = ext; b.dst = x->msg[0]; b.sbase = e; b.s0 = ne.p[0]; b.s1 = ne.p[1]; b.dbase = (long)r.offset; b.d0 = m0; b.d1 = m1; }
+            else { b.src = x->msg[1]; b.dst = ext; b.sbase = (long)r.offset; b.s0 = m0; b.s1 = m1; b.dbase = e; b.d0 = ne.p[0]; b.d1 = ne.p[1]; }
+            b.n1 = r.box.n[1];
+            n2s[k] = r.box.n[2];
+        }
+        const int vec = common_vec(jobs, n2s, (int)(16 / es));
+        long total = 0;
+        for (int k = 0; k < nreg; k++) {
+            const block2::Region &r = is_pack ? p.send[k] : p.recv[k];
+            jobs.j[k].nv = n2s[k] / vec;
+            jobs.j[k].start = total;
+            total += r.box.n[0] * r.box.n[1] * jobs.j[k].nv;
+        }
+        jobs.total = total;
+        return launch_copy(jobs, vec, st);
+    }
+    // own cells between the state array (full array of g_box) and `ext`
+    int copy_own(const NGrid &nl, void *state, void *ext, bool to_ext, void *st)
+    {
+        BoxJobs jobs;
+        jobs.n = 1;
+        BoxJob &b = jobs.j[0];
+        const long lo[3] = {0, 0, 0};
+        if (to_ext) { b.src = state; b.dst = ext; b.sbase = nl.off; b.s0 = nl.p[0]; b.s1 = nl.p[1]; b.dbase = elem_of(lo); b.d0 = ne.p[0]; b.d1 = ne.p[1]; }
+        else { b.src = ext; b.dst = state; b.sbase = elem_of(lo); b.s0 = ne.p[0]; b.s1 = ne.p[1]; b.dbase = nl.off; b.d0 = nl.p[0]; b.d1 = nl.p[1]; }
+        b.n1 = nl.n[1];
+        const long n2s[1] = {nl.n[2]};
+        const int vec = common_vec(jobs, n2s, (int)(16 / es));
+        b.nv = nl.n[2] / vec;
+        b.start = 0;
+        jobs.total = nl.n[0] * nl.n[1] * b.nv;
+        return launch_copy(jobs, vec, st);
+    }
+    int sweep2(const block2::Plan &p, void *cur, void *nxt, bool interior, void *st)
+    {
+        bool done = false;
+        long lo[3] = {0, 0, 0}, n[3] = {p.n[0], p.n[1], p.n[2]};
+        if (interior)
+            for (int a = 0; a < 3; a++)
+                if (p.cut[a]) { lo[a] = 2; n[a] -= 4; }
+        PDEHIP_TRY(euler2_box(g_box, faces, p.cut, cur, nxt, D, dt, st, &done, false, lo, n));
+        if (!done) PDEHIP_FAIL(E_RUNTIME, "internal: the two-step kernel refused a box it accepted in the dry run");
+        return 0;
+    }
+    int rim2(const block2::Plan &p, void *cur, void *nxt, void *st)
+    {
+        if (!p.nrim) return 0;
+        Rim2Args a;
+        memset(&a, 0, sizeof(a));
+        a.in = cur; a.out = nxt;
+        a.n0 = p.n[0]; a.n1 = p.n[1]; a.n2 = p.n[2];
+        a.p0 = ne.p[0]; a.p1 = ne.p[1]; a.off = own_off;
+        for (int k = 0; k < 3; k++) a.wrap[k] = p.cut[k] ? 0 : 1;
+        a.sx = ne.lap_scale[0]; a.sy = ne.lap_scale[1]; a.sz = ne.lap_scale[2];
+        a.s1 = D; a.s2 = dt;
+        const long vec = (long)(16 / es);
+        a.nzseg = (p.n[2] / vec + 59) / 60;
+        long total = 0;
+        for (int k = 0; k < p.nrim; k++) {
+            const block2::Box &b = p.rim[k];
+            if (b.n[2] != p.n[2]) PDEHIP_FAIL(E_NOTIMPL, "internal: rims of the fastest axis are not built");
+            a.job[a.njobs] = {b.lo[0], b.lo[1], b.n[0], b.n[1], total};
+            a.njobs++;
+            total += ((b.n[0] + 1) / 2) * ((b.n[1] + 1) / 2) * a.nzseg;
+        }
+        a.total = total;
+        const unsigned blocks = (unsigned)((total + 3) / 4);
+        if (es == 8) hipLaunchKernelGGL((rim2_kernel<double, 2>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+        else hipLaunchKernelGGL((rim2_kernel<float, 4>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+        PDEHIP_HIP(hipGetLastError());
+        return 0;
+    }
+};
+
+// what the fast block loop covers: 3-D, diffusion, every face of an uncut axis periodic, no cut of the fastest axis (its rim would
+// need a transposed kernel), boxes and rows the two-step kernel and the 16-byte vectors of the rim kernel take
+int block2_check(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, bool *ok)
+{
+    *ok = false;
+    if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program) return 0;
+    if (cut3[2]) return 0;
+    const long vec = 16 / elem_size(g_local->dtype);
+    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4) return 0;
+    bool done = false;
+    PDEHIP_TRY(euler2_box(g_local, rhs->bc_c, cut3, (const void *)16, (void *)32, rhs->param, 0.0, nullptr, &done, true));
+    if (done) {   // ... and the interior box of the boundary-first schedules
+        long lo[3] = {0, 0, 0}, n[3] = {g_local->shape[0], g_local->shape[1], g_local->shape[2]};
+        for (int a = 0; a < 3; a++)
+            if (cut3[a]) { lo[a] = 2; n[a] -= 4; }
+        if (n[0] < 1 || n[1] < 4) done = false;
+        else PDEHIP_TRY(euler2_box(g_local, rhs->bc_c, cut3, (const void *)16, (void *)32, rhs->param, 0.0, nullptr, &done, true, lo, n));
+    }
+    *ok = done;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdehip_block2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, int *ok)
+{
+    if (!g_local || !rhs || !cut3 || !ok) PDEHIP_FAIL(E_VALUE, "block2_supported: NULL pointer");
+    bool b = false;
+    PDEHIP_TRY(block2_check(g_local, rhs, cut3, &b));
+    *ok = b ? 1 : 0;
+    return 0;
+}
+
+int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *dims3, const int *coords3,
+                            const int *cut3, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!g_local || !rhs || !dims3 || !coords3 || !cut3 || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "block2_euler_run: NULL pointer");
+    if (nsteps < 0 || nsteps % 2) PDEHIP_FAIL(E_VALUE, "block2_euler_run: the step count must be even (two steps per sweep)");
+    bool ok = false;
+    PDEHIP_TRY(block2_check(g_local, rhs, cut3, &ok));
+    if (!ok) PDEHIP_FAIL(E_NOTIMPL, "block2_euler_run: grid, equation or faces are not covered (ask pdehip_block2_supported)");
+    const bool any = cut3[0] || cut3[1] || cut3[2];
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) {
+        if (any) PDEHIP_FAIL(E_VALUE, "a block with neighbours needs a communicator");
+        c = serial_context();
+    }
+    PDEHIP_TRY(ensure_streams(c));
+    for (int a = 0; a < 3; a++) {
+        if (dims3[a] < 1 || coords3[a] < 0 || coords3[a] >= dims3[a]) PDEHIP_FAIL(E_VALUE, "block2_euler_run: bad decomposition");
+        if (dims3[a] > 1 && !cut3[a]) PDEHIP_FAIL(E_VALUE, "block2_euler_run: an axis with several blocks must be exchanged");
+    }
+    if (any && (long)dims3[0] * dims3[1] * dims3[2] != c->size) PDEHIP_FAIL(E_VALUE, "block2_euler_run: the decomposition does not match the world size");
+    block2::Plan plan;
+    const long n[3] = {g_local->shape[0], g_local->shape[1], g_local->shape[2]};
+    if (block2::make_plan(n, dims3, coords3, cut3, &plan) != 0) PDEHIP_FAIL(E_VALUE, "block2_euler_run: the box is too small for two halo layers");
+    Block2Ctx *x = block2_ctx(c);
+    for (auto &e : x->ev)
+        if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HipOps2 ops;
+    ops.c = c; ops.x = x; ops.g_box = g_local; ops.faces = rhs->bc_c; ops.D = rhs->param; ops.dt = dt;
+    pdehip_grid_t ge = *g_local;
+    ge.shape[0] += 2; ge.shape[1] += 2;
+    PDEHIP_TRY(norm_grid(&ge, &ops.ne));
+    ops.own_off = ops.ne.off + ops.ne.p[0] + ops.ne.p[1];
+    ops.es = (size_t)elem_size(ops.ne.dtype);
+    NGrid nl;
+    PDEHIP_TRY(norm_grid(g_local, &nl));
+    hipStream_t comp = as_stream(stream);
+    // schedule and partition of the compute units (tuning aids; the defaults are what measured best on one MI355X, profiles/r05_probe_block.md)
+    static const int mode = getenv("PDEHIP_BLOCK2_MODE") ? atoi(getenv("PDEHIP_BLOCK2_MODE")) : 2;
+    static const int want_cus = getenv("PDEHIP_BLOCK2_CUS") ? atoi(getenv("PDEHIP_BLOCK2_CUS")) : 0;
+    if (mode < 0 || mode > 2) PDEHIP_FAIL(E_VALUE, "PDEHIP_BLOCK2_MODE: 0, 1 or 2");
+    ops.halo_st = c->halo;
+    hipStream_t comp2 = comp;
+    if (want_cus > 0 && any) {
+        if (x->reserved != want_cus) {
+            int ncu = 0;
+            PDEHIP_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+            if (want_cus >= ncu || ncu > 1024) PDEHIP_FAIL(E_VALUE, "PDEHIP_BLOCK2_CUS: between 1 and the number of compute units - 1");
+            uint32_t mc[32], mh[32];
+            const int words = (ncu + 31) / 32;
+            for (int w = 0; w < words; w++) { mc[w] = 0; mh[w] = 0; }
+            for (int b = 0; b < ncu; b++) (b < want_cus ? mh : mc)[b / 32] |= 1u << (b % 32);
+            if (x->comp_masked) { (void)hipStreamDestroy(x->comp_masked); (void)hipStreamDestroy(x->halo_masked); }
+            PDEHIP_HIP(hipExtStreamCreateWithCUMask(&x->comp_masked, (uint32_t)words, mc));
+            PDEHIP_HIP(hipExtStreamCreateWithCUMask(&x->halo_masked, (uint32_t)words, mh));
+            x->reserved = want_cus;
+        }
+        comp2 = x->comp_masked;
+        ops.halo_st = x->halo_masked;
+    }
+    const size_t need = (size_t)(ops.ne.pc + kAllocSlack) * ops.es;
+    if (x->ext_bytes < need) {
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        PDEHIP_HIP(hipStreamSynchronize(comp));
+        (void)hipFree(x->ext[0]); (void)hipFree(x->ext[1]);
+        x->ext[0] = x->ext[1] = nullptr; x->ext_bytes = 0;
+        PDEHIP_HIP(hipMalloc(&x->ext[0], need));
+        PDEHIP_HIP(hipMalloc(&x->ext[1], need));
+        x->ext_bytes = need;
+        PDEHIP_HIP(hipMemsetAsync(x->ext[0], 0, need, comp));
+        PDEHIP_HIP(hipMemsetAsync(x->ext[1], 0, need, comp));
+    }
+    const size_t mneed = (plan.send_total > plan.recv_total ? plan.send_total : plan.recv_total) * ops.es + 256;
+    if (x->msg_bytes < mneed) {
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        (void)hipFree(x->msg[0]); (void)hipFree(x->msg[1]);
+        x->msg[0] = x->msg[1] = nullptr; x->msg_bytes = 0;
+        PDEHIP_HIP(hipMalloc(&x->msg[0], mneed));
+        PDEHIP_HIP(hipMalloc(&x->msg[1], mneed));
+        x->msg_bytes = mneed;
+    }
+    PDEHIP_TRY(ops.copy_own(nl, buf_a, x->ext[0], true, comp));
+    void *res = x->ext[0];
+    if (comp2 != comp) { PDEHIP_HIP(hipEventRecord(x->ev[3], comp)); PDEHIP_HIP(hipStreamWaitEvent(comp2, x->ev[3], 0)); }
+    if (nsteps > 0) PDEHIP_TRY(block2::euler2_run(ops, plan, x->ext[0], x->ext[1], nsteps, &res, comp2, mode));
+    if (comp2 != comp) { PDEHIP_HIP(hipEventRecord(x->ev[3], comp2)); PDEHIP_HIP(hipStreamWaitEvent(comp, x->ev[3], 0)); }
+    PDEHIP_TRY(ops.copy_own(nl, buf_a, res, false, comp));
+    *result = buf_a;
+    return 0;
 }
 
 }  // extern "C"

@@ -97,7 +97,10 @@ inline int norm_grid(const pdehip_grid_t *g, NGrid *n)
     }
     n->lpad = row_align_bytes() / elem_size(g->dtype);
     n->p[2] = 1;
-    n->p[1] = ((n->lpad + n->n[2] + 1 + n->lpad - 1) / n->lpad) * n->lpad;
+    // pitch: a multiple of the alignment.  "tight" (PDEHIP_ROW_PITCH=tight, A/B aid): n2 + 2 rounded up - the upper ghost cell of a row may
+    // then be element 0 of the next row's segment (its padding), 3 % fewer bytes of footprint at 512 cells per row
+    static const bool tight = getenv("PDEHIP_ROW_PITCH") && !strcmp(getenv("PDEHIP_ROW_PITCH"), "tight");
+    n->p[1] = tight && n->lpad >= 4 ? ((n->n[2] + 2 + n->lpad - 1) / n->lpad) * n->lpad : ((n->lpad + n->n[2] + 1 + n->lpad - 1) / n->lpad) * n->lpad;
     n->p[0] = n->p[1] * (n->n[1] + 2 * n->gh[1]);
     n->pc = n->p[0] * (n->n[0] + 2 * n->gh[0]);
     n->off = n->gh[0] * n->p[0] + n->gh[1] * n->p[1] + n->lpad;
@@ -144,7 +147,8 @@ struct Euler2Plan {
 };
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg, int xplain,
                   hipStream_t st, bool *done, bool dry_run = false, int ends = 0, int m2 = E2_DIFFUSION,
-                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr);
+                  const InputBCs *fg1 = nullptr, double gamma = 0, Euler2Plan *plan = nullptr, const StageFuse *stage = nullptr,
+                  int yzplain = 0);   // yzplain: bit 0 / bit 1 = the rows / the fastest axis have two real halo layers in memory (a box of a larger array)
 // K Euler steps of a 2-D grid per launch, time levels in LDS (pdehip_tile2d.inc): diffusion (rhs->kind 0) or Cahn-Hilliard
 int tile2d_max_steps(int mode);
 int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
@@ -165,6 +169,9 @@ bool bcprog_second_set(void *handle, const double *const_arr, const double **c2,
 int bcprog_run_pair(void *handle, double t0, double t1, void *stream);
 int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2,
                           const pdehip_bc_face_t *faces, void *stream, bool *done, int xplain = 0, bool dry_run = false, int ends = 0);
+// two Euler steps of the diffusion equation on a box of a larger array with two real halo layers on the cut axes (pdehip_ops.hip)
+int euler2_box(const pdehip_grid_t *g_box, const pdehip_bc_face_t *faces, const int *cut3, const void *in_ext, void *out_ext, double s1,
+               double s2, void *stream, bool *done, bool dry_run = false, const long *lo3 = nullptr, const long *n3 = nullptr);
 // one Cahn-Hilliard sweep: mu = c^3 - c - gamma*lap(c) with the faces of c, then (euler) out = c + dt*lap(mu) or
 // (!euler) out = dt*lap(mu) with the faces of mu — mu never leaves the registers; *done as above
 int cahn_hilliard_fused(const pdehip_grid_t *g, const void *in, void *out, double gamma, double dt, bool euler,

@@ -483,7 +483,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
     static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
     long open_tail = 0;
-    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8) open_tail = a.n2 % CW;
+    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
     const long n2t = a.n2 - open_tail;   // the columns the tiles cover
     const int ry_want = ry;
     while (ry > 1 && a.n1 % ry) ry /= 2;
@@ -804,7 +804,7 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
 
 int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
                   int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
-                  Euler2Plan *plan, const StageFuse *stage)
+                  Euler2Plan *plan, const StageFuse *stage, int yzplain)
 {
     *done = false;
     if ((m2 == E2_CH_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage sweep without / with a stage descriptor");
@@ -832,6 +832,9 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
             continue;
         }
         if (k == 1 && n.ndim == 2) { a.per[1] = 1; continue; }
+        // block decomposition (pdehip_block2_loops.h): `n` describes a BOX of a larger array - two real halo rows (bit 0) / columns
+        // (bit 1) on either side in memory; no faces on those axes
+        if (k >= 1 && n.ndim == 3 && (yzplain & (1 << (k - 1)))) { a.per[k] = 2; continue; }
         const int ax = (k == 0) ? am : k;
         // both faces periodic, or both local (virtual point from the adjacent cell); the same for both levels
         const int cls = classify_axis(fg, ax, n.n[ax]);

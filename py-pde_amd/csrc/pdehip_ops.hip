@@ -708,6 +708,49 @@ int euler2_with_input_bcs(const pdehip_grid_t *g, const void *in, void *out, dou
     return launch_euler2(n, in, out, s1, s2, fg, xplain, as_stream(stream), done, dry_run, ends);
 }
 
+// Two Euler steps on a BOX of a larger array (fast block decomposition, pdehip_block2_loops.h).  `g_box`: the own cells of the rank;
+// `in_ext` / `out_ext`: full arrays of the grid two cells larger along the first two axes (own cell (0, 0, 0) = its interior cell
+// (1, 1, 0)), i.e. two halo planes / rows on either side; along the fastest axis the two halo cells sit in the row padding.  Cut axes
+// read those halos as they are ("plain"), the others must be periodic and wrap inside the kernel.
+int euler2_box(const pdehip_grid_t *g_box, const pdehip_bc_face_t *faces, const int *cut3, const void *in_ext, void *out_ext, double s1,
+               double s2, void *stream, bool *done, bool dry_run, const long *lo3, const long *n3)
+{
+    *done = false;
+    if (!g_box || !faces || !cut3 || !in_ext || !out_ext) PDEHIP_FAIL(E_VALUE, "euler2_box: NULL pointer");
+    if (g_box->ndim != 3) return 0;
+    pdehip_grid_t ge = *g_box;
+    ge.shape[0] += 2; ge.shape[1] += 2;
+    NGrid ne;
+    PDEHIP_TRY(norm_grid(&ge, &ne));
+    NGrid nb = ne;
+    for (int a = 0; a < 3; a++) nb.n[a] = g_box->shape[a];
+    nb.off = ne.off + ne.p[0] + ne.p[1];
+    // a part of the box (lo3 / n3: the interior two layers behind the cut faces): its halo cells are own cells - only along cut axes
+    if (lo3 && n3) {
+        for (int a = 0; a < 3; a++) {
+            if (!cut3[a] && (lo3[a] != 0 || n3[a] != nb.n[a])) PDEHIP_FAIL(E_RUNTIME, "internal: a part of a box along an axis that wraps");
+            if (lo3[a] < 0 || n3[a] < 1 || lo3[a] + n3[a] > nb.n[a]) return 0;
+            nb.off += lo3[a] * ne.p[a];
+            nb.n[a] = n3[a];
+        }
+    }
+    InputBCs fg;
+    memset(&fg, 0, sizeof(fg));
+    for (int a = 0; a < 3; a++) {
+        if (cut3[a]) continue;
+        for (int side = 0; side < 2; side++) {
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            const long want = side ? 0 : nb.n[a] - 1;
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 != want || r.const_v != 0.0 || r.factor1 != 1.0) return 0;   // periodic only
+            fg.on[a][side] = 1; fg.idx[a][side] = want; fg.c[a][side] = 0.0; fg.f[a][side] = 1.0;
+        }
+    }
+    // the two halo cells of a cut fastest axis live in the padding of the rows
+    if (cut3[2] && !(ne.lpad >= 2 && ne.p[1] >= ne.lpad + nb.n[2] + 2)) return 0;
+    return launch_euler2(nb, in_ext, out_ext, s1, s2, fg, cut3[0] ? 1 : 0, as_stream(stream), done, dry_run, 0, E2_DIFFUSION, nullptr, 0.0,
+                         nullptr, nullptr, (cut3[1] ? 1 : 0) | (cut3[2] ? 2 : 0));
+}
+
 int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *in, void *out, double dt, int nsteps, void *stream,
                    bool *done)
 {

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -240,6 +240,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     # block decomposition (csrc/pdehip_block_loops.h)
     "block_exchange": [_vp, _pg, C.POINTER(_i), _vp, _vp],
     "block_run": [_vp, _pg, _pr, C.POINTER(_i), _i, _i, _vp, _vp, _pvp, _vp, _d, _i64, _pa, _pvp, _vp],
+    "block2_supported": [_pg, _pr, C.POINTER(_i), C.POINTER(_i)],
+    "block2_euler_run": [_vp, _pg, _pr, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _vp, _vp, _d, _i64, _pvp, _vp],
     # Adams-Bashforth step in one sweep (device only: the oracle runs rhs_scaled + ab2_combine)
     "ab2_step": [_pg, _pr, _vp, _vp, _vp, _vp, _d, C.POINTER(_i), _vp],
     # fixed-step RK4 loop (device only: the oracle loops over rk4_step)

@@ -470,6 +470,33 @@ class BlockStepper:
         self.lib.slab_flags_supported(self.info.ref, C.byref(self.rhs), -1, -1, C.byref(local))
         fuse = bool(local.value & FUSED_STAGE) and self.kind == _abi.RHS_DIFFUSION
         self.fuse_stage = bool(self.control.all_and(1 if fuse else 0))
+        # The FAST loop (csrc/pdehip_block2_loops.h: two steps per sweep on the box, halos two layers deep incl. the edges in one message
+        # per neighbouring rank, the exchange hidden behind the next sweep): diffusion with fixed Euler steps on a 3-D grid that is
+        # periodic on every axis and not cut along the fastest one.  Decided for ALL ranks alike (PDEHIP_BLOCK2=0: the exact one-step loop).
+        nd = len(grid.shape)
+        self.cut = [int(self.dims[a] > 1 or (force_exchange and bool(grid.periodic[a]))) for a in range(nd)]
+        fast = 0
+        if (nd == 3 and all(grid.periodic) and self.kind == _abi.RHS_DIFFUSION and self.bc_program is None
+                and os.environ.get("PDEHIP_BLOCK2", "1") != "0"):
+            if self.cut[2] and force_exchange and self.dims[2] == 1:
+                self.cut[2] = 0          # (the probe on one device: the fastest axis keeps its periodic wrap)
+            # (the faces of the uncut axes as the kernels see them: the periodic conditions of the whole grid)
+            whole = _abi.RHS()
+            whole.kind, whole.param = self.kind, self.param
+            BlockMesh(grid, [1] * nd, 0).block_faces(bc_c).copy_into(whole.bc_c)
+            for a in range(nd):
+                for side in range(2):
+                    if not self.cut[a]:
+                        # index of the wrap inside the BOX: its last / first cell
+                        whole.bc_c[2 * a + side].index1 = 0 if side else self.mesh.local_shape[a] - 1
+            self._rhs2 = whole
+            self._cut3 = (C.c_int * 3)(*self.cut)
+            ok = C.c_int(0)
+            self.lib.block2_supported(self.info.ref, C.byref(whole), self._cut3, C.byref(ok))
+            fast = int(ok.value)
+        self.block2 = bool(self.control.all_and(fast))
+        if self.block2 and self.comm is None and any(self.cut):
+            self.block2 = False
 
     def buf(self, name: str):
         if name not in self._bufs:
@@ -494,6 +521,13 @@ class BlockStepper:
         return y if res.value == y.ptr else ynew
 
     def euler_steps(self, cur, nxt, dt: float, nsteps: int, t0: float = 0.0):
+        if self.block2 and nsteps >= 2:
+            # pairs of steps through the fast loop (in place on `cur`), an odd last step through the one-step loop
+            res = C.c_void_p()
+            dims3, coords3 = (C.c_int * 3)(*self.dims), (C.c_int * 3)(*self.mesh.index)
+            self.lib.block2_euler_run(self.comm, self.info.ref, C.byref(self._rhs2), dims3, coords3, self._cut3, cur.ptr, nxt.ptr, float(dt),
+                                      int(nsteps - nsteps % 2), C.byref(res), self.stream)
+            return self._run(0, cur, nxt, None, dt, 1, t0=t0 + (nsteps - 1) * dt) if nsteps % 2 else cur
         return self._run(0, cur, nxt, None, dt, nsteps, t0=t0)
 
     def rk4_steps(self, y, dt: float, nsteps: int, t0: float = 0.0) -> None:
@@ -513,6 +547,10 @@ class BlockStepper:
 
     def gather_local(self, arr) -> np.ndarray:
         return arr.get_valid(stream=self.stream)
+
+    def set_local(self, arr, local_valid: np.ndarray) -> None:
+        """Upload this rank's block (the interface of :meth:`SlabStepper.set_local`)."""
+        arr.set_valid(np.ascontiguousarray(local_valid, dtype=self.dtype), self.stream)
 
     def gather(self, arr) -> np.ndarray:
         """All ranks receive the global valid array (tests / tracker interrupts only)."""

@@ -31,6 +31,7 @@
 #include "../../py-pde_amd/csrc/pdehip_slab_loops.h"
 #include "../../py-pde_amd/csrc/pdehip_rk_loops.h"
 #include "../../py-pde_amd/csrc/pdehip_block_loops.h"
+#include "../../py-pde_amd/csrc/pdehip_block2_loops.h"
 
 using namespace pdehip;
 
@@ -82,6 +83,7 @@ struct Comm {
     std::vector<Op> group;
     bool in_group = false;
     std::vector<char> stg[3][2][2];   // block decomposition: packed faces, [axis][side][0 send / 1 receive]
+    std::vector<char> ext2[2], msg2[2];   // fast block loop (pdehip_block2_loops.h): boxes with two halo layers, send / receive buffer
 };
 
 double timeout_seconds()
@@ -769,6 +771,160 @@ int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_
     HostOps ops{c};
     SLAB_TRY(pdehip_layout(g_local, ops.lay));
     return block::run(ops, g_local, q, rhs, fuse_stage != 0, scheme, y_full, ynew_full, work_host, err_dev, dt, nsteps, ctl, result, stream);
+}
+
+}  // extern "C"
+
+
+// ---- the fast block loop (csrc/pdehip_block2_loops.h) on the host: the SAME schedule template, oracle passes as kernels ------------
+namespace {
+struct HostOps2 {
+    Comm *c;
+    pdehip_grid_t g_box, g_ext;       // own cells / the grid of `ext` (two cells larger along the first two axes)
+    int64_t lay[8];                   // pdehip_layout of g_ext
+    const pdehip_bc_face_t *faces;
+    double D, dt;
+    size_t es;
+    void *halo() { return (void *)1; }
+    size_t esz() const { return es; }
+    void *msg(bool send, size_t elem_off) { return c->msg2[send ? 0 : 1].data() + elem_off * es; }
+    int record2(int, void *) { return 0; }
+    int wait2(void *, int) { return 0; }
+    int group_start() { c->in_group = true; c->group.clear(); return 0; }
+    int send(const void *p, size_t bytes, int peer, void *) { c->group.push_back({true, const_cast<void *>(p), bytes, peer}); return 0; }
+    int recv(void *p, size_t bytes, int peer, void *) { c->group.push_back({false, p, bytes, peer}); return 0; }
+    int group_end()
+    {
+        c->in_group = false;
+        for (auto &op : c->group)
+            if (op.is_send) SLAB_TRY(post_send(c, op.p, op.bytes, op.peer));
+        for (auto &op : c->group)
+            if (!op.is_send) SLAB_TRY(wait_recv(c, op.p, op.bytes, op.peer));
+        c->group.clear();
+        return 0;
+    }
+    long elem_of(long i, long j, long k) const { return (long)lay[3] + (i + 1) * (long)lay[0] + (j + 1) * (long)lay[1] + k; }   // own-cell coordinates
+    int pack(const block2::Plan &p, void *ext, bool is_pack, void *)
+    {
+        const int nreg = is_pack ? p.nsend : p.nrecv;
+        for (int r = 0; r < nreg; r++) {
+            const block2::Region &reg = is_pack ? p.send[r] : p.recv[r];
+            char *buf = static_cast<char *>(msg(is_pack, reg.offset));
+            size_t m = 0;
+            for (long i = 0; i < reg.box.n[0]; i++)
+                for (long j = 0; j < reg.box.n[1]; j++)
+                    for (long k = 0; k < reg.box.n[2]; k++, m++) {
+                        char *cell = static_cast<char *>(ext) + elem_of(reg.box.lo[0] + i, reg.box.lo[1] + j, reg.box.lo[2] + k) * (long)es;
+                        if (is_pack) memcpy(buf + m * es, cell, es); else memcpy(cell, buf + m * es, es);
+                    }
+        }
+        return 0;
+    }
+    // two steps from `cur` with whatever its halo cells hold; cells `only_rim` (or all own cells) of the result into `nxt`
+    int two_steps(const block2::Plan &p, const void *cur, void *nxt, int which)   // which: 0 all own cells, 1 the rim, 2 the interior
+    {
+        const size_t bytes = (size_t)lay[2] * es;
+        std::vector<char> u0(bytes), u1(bytes, 0), u2(bytes, 0);
+        memcpy(u0.data(), cur, bytes);
+        auto at = [&](std::vector<char> &v, long i, long j) { return v.data() + elem_of(i, j, 0) * (long)es; };
+        const long n0 = p.n[0], n1 = p.n[1], rowb = p.n[2] * (long)es;
+        // an uncut (periodic) axis wraps: its two halo layers from the own cells - rows first, then whole planes (the edges follow)
+        auto wrap_xy = [&](std::vector<char> &v, long depth) {
+            if (!p.cut[1])
+                for (long i = -depth; i < n0 + depth; i++)      // (the halo planes of a cut first axis hold received rows: they wrap too)
+                    for (long h = 1; h <= depth; h++) { memcpy(at(v, i, -h), at(v, i, n1 - h), rowb); memcpy(at(v, i, n1 - 1 + h), at(v, i, h - 1), rowb); }
+            if (!p.cut[0])
+                for (long h = 1; h <= depth; h++)
+                    for (long j = -depth; j < n1 + depth; j++) { memcpy(at(v, -h, j), at(v, n0 - h, j), rowb); memcpy(at(v, n0 - 1 + h, j), at(v, h - 1, j), rowb); }
+        };
+        pdehip_bc_face_t f[2 * PDEHIP_MAX_DIM];
+        memset(f, 0, sizeof(f));                 // SKIP on the first two axes: their ghost layers hold halo data
+        f[4] = faces[4]; f[5] = faces[5];        // the fastest axis: the periodic condition of the grid
+        wrap_xy(u0, 2);
+        OTRY(oracle_set_ghost_cells(&g_ext, 1, f, u0.data()));
+        OTRY(oracle_laplace_euler(&g_ext, u0.data(), u0.data(), u1.data(), D, dt));     // level 1 on the own cells widened by one
+        OTRY(oracle_set_ghost_cells(&g_ext, 1, f, u1.data()));
+        OTRY(oracle_laplace_euler(&g_ext, u1.data(), u1.data(), u2.data(), D, dt));     // level 2: valid on the own cells
+        for (long i = 0; i < n0; i++)
+            for (long j = 0; j < n1; j++) {
+                const bool rim = (p.cut[0] && (i < 2 || i >= n0 - 2)) || (p.cut[1] && (j < 2 || j >= n1 - 2));
+                if ((which == 1 && !rim) || (which == 2 && rim)) continue;
+                memcpy(static_cast<char *>(nxt) + elem_of(i, j, 0) * (long)es, at(u2, i, j), rowb);
+            }
+        return 0;
+    }
+    int sweep2(const block2::Plan &p, void *cur, void *nxt, bool interior, void *) { return two_steps(p, cur, nxt, interior ? 2 : 0); }
+    int rim2(const block2::Plan &p, void *cur, void *nxt, void *) { return p.nrim ? two_steps(p, cur, nxt, 1) : 0; }
+};
+
+bool block2_covers(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3)
+{
+    if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program || cut3[2]) return false;
+    const long vec = g_local->dtype == PDEHIP_F64 ? 2 : 4;
+    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4 || g_local->shape[2] < 4) return false;
+    for (int a = 0; a < 3; a++) {
+        if (cut3[a]) continue;
+        for (int side = 0; side < 2; side++) {
+            const pdehip_bc_face_t &r = rhs->bc_c[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 != (side ? 0 : g_local->shape[a] - 1) || r.const_v != 0.0 || r.factor1 != 1.0) return false;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int pdehip_block2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, int *ok)
+{
+    if (!g_local || !rhs || !cut3 || !ok) return failf(E_VALUE, "block2_supported: NULL pointer");
+    *ok = block2_covers(g_local, rhs, cut3) ? 1 : 0;
+    return 0;
+}
+
+int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *dims3, const int *coords3,
+                            const int *cut3, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!g_local || !rhs || !dims3 || !coords3 || !cut3 || !buf_a || !buf_b || !result) return failf(E_VALUE, "block2_euler_run: NULL pointer");
+    if (nsteps < 0 || nsteps % 2) return failf(E_VALUE, "block2_euler_run: the step count must be even (two steps per sweep)");
+    if (!block2_covers(g_local, rhs, cut3)) return failf(E_NOTIMPL, "block2_euler_run: grid, equation or faces are not covered (ask pdehip_block2_supported)");
+    Comm *c = static_cast<Comm *>(comm);
+    const bool any = cut3[0] || cut3[1] || cut3[2];
+    if (!c) {
+        if (any) return failf(E_VALUE, "a block with neighbours needs a communicator");
+        c = serial_context();
+    }
+    if (any && (long)dims3[0] * dims3[1] * dims3[2] != c->size) return failf(E_VALUE, "block2_euler_run: the decomposition does not match the world size");
+    block2::Plan plan;
+    const long n[3] = {(long)g_local->shape[0], (long)g_local->shape[1], (long)g_local->shape[2]};
+    if (block2::make_plan(n, dims3, coords3, cut3, &plan) != 0) return failf(E_VALUE, "block2_euler_run: the box is too small for two halo layers");
+    HostOps2 ops;
+    ops.c = c; ops.g_box = *g_local; ops.g_ext = *g_local; ops.faces = rhs->bc_c; ops.D = rhs->param; ops.dt = dt;
+    ops.g_ext.shape[0] += 2; ops.g_ext.shape[1] += 2;
+    SLAB_TRY(pdehip_layout(&ops.g_ext, ops.lay));
+    ops.es = g_local->dtype == PDEHIP_F64 ? 8 : 4;
+    int64_t ll[8];
+    SLAB_TRY(pdehip_layout(g_local, ll));
+    const size_t bytes = (size_t)ops.lay[2] * ops.es;
+    for (auto &e : c->ext2) e.assign(bytes, 0);
+    const size_t mbytes = (plan.send_total > plan.recv_total ? plan.send_total : plan.recv_total) * ops.es + 16;
+    for (auto &m : c->msg2) m.assign(mbytes, 0);
+    const long rowb = n[2] * (long)ops.es;
+    auto own_rows = [&](void *ext, bool to_ext) {
+        for (long i = 0; i < n[0]; i++)
+            for (long j = 0; j < n[1]; j++) {
+                char *e = static_cast<char *>(ext) + ops.elem_of(i, j, 0) * (long)ops.es;
+                char *st = static_cast<char *>(buf_a) + ((long)ll[3] + i * (long)ll[0] + j * (long)ll[1]) * (long)ops.es;
+                if (to_ext) memcpy(e, st, rowb); else memcpy(st, e, rowb);
+            }
+    };
+    own_rows(c->ext2[0].data(), true);
+    void *res = c->ext2[0].data();
+    const int mode = getenv("PDEHIP_BLOCK2_MODE") ? atoi(getenv("PDEHIP_BLOCK2_MODE")) : 2;
+    if (nsteps > 0) SLAB_TRY(block2::euler2_run(ops, plan, c->ext2[0].data(), c->ext2[1].data(), nsteps, &res, stream, mode));
+    own_rows(res, false);
+    *result = buf_a;
+    return 0;
 }
 
 }  // extern "C"

@@ -211,6 +211,35 @@ def test_block_layer_self_exchange(shape, periodic, dtype):
         st.close()
 
 
+@pytest.mark.parametrize("shape", [(40, 36, 256), (12, 9, 136), (7, 18, 520), (16, 16, 64), (33, 12, 128)])
+@pytest.mark.parametrize("cut", [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fast_block_loop_to_self(shape, cut, dtype):
+    """The fast block loop (csrc/pdehip_block2_loops.h) on one device, the halos sent to the block itself through RCCL: two steps per
+    sweep on the box (plain halo planes / rows, the fastest axis wrapping in the kernel), the sweep of the next pair started before the
+    halos have landed, the rim recomputed behind it - bit-identical to the oracle's single steps for every combination of exchanged
+    axes, rows that end inside a chunk, odd row counts (moved tiles), several x-chunks, even and odd step counts, fp64 and fp32."""
+    import ctypes as C
+
+    from pde_hip.distributed import BlockStepper
+
+    grid = pde_hip.CartesianGrid([[0, n * 0.8] for n in shape], shape, periodic=True)
+    eq = pde_hip.DiffusionPDE(0.6)
+    data = np.random.default_rng(9).uniform(-0.5, 0.5, shape).astype(dtype)
+    st = BlockStepper(eq, grid, dtype, force_exchange=True)
+    assert st.block2 and list(st.cut) == [1, 1, 0]
+    st.cut[:2] = cut
+    st._cut3 = (C.c_int * 3)(*st.cut)
+    g = oracle_grid(grid, dtype)
+    hf = host_faces(grid.get_boundary_conditions("periodic"))
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, 0.6, hf.c, hf.c, None)
+    dt = 0.02
+    for steps in (2, 6, 7):
+        final, info = st.solve(data, t_range=steps * dt, dt=dt, solver="euler")
+        np.testing.assert_array_equal(final, interior(grid, O.euler_run(g, rhs, to_full(grid, data), dt, steps)), err_msg=f"{steps} steps")
+    st.close()
+
+
 def test_block_ghost_faces_read_from_memory():
     """The kernels of a block sweep read the ghost cells of EXCHANGED faces from memory on all three axes (faces marked SKIP) and
     evaluate the physical faces on the fly: each of the 8 blocks of a 2 x 2 x 2 cut, with its ghost layers taken from the unsplit

@@ -50,6 +50,7 @@ def parse_args():
                          "fast block loop, csrc/pdehip_block2_loops.h; the others the exact one-step loop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the operator roofline, the cfg2/cfg3/cfg5 timings and the parity bit")
+    ap.add_argument("--no-configs", action="store_true", help="skip only the cfg2/cfg3/cfg5 solves and the 2-D kernel timings (test aid: they take minutes on the host shim)")
     ap.add_argument("--repeats", type=int, default=9,
                     help="the timed region (EXACTLY --steps steps between two synchronisations) is run this many times; value / ms_per_step "
                          "are the MEDIAN, the line carries every repetition and the minimum (SURVEY.md 8d: min / median of >= 5)")
@@ -117,6 +118,7 @@ def bench_single(args) -> dict:
     import pde_hip
     from pde_hip.device import DeviceArray
 
+    t_start = time.perf_counter()
     backend = pde_hip.get_backend("hip")
     lib = backend._lib
     n = args.size
@@ -231,13 +233,28 @@ def bench_single(args) -> dict:
         },
         "device": backend.device_name,
     }
+    t_gpu = time.perf_counter()
+    out["phase_seconds_main"] = round(t_gpu - t_start, 2)
     if not args.no_extra:
         out["roofline_operator"] = operator_roofline(backend, lib, spec, cur, nxt, stream, ev, cells, max(1, args.repeats))
     del a, b
     try:
-        out["parity"] = parity_bit(backend, n)      # (always: the digest of the state is what makes the N > 1 lines checkable)
         if not args.no_extra:
+            ops = more_rooflines(backend, lib, spec, stream, ev, n, min(5, max(1, args.repeats)))
+            nt_gbs = ops["copy"]["nt_copy_gbs"]
+            # the yardstick VERDICT r4 asked for: the kernels against the fastest copy of the same run
+            out["roofline"]["nt_copy"] = nt_gbs
+            out["roofline"]["frac_of_nt_copy"] = round(out["roofline"]["achieved"] / nt_gbs, 4)
+            out["roofline_operator"]["nt_copy"] = nt_gbs
+            out["roofline_operator"]["frac_of_nt_copy"] = round(out["roofline_operator"]["achieved"] / nt_gbs, 4)
+            out["roofline_operators"] = ops
+            if not args.no_configs:
+                out["roofline_operators"]["tile2d"] = tile2d_roofline(backend, lib, stream, ev, min(5, max(1, args.repeats)))
+        out["parity"] = parity_bit(backend, n)      # (always: the digest of the state is what makes the N > 1 lines checkable)
+        t_extra = time.perf_counter()
+        if not args.no_extra and not args.no_configs:
             out["extra"] = extra_configs(backend)
+        out["phase_seconds"] = {"operators_and_parity_s": round(t_extra - t_gpu, 2), "extra_s": round(time.perf_counter() - t_extra, 2)}
     except Exception as err:   # the metric line must survive a failure of the side measurements; it says so
         out.setdefault("parity", None)
         out["extra_error"] = f"{type(err).__name__}: {err}"
@@ -272,6 +289,112 @@ def operator_roofline(backend, lib, spec, a, out, stream, ev, cells: int, repeat
             "kernel_ms": round(t * 1e3, 4), "kernel_ms_repeats": stats, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_best": round(cells * BYTES_PER_CELL_STEP / (stats["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "mcells_per_s": round(cells / t / 1e6, 1), "bytes_per_launch": cells * BYTES_PER_CELL_STEP}
+
+
+def more_rooflines(backend, lib, spec, stream, ev, n: int, repeats: int = 5) -> dict:
+    """HIP-event timings of the other operators of SURVEY.md 8 rows a3 / a4 / f1 at the benchmark size (VERDICT r4 "next" #8): gradient (8 B read +
+    24 B written per cell), divergence (24 + 8), gradient_squared (8 + 8), the vector Laplacian (three sweeps of the scalar kernel: 3 x 16) -
+    each `repeats` x 30 applications on resident arrays, median / min / every sample - and the copy yardsticks of THIS run: `pdehip_copy_nt`
+    (16 bytes per thread, streaming stores: the fastest copy order of the part) next to hipMemcpyDtoD."""
+    from pde_hip import _abi
+    from pde_hip.device import DeviceArray
+
+    info = spec.info
+    cells = n**3
+    scalar_in, scalar_out = DeviceArray(info), DeviceArray(info)
+    vec_a, vec_b = DeviceArray(info, (3,)), DeviceArray(info, (3,))
+    rng = np.random.default_rng(1)
+    scalar_in.set_valid(rng.random((n, n, n)), stream)
+    vec_a.set_valid(rng.random((3, n, n, n)), stream)
+    lib.set_ghost_cells(info.ref, 1, spec.bc_c.c, scalar_in.ptr, stream)
+    comp_bytes = vec_a.nbytes // 3
+
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        lib.stream_synchronize(stream)
+        samples = []
+        for _ in range(repeats):
+            lib.event_record(ev[2], stream)
+            for _ in range(reps):
+                fn()
+            lib.event_record(ev[3], stream)
+            lib.stream_synchronize(stream)
+            ms = C.c_float()
+            lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms))
+            samples.append(ms.value / reps)
+        return _stats(samples)
+
+    def entry(kernel, bytes_per_cell, stats, note=None):
+        t = stats["median"] * 1e-3
+        gbs = cells * bytes_per_cell / t / 1e9
+        out = {"bound": "hbm", "kernel": kernel, "bytes_per_cell": bytes_per_cell, "kernel_ms": round(t * 1e3, 4), "kernel_ms_repeats": stats,
+               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if note:
+            out["note"] = note
+        return out
+
+    # the periodic ghost cells of every component are set once (the operators read them from memory)
+    for k in range(3):
+        lib.set_ghost_cells(info.ref, 1, spec.bc_c.c, vec_a.ptr + k * comp_bytes, stream)
+    res = {}
+    res["gradient"] = entry("lap_march_kernel<double, LAP_GRAD_C> (pdehip_gradient, central)", 32,
+                            timed(lambda: lib.gradient(info.ref, _abi.CENTRAL, scalar_in.ptr, vec_b.ptr, _abi.OUT_FULL, stream)))
+    res["divergence"] = entry("div_march_kernel<double, central> (pdehip_divergence)", 32,
+                              timed(lambda: lib.divergence(info.ref, _abi.CENTRAL, vec_a.ptr, scalar_out.ptr, _abi.OUT_FULL, stream)))
+    res["gradient_squared"] = entry("lap_march_kernel<double, LAP_GRADSQ_C> (pdehip_gradient_squared, central)", 16,
+                                    timed(lambda: lib.gradient_squared(info.ref, 1, scalar_in.ptr, scalar_out.ptr, _abi.OUT_FULL, stream)))
+
+    def vector_laplace():
+        for k in range(3):
+            lib.laplace(info.ref, vec_a.ptr + k * comp_bytes, vec_b.ptr + k * comp_bytes, _abi.OUT_FULL, stream)
+
+    res["vector_laplace"] = entry("lap_march_kernel<double> x 3 components (vector_laplace: cartesian.py:999-1030 applies the scalar operator per component)",
+                                  48, timed(vector_laplace, reps=10))
+    # copy yardsticks on the same bytes as one Laplacian (1 read + 1 write per cell)
+    nbytes = scalar_in.nbytes // 16 * 16
+    nt = timed(lambda: lib.copy_nt(scalar_out.ptr, scalar_in.ptr, nbytes, stream))
+    d2d = timed(lambda: lib.memcpy_d2d(scalar_out.ptr, scalar_in.ptr, nbytes, stream))
+    res["copy"] = {"bytes": 2 * nbytes, "nt_copy_ms": nt["median"], "nt_copy_gbs": round(2 * nbytes / (nt["median"] * 1e-3) / 1e9, 1),
+                   "hipMemcpyDtoD_ms": d2d["median"], "hipMemcpyDtoD_gbs": round(2 * nbytes / (d2d["median"] * 1e-3) / 1e9, 1),
+                   "note": "pdehip_copy_nt: one 16-byte vector per thread in address order, streaming stores - the fastest copy order of the part "
+                           "(tools/microbench4.hip); whole ghost-padded array, i.e. slightly more bytes than the cells of one sweep"}
+    return res
+
+
+def tile2d_roofline(backend, lib, stream, ev, repeats: int = 5) -> dict:
+    """`tile2d_kernel` (2-D grids: K Euler steps per launch, time levels in LDS; BASELINE configs 2 and 3): HIP-event time per step of
+    `pdehip_euler_run` on resident arrays, priced at SURVEY 8d's 16 B per cell-step - these grids live in the Infinity Cache, the figure
+    says how far the launch-bound 2-D regime is from a kernel that streamed the field through HBM once per step."""
+    import pde_hip
+    from pde_hip.device import DeviceArray
+
+    out = {}
+    for name, eq, shape in (("cfg2_diffusion_1024sq", pde_hip.DiffusionPDE(1.0), (1024, 1024)), ("cfg3_cahn_hilliard_512sq", pde_hip.CahnHilliardPDE(1.0), (512, 512))):
+        grid = pde_hip.UnitGrid(shape, periodic=True)
+        state = pde_hip.ScalarField.random_uniform(grid, -0.1, 0.1, rng=np.random.default_rng(2))
+        spec = backend.make_rhs_spec(eq, state)
+        a, b = DeviceArray(spec.info).set_valid(state.data, stream), DeviceArray(spec.info)
+        res = C.c_void_p()
+        dt, steps = (0.1, 800) if name.startswith("cfg2") else (1e-3, 800)
+        lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, dt, 64, C.byref(res), stream)
+        lib.stream_synchronize(stream)
+        samples = []
+        for _ in range(repeats):
+            lib.event_record(ev[2], stream)
+            lib.euler_run(spec.info.ref, spec.ref, a.ptr, b.ptr, dt, steps, C.byref(res), stream)
+            lib.event_record(ev[3], stream)
+            lib.stream_synchronize(stream)
+            ms = C.c_float()
+            lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms))
+            samples.append(ms.value / steps)
+        st = _stats(samples)
+        cells = int(np.prod(shape))
+        gbs = cells * BYTES_PER_CELL_STEP / (st["median"] * 1e-3) / 1e9
+        out[name] = {"bound": "hbm", "kernel": "tile2d_kernel (K steps per launch, levels in LDS) through pdehip_euler_run", "us_per_step": round(st["median"] * 1e3, 3),
+                     "ms_per_step_repeats": st, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "note": "effective: 16 B per cell-step / time per step; the field is cache-resident"}
+    return out
 
 
 def parity_bit(backend, n: int) -> dict | None:
@@ -588,14 +711,18 @@ def main():
         ngpu = 1
         wall = r["wall"]
         line = {"roofline": r["roofline"]}
-        for key in ("roofline_operator", "parity", "extra", "extra_error"):
+        for key in ("roofline_operator", "roofline_operators", "parity", "extra", "extra_error"):
             if key in r:
                 line[key] = r[key]
         if isinstance(line.get("parity"), dict):
             line["state_sha256_after_6_steps"] = line["parity"].pop("sha256_full")
             if line["parity"]["ok"] is None:
                 line["parity"] = None        # no reference digest at this size
+        t_cpu = time.perf_counter()
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(n, args.cpu_seconds)
+        # wall seconds per phase of this process (VERDICT r4 "next" #8: makes the driver's clock around the run auditable)
+        line["phase_seconds"] = {"import_upload_timed_region_dominant_kernel_s": r.get("phase_seconds_main"), **(r.get("phase_seconds") or {}),
+                                 "cpu_baseline_s": round(time.perf_counter() - t_cpu, 2)}
         ref_file = ROOT / "profiles" / "reference_cpu.json"
         if ref_file.exists() and not args.no_cpu_baseline:
             # the reference itself (py-pde, eager torch-CPU backend) cannot travel to the GPU box: timed in the build container

@@ -154,6 +154,9 @@ int pdehip_memset(void *ptr, int value, size_t bytes, void *stream);
 int pdehip_memcpy_h2d(void *dst, const void *src_host, size_t bytes, void *stream);
 int pdehip_memcpy_d2h(void *dst_host, const void *src, size_t bytes, void *stream);
 int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+/* the same by a kernel with streaming stores (16-byte aligned pointers, a multiple of 16 bytes): the fastest copy order on MI355X, the
+ * yardstick bench.py prices the stencil kernels against (no reference counterpart: numpy copies on the host) */
+int pdehip_copy_nt(void *dst, const void *src, size_t bytes, void *stream);
 int pdehip_stream_create(void **stream);
 int pdehip_stream_destroy(void *stream);
 int pdehip_stream_synchronize(void *stream);
@@ -490,6 +493,17 @@ int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *n
 int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *nb6, int fuse_stage, int scheme,
                      void *y_full, void *ynew_full, void *const *work_host, double *err_dev, double dt, int64_t nsteps,
                      pdehip_adaptive_t *ctl, void **result, void *stream);
+
+/* ---- products of tensor fields, cell by cell (ABI version 6) ------------------------------------------------------------------------
+ * Replaces BackendBase.make_inner_prod_operator / make_outer_prod_operator (pde/backends/base.py:567-610; numpy: np.einsum per rank
+ * combination, pde/backends/numpy/backend.py:285-363; numba: pde/backends/numba/backend.py:654-893), which `DataFieldBase.dot` /
+ * `VectorField.outer_product` / `make_dot_operator` use (pde/fields/datafield_base.py:965).  kind 0: vector . vector -> scalar, 1: tensor
+ * . vector -> vector, 2: vector . tensor -> vector, 3: tensor . tensor -> tensor, 4: outer product of two vectors -> tensor; the vector
+ * dimension is g->ndim; all arrays FULL, component-major (tensor entries in C order).  complex_pairs != 0: every tensor entry is a
+ * planar (re, im) pair (the layout of complex states, pde_hip/complex_expr.py); conjugate != 0: the second operand is conjugated
+ * (the reference's default for `dot`). */
+int pdehip_field_product(const pdehip_grid_t *g, int kind, int complex_pairs, int conjugate, const void *a_full, const void *b_full,
+                         void *out_full, void *stream);
 
 /* ---- the FAST block decomposition: two Euler steps per sweep on a box, halos two layers deep incl. the edges, ONE message per
  * neighbouring rank, the exchange hidden behind the next sweep (csrc/pdehip_block2_loops.h; ABI version 6) -------------------------

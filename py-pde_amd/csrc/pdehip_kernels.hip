@@ -538,7 +538,10 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         // the RCCL kernel of the halo stream finds free wave slots at once — workgroups march for the whole sweep, a kernel
         // launched behind a full round waits for it to end (measured: 90 us for 13 us of work).
         const bool thin = xplain && a.n0 < 96;
-        const long cap = t2.blocks ? t2.blocks : (tall ? 1024 : (thin ? 1536 : 2048));   // (the tall tile runs one wave per SIMD)
+        // a box of the fast block loop (plain rows / columns): 7/8 of a round - the rim, pack, RCCL and unpack kernels of the halo stream
+        // otherwise wait for the END of the sweep (0.0536 -> 0.0501 ms per step at 256 x 128 x 512, profiles/r05_probe_block.md)
+        const bool boxed = a.per[1] == 2 || a.per[2] == 2;
+        const long cap = t2.blocks ? t2.blocks : (tall ? 1024 : (thin ? 1536 : (boxed ? 1792 : 2048)));   // (the tall tile runs one wave per SIMD)
         static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
         long nxc;
         if (thin) {

@@ -890,6 +890,91 @@ int pdehip_axis_derivative(const pdehip_grid_t *g, int axis, int order, int meth
     return 0;
 }
 
+}  // extern "C"
+
+// ---- products of tensor fields at every cell (numpy/backend.py:285-363: np.einsum per rank combination) --------------------------
+namespace pdehip {
+struct ProdArgs {
+    const void *a, *b;
+    void *out;
+    long pc;        // elements of one component (full array)
+    int dim, kind, cplx, conj;
+};
+// kind 0: v.v -> s   1: T.v -> v   2: v.T -> v   3: T.T -> T   4: outer v (x) v -> T.   Complex data: planar (re, im) pairs per tensor
+// entry (component index = entry * 2 + part); `conj`: the second operand is conjugated.  Sums run over the contracted index in order.
+template <typename T>
+__global__ void __launch_bounds__(256) field_product_kernel(ProdArgs p)
+{
+    const long e = blockIdx.x * 256L + threadIdx.x;
+    if (e >= p.pc) return;
+    const int d = p.dim, w = p.cplx ? 2 : 1;
+    const T *a = (const T *)p.a + e, *b = (const T *)p.b + e;
+    T *out = (T *)p.out + e;
+    auto term = [&](int ia, int ib, double &re, double &im) {   // += a[ia] * (conj) b[ib]
+        const double ar = (double)a[(long)(ia * w) * p.pc], br = (double)b[(long)(ib * w) * p.pc];
+        if (!p.cplx) { re = re + ar * br; return; }
+        const double ai = (double)a[(long)(ia * w + 1) * p.pc];
+        double bi = (double)b[(long)(ib * w + 1) * p.pc];
+        if (p.conj) bi = -bi;
+        re = re + (ar * br - ai * bi);
+        im = im + (ar * bi + ai * br);
+    };
+    auto put = [&](int io, double re, double im) {
+        out[(long)(io * w) * p.pc] = (T)re;
+        if (p.cplx) out[(long)(io * w + 1) * p.pc] = (T)im;
+    };
+    if (p.kind == 0) {
+        double re = 0, im = 0;
+        for (int i = 0; i < d; i++) term(i, i, re, im);
+        put(0, re, im);
+    } else if (p.kind == 1) {
+        for (int i = 0; i < d; i++) {
+            double re = 0, im = 0;
+            for (int j = 0; j < d; j++) term(i * d + j, j, re, im);
+            put(i, re, im);
+        }
+    } else if (p.kind == 2) {
+        for (int j = 0; j < d; j++) {
+            double re = 0, im = 0;
+            for (int i = 0; i < d; i++) term(i, i * d + j, re, im);
+            put(j, re, im);
+        }
+    } else if (p.kind == 3) {
+        for (int i = 0; i < d; i++)
+            for (int k = 0; k < d; k++) {
+                double re = 0, im = 0;
+                for (int j = 0; j < d; j++) term(i * d + j, j * d + k, re, im);
+                put(i * d + k, re, im);
+            }
+    } else {
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) {
+                double re = 0, im = 0;
+                term(i, j, re, im);
+                put(i * d + j, re, im);
+            }
+    }
+}
+}  // namespace pdehip
+
+extern "C" {
+
+int pdehip_field_product(const pdehip_grid_t *g, int kind, int complex_pairs, int conjugate, const void *a_full, const void *b_full, void *out_full,
+                         void *stream)
+{
+    if (!a_full || !b_full || !out_full) PDEHIP_FAIL(E_VALUE, "field_product: NULL pointer");
+    if (kind < 0 || kind > 4) PDEHIP_FAIL(E_VALUE, "field_product: kind 0 (v.v), 1 (T.v), 2 (v.T), 3 (T.T) or 4 (outer)");
+    if (out_full == a_full || out_full == b_full) PDEHIP_FAIL(E_VALUE, "field_product: the output must not be an operand");
+    NGrid n;
+    PDEHIP_TRY(norm_grid(g, &n));
+    ProdArgs p = {a_full, b_full, out_full, n.pc, g->ndim, kind, complex_pairs ? 1 : 0, conjugate ? 1 : 0};
+    const unsigned blocks = (unsigned)((n.pc + 255) / 256);
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL(field_product_kernel<double>, dim3(blocks), dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(field_product_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), p);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
 int pdehip_integrate(const pdehip_grid_t *g, int ncomp, const void *arr_full, double cell_volume, double *out_dev, void *stream)
 {
     NGrid n;

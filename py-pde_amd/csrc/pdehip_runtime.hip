@@ -252,6 +252,28 @@ int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
     return 0;
 }
 
+// device-to-device copy by a kernel: one 16-byte vector per thread, workgroups in address order, streaming (non-temporal) stores - the
+// access order that reaches the highest copy rate on MI355X (6.2-6.55 TB/s at 1 GiB: profiles/r03_microbench4_copy_ceiling.log; hipMemcpyDtoD:
+// 4.8-5.2).  bench.py prices the stencil kernels against it (`frac_of_nt_copy`); transfers between resident arrays may use it as well.
+namespace {
+typedef float pdehip_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) copy_nt_kernel(const pdehip_f4 *__restrict__ in, pdehip_f4 *__restrict__ out, long n)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(in[i], out + i);
+}
+}  // namespace
+int pdehip_copy_nt(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!dst || !src) PDEHIP_FAIL(E_VALUE, "copy_nt: NULL pointer");
+    if (bytes % 16 || (uintptr_t)dst % 16 || (uintptr_t)src % 16) PDEHIP_FAIL(E_VALUE, "copy_nt: 16-byte aligned pointers and a multiple of 16 bytes");
+    const long n = (long)(bytes / 16);
+    if (!n) return 0;
+    hipLaunchKernelGGL(copy_nt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), (const pdehip_f4 *)src, (pdehip_f4 *)dst, n);
+    PDEHIP_HIP(hipGetLastError());
+    return 0;
+}
+
 int pdehip_stream_create(void **stream)
 {
     if (!stream) PDEHIP_FAIL(E_VALUE, "stream is NULL");

@@ -202,6 +202,7 @@ RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
     "memcpy_h2d": ([_vp, _vp, C.c_size_t, _vp], _i),
     "memcpy_d2h": ([_vp, _vp, C.c_size_t, _vp], _i),
     "memcpy_d2d": ([_vp, _vp, C.c_size_t, _vp], _i),
+    "copy_nt": ([_vp, _vp, C.c_size_t, _vp], _i),
     "upload_valid": ([_pg, _i, _vp, C.POINTER(C.c_int64), _vp, _vp], _i),
     "download_valid": ([_pg, _i, _vp, _vp, C.POINTER(C.c_int64), _vp], _i),
     "stream_create": ([_pvp], _i),
@@ -240,6 +241,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     # block decomposition (csrc/pdehip_block_loops.h)
     "block_exchange": [_vp, _pg, C.POINTER(_i), _vp, _vp],
     "block_run": [_vp, _pg, _pr, C.POINTER(_i), _i, _i, _vp, _vp, _pvp, _vp, _d, _i64, _pa, _pvp, _vp],
+    "field_product": [_pg, _i, _i, _i, _vp, _vp, _vp, _vp],
     "block2_supported": [_pg, _pr, C.POINTER(_i), C.POINTER(_i)],
     "block2_euler_run": [_vp, _pg, _pr, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _vp, _vp, _d, _i64, _pvp, _vp],
     # Adams-Bashforth step in one sweep (device only: the oracle runs rhs_scaled + ab2_combine)

@@ -205,6 +205,35 @@ def pde_kind(eq) -> str:
     return cls.__name__ if cls is not None else eq.__class__.__name__
 
 
+class HostSetterTable:
+    """Boundary conditions given as a Python FUNCTION that writes the ghost cells of a full array (``BoundariesSetter``,
+    pde/grids/boundaries/axes.py:504-560: ``setter(data_full, args)``).  Arbitrary numpy code cannot run on the device: before every pass
+    that applies operators with these conditions the operand crosses PCIe twice (download -> user function -> upload) and the kernels
+    then read the ghost cells from memory (every face SKIP).  The interface of the expression face tables (pde_hip/bc_expr.py):
+    `time_dependent` + `reads_value` make every evaluation refresh from the pass's own input, `host_only` keeps the C loops away."""
+
+    time_dependent = True
+    reads_value = True
+    host_only = True
+
+    def __init__(self, backend, bcs, grid):
+        self.backend, self.bcs, self.grid = backend, bcs, grid
+        self.table = FaceTable()                 # all faces SKIP: ghost cells come from memory
+        self.c = self.table.c
+        _logger.warning("boundary conditions set by a Python function run on the host: the field crosses PCIe twice per operator application")
+
+    def copy_into(self, dst) -> None:
+        self.table.copy_into(dst)
+
+    def update(self, args=None, state=None, stream=None) -> None:
+        if state is None:
+            msg = "hip backend: a ghost-cell setter function needs the field it is applied to"
+            raise NotImplementedError(msg)
+        host = state.get_hostfull(stream=stream)
+        res = self.bcs._setter(host, args=dict(args or {}))
+        state.set_hostfull(host if res is None else np.asarray(res), stream)
+
+
 def class_expressions(eq):
     """The built-in PDE classes of the reference beyond Diffusion / Cahn-Hilliard as expression systems for the run-time
     specialised kernels: ``(rhs: {variable: expression}, consts, bcs: {(variable, operator name): condition}, aliases)`` or None.
@@ -789,6 +818,154 @@ class HipBackendMixin:
         apply_op.grid = grid  # type: ignore[attr-defined]
         return apply_op
 
+    # --- products of tensor fields (base.py:567-610) -----------------------------------------------------------
+    def _make_product(self, grid, outer: bool, conjugate: bool):
+        """``prod(a, b, out=None)``: host valid arrays (real or complex) or :class:`DeviceArray` operands -> the product cell by cell on
+        the device (``pdehip_field_product``); host in -> host out, device in -> device out."""
+        nd, dim = len(grid.shape), grid.dim
+        lib = self._lib
+
+        def to_device(v, cplx: bool, real):
+            if isinstance(v, DeviceArray):
+                return v
+            v = np.asarray(v)
+            info = self.grid_info(grid, real)
+            rank = v.ndim - nd
+            if cplx:
+                return DeviceArray(info, (dim,) * rank + (2,), complex_pairs=True).set_valid(v.astype(np.result_type(v.dtype, np.complex64), copy=False), self.stream)
+            return DeviceArray(info, (dim,) * rank).set_valid(np.ascontiguousarray(v, dtype=real), self.stream)
+
+        def prod(a, b, out=None):
+            host = not isinstance(a, DeviceArray) and not isinstance(b, DeviceArray)
+            if host:
+                a, b = np.asarray(a), np.asarray(b)
+                cplx = np.iscomplexobj(a) or np.iscomplexobj(b)
+                real = real_dtype_of(np.result_type(a.dtype, b.dtype))
+                if real.kind != "f":
+                    real = np.dtype(np.float64)
+                rank_a, rank_b = a.ndim - nd, b.ndim - nd
+            else:
+                if not (isinstance(a, DeviceArray) and isinstance(b, DeviceArray)):
+                    msg = "hip backend: both operands of a product on the device or both on the host"
+                    raise TypeError(msg)
+                cplx = bool(getattr(a, "complex_pairs", False))
+                if cplx != bool(getattr(b, "complex_pairs", False)):
+                    msg = "hip backend: products of a complex and a real device array are not supported"
+                    raise NotImplementedError(msg)
+                real = a.dtype
+                rank_a, rank_b = len(a.comp_shape) - int(cplx), len(b.comp_shape) - int(cplx)
+            if outer:
+                if rank_a != 1 or rank_b != 1:
+                    msg = "Can only define outer product between vector fields"
+                    raise TypeError(msg)
+                kind, rank_out = 4, 2
+            else:
+                if rank_a < 1 or rank_b < 1:
+                    msg = "Fields in dot product must have rank >= 1"
+                    raise TypeError(msg)
+                kinds = {(1, 1): (0, 0), (2, 1): (1, 1), (1, 2): (2, 1), (2, 2): (3, 2)}
+                if (rank_a, rank_b) not in kinds:
+                    msg = f"Unsupported ranks ({rank_a}, {rank_b})"
+                    raise TypeError(msg)
+                kind, rank_out = kinds[rank_a, rank_b]
+            if host and a.shape[rank_a:] != b.shape[rank_b:]:
+                msg = "Shapes of fields are not compatible for dot product"
+                raise ValueError(msg)
+            da, db = to_device(a, cplx, real), to_device(b, cplx, real)
+            comp = (dim,) * rank_out + ((2,) if cplx else ())
+            res = out if isinstance(out, DeviceArray) else DeviceArray(da.info, comp, complex_pairs=cplx)
+            lib.field_product(da.info.ref, kind, int(cplx), int(bool(conjugate) and not outer), da.ptr, db.ptr, res.ptr, self.stream)
+            if isinstance(out, DeviceArray) or not host:
+                return res
+            data = res.get_valid(stream=self.stream)
+            if out is not None:
+                out[...] = data
+                return out
+            return data
+
+        return prod
+
+    def make_inner_prod_operator(self, field, *, conjugate: bool = True):
+        """Dot product of two tensor fields (vector . vector, tensor . vector, vector . tensor, tensor . tensor), base.py:567-587;
+        numpy twin: np.einsum per rank combination (numpy/backend.py:285-337)."""
+        return self._make_product(field.grid, False, conjugate)
+
+    def make_outer_prod_operator(self, field):
+        """Outer product of two vector fields (base.py:589-605, numpy/backend.py:339-363)."""
+        if field.__class__.__name__ != "VectorField":
+            msg = "Can only define outer product between vector fields"
+            raise TypeError(msg)
+        return self._make_product(field.grid, True, False)
+
+    # --- expressions as functions (base.py:653-676) -----------------------------------------------------------------
+    def make_expression_function(self, expression, *, single_arg: bool = False, user_funcs=None):
+        """``f(*values)`` evaluating a sympy expression of arrays and numbers cell by cell ON THE DEVICE: the expression is lowered by the
+        planner of the expression PDEs (pde_hip/expr.py) into pointwise passes of the run-time compiled kernels - the first array argument
+        is the pass's main input, the others enter as further centre-value inputs, numbers are compiled in (one build per distinct set of
+        numbers).  Host arrays in -> host array out; :class:`DeviceArray` in -> :class:`DeviceArray` out.  What the reference backends
+        return here also accepts differential operators as `user_funcs` (pde/pdes/pde.py:460-467): those enter this backend through
+        `make_pde_rhs`, which plans the whole right-hand side at once.  User functions are traced symbolically."""
+        from .device import GridInfo
+        from .expr import ExpressionPlan, ExpressionRhs
+
+        names = [str(v) for v in expression.vars]
+        consts = dict(getattr(expression, "consts", {}) or {})
+        funcs = dict(getattr(expression, "user_funcs", {}) or {})
+        funcs.update(user_funcs or {})
+        expr_str = str(getattr(expression, "_sympy_expr", expression))
+        cache: dict[tuple, Any] = {}
+
+        def evaluate(*values):
+            if single_arg:
+                (packed,) = values
+                values = tuple(packed[i] for i in range(len(names)))
+            if len(values) != len(names):
+                msg = f"expression takes {len(names)} arguments ({names}), {len(values)} given"
+                raise TypeError(msg)
+            arrays = {n: v for n, v in zip(names, values) if isinstance(v, DeviceArray) or np.ndim(v) > 0}
+            arrays.update({n: v for n, v in consts.items() if np.ndim(v) > 0})
+            numbers = {n: float(v) for n, v in zip(names, values) if n not in arrays}
+            numbers.update({n: float(v) for n, v in consts.items() if n not in arrays})
+            if not arrays:
+                import sympy as sp
+
+                return float(sp.sympify(expr_str, locals={k: sp.Symbol(k) for k in numbers}).subs(numbers))
+            first = next(iter(arrays))
+            on_device = isinstance(arrays[first], DeviceArray)
+            if on_device:
+                info = arrays[first].info
+            else:
+                shape = np.shape(arrays[first])
+                dtype = real_dtype_of(np.result_type(*[np.asarray(v).dtype for v in arrays.values()]))
+                if dtype.kind != "f":
+                    dtype = np.dtype(np.float64)
+                cells = tuple(shape) if 1 <= len(shape) <= 3 else (int(np.prod(shape)),)
+                info = GridInfo(cells, [1.0] * len(cells), dtype)
+            key = (tuple(sorted(numbers.items())), tuple(arrays), info.shape, str(info.dtype))
+            if key not in cache:
+                others = tuple(n for n in arrays if n != first)
+                plan = ExpressionPlan(expr_str, first, numbers, aux=others, user_funcs=funcs)
+                if plan.operators_used:
+                    msg = f"hip backend: differential operators {sorted(plan.operators_used)} inside a plain expression function (use make_pde_rhs)"
+                    raise NotImplementedError(msg)
+                cache[key] = (plan, ExpressionRhs(self, plan, info, {}, {n: DeviceArray(info) for n in others if n in plan.aux_used}))
+            plan, erhs = cache[key]
+            dev = {}
+            for n, v in arrays.items():
+                if isinstance(v, DeviceArray):
+                    dev[n] = v
+                elif n == first or n in plan.aux_used:
+                    dev[n] = DeviceArray(info).set_valid(np.ascontiguousarray(np.reshape(np.asarray(v, dtype=info.dtype), info.shape)), self.stream)
+            for n in plan.aux_used:
+                erhs.aux[f"aux:{n}"] = dev[n]
+            out = DeviceArray(info)
+            erhs.apply(dev[first], out, "rate", 0.0, 0.0)
+            if on_device:
+                return out
+            return out.get_valid(stream=self.stream).reshape(np.shape(arrays[first]))
+
+        return evaluate
+
     # --- PDE right hand sides ---------------------------------------------------------------------------
     def make_rhs_spec(self, eq, state) -> RhsSpec:
         """Map a PDE object onto one of the fused device right-hand sides."""
@@ -892,7 +1069,10 @@ class HipBackendMixin:
                 raise NotImplementedError(msg)
             return convert_bcs(bcs, part=comp)
         if comp is None:
-            return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0))
+            bcs = grid.get_boundary_conditions(bc, rank=0)
+            if not hasattr(bcs, "__iter__") and callable(getattr(bcs, "_setter", None)):
+                return HostSetterTable(self, bcs, grid)      # a user function that writes the ghost cells (BoundariesSetter)
+            return convert_bcs_with_expressions(bcs)
         rank = 2 if isinstance(comp, tuple) else 1
         return convert_bcs(grid.get_boundary_conditions(bc, rank=rank), (grid.num_axes,) * rank, component=comp)
 

@@ -89,6 +89,33 @@ class HipBackend(HipBackendMixin, BackendBase):
 _operators.register_all(HipBackend, CartesianGrid)
 
 
+def _install_evolution_rate_dispatch() -> None:
+    """``pde.PDE.make_evolution_rate(state, backend)`` assembles the right-hand side from backend operators and
+    ``backend.make_expression_function`` and wraps it per ``backend.implementation`` - with branches for "numpy" / "numba" / "jax" /
+    "torch" only (pde/pdes/pde.py:469-494: any other implementation raises NotImplementedError).  This backend plans the WHOLE
+    right-hand side at once (operators, user functions traced symbolically, conditions) in ``make_pde_rhs``; the three lines a maintainer
+    would add there ("PDE.make_evolution_rate") are applied here at import time when the installed py-pde lacks them."""
+    from pde.backends import get_backend
+    from pde.pdes.pde import PDE
+
+    if getattr(PDE.make_evolution_rate, "_hip_dispatch", False):
+        return
+    original = PDE.make_evolution_rate
+
+    def make_evolution_rate(self, state, backend):
+        resolved = get_backend(backend)
+        if getattr(resolved, "implementation", None) == "hip":
+            return resolved.make_pde_rhs(self, state)
+        return original(self, state, backend)
+
+    make_evolution_rate._hip_dispatch = True  # type: ignore[attr-defined]
+    make_evolution_rate.__doc__ = original.__doc__
+    PDE.make_evolution_rate = make_evolution_rate  # type: ignore[method-assign]
+
+
+_install_evolution_rate_dispatch()
+
+
 class _Statistics(dict):
     """Step-size statistics gathered by the C loop, with the one method py-pde's controller uses
     (``OnlineStatistics.to_dict``, pde/solvers/controller.py:285-287)."""

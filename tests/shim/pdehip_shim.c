@@ -103,6 +103,7 @@ int pdehip_memset(void *ptr, int value, size_t bytes, void *stream) { (void)stre
 int pdehip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
 int pdehip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
 int pdehip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
+int pdehip_copy_nt(void *dst, const void *src, size_t bytes, void *stream) { (void)stream; memmove(dst, src, bytes); return 0; }
 int pdehip_host_alloc(void **ptr, size_t bytes) { return pdehip_malloc(ptr, bytes); }
 int pdehip_host_free(void *ptr) { free(ptr); return 0; }
 int pdehip_stream_create(void **stream) { *stream = malloc(8); return 0; }
@@ -240,6 +241,47 @@ int pdehip_lincomb(const pdehip_grid_t *g, int ncomp, void *out_full, const void
     (void)stream; GRID(g);
     if (n < 0 || n > 6) return fail(E_VALUE, "lincomb: n must be 0..6");
     TRY(oracle_lincomb(g, ncomp, out_full, y_full, n, coef_host, k_full_host));
+    return 0;
+}
+/* products of tensor fields, cell by cell (the arithmetic of the device kernel: sums over the contracted index in order) */
+#define FIELD_PRODUCT(T)                                                                                                      \
+    for (long e = 0; e < pc; e++) {                                                                                           \
+        const T *a = (const T *)a_full + e, *b = (const T *)b_full + e;                                                       \
+        T *out = (T *)out_full + e;                                                                                           \
+        const int nout = kind == 0 ? 1 : (kind == 1 || kind == 2 ? d : d * d);                                                \
+        for (int io = 0; io < nout; io++) {                                                                                   \
+            double re = 0, im = 0;                                                                                            \
+            const int nsum = kind == 4 ? 1 : d;                                                                               \
+            for (int m = 0; m < nsum; m++) {                                                                                  \
+                int ia, ib;                                                                                                   \
+                if (kind == 0) { ia = m; ib = m; }                                                                            \
+                else if (kind == 1) { ia = io * d + m; ib = m; }                                                              \
+                else if (kind == 2) { ia = m; ib = m * d + io; }                                                              \
+                else if (kind == 3) { ia = (io / d) * d + m; ib = m * d + io % d; }                                           \
+                else { ia = io / d; ib = io % d; }                                                                            \
+                const double ar = (double)a[(long)(ia * w) * pc], br = (double)b[(long)(ib * w) * pc];                       \
+                if (!complex_pairs) { re = re + ar * br; continue; }                                                          \
+                const double ai = (double)a[(long)(ia * w + 1) * pc];                                                         \
+                double bi = (double)b[(long)(ib * w + 1) * pc];                                                               \
+                if (conjugate) bi = -bi;                                                                                      \
+                re = re + (ar * br - ai * bi);                                                                                \
+                im = im + (ar * bi + ai * br);                                                                                \
+            }                                                                                                                 \
+            out[(long)(io * w) * pc] = (T)re;                                                                                 \
+            if (complex_pairs) out[(long)(io * w + 1) * pc] = (T)im;                                                          \
+        }                                                                                                                     \
+    }
+int pdehip_field_product(const pdehip_grid_t *g, int kind, int complex_pairs, int conjugate, const void *a_full, const void *b_full, void *out_full,
+                         void *stream)
+{
+    (void)stream; GRID(g);
+    if (!a_full || !b_full || !out_full) return fail(E_VALUE, "field_product: NULL pointer");
+    if (kind < 0 || kind > 4) return fail(E_VALUE, "field_product: kind 0 (v.v), 1 (T.v), 2 (v.T), 3 (T.T) or 4 (outer)");
+    int64_t lay[8];
+    pdehip_layout(g, lay);
+    const long pc = (long)lay[2];
+    const int d = g->ndim, w = complex_pairs ? 2 : 1;
+    if (g->dtype == PDEHIP_F64) { FIELD_PRODUCT(double) } else { FIELD_PRODUCT(float) }
     return 0;
 }
 int pdehip_rk4_combine(const pdehip_grid_t *g, int ncomp, void *y, const void *k1, const void *k2, const void *k3, const void *k4,

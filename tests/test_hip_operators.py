@@ -310,3 +310,42 @@ def test_spectral_laplace_against_numpy_fft(rng, shape, bounds, dtype):
         assert max_rel(O.laplace_spectral(oracle_grid(grid, dtype), to_full(grid, data)), expect) < tol
     with pytest.raises(NotImplementedError):
         pde_hip.ScalarField(pde_hip.UnitGrid([8, 8, 8], periodic=True), 1.0).laplace("periodic", backend=backend, spectral=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(7, 9), (5, 6, 130)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_field_products_and_expression_functions(shape, dtype):
+    """`pdehip_field_product` (make_inner_prod_operator / make_outer_prod_operator, pde/backends/base.py:567-610) against numpy's einsum for
+    every rank combination, real and complex, conjugated or not; `make_expression_function` (:653-676) - pointwise expressions of arrays
+    and numbers through the run-time compiled kernels - against numpy."""
+    import sympy as sp
+
+    backend = pde_hip.get_backend("hip")
+    grid = pde_hip.UnitGrid(list(shape), periodic=True)
+    d = len(shape)
+    rng = np.random.default_rng(12)
+    tol = 1e-13 if dtype == np.float64 else 2e-6
+    cdtype = np.complex128 if dtype == np.float64 else np.complex64
+    v1, v2 = rng.random((d, *shape)).astype(dtype), rng.random((d, *shape)).astype(dtype)
+    t1 = (rng.random((d, d, *shape)) + 1j * rng.random((d, d, *shape))).astype(cdtype)
+    t2 = rng.random((d, d, *shape)).astype(dtype)
+    for conj in (True, False):
+        dot = backend._make_product(grid, False, conj)
+        cj = (lambda x: x.conj()) if conj else (lambda x: x)
+        np.testing.assert_allclose(dot(v1, v2), np.einsum("i...,i...->...", v1, v2), rtol=tol)
+        np.testing.assert_allclose(dot(t2, v1), np.einsum("ij...,j...->i...", t2, v1), rtol=tol)
+        np.testing.assert_allclose(dot(v1, t1), np.einsum("i...,ij...->j...", v1, cj(t1)), rtol=tol)
+        np.testing.assert_allclose(dot(t1, t1), np.einsum("ij...,jk...->ik...", t1, cj(t1)), rtol=tol)
+    np.testing.assert_allclose(backend._make_product(grid, True, False)(v1, v2), np.einsum("i...,j...->ij...", v1, v2), rtol=tol)
+
+    class Expr:       # the attributes of pde.tools.expressions.ExpressionBase that the backend reads
+        def __init__(self, text, names, consts=None, funcs=None):
+            self._sympy_expr, self.vars, self.consts, self.user_funcs = sp.sympify(text), tuple(names), dict(consts or {}), dict(funcs or {})
+
+    a, b = rng.random(shape).astype(dtype), rng.random(shape).astype(dtype)
+    f = backend.make_expression_function(Expr("sin(a) * b + s * a**2 - sq(b) + k", ["a", "b", "s"], {"k": 0.25}, {"sq": lambda x: x * x}))
+    for sval in (0.7, -1.5):
+        np.testing.assert_allclose(f(a, b, sval), np.sin(a.astype(float)) * b + sval * a.astype(float) ** 2 - b.astype(float) ** 2 + 0.25, rtol=10 * tol)
+    f1 = backend.make_expression_function(Expr("a * b + 2", ["a", "b"]), single_arg=True)
+    np.testing.assert_allclose(f1(np.stack([a, b])), a.astype(float) * b + 2, rtol=10 * tol)

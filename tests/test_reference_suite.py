@@ -55,7 +55,6 @@ SUITES: dict[str, dict[str, str]] = {
         "test_stop_iteration_hook": "user-defined right-hand side in Python (hooks themselves are supported: tests/test_pypde_dropin.py)",
         "test_custom_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
         "test_array_data_hook": "user-defined right-hand side in Python (a PDEBase subclass with its own array code)",
-        "test_pde_with_bc_setter": "boundary conditions set by a user function on the array",
     },
     # the generic `PDE` class (tests/pdes/test_pde_class.py): explicit time, multi-field systems, per-field noise, coordinates,
     # `integral`, heaviside, BC handling and errors, time-dependent BCs, Swift-Hohenberg class vs expression, vector fields as
@@ -63,12 +62,11 @@ SUITES: dict[str, dict[str, str]] = {
     "pdes/test_pde_class.py": {
         "test_compare_swift_hohenberg[grid3": "curvilinear grids are out of scope (Cartesian path only)",
         "test_compare_swift_hohenberg[grid4": "curvilinear grids are out of scope (Cartesian path only)",
-        "test_pde_user_funcs": "calls PDE.make_evolution_rate, i.e. the reference's own sympy -> backend.make_expression_function path "
-                               "(user functions work through make_pde_rhs / eq.solve, where they are traced symbolically: "
-                               "tests/test_pypde_dropin.py::test_user_funcs_are_traced_symbolically)",
     },
     "fields/test_scalar_fields.py": {},
     "fields/test_vectorial_fields.py": {},
+    # dot / outer products of (complex) tensor fields through backend.make_inner_prod_operator / make_outer_prod_operator
+    "fields/test_tensorial_fields.py": {},
 }
 
 

@@ -28,6 +28,11 @@ if os.environ.get("PROBE_ONLY"):      # (a kernel trace of one configuration: PR
 for label, force, fast in configs:
     os.environ["PDEHIP_BLOCK2"] = fast
     st = BlockStepper(eq, grid, force_exchange=force)
+    if force and st.block2 and os.environ.get("PROBE_CUT"):      # e.g. PROBE_CUT=1,0,0: only the first axis travels (a slab through the block loop)
+        import ctypes as C
+
+        st.cut[:] = [int(v) for v in os.environ["PROBE_CUT"].split(",")]
+        st._cut3 = (C.c_int * 3)(*st.cut)
     cur, nxt = st.scatter(np.random.default_rng(0).random(shape)), st.buf("state_b")
     cur = st.euler_steps(cur, nxt, 0.1, 20)
     nxt = st.buf("state_b") if cur is st.buf("state_a") else st.buf("state_a")

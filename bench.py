@@ -136,26 +136,7 @@ def bench_single(args) -> dict:
         lib.event_create(C.byref(e))
     res = C.c_void_p()
     dt = 0.1
-    lib.euler_run(info.ref, spec.ref, a.ptr, b.ptr, dt, args.warmup, C.byref(res), stream)
-    lib.stream_synchronize(stream)
-    cur = res.value
-    nxt = b.ptr if cur == a.ptr else a.ptr
-    # timed region: exactly K steps, bracketed by synchronisation - repeated `--repeats` times (each repetition is a complete timed
-    # region of its own and continues from the state the previous one left; the line reports the MEDIAN, every sample and the minimum)
-    walls, ms_events = [], C.c_float()
-    for _ in range(max(1, args.repeats)):
-        lib.stream_synchronize(stream)
-        t0 = time.perf_counter()
-        lib.event_record(ev[0], stream)
-        lib.euler_run(info.ref, spec.ref, cur, nxt, dt, args.steps, C.byref(res), stream)
-        lib.event_record(ev[1], stream)
-        lib.stream_synchronize(stream)
-        walls.append(time.perf_counter() - t0)
-        lib.event_elapsed_ms(ev[0], ev[1], C.byref(ms_events))
-        if res.value != cur:
-            cur, nxt = nxt, cur
-    wall_stats = _stats([w / args.steps * 1e3 for w in walls])
-    wall = wall_stats["median"] * 1e-3 * args.steps
+    cur, nxt = a.ptr, b.ptr
     # dominant kernel alone, HIP events on its launch stream: the two-steps-per-sweep kernel where it covers the
     # grid (temporal blocking: ONE launch = TWO Euler steps, intermediate level in registers), else the one-step kernel
     reps = max(20, min(args.steps, 200))
@@ -176,6 +157,29 @@ def bench_single(args) -> dict:
         ms_kernel = C.c_float()
         lib.event_elapsed_ms(ev[2], ev[3], C.byref(ms_kernel))
         kernel_ms.append(ms_kernel.value / reps)
+    # (the kernel timing above runs BEFORE warm-up and timed region: with the driver's 20-step regions of 5 ms each the first repetitions
+    # used to see the clocks still ramping - r04: 0.2588 ... 0.2434 ms per step over the nine repetitions)
+    # W untimed warm-up steps, then ...
+    lib.euler_run(info.ref, spec.ref, cur, nxt, dt, args.warmup, C.byref(res), stream)
+    lib.stream_synchronize(stream)
+    if res.value != cur:
+        cur, nxt = nxt, cur
+    # timed region: exactly K steps, bracketed by synchronisation - repeated `--repeats` times (each repetition is a complete timed
+    # region of its own and continues from the state the previous one left; the line reports the MEDIAN, every sample and the minimum)
+    walls, ms_events = [], C.c_float()
+    for _ in range(max(1, args.repeats)):
+        lib.stream_synchronize(stream)
+        t0 = time.perf_counter()
+        lib.event_record(ev[0], stream)
+        lib.euler_run(info.ref, spec.ref, cur, nxt, dt, args.steps, C.byref(res), stream)
+        lib.event_record(ev[1], stream)
+        lib.stream_synchronize(stream)
+        walls.append(time.perf_counter() - t0)
+        lib.event_elapsed_ms(ev[0], ev[1], C.byref(ms_events))
+        if res.value != cur:
+            cur, nxt = nxt, cur
+    wall_stats = _stats([w / args.steps * 1e3 for w in walls])
+    wall = wall_stats["median"] * 1e-3 * args.steps
     kernel_stats = _stats(kernel_ms)
     t_kernel = kernel_stats["median"] * 1e-3
     # device-copy ceiling of THIS GPU on the same bytes: hipMemcpyDtoD of the state = 1 read + 1 write per cell

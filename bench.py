@@ -311,7 +311,7 @@ def more_rooflines(backend, lib, spec, stream, ev, n: int, repeats: int = 5) -> 
     scalar_in.set_valid(rng.random((n, n, n)), stream)
     vec_a.set_valid(rng.random((3, n, n, n)), stream)
     lib.set_ghost_cells(info.ref, 1, spec.bc_c.c, scalar_in.ptr, stream)
-    comp_bytes = vec_a.nbytes // 3
+    comp_bytes = int(info.comp_elems) * vec_a.itemsize      # bytes between the components of a full array
 
     def timed(fn, reps=30):
         for _ in range(3):

@@ -66,7 +66,10 @@ struct Plan {
     size_t send_total, recv_total;   // elements
     int nrim;
     Box rim[6];         // boxes of own cells whose two-step domain of dependence reaches a halo cell
+    int send_dir[27], recv_dir[27];   // region index by direction code (d0 + 1) * 9 + (d1 + 1) * 3 + (d2 + 1): the region sent TOWARDS d / the halo region IN direction d; -1: none
 };
+
+inline int dir_code(const int *d) { return (d[0] + 1) * 9 + (d[1] + 1) * 3 + (d[2] + 1); }
 
 inline int rank_of(const int *dims, const int *c) { return (c[0] * dims[1] + c[1]) * dims[2] + c[2]; }
 
@@ -130,6 +133,7 @@ inline int make_plan(const long *n, const int *dims, const int *coords, const in
         p->n[a] = n[a]; p->dims[a] = dims[a]; p->coords[a] = coords[a]; p->cut[a] = cut[a];
         if (cut[a] && n[a] < 4) return -1;
     }
+    for (int k = 0; k < 27; k++) p->send_dir[k] = p->recv_dir[k] = -1;
     const int me = rank_of(dims, coords);
     int dirs[kMaxRegions][3];
     const int nd = directions(cut, dirs);
@@ -149,6 +153,7 @@ inline int make_plan(const long *n, const int *dims, const int *coords, const in
         p->peers[q].send_off = off;
         for (int k = 0; k < nd; k++) {
             if (peer_of_dir[k] != q) continue;
+            p->send_dir[dir_code(dirs[k])] = p->nsend;
             Region &r = p->send[p->nsend++];
             r.box = send_box(n, dirs[k]);
             r.offset = off;
@@ -170,6 +175,7 @@ inline int make_plan(const long *n, const int *dims, const int *coords, const in
             if (neighbour(dims, pc, dirs[k]) != me) continue;
             // several directions of the peer may lead to me (two blocks along a periodic axis): each one is a region of its own
             const int back[3] = {-dirs[k][0], -dirs[k][1], -dirs[k][2]};
+            p->recv_dir[dir_code(back)] = p->nrecv;
             Region &r = p->recv[p->nrecv++];
             r.box = halo_box(n, back);
             r.offset = off;

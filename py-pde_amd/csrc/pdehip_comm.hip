@@ -148,6 +148,10 @@ __global__ void __launch_bounds__(256) face_copy_kernel(FaceCopyMany a)
     }
 }
 
+// (defined below, next to rim2_kernel) the two-ended boundary sweep of a slab - own layers 0, 1 and n-2, n-1 - by the rim kernel of the fast
+// block loop: no march, every operand of a tile requested at once.  *done = false: not covered (the two-level kernel takes it).
+int slab_rim2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *st, bool *done);
+
 // The `Ops` policy of pdehip_slab_loops.h on the device: HIP streams / events, RCCL point-to-point over xGMI, gfx950 kernels.
 struct HipOps {
     Comm *c;
@@ -185,6 +189,13 @@ struct HipOps {
     int euler2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *st, bool *done,
                int xplain, bool dry, int ends)
     {
+        // The two-ended boundary sweep of a slab between two neighbours: 2 + 2 planes.  As a march of the two-level kernel it is a chain of
+        // seven dependent plane loads per wave (41 us for 512 x 512 planes next to the interior sweep, profiles/r03_probe_slab.md) and
+        // heads the critical path boundary -> send / receive -> next boundary; the rim kernel asks for everything at once.
+        if (ends == 2 && xplain == 1 && !dry) {
+            PDEHIP_TRY(slab_rim2(gs, in, out, D, dt, faces, st, done));
+            if (*done) return 0;
+        }
         return euler2_with_input_bcs(gs, in, out, D, dt, faces, st, done, xplain, dry, ends);
     }
     int ch_fused(const pdehip_grid_t *gs, const void *in, void *out, double gamma, double dt, bool euler, const pdehip_bc_face_t *fc,
@@ -728,9 +739,15 @@ struct Rim2Args {
     struct Job { long i0, j0, ni, nj; long start; } job[6];   // box of own cells, tiles of 2 x 2 (the last one moved back)
     long nzseg;             // lane segments per row
     long total;             // wave tiles
+    // DIRECT (the fastest axis not cut): the halo cells are read from the RECEIVE buffer where the messages land (no unpack launch) and the
+    // results are stored into the SEND buffer as well (no pack launch) - a pair of steps then has rim -> send / receive on its critical
+    // path instead of rim -> pack -> send / receive -> unpack.  Regions by direction code (dx + 1) * 3 + (dy + 1); rows of n2 cells.
+    const void *recv;
+    void *send;
+    struct Reg { long off, lo0, lo1, rows; } rreg[9], sreg[9];   // off < 0: no such region
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool DIRECT = false>
 __global__ void __launch_bounds__(256) rim2_kernel(Rim2Args a)
 {
     typedef typename VecT<T, VEC>::type V;
@@ -763,6 +780,15 @@ __global__ void __launch_bounds__(256) rim2_kernel(Rim2Args a)
         for (int rr = 0; rr < 6; rr++) {
             const int dp = pp < 2 ? 2 - pp : (pp > 3 ? pp - 3 : 0), dr = rr < 2 ? 2 - rr : (rr > 3 ? rr - 3 : 0);
             if (dp + dr > 2) continue;
+            if constexpr (DIRECT) {
+                const long i = i0 - 2 + pp, j = j0 - 2 + rr;
+                const int di = a.wrap[0] ? 0 : (i < 0 ? -1 : (i >= a.n0 ? 1 : 0)), dj = a.wrap[1] ? 0 : (j < 0 ? -1 : (j >= a.n1 ? 1 : 0));
+                if (di != 0 || dj != 0) {   // uniform: a halo row - out of the message it arrived in
+                    const Rim2Args::Reg &r = a.rreg[(di + 1) * 3 + (dj + 1)];
+                    u0[pp][rr] = *(const V *)((const T *)a.recv + r.off + ((xs(i) - r.lo0) * r.rows + (ys(j) - r.lo1)) * a.n2 + vs * VEC);
+                    continue;
+                }
+            }
             u0[pp][rr] = *(const V *)(base + xs(i0 - 2 + pp) * a.p0 + ys(j0 - 2 + rr) * a.p1);
         }
     auto step = [&](double xm, double xp, double up, double dn, double left, double right, double cen) {
@@ -806,7 +832,136 @@ __global__ void __launch_bounds__(256) rim2_kernel(Rim2Args a)
                 res[e] = (T)step((double)u1[q][s + 1][e], (double)u1[q + 2][s + 1][e], (double)u1[q + 1][s][e], (double)u1[q + 1][s + 2][e], left, right, (double)cc[e]);
             }
             if (store) *(V *)(ob + (i0 + q) * a.p0 + (j0 + s) * a.p1) = res;
+            if constexpr (DIRECT) {
+                // ... and into every message this cell travels in: the face(s) it lies behind and the edge between them
+                const long i = i0 + q, j = j0 + s;
+                const int ox = a.wrap[0] ? 0 : (i < 2 ? -1 : (i >= a.n0 - 2 ? 1 : 0)), oy = a.wrap[1] ? 0 : (j < 2 ? -1 : (j >= a.n1 - 2 ? 1 : 0));
+                auto put = [&](int dx, int dy) {
+                    const Rim2Args::Reg &r = a.sreg[(dx + 1) * 3 + (dy + 1)];
+                    if (store && r.off >= 0) *(V *)((T *)a.send + r.off + ((i - r.lo0) * r.rows + (j - r.lo1)) * a.n2 + vi * VEC) = res;
+                };
+                if (ox) put(ox, 0);
+                if (oy) put(0, oy);
+                if (ox && oy) put(ox, oy);
+            }
         }
+}
+
+// The rim behind a cut face of the FASTEST axis: two columns of every row.  Lanes along that axis would idle (2 cells = one lane's vector), so
+// the layout is transposed: a lane stands for a ROW and holds the strip k0-2 .. k0+3 of six planes (three 2-element vectors per plane and
+// row); row neighbours are the neighbouring lanes (DPP), plane neighbours other registers.  A wave = 2 planes x 60 rows (lanes 0, 1, 62, 63
+// only feed their neighbours).  Same expressions in the same order as rim2_kernel.
+struct RimzArgs {
+    const void *in;
+    void *out;
+    long n0, n1, n2;
+    long p0, p1, off;
+    int wrap[3];            // (wrap[2] is 0: this kernel exists for cut fastest axes)
+    double sx, sy, sz, s1, s2;
+    long nrseg;             // row segments of 60 rows
+    long total;             // wave tiles: 2 sides x plane pairs x row segments
+};
+template <typename T>
+__global__ void __launch_bounds__(256) rimz_kernel(RimzArgs a)
+{
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (w >= a.total) return;
+    const long npair = (a.n0 + 1) / 2;
+    const long rseg = w % a.nrseg, ti = (w / a.nrseg) % npair, side = w / (a.nrseg * npair);
+    long i0 = 2 * ti;
+    if (i0 + 2 > a.n0) i0 = a.n0 - 2;
+    const long k0 = side ? a.n2 - 2 : 0;
+    const long jr = rseg * 60 - 2 + lane;      // the lane's row
+    long js = jr;
+    if (a.wrap[1]) js = ((jr % a.n1) + a.n1) % a.n1;
+    else js = jr < -2 ? -2 : (jr > a.n1 + 1 ? a.n1 + 1 : jr);   // two halo rows on either side; lanes further out store nothing
+    auto xs = [&](long i) { return a.wrap[0] ? ((i % a.n0) + a.n0) % a.n0 : i; };
+    const T *base = (const T *)a.in + a.off + js * a.p1 + (k0 - 2);
+    double u0[6][6];
+#pragma unroll
+    for (int pp = 0; pp < 6; pp++) {
+        const T *row = base + xs(i0 - 2 + pp) * a.p0;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            // strip cells 2v, 2v+1; skipped when both lie in a corner of the diamond
+            const int dp = pp < 2 ? 2 - pp : (pp > 3 ? pp - 3 : 0);
+            const int dk0 = (2 * v) < 2 ? 2 - 2 * v : ((2 * v) > 3 ? 2 * v - 3 : 0), dk1 = (2 * v + 1) < 2 ? 1 - 2 * v : ((2 * v + 1) > 3 ? 2 * v - 2 : 0);
+            if (dp + dk0 > 2 && dp + dk1 > 2) { u0[pp][2 * v] = 0; u0[pp][2 * v + 1] = 0; continue; }
+            const V2 x = *(const V2 *)(row + 2 * v);
+            u0[pp][2 * v] = (double)x[0];
+            u0[pp][2 * v + 1] = (double)x[1];
+        }
+    }
+    auto step = [&](double xm, double xp, double up, double dn, double left, double right, double cen) {
+        const double vm = 2 * cen;
+        const double lx = (xm - vm + xp) * a.sx;
+        const double ly = (up - vm + dn) * a.sy;
+        const double lz = (left - vm + right) * a.sz;
+        const double lap = lx + ly + lz;
+        return cen + a.s2 * (a.s1 * lap);
+    };
+    double u1[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            u1[q][kk] = 0;
+            if (((q == 0 || q == 3) ? 1 : 0) + ((kk == 0 || kk == 3) ? 1 : 0) > 1) continue;
+            const double cen = u0[q + 1][kk + 1];
+            const double up = wave_shr1(0.0, cen), dn = wave_shl1(0.0, cen);
+            u1[q][kk] = (double)(T)step(u0[q][kk + 1], u0[q + 2][kk + 1], up, dn, u0[q + 1][kk], u0[q + 1][kk + 2], cen);
+        }
+    T *ob = (T *)a.out + a.off + jr * a.p1 + k0;
+    const bool store = lane >= 2 && lane <= 61 && jr >= 0 && jr < a.n1;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        V2 res;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const double cen = u1[q + 1][kk + 1];
+            const double up = wave_shr1(0.0, cen), dn = wave_shl1(0.0, cen);
+            res[kk] = (T)step(u1[q][kk + 1], u1[q + 2][kk + 1], up, dn, u1[q + 1][kk], u1[q + 1][kk + 2], cen);
+        }
+        if (store) *(V2 *)(ob + (i0 + q) * a.p0) = res;
+    }
+}
+
+int slab_rim2(const pdehip_grid_t *gs, const void *in, void *out, double D, double dt, const pdehip_bc_face_t *faces, void *st, bool *done)
+{
+    *done = false;
+    static const bool off = getenv("PDEHIP_SLAB_RIM") && getenv("PDEHIP_SLAB_RIM")[0] == '0';   // A/B aid
+    if (off || gs->ndim != 3 || gs->shape[0] < 4 || gs->shape[1] < 2) return 0;
+    NGrid n;
+    PDEHIP_TRY(norm_grid(gs, &n));
+    const long vec = 16 / elem_size(n.dtype);
+    if (n.n[2] % vec) return 0;
+    for (int a = 1; a < 3; a++)
+        for (int side = 0; side < 2; side++) {
+            const pdehip_bc_face_t &r = faces[2 * a + side];
+            if (r.kind != PDEHIP_BC_ORDER1 || r.flags != 0 || r.index1 != (side ? 0 : n.n[a] - 1) || r.const_v != 0.0 || r.factor1 != 1.0) return 0;   // periodic rows / columns only
+        }
+    Rim2Args a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out;
+    a.n0 = n.n[0]; a.n1 = n.n[1]; a.n2 = n.n[2];
+    a.p0 = n.p[0]; a.p1 = n.p[1]; a.off = n.off;
+    a.wrap[0] = 0; a.wrap[1] = 1; a.wrap[2] = 1;
+    a.sx = n.lap_scale[0]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
+    a.s1 = D; a.s2 = dt;
+    a.nzseg = (n.n[2] / vec + 59) / 60;
+    const long per = ((n.n[1] + 1) / 2) * a.nzseg;
+    a.job[0] = {0, 0, 2, n.n[1], 0};
+    a.job[1] = {n.n[0] - 2, 0, 2, n.n[1], per};
+    a.njobs = 2;
+    a.total = 2 * per;
+    const unsigned blocks = (unsigned)((a.total + 3) / 4);
+    if (n.dtype == PDEHIP_F64) hipLaunchKernelGGL((rim2_kernel<double, 2>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+    else hipLaunchKernelGGL((rim2_kernel<float, 4>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+    PDEHIP_HIP(hipGetLastError());
+    *done = true;
+    return 0;
 }
 
 struct Block2Ctx {
@@ -875,9 +1030,13 @@ struct HipOps2 {
         }
         return vec;
     }
+    // DIRECT (schedules 1 / 2, the fastest axis not cut): the rim kernel reads the halo cells out of the receive buffer and writes its
+    // results into the send buffer itself - only the very first exchange of a run packs, nothing is ever unpacked
+    bool direct = false, send_ready = false;
     // all regions of an exchange: own cells -> send buffer (is_pack) / receive buffer -> halo cells
     int pack(const block2::Plan &p, void *ext, bool is_pack, void *st)
     {
+        if (direct && (!is_pack || send_ready)) return 0;
         BoxJobs jobs;
         long n2s[block2::kMaxRegions];
         const int nreg = is_pack ? p.nsend : p.nrecv;
@@ -947,29 +1106,65 @@ struct HipOps2 {
         long total = 0;
         for (int k = 0; k < p.nrim; k++) {
             const block2::Box &b = p.rim[k];
-            if (b.n[2] != p.n[2]) PDEHIP_FAIL(E_NOTIMPL, "internal: rims of the fastest axis are not built");
+            if (b.n[2] != p.n[2]) continue;   // the rims of the fastest axis: rimz_kernel below
             a.job[a.njobs] = {b.lo[0], b.lo[1], b.n[0], b.n[1], total};
             a.njobs++;
             total += ((b.n[0] + 1) / 2) * ((b.n[1] + 1) / 2) * a.nzseg;
         }
         a.total = total;
-        const unsigned blocks = (unsigned)((total + 3) / 4);
-        if (es == 8) hipLaunchKernelGGL((rim2_kernel<double, 2>), dim3(blocks), dim3(256), 0, as_stream(st), a);
-        else hipLaunchKernelGGL((rim2_kernel<float, 4>), dim3(blocks), dim3(256), 0, as_stream(st), a);
-        PDEHIP_HIP(hipGetLastError());
+        if (direct) {
+            a.recv = x->msg[1]; a.send = x->msg[0];
+            for (int dx = -1; dx <= 1; dx++)
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int d[3] = {dx, dy, 0};
+                    const int c9 = (dx + 1) * 3 + (dy + 1), ri = p.recv_dir[block2::dir_code(d)], si = p.send_dir[block2::dir_code(d)];
+                    a.rreg[c9] = {-1, 0, 0, 0};
+                    a.sreg[c9] = {-1, 0, 0, 0};
+                    if (ri >= 0) a.rreg[c9] = {(long)p.recv[ri].offset, p.recv[ri].box.lo[0], p.recv[ri].box.lo[1], p.recv[ri].box.n[1]};
+                    if (si >= 0) a.sreg[c9] = {(long)p.send[si].offset, p.send[si].box.lo[0], p.send[si].box.lo[1], p.send[si].box.n[1]};
+                }
+        }
+        if (total) {
+            const unsigned blocks = (unsigned)((total + 3) / 4);
+            if (direct) {
+                if (es == 8) hipLaunchKernelGGL((rim2_kernel<double, 2, true>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+                else hipLaunchKernelGGL((rim2_kernel<float, 4, true>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+                send_ready = true;
+            } else {
+                if (es == 8) hipLaunchKernelGGL((rim2_kernel<double, 2>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+                else hipLaunchKernelGGL((rim2_kernel<float, 4>), dim3(blocks), dim3(256), 0, as_stream(st), a);
+            }
+            PDEHIP_HIP(hipGetLastError());
+        }
+        if (p.cut[2]) {
+            RimzArgs z;
+            memset(&z, 0, sizeof(z));
+            z.in = cur; z.out = nxt;
+            z.n0 = p.n[0]; z.n1 = p.n[1]; z.n2 = p.n[2];
+            z.p0 = ne.p[0]; z.p1 = ne.p[1]; z.off = own_off;
+            for (int k = 0; k < 3; k++) z.wrap[k] = p.cut[k] ? 0 : 1;
+            z.sx = a.sx; z.sy = a.sy; z.sz = a.sz; z.s1 = D; z.s2 = dt;
+            z.nrseg = (p.n[1] + 59) / 60;
+            z.total = 2 * ((p.n[0] + 1) / 2) * z.nrseg;
+            const unsigned blocks = (unsigned)((z.total + 3) / 4);
+            if (es == 8) hipLaunchKernelGGL((rimz_kernel<double>), dim3(blocks), dim3(256), 0, as_stream(st), z);
+            else hipLaunchKernelGGL((rimz_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(st), z);
+            PDEHIP_HIP(hipGetLastError());
+        }
         return 0;
     }
 };
 
-// what the fast block loop covers: 3-D, diffusion, every face of an uncut axis periodic, no cut of the fastest axis (its rim would
-// need a transposed kernel), boxes and rows the two-step kernel and the 16-byte vectors of the rim kernel take
+// what the fast block loop covers: 3-D, diffusion, every face of an uncut axis periodic, boxes and rows the two-step kernel and the 16-byte
+// vectors of the rim kernel take (a cut fastest axis: its two halo cells must fit the padding of the rows, euler2_box checks)
 int block2_check(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, bool *ok)
 {
     *ok = false;
     if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program) return 0;
-    if (cut3[2]) return 0;
     const long vec = 16 / elem_size(g_local->dtype);
-    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4) return 0;
+    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4 || (cut3[2] && g_local->shape[2] < 8)) return 0;
+    // (fp32 with a cut fastest axis: the interior box would start two cells into a four-cell vector - the exact one-step loop takes it)
+    if (cut3[2] && g_local->dtype != PDEHIP_F64) return 0;
     bool done = false;
     PDEHIP_TRY(euler2_box(g_local, rhs->bc_c, cut3, (const void *)16, (void *)32, rhs->param, 0.0, nullptr, &done, true));
     if (done) {   // ... and the interior box of the boundary-first schedules
@@ -1055,6 +1250,8 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
         comp2 = x->comp_masked;
         ops.halo_st = x->halo_masked;
     }
+    static const bool direct_off = getenv("PDEHIP_BLOCK2_DIRECT") && getenv("PDEHIP_BLOCK2_DIRECT")[0] == '0';   // A/B aid
+    ops.direct = mode >= 1 && !cut3[2] && any && !direct_off && g_local->shape[2] % (16 / elem_size(g_local->dtype)) == 0;
     const size_t need = (size_t)(ops.ne.pc + kAllocSlack) * ops.es;
     if (x->ext_bytes < need) {
         PDEHIP_HIP(hipStreamSynchronize(c->halo));

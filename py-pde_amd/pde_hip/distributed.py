@@ -478,8 +478,8 @@ class BlockStepper:
         fast = 0
         if (nd == 3 and all(grid.periodic) and self.kind == _abi.RHS_DIFFUSION and self.bc_program is None
                 and os.environ.get("PDEHIP_BLOCK2", "1") != "0"):
-            if self.cut[2] and force_exchange and self.dims[2] == 1:
-                self.cut[2] = 0          # (the probe on one device: the fastest axis keeps its periodic wrap)
+            if self.cut[2] and force_exchange and self.dims[2] == 1 and os.environ.get("PDEHIP_PROBE_CUT_FASTEST", "0") != "1":
+                self.cut[2] = 0          # (the probe on one device: the fastest axis keeps its periodic wrap unless asked otherwise)
             # (the faces of the uncut axes as the kernels see them: the periodic conditions of the whole grid)
             whole = _abi.RHS()
             whole.kind, whole.param = self.kind, self.param

@@ -803,7 +803,8 @@ struct HostOps2 {
         c->group.clear();
         return 0;
     }
-    long elem_of(long i, long j, long k) const { return (long)lay[3] + (i + 1) * (long)lay[0] + (j + 1) * (long)lay[1] + k; }   // own-cell coordinates
+    int zcut = 0;                     // the fastest axis is cut: g_ext is two cells larger along it as well (own cell k = its interior cell k + 1)
+    long elem_of(long i, long j, long k) const { return (long)lay[3] + (i + 1) * (long)lay[0] + (j + 1) * (long)lay[1] + k + zcut; }   // own-cell coordinates
     int pack(const block2::Plan &p, void *ext, bool is_pack, void *)
     {
         const int nreg = is_pack ? p.nsend : p.nrecv;
@@ -826,8 +827,9 @@ struct HostOps2 {
         const size_t bytes = (size_t)lay[2] * es;
         std::vector<char> u0(bytes), u1(bytes, 0), u2(bytes, 0);
         memcpy(u0.data(), cur, bytes);
-        auto at = [&](std::vector<char> &v, long i, long j) { return v.data() + elem_of(i, j, 0) * (long)es; };
-        const long n0 = p.n[0], n1 = p.n[1], rowb = p.n[2] * (long)es;
+        const long hz = zcut ? 2 : 0;      // halo cells of a cut fastest axis travel with their rows (the edges)
+        auto at = [&](std::vector<char> &v, long i, long j) { return v.data() + elem_of(i, j, -hz) * (long)es; };
+        const long n0 = p.n[0], n1 = p.n[1], rowb = (p.n[2] + 2 * hz) * (long)es;
         // an uncut (periodic) axis wraps: its two halo layers from the own cells - rows first, then whole planes (the edges follow)
         auto wrap_xy = [&](std::vector<char> &v, long depth) {
             if (!p.cut[1])
@@ -839,18 +841,19 @@ struct HostOps2 {
         };
         pdehip_bc_face_t f[2 * PDEHIP_MAX_DIM];
         memset(f, 0, sizeof(f));                 // SKIP on the first two axes: their ghost layers hold halo data
-        f[4] = faces[4]; f[5] = faces[5];        // the fastest axis: the periodic condition of the grid
+        if (!zcut) { f[4] = faces[4]; f[5] = faces[5]; }   // the fastest axis: the periodic condition of the grid - or halo data like the others
         wrap_xy(u0, 2);
         OTRY(oracle_set_ghost_cells(&g_ext, 1, f, u0.data()));
         OTRY(oracle_laplace_euler(&g_ext, u0.data(), u0.data(), u1.data(), D, dt));     // level 1 on the own cells widened by one
         OTRY(oracle_set_ghost_cells(&g_ext, 1, f, u1.data()));
         OTRY(oracle_laplace_euler(&g_ext, u1.data(), u1.data(), u2.data(), D, dt));     // level 2: valid on the own cells
         for (long i = 0; i < n0; i++)
-            for (long j = 0; j < n1; j++) {
-                const bool rim = (p.cut[0] && (i < 2 || i >= n0 - 2)) || (p.cut[1] && (j < 2 || j >= n1 - 2));
-                if ((which == 1 && !rim) || (which == 2 && rim)) continue;
-                memcpy(static_cast<char *>(nxt) + elem_of(i, j, 0) * (long)es, at(u2, i, j), rowb);
-            }
+            for (long j = 0; j < n1; j++)
+                for (long k = 0; k < p.n[2]; k++) {
+                    const bool rim = (p.cut[0] && (i < 2 || i >= n0 - 2)) || (p.cut[1] && (j < 2 || j >= n1 - 2)) || (p.cut[2] && (k < 2 || k >= p.n[2] - 2));
+                    if ((which == 1 && !rim) || (which == 2 && rim)) continue;
+                    memcpy(static_cast<char *>(nxt) + elem_of(i, j, k) * (long)es, u2.data() + elem_of(i, j, k) * (long)es, es);
+                }
         return 0;
     }
     int sweep2(const block2::Plan &p, void *cur, void *nxt, bool interior, void *) { return two_steps(p, cur, nxt, interior ? 2 : 0); }
@@ -859,9 +862,9 @@ struct HostOps2 {
 
 bool block2_covers(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3)
 {
-    if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program || cut3[2]) return false;
+    if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program || (cut3[2] && g_local->dtype != PDEHIP_F64)) return false;
     const long vec = g_local->dtype == PDEHIP_F64 ? 2 : 4;
-    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4 || g_local->shape[2] < 4) return false;
+    if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4 || g_local->shape[2] < 4 || (cut3[2] && g_local->shape[2] < 8)) return false;
     for (int a = 0; a < 3; a++) {
         if (cut3[a]) continue;
         for (int side = 0; side < 2; side++) {
@@ -901,6 +904,8 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
     HostOps2 ops;
     ops.c = c; ops.g_box = *g_local; ops.g_ext = *g_local; ops.faces = rhs->bc_c; ops.D = rhs->param; ops.dt = dt;
     ops.g_ext.shape[0] += 2; ops.g_ext.shape[1] += 2;
+    ops.zcut = cut3[2] ? 1 : 0;
+    if (ops.zcut) ops.g_ext.shape[2] += 2;
     SLAB_TRY(pdehip_layout(&ops.g_ext, ops.lay));
     ops.es = g_local->dtype == PDEHIP_F64 ? 8 : 4;
     int64_t ll[8];

@@ -511,8 +511,9 @@ int pdehip_field_product(const pdehip_grid_t *g, int kind, int complex_pairs, in
  * every right-hand side pde/backends/numba_mpi/backend.py:163-194, pde/grids/boundaries/local.py:561-662) for the case the benchmark
  * runs: DiffusionPDE, fixed-step Euler, a 3-D grid that is periodic on every axis.  dims3 / coords3: blocks per axis and the block of
  * this rank (ranks in C order of the block indices, like GridMesh); cut3[a] != 0: axis a is exchanged (several blocks - or one block
- * that sends its halo to itself: the probe of the exchange path on one device), else it wraps inside the kernels.  The fastest axis
- * cannot be cut (pdehip_block2_supported answers 0; the caller then takes pdehip_block_run).  buf_a: the state (full array of
+ * that sends its halo to itself: the probe of the exchange path on one device), else it wraps inside the kernels.  A cut of the fastest
+ * axis is covered for fp64 (its halo cells live in the padding of the rows); where pdehip_block2_supported answers 0 the caller takes
+ * pdehip_block_run.  buf_a: the state (full array of
  * g_local), advanced in place by `nsteps` (EVEN) steps; buf_b is not touched (kept for the signature of the other loops).
  * Bit-identical to single steps. */
 int pdehip_block2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, int *ok);

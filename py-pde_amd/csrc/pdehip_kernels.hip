@@ -470,8 +470,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     if (sizeof(T) == 4) ry = ry_f32;
     // the tall tile (8 rows, one wave per SIMD, four plane buffers: pdehip_march2.inc): the plain two-step diffusion sweep of fp64
     // grids whose rows end at chunk boundaries.  PDEHIP_EULER2=8 selects it (measurement: profiles/r03_e2_tile_shapes.log)
-    const bool tall = sizeof(T) == 8 && VEC == 2 && t2.ry == 8 && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
-                      (m2 == E2_DIFFUSION);
+    // Round 5 (rows on 128-byte lines): the tall tile wins for fields well beyond the Infinity Cache - 512^3 0.2157 -> 0.2108 ms per step (mean of
+    // four alternations), 512 x 512 x 256 +3.7 %, 384^3 +2.6 % - and loses below (256^3 -3 %, 128 x 512 x 512 -0.7 %): profiles/r05_ab_tall_tile.log.
+    // PDEHIP_EULER2=8 forces it, PDEHIP_EULER2=4 the 4-row tile.
+    const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0;
+    const bool tall = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
+                      (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
     // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
     // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
     // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number

@@ -889,7 +889,7 @@ def test_bare_bench_spawns_its_own_ranks_and_refuses_a_mismatch():
 
 def test_bench_with_a_block_decomposition():
     """`bench.py --gpus 8 --decomposition 2,4,1` (started bare: it spawns its ranks) runs the fast block loop and prints the parity digest
-    of the single-device run; `--decomposition auto` (2 x 2 x 2: the fastest axis is cut) takes the exact one-step block loop."""
+    of the single-device run; `--decomposition auto` (2 x 2 x 2, the reference's rule: the fastest axis is cut too) likewise."""
     import json
     import subprocess
 
@@ -898,7 +898,7 @@ def test_bench_with_a_block_decomposition():
     so = shimlib.build()
     env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    for dec, fast, dims in (("2,4,1", True, [2, 4, 1]), ("auto", False, [2, 2, 2])):
+    for dec, fast, dims in (("2,4,1", True, [2, 4, 1]), ("auto", True, [2, 2, 2])):
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32", "--decomposition", dec]
         proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**clean, **env}, cwd=str(ROOT))
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]

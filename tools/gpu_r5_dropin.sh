@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4: the REAL py-pde (shipped as git-ignored scratch, removed after the call) against the real libpdehip.so on the MI355X -
-# the drop-in files of round 3 plus this round's: complex fields, the reference's adaptive Euler, hooks traced onto the device
-O=gpurun_out/r4dropin
+# round 5: the REAL py-pde (shipped as git-ignored scratch, removed after the call) against the real libpdehip.so on the MI355X -
+# all drop-in files incl. this round's backend methods (products, expression functions, ghost-cell setters) on the 128-byte row layout
+O=gpurun_out/r5dropin
 mkdir -p $O
 R=$PWD
 export TMPDIR=/tmp

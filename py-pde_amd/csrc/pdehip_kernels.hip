@@ -250,6 +250,8 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
 #define PDEHIP_CFG2(RY_, CZ_) \
     if (n.ndim == 2 && ry == RY_ && cz == CZ_) return launch_march<T, VEC, RY_, CZ_, 1, 1, MODE, false>(a, y_is_in, blocks, st);
         PDEHIP_CFG3(2, 4, 1, 1)
+        PDEHIP_CFG3(2, 4, 1, 2)   // (PDEHIP_TUNE only: two planes of prefetch, one wave per SIMD - measured in profiles/r05_lap_prefetch.log)
+        PDEHIP_CFG3(2, 2, 1, 2)
         PDEHIP_CFG3(2, 2, 1, 1)
         PDEHIP_CFG3(2, 1, 1, 1)
         PDEHIP_CFG3(4, 4, 1, 1)

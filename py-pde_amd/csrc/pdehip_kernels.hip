@@ -244,6 +244,11 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         // narrow tiles over a long row (e.g. 5 x 1 chunk for 513 cells): a wave carries 1/4 or 1/2 of the bytes of a whole-row
         // tile per plane, so keep the bytes in flight by marching shorter x-chunks with more waves
         if (chunks > cz && cz < 4) blocks *= 4 / cz;
+        // Round 5: two planes of prefetch and half the waves (4 x-chunks of 128 planes) for the whole-row fp64 tile on fields beyond the Infinity
+        // Cache: 0.3629-0.3662 against 0.3677-0.3800 ms per 512^3 Laplacian, three alternations (profiles/r05_lap_prefetch.log); the plain
+        // epilogues only (the stage sweeps carry up to eight more streams: not measured)
+        if (n.ndim == 3 && sizeof(T) == 8 && ry == 2 && cz == 4 && wy == 1 && chunks % 4 == 0 && n.n[2] % VEC == 0 && MODE <= LAP_CH_MU &&
+            (double)n.n[0] * n.n[1] * n.n[2] * sizeof(T) > 400.0 * 1048576.0) { pf = 2; blocks = 512; }
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
 #define PDEHIP_CFG3(RY_, CZ_, WY_, PF_) \
     if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st);

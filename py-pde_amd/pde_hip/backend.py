@@ -1593,8 +1593,32 @@ class HipBackendMixin:
             if "make_noise_variance" in vars(cls):
                 custom_variance = cls.__name__ not in {"SDEBase", "PDEBase"}
                 break
-        if getattr(eq, "use_noise_realization", False) or not getattr(eq, "use_noise_variance", True):
-            msg = f"Backend `{self.name}` supports Gaussian white noise given by its variance only (noise realisations are user code on host arrays)"
+        if getattr(eq, "use_noise_realization", False):
+            # Noise given as a REALISATION (pde/pdes/base.py:578, pde/solvers/euler.py:99-127: `state += sqrt(dt) * realization(state_old, t)`):
+            # arbitrary Python on host arrays - the reference's own device backend refuses it (pde/backends/torch/_solvers.py:312-314).  Here:
+            # a host round trip per step (the old state down, the realisation up), warned like the hooks that cannot be traced.
+            realization = eq.make_noise_realization(state, backend=self)
+            _logger.warning("noise realisations of %s are user code on host arrays: the state crosses PCIe twice per step", type(eq).__name__)
+            dt_sqrt = (C.c_double * 1)(float(np.sqrt(float(solver.info["dt"]))))
+            has_var = not np.allclose(np.asarray(getattr(eq, "noise", 0), dtype=float), 0, atol=1e-14)
+            if getattr(eq, "use_noise_variance", True) and has_var:
+                msg = f"Backend `{self.name}`: a noise variance next to a noise realisation is not supported"
+                raise NotImplementedError(msg)
+            ninfo = self.grid_info(state.grid, state.dtype)
+            comp = tuple(np.shape(state.data))[: np.ndim(state.data) - len(ninfo.shape)]
+
+            def add_realization(arr: DeviceArray, prev=None, t: float = 0.0) -> None:
+                host_old = (prev if prev is not None else arr).get_valid(stream=self.stream)
+                noise = realization(host_old, t)
+                if noise is None:
+                    return
+                up = DeviceArray(ninfo, comp).set_valid(np.ascontiguousarray(np.broadcast_to(noise, host_old.shape), dtype=ninfo.dtype), self.stream)
+                self._lib.lincomb(ninfo.ref, int(np.prod(comp)) if comp else 1, arr.ptr, arr.ptr, 1, dt_sqrt, ptr_array([up]), self.stream)
+
+            solver.info["stochastic"] = True
+            return add_realization
+        if not getattr(eq, "use_noise_variance", True):
+            msg = f"Backend `{self.name}`: a stochastic equation without noise variance and without noise realisation"
             raise NotImplementedError(msg)
         if custom_variance:
             return self._make_traced_noise_step(solver, state)

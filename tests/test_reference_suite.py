@@ -43,9 +43,8 @@ SUITES: dict[str, dict[str, str]] = {
     "pdes/test_diffusion_pdes.py": {},
     # (multiplicative noise - `make_noise_variance` overridden by the test's classes - is traced symbolically: geometric Brownian
     # motion against its analytical moments, the equilibrium distribution in the Ito / Stratonovich / ... interpretations)
-    "solvers/test_explicit_solvers.py": {
-        "test_stochastic_solvers_two_interfaces": "noise realisations supplied by user code (SURVEY §8 f3 next)",
-    },
+    # ... noise given as a realisation function (`use_noise_realization`): a host round trip per step (the reference's torch backend refuses it)
+    "solvers/test_explicit_solvers.py": {},
     # backend.make_gaussian_noise: Kolmogorov-Smirnov test of 10^4 samples (tests/backends/generic/test_generic_functions.py)
     "backends/generic/test_generic_functions.py": {},
     # user Python code on the state arrays (custom `make_evolution_rate`, BC setter functions): the arrays live on the device, and

@@ -552,7 +552,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         // a box of the fast block loop (plain rows / columns): 7/8 of a round - the rim, pack, RCCL and unpack kernels of the halo stream
         // otherwise wait for the END of the sweep (0.0536 -> 0.0501 ms per step at 256 x 128 x 512, profiles/r05_probe_block.md)
         const bool boxed = a.per[1] == 2 || a.per[2] == 2;
-        const long cap = t2.blocks ? t2.blocks : (tall ? 1024 : (thin ? 1536 : (boxed ? 1792 : 2048)));   // (the tall tile runs one wave per SIMD)
+        const bool wide1 = sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y;   // (euler2_stage1w_kernel: one wave per SIMD)
+        const long cap = t2.blocks ? t2.blocks : ((tall || wide1) ? 1024 : (thin ? 1536 : (boxed ? 1792 : 2048)));   // (the tall tile runs one wave per SIMD)
         static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
         long nxc;
         if (thin) {
@@ -632,7 +633,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         else if (sizeof(T) == 8) have = ry == 4 || ry == 2;
         else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_);
         else have = ry == 4 || ry == 2 || (ry == 1 && !xs_);
-        if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = false;   // (256 VGPRs + scratch)
+        if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = ry == 2 && !xs_;   // (two waves per SIMD: 256 VGPRs + scratch; ry 2: euler2_stage1w_kernel)
         // a 1-row tile of a 3-D grid is its own neighbour's halo: the tile of row 1 reads the virtual row -1, which only the
         // tile of row 0 transforms (`ylo`) - correct for periodic rows only
         if (has_y && ry == 1 && !a.per[1]) have = false;
@@ -674,6 +675,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
     }
     bool launched = false;
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        if (m2 == E2_CH_STAGE && ry == 2 && has_y && !xs) {   // the wide fp32 stage tile at one wave per SIMD (pdehip_march2.inc)
+            hipLaunchKernelGGL((euler2_stage1w_kernel<T, VEC, 2, true>), grid, block, 0, st, a);
+            launched = true;
+        }
+    }
     if constexpr (sizeof(T) == 8 || VEC == 4) {
         PDEHIP_E2(1, false, true, false, false)
         PDEHIP_E2(2, true, true, false, false)
@@ -725,7 +732,10 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
                 if (narrow > 1.15 * wide) { vec = 2; ry = 4; }
             }
         }
-        if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
+        // PDEHIP_F32_STAGE_WIDE=1: the stage sweeps on the wide 2-row tile at ONE wave per SIMD (16-byte accesses; euler2_stage1w_kernel)
+        static const int stage_wide = getenv("PDEHIP_F32_STAGE_WIDE") ? atoi(getenv("PDEHIP_F32_STAGE_WIDE")) : 0;
+        if (stage && stage_wide && n.ndim == 3 && !plan && !tf.svec) { vec = 4; ry = 2; }
+        else if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
         if (vec == 2) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
         PDEHIP_TRY((launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry)));
         // what the wide tile declines (rows shorter than its chunk that end inside a 4-cell vector, moved last tiles next to

@@ -250,13 +250,18 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         if (n.ndim == 3 && sizeof(T) == 8 && ry == 2 && cz == 4 && wy == 1 && chunks % 4 == 0 && n.n[2] % VEC == 0 && MODE <= LAP_CH_MU &&
             (double)n.n[0] * n.n[1] * n.n[2] * sizeof(T) > 400.0 * 1048576.0) { pf = 2; blocks = 512; }
         if (tn.ry) { ry = tn.ry; cz = tn.cz; wy = tn.wy; pf = tn.pf; blocks = tn.blocks; }
+        // (two planes of prefetch exist for fp64 and the plain epilogues only: the fp32 stage instance would spill 20 bytes to scratch)
+        constexpr bool kHasPf2 = sizeof(T) == 8 && MODE <= LAP_CH_MU;
+        if (!kHasPf2) pf = 1;
+#define PDEHIP_CFG3P2(RY_, CZ_) \
+    if constexpr (kHasPf2) { if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == 1 && pf == 2) return launch_march<T, VEC, RY_, CZ_, 1, 2, MODE, true>(a, y_is_in, blocks, st); }
 #define PDEHIP_CFG3(RY_, CZ_, WY_, PF_) \
     if (n.ndim == 3 && ry == RY_ && cz == CZ_ && wy == WY_ && pf == PF_) return launch_march<T, VEC, RY_, CZ_, WY_, PF_, MODE, true>(a, y_is_in, blocks, st);
 #define PDEHIP_CFG2(RY_, CZ_) \
     if (n.ndim == 2 && ry == RY_ && cz == CZ_) return launch_march<T, VEC, RY_, CZ_, 1, 1, MODE, false>(a, y_is_in, blocks, st);
         PDEHIP_CFG3(2, 4, 1, 1)
-        PDEHIP_CFG3(2, 4, 1, 2)   // (PDEHIP_TUNE only: two planes of prefetch, one wave per SIMD - measured in profiles/r05_lap_prefetch.log)
-        PDEHIP_CFG3(2, 2, 1, 2)
+        PDEHIP_CFG3P2(2, 4)       // two planes of prefetch, one wave per SIMD (profiles/r05_lap_prefetch.log)
+        PDEHIP_CFG3P2(2, 2)
         PDEHIP_CFG3(2, 2, 1, 1)
         PDEHIP_CFG3(2, 1, 1, 1)
         PDEHIP_CFG3(4, 4, 1, 1)
@@ -265,6 +270,7 @@ static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, h
         PDEHIP_CFG2(2, 2)
         PDEHIP_CFG2(2, 1)
 #undef PDEHIP_CFG3
+#undef PDEHIP_CFG3P2
 #undef PDEHIP_CFG2
         PDEHIP_FAIL(E_VALUE, "PDEHIP_TUNE selects a tile shape that is not instantiated (%d,%d,%d,%d)", ry, cz, wy, pf);
     }

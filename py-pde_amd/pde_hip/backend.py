@@ -783,12 +783,12 @@ class HipBackendMixin:
         if info.rank_in != 0 or operator in _NONLINEAR_OPERATORS:
             msg = f"hip backend: operator `{operator}` on complex fields is not supported"
             raise NotImplementedError(msg)
-        if expression_faces(bcs):
-            msg = "hip backend: expression boundary conditions on complex fields are not supported"
-            raise NotImplementedError(msg)
+        from .bc_expr import convert_bcs_with_expressions
+
         real = real_dtype_of(dtype)
         ginfo = self.grid_info(grid, real)
-        tables = {part: convert_bcs(bcs, part=part) for part in ("re", "im")}
+        # (expression conditions: evaluated per part for `args["t"]` before they are applied, like for real fields)
+        tables = {part: convert_bcs_with_expressions(bcs, part=part) if expression_faces(bcs) else convert_bcs(bcs, part=part) for part in ("re", "im")}
         lib, nd = self._lib, len(grid.shape)
 
         def apply_op(arr, out=None, args=None):
@@ -805,6 +805,8 @@ class HipBackendMixin:
             parts = []
             for part, take in (("re", np.real), ("im", np.imag)):
                 native = DeviceArray(ginfo).set_valid(np.ascontiguousarray(take(arr), dtype=real), self.stream)
+                if getattr(tables[part], "time_dependent", False):
+                    tables[part].update(args, state=native, stream=self.stream)
                 lib.set_ghost_cells(ginfo.ref, 1, tables[part].c, native.ptr, self.stream)
                 res = DeviceArray(ginfo, shape_out[: len(shape_out) - nd])
                 op_no_bc(native, res)
@@ -1063,11 +1065,8 @@ class HipBackendMixin:
         from .bc_expr import convert_bcs_with_expressions, expression_faces
 
         if comp in ("re", "im"):
-            bcs = grid.get_boundary_conditions(bc, rank=0)
-            if expression_faces(bcs):
-                msg = "hip backend: expression boundary conditions on complex fields are not supported"
-                raise NotImplementedError(msg)
-            return convert_bcs(bcs, part=comp)
+            # (expression conditions of a complex field: the parts of `A + B * value` with a real `B`, pde_hip/bc_expr.py)
+            return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0), part=comp)
         if comp is None:
             bcs = grid.get_boundary_conditions(bc, rank=0)
             if not hasattr(bcs, "__iter__") and callable(getattr(bcs, "_setter", None)):
@@ -2022,14 +2021,16 @@ class ResidentState:
     @staticmethod
     def attach(field, dev_state: DeviceArray, backend) -> "ResidentState":
         link = field.__dict__.get("_hip_link")
-        if link is not None and link.dev_state is dev_state:
-            return link
-        if link is not None:             # a stepper of an earlier run: settle it first
-            link.pull(field)
         cls = type(field)
         base = getattr(cls, "_hip_base_class", cls)
         if base not in _SYNCED_CLASSES:
             _SYNCED_CLASSES[base] = _make_synced_class(base)
+        if link is not None and link.dev_state is dev_state:
+            if cls is base:              # a host access since the last call put the plain class back (before_host_access)
+                field.__class__ = _SYNCED_CLASSES[base]
+            return link
+        if link is not None:             # a stepper of an earlier run: settle it first
+            link.pull(field)
         link = ResidentState(field, dev_state, backend)
         field.__dict__["_hip_link"] = link
         link._field_ref = field
@@ -2037,9 +2038,17 @@ class ResidentState:
             field.__class__ = _SYNCED_CLASSES[base]
         return link
 
+    def __reduce__(self):
+        # a field that was read after the run is a plain py-pde object again but still carries this link in its `__dict__` (the next
+        # stepper call picks it up): copies and pickles of the field get `None` in its place
+        return (type(None), ())
+
+    def __deepcopy__(self, memo):
+        return None
+
     def _host_valid(self):
         field = self._field_ref
-        base = type(field)._hip_base_class
+        base = getattr(type(field), "_hip_base_class", type(field))
         return base.data.fget(field) if isinstance(getattr(base, "data", None), property) else object.__getattribute__(field, "data")
 
     def push(self) -> None:
@@ -2069,8 +2078,15 @@ class ResidentState:
             self.downloads += 1
 
     def before_host_access(self) -> None:
+        """First access to the data after a stepper call: the host arrays are current from here on and may be written, so nothing
+        needs intercepting until the next stepper call - the field gets its own class back (``type(result) is pde.ScalarField`` once
+        the result has been looked at; `attach` swaps the intercepting subclass in again)."""
         self.pull()
         self.host_touched = True
+        field = self._field_ref
+        base = getattr(type(field), "_hip_base_class", None)
+        if base is not None:
+            object.__dict__["__class__"].__set__(field, base)
 
 
 def _make_synced_class(base: type) -> type:

@@ -47,8 +47,14 @@ class _AffineFace:
     wall coordinates of the WHOLE grid (bit-identical to the undecomposed run; the reference rebuilds the conditions on a
     sub-grid with its own bounds, ``pde/grids/_mesh.py:535-569``), and the value cell is counted from the box's first cell."""
 
-    def __init__(self, bc, window=None):
+    def __init__(self, bc, window=None, part: str | None = None):
+        """``part``: "re" / "im" - the face of the real / imaginary part of a COMPLEX field.  ``F = A + B * value`` with complex ``A``
+        and REAL ``B`` (every value / derivative condition whose expression does not read the field) acts on the parts separately,
+        ``ghost_re = Re A + B * value_re``, ``ghost_im = Im A + B * value_im``; a complex ``B`` or an ``F`` that is not affine in
+        ``value`` couples the parts and is refused."""
         import sympy as sp
+
+        self.part = part
 
         if getattr(bc, "rank", 0) != 0:
             msg = "Expression boundary conditions only work for scalar conditions"
@@ -89,6 +95,23 @@ class _AffineFace:
             offset, slope = expr, sp.Integer(0)
         else:
             offset = expr.subs(value, 0)
+        if part is not None:
+            if self.reads_value:
+                msg = f"hip backend: the boundary expression `{expr}` of a complex field is not affine in `value` (it couples real and imaginary part)"
+                raise NotImplementedError(msg)
+            # dx, the coordinates and t are real: split A and B with sympy (the symbols of the parsed expression carry no assumptions)
+            real = {sym: sp.Symbol(name, real=True) for name, sym in by_name.items()}
+            by_name = {name: real[sym] for name, sym in by_name.items()}
+            value = by_name.get("value", sp.Symbol("value", real=True))
+            a_re, a_im = sp.expand(offset.xreplace(real)).as_real_imag()
+            b_re, b_im = sp.expand(slope.xreplace(real)).as_real_imag()
+            if sp.simplify(b_im) != 0:
+                msg = f"hip backend: the boundary expression `{expr}` multiplies the field value by a complex number (it couples real and imaginary part)"
+                raise NotImplementedError(msg)
+            offset, slope = (a_re if part == "re" else a_im), b_re
+            if (offset.atoms(sp.re, sp.im, sp.arg) | slope.atoms(sp.re, sp.im, sp.arg)):
+                msg = f"hip backend: cannot split the boundary expression `{expr}` into real and imaginary part"
+                raise NotImplementedError(msg)
         args = [by_name.get(n, sp.Symbol(n)) for n in names[1:]]
         self._offset = sp.lambdify([value, *args], offset, modules="numpy")
         self._slope = sp.lambdify(args, slope, modules="numpy")
@@ -142,22 +165,35 @@ class _AffineFace:
         shape = self.face_shape
         probe = [np.full(shape, v, dtype=np.float64) for v in (0.0, 1.0, 2.0)]
 
+        part = getattr(self, "part", None)
+
         def call(func, v):
-            return np.array(np.broadcast_to(np.asarray(func(v, self.dx, *self.coords, t), dtype=np.float64), shape), dtype=np.float64, order="C")
+            res = np.asarray(func(v, self.dx, *self.coords, t))
+            if part is not None:      # complex field: the function is probed with real values; its result splits when the slope is real
+                return np.array(np.broadcast_to(res.astype(np.complex128), shape), order="C")
+            return np.array(np.broadcast_to(np.asarray(res, dtype=np.float64), shape), dtype=np.float64, order="C")
+
+        def take(a, b):
+            if part is None:
+                return a, b
+            if np.any(np.imag(b) != 0):
+                msg = "hip backend: boundary condition function multiplies the field value by a complex number (it couples real and imaginary part)"
+                raise NotImplementedError(msg)
+            return np.ascontiguousarray(np.real(a) if part == "re" else np.imag(a)), np.ascontiguousarray(np.real(b))
 
         with np.errstate(all="ignore"):
             if self._target in ("value", "derivative"):
                 f0, f1 = call(self._value_func, probe[0]), call(self._value_func, probe[1])
                 if np.array_equal(f0, f1, equal_nan=True) and np.array_equal(f0, call(self._value_func, probe[2]), equal_nan=True):
                     # the usual case - a function of position and time only: exactly the reference's `2 f - value` / `dx f + value`
-                    return (2 * f0, np.full(shape, -1.0)) if self._target == "value" else (self.dx * f0, np.full(shape, 1.0))
+                    return take(*((2 * f0, np.full(shape, -1.0)) if self._target == "value" else (self.dx * f0, np.full(shape, 1.0))))
             a = call(self._callable, probe[0])
             b = call(self._callable, probe[1]) - a
             check = call(self._callable, probe[2])
         if not np.allclose(check, a + 2 * b, rtol=1e-12, atol=1e-12, equal_nan=True):
             msg = "hip backend: boundary condition function is not affine in the adjacent value (needs run-time code generation)"
             raise NotImplementedError(msg)
-        return a, b
+        return take(a, b)
 
     def evaluate(self, t: float, value: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
         """``value``: the field in the value cells of the face (only read by conditions that are not affine in it; without it
@@ -376,11 +412,11 @@ def expression_faces(bcs, skip=None) -> dict[tuple[int, bool], Any]:
     return found
 
 
-def lower_expression_face(bc, table, upload, window=None):
+def lower_expression_face(bc, table, upload, window=None, part=None):
     """Write the expression face ``bc`` into ``table`` (a first-order face with coefficient arrays, evaluated for t = 0) - cut
     to the box ``window`` of a decomposed grid -; returns its ``(evaluator, const buffer, factor buffer)`` entry when it has
     to be refreshed later (it depends on time or reads the field), else None."""
-    face = _AffineFace(bc, window)
+    face = _AffineFace(bc, window, part)
     a, b = face.evaluate(0.0)
     buf_a, buf_b = upload(a), upload(b)
     table.keepalive += [buf_a, buf_b]
@@ -392,20 +428,21 @@ def lower_expression_face(bc, table, upload, window=None):
     return (face, buf_a, buf_b) if face.time_dependent else None
 
 
-def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None) -> ExprFaceTable:
-    """``convert_bcs`` that also lowers expression conditions onto coefficient arrays."""
+def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=None, upload=None, part=None) -> ExprFaceTable:
+    """``convert_bcs`` that also lowers expression conditions onto coefficient arrays (``part``: the table of the real / imaginary part
+    of a complex field, see :class:`_AffineFace`)."""
     from .backend import _upload_f64, convert_bcs
 
     if upload is None:
         upload = _upload_f64
     expr_faces = expression_faces(bcs, skip)
-    table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload)
+    table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload, part=part)
     dynamic = []
     for bc in expr_faces.values():
         if comp_shape:
             msg = "Expression boundary conditions only work for scalar conditions"
             raise NotImplementedError(msg)
-        entry = lower_expression_face(bc, table, upload)
+        entry = lower_expression_face(bc, table, upload, part=part)
         if entry is not None:
             dynamic.append(entry)
     return ExprFaceTable(table, dynamic, _write_buffer)

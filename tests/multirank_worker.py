@@ -54,6 +54,10 @@ MORE = {
     "slab_expression_bcs_rk4": ("slab", lambda: pde_hip.DiffusionPDE(0.05, bc=_BC_EXPR), (48, 8, 128), [False, True, False], 0.06, 0.01, "runge-kutta"),
     "block_expression_bcs_rkf45": ("block", lambda: pde_hip.DiffusionPDE(0.05, bc=_BC_EXPR), (32, 16, 128), [False, True, False], 0.1, None, "runge-kutta"),
     "block_cahn_hilliard_euler": ("block", lambda: pde_hip.CahnHilliardPDE(0.9), (32, 16, 128), [True, False, True], 0.005, 1e-3, "euler"),
+    # the fast block loop (two steps per sweep, two-layer halos incl. edges, one message per neighbouring rank); 13 steps: 12 fast + 1
+    "block_diffusion_euler_fast": ("block", lambda: pde_hip.DiffusionPDE(0.8), (32, 16, 128), [True, True, True], 1.3, 0.1, "euler"),
+    "block_diffusion_euler_walls": ("block", lambda: pde_hip.DiffusionPDE(0.6, bc={"x": "periodic", "y": "periodic", "z": {"value": 0.2}}),
+                                         (32, 16, 128), [True, True, False], 0.6, 0.05, "euler"),
     # any expression PDE: compiled passes per rank + ghost exchange per operator operand (slabs and the blocks of the reference's rule)
     "generic_nested_rk4": ("generic:slab", lambda: pde_hip.PDE({"c": "laplace(c**3 - c - 0.8 * laplace(c)) + 0.01 * x"}, bc={"x": {"derivative": 0}, "y": "periodic", "z": {"value": 0.1}}),
                            (32, 8, 128), [False, True, False], 0.004, 1e-3, "runge-kutta"),
@@ -133,6 +137,8 @@ def main() -> int:
         final, info = st.solve(data, t_range, dt, solver)
         st.close()
         report[name] = {"steps": info["steps"], "decomposition": [int(d) for d in getattr(st, "dims", [world])]}
+        if "fast" in name:
+            report[name]["fast_block_loop"] = bool(getattr(st, "block2", False))
         if rank == 0:
             expect, sinfo = eq.solve(state, t_range, dt, solver=solver, ret_info=True)
             if info["steps"] != sinfo["solver"]["steps"]:

@@ -805,9 +805,11 @@ def test_multirank_worker_and_bench_under_torchrun(world):
 
     so = shimlib.build()
     env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "2"}
-    cases = ["diffusion_euler_thin", "cahn_hilliard_rk4", "diffusion_rkf45", "slab_expression_bcs_rk4", "block_expression_bcs_rkf45", "generic_divgrad_rkf45"]
+    cases = ["diffusion_euler_thin", "cahn_hilliard_rk4", "diffusion_rkf45", "slab_expression_bcs_rk4", "block_expression_bcs_rkf45", "generic_divgrad_rkf45",
+             "block_diffusion_euler_fast", "block_diffusion_euler_walls"]
     report = launch_worker(world, env, timeout=900, args=cases)
     assert report["world"] == world and set(report["cases"]) == set(cases)
+    assert report["cases"]["block_diffusion_euler_fast"]["fast_block_loop"] is True
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--size", "32"]

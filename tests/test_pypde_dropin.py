@@ -751,6 +751,7 @@ def test_state_stays_resident_between_tracker_interrupts(hip1):
     ref = eq.solve(state, t_range=1.0, dt=0.05, solver="euler", backend="hip", tracker=None)
     np.testing.assert_array_equal(data, ref.data)
     assert type(res).__name__ == "ScalarField" and isinstance(res, pde.ScalarField)
+    assert type(res) is pde.ScalarField        # (once the result has been read the intercepting subclass is gone)
     assert pde.fields.base.FieldBase._subclasses["ScalarField"] is pde.ScalarField      # py-pde's class registry is untouched
     # derived quantities, copies and pickles behave like on any field
     assert res.average == pytest.approx(ref.data.mean()) and res.copy().__dict__.get("_hip_link") is None

@@ -31,6 +31,10 @@ CASES = [
          consts={"g": [G.real, G.imag]}, bc={"x": "periodic", "y": {"derivative": [0.1, -0.2]}}, t_range=0.05, dt=1e-3),
     dict(id="schroedinger_3d", shape=[12, 10, 64], periodic=[True, False, True], rhs="(0.2 + I) * laplace(p)", var="p",
          bc={"x": "periodic", "y": {"derivative": [0.05, 0.1]}, "z": "periodic"}, t_range=0.04, dt=2e-3),
+    # round 5: conditions given as EXPRESSIONS of time and position with complex values (the factor of `value` is real: the parts decouple)
+    dict(id="gross_pitaevskii_expression_bcs_2d", shape=[8, 6], periodic=[False, True], rhs="I * laplace(p) - 0.1 * p * Abs(p)**2", var="p",
+         bc={"x-": {"value_expression": "I*t + 0.1*y"}, "x+": {"derivative_expression": "(1 + 2*I)*cos(t) - 0.5*value"}, "y": "periodic"},
+         t_range=0.05, dt=1e-3),
 ]
 SOLVERS = [("euler", False), ("runge-kutta", False), ("runge-kutta", True), ("euler", True)]
 
@@ -55,6 +59,9 @@ def main():
             complex_valued = True
 
             def evolution_rate(self, state, t=0, cid=cid, bc=bc):
+                if cid == "gross_pitaevskii_expression_bcs_2d":
+                    c = state.data
+                    return pde.ScalarField(state.grid, 1j * state.laplace(bc, args={"t": t}).data - 0.1 * c * np.abs(c) ** 2)
                 c, lap = state.data, state.laplace(bc).data
                 if cid == "schroedinger_2d":
                     rate = 1j * lap

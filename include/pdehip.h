@@ -612,7 +612,10 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
  * step, p[1] = time of the stage).  work: 5 (RK4: k1..k4, tmp) or 7 (RKF45: k1..k6, tmp) arrays of ncomp components each; y
  * is advanced in place (RK4) or ping-pongs with ynew (adaptive: *result names the array holding the final state).  A single-
  * component expression whose last pass runs on the vectorised kernel takes the stage epilogue of pdehip_jit_apply_stage
- * (stage_fuse != 0); everything else combines with pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine: bit-identical.
+ * (stage_fuse bit 0); everything else combines with pdehip_lincomb / pdehip_rk4_combine / pdehip_rkf45_combine: bit-identical.
+ * stage_fuse bit 1 (adaptive loops only): the components are the planar (re, im) PAIRS of complex fields - the error norm is the
+ * modulus, `np.abs(error).max()` of a complex array (runge_kutta.py:147-148, pde/solvers/euler.py:253): new state and an explicit error
+ * field through pdehip_lincomb, then pdehip_max_abs_pairs; the error field is ONE MORE work array (work[7]; adaptive Euler: work3[3]).
  * bc_program (or NULL): time-dependent faces, refreshed for every stage time. */
 int pdehip_jit_rk_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes, int npasses, void *const *fixed, int nfixed,
                       int ncomp, void *y, void *ynew, void *const *work_host, double *err_dev, double dt, double t0, int64_t nsteps,

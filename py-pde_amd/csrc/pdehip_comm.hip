@@ -156,6 +156,15 @@ int slab_rim2(const pdehip_grid_t *gs, const void *in, void *out, double D, doub
 struct HipOps {
     Comm *c;
     void *halo() { return c->halo; }
+    // layers per side of the thick boundary chunks of slab::euler2_run (PDEHIP_SLAB_THICK; default 0: the thin boundary sweep on the halo
+    // stream - the thick schedule measured SLOWER to self, 0.047-0.048 against 0.043 ms per step at 64 x 512 x 512: the RCCL kernel
+    // starves next to the inner launch and the next boundary chunks wait for it, profiles/r05_probe_block.md)
+    long slab_thick()
+    {
+        const char *e = getenv("PDEHIP_SLAB_THICK");   // (read per run: a test switches it inside one process)
+        const long v = e ? atol(e) : 0;
+        return v < 0 ? 0 : v;
+    }
     int record(int ev, void *st) { PDEHIP_HIP(hipEventRecord(c->ev[ev], as_stream(st))); return 0; }
     int wait(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), c->ev[ev], 0)); return 0; }
     int group_start() { PDEHIP_NCCL(g_rccl.GroupStart()); return 0; }

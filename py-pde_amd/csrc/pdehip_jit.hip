@@ -1045,6 +1045,10 @@ struct JitEval {
     size_t comp_bytes;
     int stage_fuse;     // 1: try the stage epilogue of the last pass, 0: never, -1: refused once (stays off)
     void *bc_program;
+    // complex states as planar (re, im) pairs of components (pde_hip/complex_expr.py): the error norm of the adaptive schemes is the
+    // modulus, `np.abs(error).max()` of a complex array (pde/solvers/runge_kutta.py:147-148, pde/solvers/euler.py:253) - new state and an
+    // explicit error field through the pointwise kernels, then pdehip_max_abs_pairs (the same calls as the host-driven loop)
+    void *efield = nullptr;
 
     int refresh(double t, const void *in, void *st) { return bc_program ? pdehip_bcprog_run(bc_program, t, in, st) : 0; }
     // k_out = dt * F(in; t) and - where the last pass carries it - the combination `sf` in the same sweep (*fused)
@@ -1076,10 +1080,27 @@ struct JitEval {
     }
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *st) { return pdehip_lincomb(g, ncomp, out, y, n, c, k, st); }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *st) { return pdehip_rk4_combine(g, ncomp, y, k1, k2, k3, k4, st); }
-    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st) { return pdehip_rkf45_combine(g, ncomp, y, ynew, k6, err, st); }
+    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st)
+    {
+        if (!efield) return pdehip_rkf45_combine(g, ncomp, y, ynew, k6, err, st);
+        const double c[4] = {25.0 / 216, 1408.0 / 2565, 2197.0 / 4104, -1.0 / 5};                        // runge_kutta.py:150
+        const double r[5] = {1.0 / 360, -128.0 / 4275, -2197.0 / 75240, 1.0 / 50, 2.0 / 55};             // runge_kutta.py:147
+        const void *kc[4] = {k6[0], k6[2], k6[3], k6[4]}, *kr[5] = {k6[0], k6[2], k6[3], k6[4], k6[5]};
+        PDEHIP_TRY(pdehip_lincomb(g, ncomp, ynew, y, 4, c, kc, st));
+        PDEHIP_TRY(pdehip_lincomb(g, ncomp, efield, nullptr, 5, r, kr, st));
+        return pdehip_max_abs_pairs(g, ncomp / 2, efield, err, st);
+    }
     int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *st)
     {
-        return pdehip_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err, st);
+        if (!efield) return pdehip_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err, st);
+        const double one = 1.0, minus = -1.0;
+        const void *kk[1] = {k};
+        PDEHIP_TRY(pdehip_lincomb(g, ncomp, out, half, 1, &one, kk, st));         // step_small += 0.5 * dt * rate_midpoint
+        kk[0] = rate;
+        PDEHIP_TRY(pdehip_lincomb(g, ncomp, efield, y, 1, &dt, kk, st));          // step_large
+        kk[0] = out;
+        PDEHIP_TRY(pdehip_lincomb(g, ncomp, efield, efield, 1, &minus, kk, st));  // step_large - step_small
+        return pdehip_max_abs_pairs(g, ncomp / 2, efield, err, st);
     }
     int zero(void *ptr, size_t bytes, void *st) { PDEHIP_HIP(hipMemsetAsync(ptr, 0, bytes, as_stream(st))); return 0; }
     // decomposed grids: MAX over the ranks of the communicator the passes exchange through (NaN wins); nothing on one device
@@ -1118,7 +1139,12 @@ static int jit_loop_run(const char *who, int scheme, const pdehip_grid_t *g, con
                 PDEHIP_FAIL(E_VALUE, "jit_rk_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
         }
     }
-    JitEval ev{g, passes, npasses, fixed, ncomp, (size_t)n.pc * elem_size(n.dtype), stage_fuse ? 1 : 0, bc_program};
+    JitEval ev{g, passes, npasses, fixed, ncomp, (size_t)n.pc * elem_size(n.dtype), (stage_fuse & 1) ? 1 : 0, bc_program};
+    if (stage_fuse & 2) {   // complex pairs: one more work array, the error field (RKF45: work[7], adaptive Euler: work[3])
+        if (ncomp % 2 || !ctl) PDEHIP_FAIL(E_VALUE, "%s: complex pairs need an even number of components and the adaptive loop", who);
+        ev.efield = work_host[scheme == 1 ? 3 : 7];
+        if (!ev.efield) PDEHIP_FAIL(E_VALUE, "%s: complex pairs need the error field as one more work array", who);
+    }
     if (scheme == 1) return rk::euler_adaptive_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     for (int64_t s = 0; s < nsteps; s++) PDEHIP_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));

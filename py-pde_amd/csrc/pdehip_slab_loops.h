@@ -221,6 +221,43 @@ int euler2_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_
     SLAB_TRY(exchange2(ops, q, cur, lower, upper, halo));
     int64_t s = 0;
     int pair = 0;
+    // Round 5 (PDEHIP_SLAB_THICK=<layers>, off by default: measured slower): THICK boundary chunks on the compute stream.  The thin boundary sweep below (2 + 2 layers on the halo
+    // stream) starves next to the interior sweep - workgroups of a full-occupancy sweep hold their registers for the whole sweep - and
+    // ends ~12 us after it; the next interior sweep waits for it (profiles/r05_probe_block.md).  Here the sweep itself is cut in two
+    // launches on ONE stream: the first and the last `thick` layers (they need the received halos; as chunks of the ordinary march they
+    // cost what they cost inside the whole sweep), then the layers in between while the halo stream sends / receives the new boundary
+    // layers.  The critical path of a pair was meant to be the sweep, with the whole inner launch for the exchange to hide in.  Measured
+    // (profiles/r05_probe_block.md): the RCCL kernel, dispatched next to the inner launch, takes 46 us instead of 12 and ends after it, the
+    // next boundary chunks follow a stream hand-over later - 99 us per pair against 86 with the thin sweep below.
+    long thick = ops.slab_thick();
+    if (thick > (q.nloc - 4) / 2) thick = (q.nloc - 4) / 2;
+    if (thick >= 2 && (lower >= 0 || upper >= 0)) {
+        // (both launches must be ones the two-step kernel takes: asked with a dry run, else the schedule below)
+        auto covered = [&](long first, long count, int ends) -> bool {
+            pdehip_grid_t gs = *g;
+            gs.shape[0] = count;
+            bool done = false;
+            return ops.euler2(&gs, layer(cur, q, first - 1), layer(nxt, q, first - 1), rhs->param, dt, faces, comp, &done, ends ? xe : 1, true, ends) == 0 && done;
+        };
+        if (!covered(2, q.nloc, (int)thick) || !covered(2 + thick, q.nloc - 2 * thick, 0)) thick = 0;
+    }
+    if (thick >= 2 && (lower >= 0 || upper >= 0)) {
+        SLAB_TRY(ops.record(EV_HALO, halo));
+        for (; s + 2 <= nsteps; s += 2, pair++) {
+            SLAB_TRY(ops.wait(comp, EV_HALO));                 // halos of `cur` (exchange of the previous pair)
+            SLAB_TRY(sweep2(comp, 2, q.nloc, (int)thick));     // own layers 2 .. thick+1 and nloc+2-thick .. nloc+1
+            SLAB_TRY(ops.record(EV_BND, comp));
+            if (s + 2 < nsteps) {
+                SLAB_TRY(ops.wait(halo, EV_BND));
+                SLAB_TRY(exchange2(ops, q, nxt, lower, upper, halo));   // overlaps the inner launch
+                SLAB_TRY(ops.record(EV_HALO, halo));
+            }
+            SLAB_TRY(sweep2(comp, 2 + thick, q.nloc - 2 * thick, 0));
+            char *t = cur; cur = nxt; nxt = t;
+        }
+        SLAB_TRY(ops.record(EV_COMP, comp));
+        SLAB_TRY(ops.wait(halo, EV_COMP));
+    }
     for (; s + 2 <= nsteps; s += 2, pair++) {
         // The boundary sweep and the exchange are ENQUEUED FIRST, on the (high-priority) halo stream: their few workgroups are
         // dispatched before the interior sweep fills the chip with workgroups that live for the whole sweep - enqueued behind it

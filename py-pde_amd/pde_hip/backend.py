@@ -1059,14 +1059,18 @@ class HipBackendMixin:
     def _expression_info(self, grid, dtype):
         return self.grid_info(grid, dtype)
 
-    def _expression_faces(self, grid, bc, comp):
+    def _expression_faces(self, grid, bc, comp, part=None):
         """Face table of one operator: scalar conditions (``comp`` None), or those of component ``comp`` (k / (i, j)) of a vector /
-        tensor operand; ``comp`` "re" / "im": the conditions of the real / imaginary part of a complex scalar field."""
+        tensor operand; ``part`` "re" / "im": the conditions of the real / imaginary part of a complex operand."""
         from .bc_expr import convert_bcs_with_expressions, expression_faces
 
-        if comp in ("re", "im"):
+        if part is not None and comp is None:
             # (expression conditions of a complex field: the parts of `A + B * value` with a real `B`, pde_hip/bc_expr.py)
-            return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0), part=comp)
+            return convert_bcs_with_expressions(grid.get_boundary_conditions(bc, rank=0), part=part)
+        if part is not None:
+            # one component of the complex vector a vector operator is applied to (`divergence(... gradient(c))` of a complex field)
+            rank = 2 if isinstance(comp, tuple) else 1
+            return convert_bcs(grid.get_boundary_conditions(bc, rank=rank), (grid.num_axes,) * rank, component=comp, part=part)
         if comp is None:
             bcs = grid.get_boundary_conditions(bc, rank=0)
             if not hasattr(bcs, "__iter__") and callable(getattr(bcs, "_setter", None)):
@@ -1153,34 +1157,32 @@ class HipBackendMixin:
             for op in plan.operators_used:
                 # components of the vector operators take the conditions of `gradient` (scalar argument) resp. of component k
                 # of the vector that `divergence` is applied to (rank-1 conditions)
-                base, comp = op, None
-                if op in getattr(plan, "vector_ops", {}):
-                    idx = [int(x) for x in op.split("_")[1:]]
-                    base, comp = {"grad": ("gradient", None), "div": ("divergence", idx[0]), "vlap": ("vector_laplace", idx[0]),
-                                  "vgrad": ("vector_gradient", idx[0]), "tdiv": ("tensor_divergence", tuple(idx))}[op.split("_")[0]]
+                base, comp, op_part = op, None, None
                 if part is not None:
                     # complex fields: the operand of `<op>_imop` is the imaginary part of the operator's complex argument (complex_expr.py)
                     from .complex_expr import IM_OPERAND
 
-                    if comp is not None:
-                        msg = f"hip backend: operator `{base}` on complex fields inside an expression is not supported"
-                        raise NotImplementedError(msg)
-                    comp = "im" if op.endswith(IM_OPERAND) else "re"
+                    op_part = "im" if op.endswith(IM_OPERAND) else "re"
                     base = base[: -len(IM_OPERAND)] if base.endswith(IM_OPERAND) else base
                     if base.startswith("gradient_squared_d"):   # the central differences inside gradient_squared of a complex argument
                         base = "gradient_squared"
+                if op in getattr(plan, "vector_ops", {}):
+                    idx = [int(x) for x in base.split("_")[1:]]
+                    base, comp = {"grad": ("gradient", None), "div": ("divergence", idx[0]), "vlap": ("vector_laplace", idx[0]),
+                                  "vgrad": ("vector_gradient", idx[0]), "tdiv": ("tensor_divergence", tuple(idx))}[base.split("_")[0]]
                 bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
-                for other, other_comp, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
+                key = (comp, op_part)
+                for other, other_key, table in specs:   # equal conditions share one table object (ExpressionRhs compares identities)
                     try:
-                        same = other_comp == comp and (other is bc or bool(other == bc))
+                        same = other_key == key and (other is bc or bool(other == bc))
                     except (ValueError, TypeError):   # array-valued entries do not compare to a bool
                         same = False
                     if same:
                         tables[op] = table
                         break
                 else:
-                    tables[op] = self._expression_faces(grid, bc, comp)
-                    specs.append((bc, comp, tables[op]))
+                    tables[op] = self._expression_faces(grid, bc, comp, op_part)
+                    specs.append((bc, key, tables[op]))
             return tables
 
         # further arrays an expression may name: array-valued constants (fields or arrays on the grid, pde/pdes/pde.py:170-185)
@@ -1396,7 +1398,7 @@ class HipBackendMixin:
         ctl = None
         # (decomposed grids: the C loops reduce the error over the ranks themselves when the passes carry their exchange descriptor)
         reduces_in_c = reduce_error is None or bool(getattr(erhs, "reduces_error_in_loops", False))
-        if post_step is None and hasattr(erhs, "rk_run") and reduces_in_c and not is_complex and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
+        if post_step is None and hasattr(erhs, "rk_run") and reduces_in_c and os.environ.get("PDEHIP_EXPR_LOOP") != "0":
             # the adaptive loop itself in C (pdehip_jit_rk_run: pde/backends/numba/_solvers.py:199-319 is jitted in the reference)
             from .solvers import AdaptiveStatistics
 
@@ -1410,9 +1412,10 @@ class HipBackendMixin:
                 before = int(ctl.steps)
                 try:
                     if is_rk:
-                        res = erhs.rk_run(state_data, ynew0, work[:7], err_dev, 0.0, 0.0, 0, ctl)
+                        # (complex states: one more array, the error field of the modulus norm - round 5)
+                        res = erhs.rk_run(state_data, ynew0, work[:7] + ([work[-1]] if is_complex else []), err_dev, 0.0, 0.0, 0, ctl)
                     else:   # the reference's adaptive Euler loop in one C call (pdehip_jit_euler_adaptive_run)
-                        res = erhs.rk_run(state_data, ynew0, work[:3], err_dev, 0.0, 0.0, 0, ctl, euler_adaptive=True)
+                        res = erhs.rk_run(state_data, ynew0, work[:3] + ([work[-1]] if is_complex else []), err_dev, 0.0, 0.0, 0, ctl, euler_adaptive=True)
                 finally:
                     solver.info["steps"] += int(ctl.steps) - before
                     solver.info["attempts"] = int(ctl.attempts)

@@ -7,7 +7,11 @@ REAL coefficients, so a complex field ``u = a + i b`` is carried on the device a
 components of a vector field - and an equation ``du/dt = F(u)`` becomes the real system ``da/dt = Re F``, ``db/dt = Im F``:
 
 * linear operators act on the parts separately, ``laplace(a + i b) = laplace(a) + i laplace(b)`` (the same for ``d_dx``, ``d2_dx2`` ...);
-  ``gradient_squared(w) = sum (d w)^2`` gives ``gs(a) - gs(b) + 2 i sum d(a) d(b)``; the vector operators are not built;
+  ``gradient_squared(w) = sum (d w)^2`` gives ``gs(a) - gs(b) + 2 i sum d(a) d(b)``;
+* the vector operators (round 5) are lowered to their per-axis atoms first (:func:`lower_vector_operators`: ``gradient(w)`` ->
+  ``[grad_k(w)]``, ``divergence(v)`` -> ``sum div_k(v_k)``, ``vector_laplace(v)`` -> ``[vlap_k(v_k)]``, ``dot(v, w)`` ->
+  ``sum v_k conjugate(w_k)`` like ``make_dot_operator`` of the reference, pde/fields/datafield_base.py:965-986), which are linear with
+  real coefficients again;
 * everything pointwise (``I``, products, integer powers, ``conjugate``, ``Abs``, ``re``, ``im``, ``exp``) is split by sympy's
   ``as_real_imag`` after the operator applications have been replaced by real place-holders.
 
@@ -26,6 +30,63 @@ IM_OPERAND = "_imop"     # suffix of an operator name whose operand is the IMAGI
 def part_names(var: str) -> tuple[str, str]:
     """Names of the real and the imaginary part of ``var`` inside the real system."""
     return f"{var}_re_", f"{var}_im_"
+
+
+def lower_vector_operators(e, nd: int):
+    """Vector-valued sub-expressions of a COMPLEX expression component by component (the twin of ``ExpressionPlan._lower_vectors`` for
+    scalar complex fields: there are no vector fields in a complex state, vectors only arise from ``gradient``): returns ``("s", expr)``
+    or ``("v", [components])`` with the atoms ``grad_<k>`` / ``div_<k>`` / ``vlap_<k>`` (one scalar argument each)."""
+    import sympy as sp
+
+    def fn(name):
+        return sp.Function(name)
+
+    if isinstance(e, sp.core.function.AppliedUndef):
+        name = e.func.__name__
+        args = [lower_vector_operators(a, nd) for a in e.args]
+        if name == "gradient":
+            if len(args) != 1 or args[0][0] != "s":
+                msg = "hip backend: `gradient` inside expressions takes one scalar argument"
+                raise NotImplementedError(msg)
+            return "v", [fn(f"grad_{k}")(args[0][1]) for k in range(nd)]
+        if name == "divergence":
+            if len(args) != 1 or args[0][0] != "v":
+                msg = "`divergence` needs a vector argument"
+                raise ValueError(msg)
+            return "s", sp.Add(*[fn(f"div_{k}")(c) for k, c in enumerate(args[0][1])])
+        if name == "vector_laplace":
+            if len(args) != 1 or args[0][0] != "v":
+                msg = "`vector_laplace` needs a vector argument"
+                raise ValueError(msg)
+            return "v", [fn(f"vlap_{k}")(c) for k, c in enumerate(args[0][1])]
+        if name in ("dot", "inner"):
+            if len(args) != 2 or args[0][0] != "v" or args[1][0] != "v":
+                msg = "hip backend: `dot` inside complex-valued expressions takes two vectors"
+                raise NotImplementedError(msg)
+            return "s", sp.Add(*[x * sp.conjugate(y) for x, y in zip(args[0][1], args[1][1])])
+        if name in ("vector_gradient", "tensor_divergence", "outer"):
+            msg = f"hip backend: operator `{name}` inside complex-valued expressions is not supported"
+            raise NotImplementedError(msg)
+        if any(k != "s" for k, _ in args):
+            msg = f"hip backend: operator `{name}` of a vector inside expressions is not supported"
+            raise NotImplementedError(msg)
+        return "s", e.func(*[a for _, a in args])
+    if not e.args:
+        return "s", e
+    parts = [lower_vector_operators(a, nd) for a in e.args]
+    if all(k == "s" for k, _ in parts):
+        return "s", e.func(*[a for _, a in parts])
+    if e.is_Add:
+        if any(k != "v" for k, _ in parts):
+            msg = "cannot add fields of different rank"
+            raise ValueError(msg)
+        return "v", [sp.Add(*[p[1][k] for p in parts]) for k in range(nd)]
+    if e.is_Mul and sum(k != "s" for k, _ in parts) == 1:
+        val = next(p[1] for p in parts if p[0] != "s")
+        scal = sp.Mul(*[p[1] for p in parts if p[0] == "s"])
+        return "v", [scal * c for c in val]
+    msg = f"hip backend: vector expression `{e}` is not supported (sums, scalar multiples, dot, divergence)"
+    raise NotImplementedError(msg)
 
 
 def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any], axes: tuple[str, ...], aliases: dict[str, str] | None = None,
@@ -76,6 +137,14 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
     for name in ("laplace", "gradient_squared", *linear_axis_ops, *aliases):
         local.setdefault(name, sp.Function(name))
     expr = sp.sympify(expr_str, locals=local)
+    nd = len(axes)
+    vector_atoms = {f"{kind}_{k}" for kind in ("grad", "div", "vlap") for k in range(nd)}
+    if any(f.func.__name__ in ("gradient", "divergence", "vector_laplace", "dot", "inner", "vector_gradient", "tensor_divergence", "outer")
+           for f in expr.atoms(sp.core.function.AppliedUndef)):
+        kind, expr = lower_vector_operators(expr, nd)
+        if kind != "s":
+            msg = f"hip backend: the right-hand side `{expr_str}` is a vector, the field is a scalar"
+            raise NotImplementedError(msg)
     parts = {fields[v]: tuple(sp.Symbol(n, real=True) for n in part_names(v)) for v in variables}
     holders: dict[Any, Any] = {}
     new_aliases: dict[str, str] = dict(aliases)
@@ -100,9 +169,9 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
                 raise NotImplementedError(msg)
             ar, ai = split(call.args[0].xreplace(sub))
             fn = call.func
-            if base == "laplace" or base in linear_axis_ops:
-                # linear with real coefficients (the Laplacian, d_dx, d2_dx2 ...): acts on the parts separately; the imaginary operand takes
-                # the imaginary parts of the operator's boundary values
+            if base == "laplace" or base in linear_axis_ops or base in vector_atoms:
+                # linear with real coefficients (the Laplacian, d_dx, d2_dx2 ..., the per-axis atoms of the vector operators): acts on the
+                # parts separately; the imaginary operand takes the imaginary parts of the operator's boundary values
                 re_part = hold(fn(ar)) if ar != 0 else sp.Integer(0)
                 im_part = sp.Integer(0)
                 if ai != 0:

@@ -728,7 +728,10 @@ class DecomposedExpressionStepper:
     def _expression_info(self, grid, dtype):
         return self.info
 
-    def _expression_faces(self, grid, bc, comp):
+    def _expression_faces(self, grid, bc, comp, part=None):
+        if part is not None:
+            msg = "hip backend: complex fields on decomposed grids are not supported"
+            raise NotImplementedError(msg)
         rank = 0 if comp is None else (2 if isinstance(comp, tuple) else 1)
         bcs = grid.get_boundary_conditions(bc, rank=rank)
         kw = {} if comp is None else {"comp_shape": (grid.num_axes,) * rank, "component": comp}

@@ -104,13 +104,6 @@ class ExpressionPlan:
             self.axis_ops[f"d_d{ax}"] = ("d1", 3 - len(axes) + k)
             self.axis_ops[f"d2_d{ax}2"] = ("d2", 3 - len(axes) + k)
         self.aliases = dict(aliases or {})
-        for alias, base in list(self.aliases.items()):
-            if base in self.axis_ops:      # another name of a per-axis derivative (its own conditions: complex_expr.py)
-                self.axis_ops[alias] = self.axis_ops[base]
-                del self.aliases[alias]
-            elif base not in OPERATORS:
-                msg = f"operator alias `{alias}` must stand for one of {OPERATORS} or a per-axis derivative"
-                raise ValueError(msg)
         # components of the vector operators `gradient` / `divergence` (central), lowered to per-axis atoms by `_lower_vectors`
         nd = len(axes)
         self.vector_ops = {}
@@ -124,6 +117,20 @@ class ExpressionPlan:
                 # tensor_divergence(T)[k] = sum_j d_j T[k][j] with component (k, j) of the rank-2 conditions (cartesian.py:999-1096)
                 self.vector_ops[f"vgrad_{k}_{j}"] = ("gr", 3 - nd + j)
                 self.vector_ops[f"tdiv_{k}_{j}"] = ("gr", 3 - nd + j)
+        for alias, base in list(self.aliases.items()):
+            if base in self.vector_ops and alias not in self.vector_ops:
+                # another name of a per-axis atom of a vector operator (`grad_0_imop`: the imaginary operand, complex_expr.py)
+                self.vector_ops[alias] = self.vector_ops[base]
+                if self.vector_ops[base][0] == "lap":
+                    self.aliases[alias] = "laplace"
+                else:
+                    del self.aliases[alias]
+            elif base in self.axis_ops:    # another name of a per-axis derivative (its own conditions: complex_expr.py)
+                self.axis_ops[alias] = self.axis_ops[base]
+                del self.aliases[alias]
+            elif base not in OPERATORS:
+                msg = f"operator alias `{alias}` must stand for one of {OPERATORS} or a per-axis derivative"
+                raise ValueError(msg)
         self.axis_ops.update({k: v for k, v in self.vector_ops.items() if v[0] != "lap"})
         self._ops = {name: sp.Function(name) for name in (*OPERATORS, *self.axis_ops, *self.aliases)}
         # `integral(f)`: the integral of a (pointwise) expression over the grid, a number (pde/pdes/pde.py:355-373 takes the
@@ -508,11 +515,11 @@ def _run_rk(lib, info, loop, ncomp: int, y, ynew, work, err, dt: float, t0: floa
     result = C.c_void_p()
     if euler_adaptive:
         lib.jit_euler_adaptive_run(info.ref, passes, len(passes), fixed, nfixed, ncomp, y.ptr, ynew.ptr, ptr_array(work), err.ptr, C.byref(ctl),
-                                   int(bool(stage_fuse)), None if program is None else program.ptr, C.byref(result), stream)
+                                   int(stage_fuse), None if program is None else program.ptr, C.byref(result), stream)
         return y if result.value == y.ptr else ynew
     lib.jit_rk_run(info.ref, passes, len(passes), fixed, nfixed, ncomp, y.ptr, None if ynew is None else ynew.ptr, ptr_array(work),
                    None if err is None else err.ptr, float(dt), float(t0), int(nsteps), None if ctl is None else C.byref(ctl),
-                   int(bool(stage_fuse)), None if program is None else program.ptr, C.byref(result), stream)
+                   int(stage_fuse), None if program is None else program.ptr, C.byref(result), stream)
     return y if result.value == y.ptr else ynew
 
 
@@ -909,5 +916,8 @@ class SystemRhs:
         if not all(p.loop_ok() for p in self.parts):
             return None
         part0 = self.parts[0]
-        return _run_rk(part0.lib, self.info, self._loop_desc("scaled"), self.ncomp, y, ynew, work, err, dt, t0, nsteps, ctl, False,
+        # (stage_fuse bit 1: the components are the (re, im) pairs of complex fields - modulus error norm from an explicit error field,
+        # the last array of `work`)
+        pairs = 2 if (ctl is not None and getattr(self, "complex_pairs", False)) else 0
+        return _run_rk(part0.lib, self.info, self._loop_desc("scaled"), self.ncomp, y, ynew, work, err, dt, t0, nsteps, ctl, pairs,
                        part0.backend.stream, self.bc_program(), euler_adaptive)

@@ -35,6 +35,10 @@ CASES = [
     dict(id="gross_pitaevskii_expression_bcs_2d", shape=[8, 6], periodic=[False, True], rhs="I * laplace(p) - 0.1 * p * Abs(p)**2", var="p",
          bc={"x-": {"value_expression": "I*t + 0.1*y"}, "x+": {"derivative_expression": "(1 + 2*I)*cos(t) - 0.5*value"}, "y": "periodic"},
          t_range=0.05, dt=1e-3),
+    # round 5: vector operators of complex arguments (`dot` conjugates its second operand, pde/fields/datafield_base.py:965-986)
+    dict(id="divgrad_dot_2d", shape=[8, 6], periodic=[True, False], var="c",
+         rhs="I * divergence((1 + 0.5*I) * gradient(c)) + 0.1 * dot(gradient(c), gradient(c)) - 0.1 * c",
+         bc={"x": "periodic", "y": {"value": [0.3, -0.2]}}, t_range=0.02, dt=1e-3),
 ]
 SOLVERS = [("euler", False), ("runge-kutta", False), ("runge-kutta", True), ("euler", True)]
 
@@ -62,6 +66,11 @@ def main():
                 if cid == "gross_pitaevskii_expression_bcs_2d":
                     c = state.data
                     return pde.ScalarField(state.grid, 1j * state.laplace(bc, args={"t": t}).data - 0.1 * c * np.abs(c) ** 2)
+                if cid == "divgrad_dot_2d":
+                    grad = state.gradient(bc)
+                    div = ((1 + 0.5j) * grad).divergence(bc)
+                    dot = np.einsum("i...,i...->...", grad.data, grad.data.conjugate())
+                    return pde.ScalarField(state.grid, 1j * div.data + 0.1 * dot - 0.1 * state.data)
                 c, lap = state.data, state.laplace(bc).data
                 if cid == "schroedinger_2d":
                     rate = 1j * lap

@@ -150,6 +150,7 @@ size_t full_bytes(const pdehip_grid_t *g)
 
 struct HostOps {
     Comm *c;
+    long slab_thick() { const char *e = getenv("PDEHIP_SLAB_THICK"); const long v = e ? atol(e) : 0; return v < 0 ? 0 : v; }
     void *halo() { return (void *)1; }
     int record(int, void *) { return 0; }
     int wait(void *, int) { return 0; }
@@ -672,11 +673,28 @@ struct JitEval {
     }
     int lincomb(void *out, const void *y, int n, const double *c, const void *const *k, void *) { OTRY(oracle_lincomb(g, ncomp, out, y, n, c, k)); return 0; }
     int rk4_combine(void *y, const void *k1, const void *k2, const void *k3, const void *k4, void *) { OTRY(oracle_rk4_combine(g, ncomp, y, k1, k2, k3, k4)); return 0; }
-    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *) { OTRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6, err)); return 0; }
-    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *)
+    void *efield = nullptr;   // complex pairs (stage_fuse bit 1): the error field; modulus norm through the pointwise entry points
+    int rkf45_combine(const void *y, void *ynew, const void *const *k6, double *err, void *st)
     {
-        OTRY(oracle_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err));
-        return 0;
+        if (!efield) { OTRY(oracle_rkf45_combine(g, ncomp, y, ynew, k6, err)); return 0; }
+        const double c[4] = {25.0 / 216, 1408.0 / 2565, 2197.0 / 4104, -1.0 / 5};
+        const double r[5] = {1.0 / 360, -128.0 / 4275, -2197.0 / 75240, 1.0 / 50, 2.0 / 55};
+        const void *kc[4] = {k6[0], k6[2], k6[3], k6[4]}, *kr[5] = {k6[0], k6[2], k6[3], k6[4], k6[5]};
+        if (int rc = pdehip_lincomb(g, ncomp, ynew, y, 4, c, kc, st)) return rc;
+        if (int rc = pdehip_lincomb(g, ncomp, efield, nullptr, 5, r, kr, st)) return rc;
+        return pdehip_max_abs_pairs(g, ncomp / 2, efield, err, st);
+    }
+    int euler_adaptive_combine(const void *y, const void *rate, double dt, const void *half, const void *k, void *out, double *err, void *st)
+    {
+        if (!efield) { OTRY(oracle_euler_adaptive_combine(g, ncomp, y, rate, dt, half, k, out, err)); return 0; }
+        const double one = 1.0, minus = -1.0;
+        const void *kk[1] = {k};
+        if (int rc = pdehip_lincomb(g, ncomp, out, half, 1, &one, kk, st)) return rc;
+        kk[0] = rate;
+        if (int rc = pdehip_lincomb(g, ncomp, efield, y, 1, &dt, kk, st)) return rc;
+        kk[0] = out;
+        if (int rc = pdehip_lincomb(g, ncomp, efield, efield, 1, &minus, kk, st)) return rc;
+        return pdehip_max_abs_pairs(g, ncomp / 2, efield, err, st);
     }
     int zero(void *p, size_t bytes, void *) { memset(p, 0, bytes); return 0; }
     int reduce_error(double *err_dev, void *st)
@@ -719,7 +737,12 @@ static int jit_loop_run(int scheme, const pdehip_grid_t *g, const pdehip_jit_pas
                 return failf(E_VALUE, "jit_rk_run: pass %d refers to array %d (fixed: %d, components: %d)", q, (int)idx[m], nfixed, ncomp);
         }
     }
-    JitEval ev{g, passes, npasses, fixed, ncomp, full_bytes(g), stage_fuse ? 1 : 0, bc_program};
+    JitEval ev{g, passes, npasses, fixed, ncomp, full_bytes(g), (stage_fuse & 1) ? 1 : 0, bc_program};
+    if (stage_fuse & 2) {
+        if (ncomp % 2 || !ctl) return failf(E_VALUE, "jit_rk_run: complex pairs need an even number of components and the adaptive loop");
+        ev.efield = work_host[scheme == 1 ? 3 : 7];
+        if (!ev.efield) return failf(E_VALUE, "jit_rk_run: complex pairs need the error field as one more work array");
+    }
     if (scheme == 1) return rk::euler_adaptive_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     if (ctl) return rk::rkf45_run(ev, y, ynew, work_host, err_dev, ctl, result, stream);
     for (int64_t s = 0; s < nsteps; s++) SLAB_TRY(rk::rk4_step(ev, y, work_host, dt, t0 + (double)s * dt, stream));

@@ -152,6 +152,26 @@ def _serial_reference(eq, grid, data, t_range, dt, solver):
     return oracle_solve(case, grid, np.float64, data)
 
 
+def test_two_step_slab_loop_with_thick_boundary_chunks(monkeypatch):
+    """PDEHIP_SLAB_THICK=<layers> (round 5; off by default): the schedule that cuts the two-step sweep of a slab into its
+    first / last layers and the layers in between on ONE stream, with the exchange next to the second launch - two ranks, bit-exact."""
+    monkeypatch.setenv("PDEHIP_SLAB_THICK", "3")
+    results = run_distributed("solve_all_cases", 2, True)
+    checked = 0
+    for name, (mk_eq, mk_grid, t_range, dt, solver) in CASES.items():
+        if not name.startswith("diff3d_thick"):
+            continue
+        eq, grid = mk_eq(), mk_grid()
+        data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)
+        expect, steps, _ = _serial_reference(eq, grid, data, t_range, dt, solver)
+        for rank in range(2):
+            final, nsteps, _, _, two = results[rank][name]
+            assert two and nsteps == steps
+            np.testing.assert_array_equal(final, expect, err_msg=f"{name} rank {rank}")
+            checked += 1
+    assert checked == 4
+
+
 CASES = {
     "diff3d_periodic": (lambda: pde_hip.DiffusionPDE(0.8), lambda: pde_hip.UnitGrid([12, 6, 8], periodic=True), 2.0, 0.1, "euler"),
     "diff2d_dirichlet": (lambda: pde_hip.DiffusionPDE(1.0, bc={"x-": {"value": 1.0}, "x+": {"derivative": 0.5}, "y": "periodic"}),

@@ -96,6 +96,20 @@ def test_axis_derivatives_and_gradient_squared_of_a_complex_field(rng):
     assert max_rel(got, c) < 1e-12
 
 
+def test_vector_operators_of_a_complex_field(rng):
+    """Round 5: `divergence` / `gradient` / `dot` of c = a + i b inside an expression against the real system written out by hand -
+    -I div grad c = div grad b - I div grad a; dot(grad c, grad c) = sum |d_k c|^2 (the second operand is conjugated) - to rounding."""
+    grid = pde_hip.CartesianGrid([[0, 6], [0, 5], [0, 4]], [12, 10, 136], periodic=True)
+    a, b = rng.uniform(-1, 1, grid.shape), rng.uniform(-1, 1, grid.shape)
+    eq_c = pde_hip.PDE({"c": "-I * divergence(gradient(c)) + 0.1 * dot(gradient(c), gradient(c))"})
+    eq_r = pde_hip.PDE({"a": "divergence(gradient(b)) + 0.1 * (dot(gradient(a), gradient(a)) + dot(gradient(b), gradient(b)))", "b": "-divergence(gradient(a))"})
+    res_c = eq_c.solve(pde_hip.ScalarField(grid, a + 1j * b), t_range=0.01, dt=1e-3, solver="runge-kutta", backend="hip")
+    res_r = eq_r.solve(pde_hip.FieldCollection([pde_hip.ScalarField(grid, a), pde_hip.ScalarField(grid, b)]), t_range=0.01, dt=1e-3, solver="runge-kutta", backend="hip")
+    got = np.array(res_c.data)
+    assert max_rel(got.real, np.array(res_r.data)[0]) < 1e-13 and max_rel(got.imag, np.array(res_r.data)[1]) < 1e-13
+    assert np.abs(got - (a + 1j * b)).max() > 1e-3
+
+
 def test_a_real_state_turns_complex_and_complex64_stays_single(rng):
     grid = pde_hip.UnitGrid([16, 64], periodic=True)
     eq = pde_hip.PDE({"p": "I * laplace(p)"})

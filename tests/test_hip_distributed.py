@@ -78,6 +78,24 @@ def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
     np.testing.assert_array_equal(final2, final)
 
 
+@pytest.mark.parametrize("thick", [2, 5, 8])
+def test_two_steps_per_sweep_slab_loop_with_thick_boundary_chunks(monkeypatch, thick):
+    """PDEHIP_SLAB_THICK (round 5; off by default - measured slower to self, profiles/r05_probe_block.md): the first and
+    the last `thick` layers as chunks of the ordinary sweep on the compute stream, the layers in between while the halo stream exchanges."""
+    from pde_hip.distributed import SlabStepper
+
+    monkeypatch.setenv("PDEHIP_SLAB_THICK", str(thick))
+    grid = pde_hip.UnitGrid((24, 8, 128), periodic=[True, False, True])
+    data = np.random.default_rng(6).uniform(-1, 1, grid.shape)
+    eq = pde_hip.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 0.2}, "z": "periodic"})
+    for steps in (2, 7, 12):
+        st = SlabStepper(eq, grid, force_exchange=True)
+        assert st._euler2
+        final, info = st.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
+        st.close()
+        np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps))
+
+
 @pytest.mark.parametrize("solver,steps", [("euler", 5), ("runge-kutta", 3)])
 @pytest.mark.parametrize("shape", [(8, 8, 128), (6, 6, 72), (12, 128)])
 def test_cahn_hilliard_slab_one_sweep_per_rhs(solver, steps, shape):

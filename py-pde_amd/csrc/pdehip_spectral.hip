@@ -9,6 +9,7 @@
 // reference takes `.real` of the complex inverse).
 #include <dlfcn.h>
 
+#include <cstdint>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -56,7 +57,8 @@ int load_fft()
     return 0;
 }
 
-// one plan pair + factor table + work arrays per (shape, spacing, dtype), for the life of the process
+// one plan pair + factor table + work arrays per (device, stream, shape, spacing, dtype), for the life of the process (plans and
+// scratch arrays belong to the device that was current when they were made, and two streams must not share the scratch arrays)
 struct Spectral {
     hipfftHandle fwd = nullptr, inv = nullptr;
     double *factor = nullptr;     // n0 * (n1 / 2 + 1) values, already divided by the number of cells
@@ -80,11 +82,13 @@ __global__ void __launch_bounds__(256) scale_kernel(T *freq, const double *facto
 // numpy.fft.fftfreq(n, d)[k]
 inline double fftfreq(long k, long n, double d) { return (double)(k < (n + 1) / 2 ? k : k - n) / ((double)n * d); }
 
-int get_plan(const NGrid &n, Spectral **out)
+int get_plan(const NGrid &n, void *stream, Spectral **out)
 {
     const int nd = n.ndim;
     const long n0 = nd == 2 ? n.n[1] : 1, n1 = n.n[2];     // normalised axes: a 2-D grid uses entries 1 and 2
-    std::vector<double> key = {(double)nd, (double)n0, (double)n1, n.dx[1], n.dx[2], (double)n.dtype};
+    int device = 0;
+    PDEHIP_HIP(hipGetDevice(&device));
+    std::vector<double> key = {(double)nd, (double)n0, (double)n1, n.dx[1], n.dx[2], (double)n.dtype, (double)device, (double)(uintptr_t)stream};
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *out = &it->second; return 0; }
@@ -122,6 +126,9 @@ int get_plan(const NGrid &n, Spectral **out)
     PDEHIP_HIP(hipMemcpy(s.factor, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
     PDEHIP_HIP(hipMalloc(&s.dense, esz * (size_t)(n0 * n1)));
     PDEHIP_HIP(hipMalloc(&s.freq, 2 * esz * (size_t)s.nfreq));
+    rc = g_fft.SetStream(s.fwd, as_stream(stream));
+    if (!rc) rc = g_fft.SetStream(s.inv, as_stream(stream));
+    if (rc) PDEHIP_FAIL(E_RUNTIME, "hipfftSetStream failed (code %d)", rc);
     *out = &g_cache.emplace(key, s).first->second;
     return 0;
 }
@@ -138,14 +145,12 @@ int pdehip_laplace_spectral(const pdehip_grid_t *g, const void *in_full, void *o
     if (n.ndim > 2) PDEHIP_FAIL(E_NOTIMPL, "Spectral Laplace operator not implemented for %d dimensions", n.ndim);   // cartesian.py:369-370
     if (out_layout != PDEHIP_OUT_VALID && out_layout != PDEHIP_OUT_FULL) PDEHIP_FAIL(E_VALUE, "laplace_spectral: unknown output layout %d", out_layout);
     Spectral *s = nullptr;
-    PDEHIP_TRY(get_plan(n, &s));
+    PDEHIP_TRY(get_plan(n, stream, &s));
     hipStream_t st = as_stream(stream);
     const bool f64 = n.dtype == PDEHIP_F64;
-    // full -> dense (one plan serves one stream at a time: the calls of a process are serialised by the GIL / by the stream order)
+    // full -> dense (plans and scratch arrays belong to this device and stream: calls on one stream are ordered by it)
     PDEHIP_TRY(pdehip_full_to_valid(g, 1, in_full, s->dense, stream));
-    int rc = g_fft.SetStream(s->fwd, st);
-    if (!rc) rc = g_fft.SetStream(s->inv, st);
-    if (!rc) rc = f64 ? g_fft.ExecD2Z(s->fwd, (double *)s->dense, s->freq) : g_fft.ExecR2C(s->fwd, (float *)s->dense, s->freq);
+    int rc = f64 ? g_fft.ExecD2Z(s->fwd, (double *)s->dense, s->freq) : g_fft.ExecR2C(s->fwd, (float *)s->dense, s->freq);
     if (rc) PDEHIP_FAIL(E_RUNTIME, "hipFFT forward transform failed (code %d)", rc);
     const unsigned blocks = (unsigned)((s->nfreq + 255) / 256 < 4096 ? (s->nfreq + 255) / 256 : 4096);
     if (f64) hipLaunchKernelGGL((scale_kernel<double>), dim3(blocks), dim3(256), 0, st, (double *)s->freq, s->factor, s->nfreq);

@@ -98,6 +98,9 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
     operator's boundary values (``convert_bcs(part="im")``), whatever equation the term ends up in."""
     import sympy as sp
 
+    if user_funcs:
+        msg = "hip backend: user functions inside complex-valued expressions are not supported"
+        raise NotImplementedError(msg)
     aliases = aliases or {}
     linear_axis_ops = {f"d_d{ax}" for ax in axes} | {f"d2_d{ax}2" for ax in axes}
     expr_str = expr_str.replace("∇²", "laplace").replace("^", "**")
@@ -116,6 +119,11 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
         try:
             scalar = complex(value)
         except (TypeError, ValueError):
+            import numpy as np
+
+            if np.iscomplexobj(getattr(value, "data", value)):     # (its imaginary part would be dropped silently)
+                msg = f"hip backend: the array-valued constant `{name}` of a complex-valued expression must be real"
+                raise NotImplementedError(msg)
             keep[name] = value          # an array / field on the grid: stays a (real) symbol of the plan
             continue
         if scalar.imag != 0:
@@ -125,9 +133,6 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
     for name in (*axes, "t"):
         if name not in local:
             local[name] = sp.Symbol(name, real=True)
-    if user_funcs:
-        msg = "hip backend: user functions inside complex-valued expressions are not supported"
-        raise NotImplementedError(msg)
     # every other name followed by "(" is an operator: an undefined function
     import re as _re
 

@@ -149,8 +149,10 @@ class Traced:
 
     # indexing: masks and "everything" ---------------------------------------------------------------------------
     def __getitem__(self, key):
-        if isinstance(key, Mask) or _is_everything(key):
-            return self._new(self.expr)      # the values at the selected cells: the same expression of each cell's own value
+        if _is_everything(key):
+            return self                      # `state[:]` / `state[...]` are VIEWS in numpy: `v = state[:]; v += 1` changes the state
+        if isinstance(key, Mask):
+            return self._new(self.expr)      # the values at the selected cells (a copy, like boolean indexing): the same expression of each cell's own value
         msg = "indexing single cells / sub-arrays of the state is not pointwise"
         raise TraceError(msg)
 

@@ -318,5 +318,7 @@ def test_what_is_refused(hip):
     field = pde.ScalarField(grid, 1.0 + 1j)
     with pytest.raises((NotImplementedError, RuntimeError)):   # mixed condition with a complex coefficient couples the parts
         pde.PDE({"c": "I * laplace(c)"}, bc={"type": "mixed", "value": 1j, "const": 1}).solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
+    with pytest.raises((NotImplementedError, RuntimeError), match="must be real"):   # a complex array constant (its imaginary part was dropped)
+        pde.PDE({"c": "I * laplace(c) + w * c"}, consts={"w": np.full(grid.shape, 1 + 2j)}).solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)
     with pytest.raises((NotImplementedError, RuntimeError)):   # tensors built from complex vectors inside an expression
         pde.PDE({"c": "dot(gradient(c), dot(vector_gradient(gradient(c)), gradient(c))) + I * c"}).solve(field, t_range=0.01, dt=1e-3, backend="hip", tracker=None)

@@ -52,7 +52,13 @@ def test_tracer_reproduces_typical_hooks():
     def bounded(state_data, t, data):
         return np.minimum(np.maximum(state_data, -1.0), 1.0 + 0.2 * t)
 
-    for hook in (clip_in_place, clip_call, relax, where, bounded):
+    def through_a_view(state_data, t, data):
+        view = state_data[:]          # a VIEW in numpy: changes reach the state (the tracer handed out a copy)
+        view += 0.25
+        other = state_data[...]
+        other[other > 1] = 1
+
+    for hook in (clip_in_place, clip_call, relax, where, bounded, through_a_view):
         _check(hook)
 
 

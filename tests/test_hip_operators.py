@@ -349,3 +349,26 @@ def test_field_products_and_expression_functions(shape, dtype):
         np.testing.assert_allclose(f(a, b, sval), np.sin(a.astype(float)) * b + sval * a.astype(float) ** 2 - b.astype(float) ** 2 + 0.25, rtol=10 * tol)
     f1 = backend.make_expression_function(Expr("a * b + 2", ["a", "b"]), single_arg=True)
     np.testing.assert_allclose(f1(np.stack([a, b])), a.astype(float) * b + 2, rtol=10 * tol)
+    # what `pde.tools.expressions.evaluate` asks for (pde/tools/expressions.py:986-1080): operators of this backend as user functions
+    # (called as `op(arg, none, bc_args)`), results of any rank, products expanded symbolically, complex fields split into their parts
+    bc = {"value": 0.3} if len(shape) == 1 else "auto_periodic_neumann"
+    ops = {"laplace": backend.make_operator(grid, "laplace", bcs=grid.get_boundary_conditions(bc, rank=0)),
+           "gradient": backend.make_operator(grid, "gradient", bcs=grid.get_boundary_conditions(bc, rank=0)),
+           "dot": backend._make_product(grid, False, True), "outer": backend._make_product(grid, True, False)}
+    sig = ["a", "b", "none", "bc_args"]
+    lap = ops["laplace"](a)
+    grad = ops["gradient"](a)
+    call = lambda text, *arrays: backend.make_expression_function(Expr(text, sig), user_funcs=ops)(*arrays, None, {})    # noqa: E731
+    np.testing.assert_allclose(call("laplace(a, none, bc_args) * b + 2 * a", a, b), lap.astype(float) * b + 2 * a.astype(float), rtol=20 * tol, atol=20 * tol)
+    np.testing.assert_allclose(call("laplace(a**2 + b, none, bc_args)", a, b), ops["laplace"]((a.astype(float) ** 2 + b).astype(dtype)), rtol=50 * tol, atol=50 * tol)
+    res = call("b * gradient(a, none, bc_args)", a, b)
+    assert res.shape == (len(shape), *shape)
+    np.testing.assert_allclose(res, b.astype(float) * grad, rtol=20 * tol, atol=20 * tol)
+    np.testing.assert_allclose(call("dot(gradient(a, none, bc_args), gradient(a, none, bc_args))", a, b), np.einsum("i...,i...->...", grad, grad).astype(float), rtol=50 * tol, atol=50 * tol)
+    np.testing.assert_allclose(call("outer(gradient(a, none, bc_args), gradient(b, none, bc_args))", a, b),
+                               np.einsum("i...,j...->ij...", grad, ops["gradient"](b)).astype(float), rtol=50 * tol, atol=50 * tol)
+    z = (a + 1j * b).astype(np.complex128 if dtype == np.float64 else np.complex64)
+    np.testing.assert_allclose(call("abs(a)**2 + b", z, b), np.abs(z.astype(complex)) ** 2 + b, rtol=20 * tol)
+    got = call("(1 + 2*I) * a * b", z, b)
+    assert np.iscomplexobj(got)
+    np.testing.assert_allclose(got, (1 + 2j) * z.astype(complex) * b, rtol=20 * tol)

@@ -498,6 +498,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // against 0.167).  Instead the tiles cover the whole chunks - the halo columns right of the last one are real cells, or the virtual
     // column through the `zhi2` code of the ragged instances - and the remaining columns are recomputed from the input by the LDS-tiled
     // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
+#if defined(PDEHIP_TALL_RAGGED)
+    const bool tall_r = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && !tall && m2 == E2_DIFFUSION &&
+                        a.per[1] != 2 && a.per[2] != 2 && a.n1 >= 64 && a.n2 >= CW;
+#else
+    const bool tall_r = false;
+#endif
     static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
     long open_tail = 0;
     if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
@@ -514,8 +520,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const long n2v = (n2t + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
     if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
-    if (tall) ry = 8;
-    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
+    if (tall || tall_r) ry = 8;
+    if ((ry != 1 && ry != 2 && ry != 4 && !tall && !tall_r) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
     const bool overlap = n2v != n2t || a.n1 % ry != 0;
     // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
     // with local faces): the narrow tile takes those grids (launch_euler2_t)
@@ -632,6 +638,20 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
             return 0;
         }
     }
+#if defined(PDEHIP_TALL_RAGGED)
+    if constexpr (sizeof(T) == 8 && VEC == 2) {
+        if (tall_r) {
+            if (dry_run) { *done = true; return 0; }
+            const bool unit_ = a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
+            if (unit_) hipLaunchKernelGGL((euler2_tall_ragged_kernel<T, VEC, 8, E2_DIFFUSION_UNIT>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((euler2_tall_ragged_kernel<T, VEC, 8, E2_DIFFUSION>), grid, block, 0, st, a);
+            PDEHIP_HIP(hipGetLastError());
+            if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, st));
+            *done = true;
+            return 0;
+        }
+    }
+#endif
     {   // is there an offline instance of this tile?  (the list below, PDEHIP_E2; asked before a dry run answers "covered")
         const bool xs_ = xplain > 1;
         bool have;

@@ -485,7 +485,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // grids whose rows end at chunk boundaries.  PDEHIP_EULER2=8 selects it (measurement: profiles/r03_e2_tile_shapes.log)
     // Round 5 (rows on 128-byte lines): the tall tile wins for fields well beyond the Infinity Cache - 512^3 0.2157 -> 0.2108 ms per step (mean of
     // four alternations), 512 x 512 x 256 +3.7 %, 384^3 +2.6 % - and loses below (256^3 -3 %, 128 x 512 x 512 -0.7 %): profiles/r05_ab_tall_tile.log.
-    // PDEHIP_EULER2=8 forces it, PDEHIP_EULER2=4 the 4-row tile.
+    // PDEHIP_EULER2=8 forces it, PDEHIP_EULER2=4 the 4-row tile.  (The tall tile WITH the ragged-row code, for extents that are not multiples of the tile,
+    // was built and measured slower than the 4-row tile everywhere - 513^3 440 against 479, 511^3 538 against 599 Gcell-steps/s: profiles/r05_ab_tall_ragged.log.)
     const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0;
     const bool tall = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
                       (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
@@ -498,12 +499,6 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // against 0.167).  Instead the tiles cover the whole chunks - the halo columns right of the last one are real cells, or the virtual
     // column through the `zhi2` code of the ragged instances - and the remaining columns are recomputed from the input by the LDS-tiled
     // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
-#if defined(PDEHIP_TALL_RAGGED)
-    const bool tall_r = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && !tall && m2 == E2_DIFFUSION &&
-                        a.per[1] != 2 && a.per[2] != 2 && a.n1 >= 64 && a.n2 >= CW;
-#else
-    const bool tall_r = false;
-#endif
     static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
     long open_tail = 0;
     if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
@@ -520,8 +515,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const long n2v = (n2t + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
     if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
-    if (tall || tall_r) ry = 8;
-    if ((ry != 1 && ry != 2 && ry != 4 && !tall && !tall_r) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
+    if (tall) ry = 8;
+    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
     const bool overlap = n2v != n2t || a.n1 % ry != 0;
     // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
     // with local faces): the narrow tile takes those grids (launch_euler2_t)
@@ -638,20 +633,6 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
             return 0;
         }
     }
-#if defined(PDEHIP_TALL_RAGGED)
-    if constexpr (sizeof(T) == 8 && VEC == 2) {
-        if (tall_r) {
-            if (dry_run) { *done = true; return 0; }
-            const bool unit_ = a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
-            if (unit_) hipLaunchKernelGGL((euler2_tall_ragged_kernel<T, VEC, 8, E2_DIFFUSION_UNIT>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((euler2_tall_ragged_kernel<T, VEC, 8, E2_DIFFUSION>), grid, block, 0, st, a);
-            PDEHIP_HIP(hipGetLastError());
-            if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, st));
-            *done = true;
-            return 0;
-        }
-    }
-#endif
     {   // is there an offline instance of this tile?  (the list below, PDEHIP_E2; asked before a dry run answers "covered")
         const bool xs_ = xplain > 1;
         bool have;

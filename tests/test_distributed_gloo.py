@@ -864,6 +864,29 @@ def _check_distributed_bench_line(out, world, size, env):
     assert len(out["state_sha256_after_6_steps"]) == 64 and out["state_sha256_after_6_steps"] == _SERIAL_DIGEST[size]
 
 
+def test_bench_side_measurements_run_on_the_host_shim():
+    """The `extra` part of the N = 1 bench line (the other BASELINE configurations through `eq.solve`, differential timing, fastest of three)
+    on grids 16 times smaller per axis (`--configs-scale`): the code the driver's run executes, in seconds on the host shim."""
+    import json
+    import subprocess
+
+    import shimlib
+
+    env = {**os.environ, "PDEHIP_LIB": str(shimlib.build()), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "OMP_NUM_THREADS": "2"}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--size", "32", "--no-cpu-baseline", "--repeats", "1",
+           "--configs-scale", "16"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, proc.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out.get("extra_error") is None and out["n_gpus"] == 1
+    extra = out["extra"]
+    assert set(extra) == {"cfg2_diffusion_1024sq_f64_euler", "cfg3_cahn_hilliard_512sq_f64_euler_1e4_steps", "cfg5_expression_256cube_f32_rkf45_fused_CH_form",
+                          "generic_two_pass_expression_256cube_f32_rkf45", "diffusion_512cube_f64_euler_walls_of_time_and_position"}
+    assert extra["cfg3_cahn_hilliard_512sq_f64_euler_1e4_steps"]["steps"] == 625 and extra["cfg5_expression_256cube_f32_rkf45_fused_CH_form"]["attempts"] >= 40
+    assert all(v.get("us_per_step", 0) > 0 for v in extra.values()) and "roofline_operators" in out and out["phase_seconds"]["extra_s"] > 0
+
+
 def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     """`bench.py --gpus 8` as the driver launches it (torch.distributed.run, one rank per device) on the host shim: the 8-slab run of
     the seeded field hashes to the same digest as the single-device run."""

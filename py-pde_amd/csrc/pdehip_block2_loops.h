@@ -199,12 +199,17 @@ inline int make_plan(const long *n, const int *dims, const int *coords, const in
 
 enum { EV_RIM = 0, EV_HALO = 1, EV_INT = 2 };
 
-// One exchange of the halos of `ext` (pack -> one group -> unpack) on stream `st`.
+// One exchange of the halos of `ext` (pack -> one group -> unpack) on stream `st`.  `ev_packed` >= 0: that event is recorded between the
+// pack launch and the send / receive group (see schedule 2 of euler2_run).
 template <class Ops>
-int exchange(Ops &ops, const Plan &p, void *ext, void *st)
+int exchange(Ops &ops, const Plan &p, void *ext, void *st, int ev_packed = -1)
 {
-    if (!p.npeers) return 0;
+    if (!p.npeers) {
+        if (ev_packed >= 0) SLAB_TRY(ops.record2(ev_packed, st));
+        return 0;
+    }
     SLAB_TRY(ops.pack(p, ext, true, st));
+    if (ev_packed >= 0) SLAB_TRY(ops.record2(ev_packed, st));
     SLAB_TRY(ops.group_start());
     for (int q = 0; q < p.npeers; q++) {
         const Peer &pe = p.peers[q];
@@ -264,8 +269,12 @@ int euler2_run(Ops &ops, const Plan &p, void *ext0, void *ext1, int64_t nsteps, 
             SLAB_TRY(ops.wait2(comp, EV_RIM));
             SLAB_TRY(ops.sweep2(p, cur, nxt, true, comp));
             SLAB_TRY(ops.record2(EV_INT, comp));
-            SLAB_TRY(ops.record2(EV_RIM, halo));
-            if (more) SLAB_TRY(exchange(ops, p, nxt, halo));
+            // The next interior sweep waits for this pair's rim - and, where the rim is packed by a launch of its own (a cut fastest axis), for
+            // that launch too: released straight behind the rim it filled the chip ~10 us before the RCCL kernel was dispatched, which then ran
+            // 67 us instead of 12 and held up unpack -> rim -> pack of the next pair (141 us per pair at 256^3 with three cut axes,
+            // profiles/r05_probe_block.md); released behind the pack it is dispatched a stream hand-over AFTER the RCCL kernel.
+            if (more) SLAB_TRY(exchange(ops, p, nxt, halo, EV_RIM));
+            else SLAB_TRY(ops.record2(EV_RIM, halo));
         }
         void *t = cur; cur = nxt; nxt = t;
     }

@@ -104,6 +104,12 @@ def test_reference_generic_tests_with_hip(rel, fused):
     results = _run(rel, fused)
     assert all("hip" in name for name in results), results
     unexpected = {n: r for n, r in results.items() if r != "PASSED" and not any(k in n for k in expected_fail)}
+    if unexpected:
+        # some of the reference's tests are statistical with an UNSEEDED generator (`np.random.randn` inside a user function of
+        # test_stochastic_solvers_two_interfaces, Kolmogorov-Smirnov tests): one in a few hundred runs fails for every backend.  A failure must
+        # repeat to count; a deterministic one does
+        again = _run(rel, fused)
+        unexpected = {n: r for n, r in unexpected.items() if again.get(n) != "PASSED"}
     assert not unexpected, f"{rel}: {unexpected}"
     stale = [k for k in expected_fail if any(k in n and r == "PASSED" for n, r in results.items())]
     assert not stale, f"{rel}: listed as 'next' but passing now: {stale}"

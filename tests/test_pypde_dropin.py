@@ -1124,3 +1124,36 @@ def test_conditions_with_constants_and_functions_without_a_c_form(hip1):
                 assert max_rel(np.array(got.data), ref.data) < 1e-10, (expr, solver)
     finally:
         pde.config["default_backend"] = old
+
+
+@pytest.mark.parametrize("shape,periodic", [((8, 6), [True, False]), ((5, 6, 7), [False, True, False])])
+def test_evaluate_of_expressions_with_operators(hip1, monkeypatch, shape, periodic):
+    """`pde.tools.expressions.evaluate(expression, fields, backend="hip")` (round 5: `make_expression_function` with this backend's operators as
+    user functions, pde/tools/expressions.py:986-1080): scalar / vector / tensor operators, products, coordinates, results of every rank - against
+    the reference's scipy operators (its torch backend where scipy has none)."""
+    from pde.tools.expressions import evaluate
+
+    monkeypatch.setitem(pde.config, "backend.torch.compile", False)
+    rng = np.random.default_rng(12)
+    grid = pde.CartesianGrid([[0, n * 0.5] for n in shape], shape, periodic=periodic)
+    a, b = (pde.ScalarField(grid, rng.normal(size=shape)) for _ in range(2))
+    v = pde.VectorField(grid, rng.normal(size=(len(shape), *shape)))
+    cases = [("laplace(a**2 + b) * b - gradient_squared(a)", {"a": a, "b": b}, pde.ScalarField),
+             ("divergence(b * gradient(a)) + dot(v, gradient(b))", {"a": a, "b": b, "v": v}, pde.ScalarField),
+             ("a * v + gradient(a * b)", {"a": a, "b": b, "v": v}, pde.VectorField),
+             ("outer(v, gradient(a))", {"a": a, "v": v}, pde.Tensor2Field),
+             ("vector_laplace(v) * x", {"v": v}, pde.VectorField),
+             ("tensor_divergence(outer(v, v)) + divergence(v) * v", {"v": v}, pde.VectorField),
+             ("sin(a) * heaviside(b, 0.5) + 2", {"a": a, "b": b}, pde.ScalarField)]
+    for expr, fields, cls in cases:
+        ref = None
+        for backend in ("scipy", "torch"):
+            try:
+                ref = evaluate(expr, fields, backend=backend)
+                break
+            except Exception:   # noqa: BLE001 - the reference's scipy backend lacks some operators
+                continue
+        assert ref is not None, expr
+        res = evaluate(expr, fields, backend="hip")
+        assert isinstance(res, cls) and res.data.shape == ref.data.shape
+        np.testing.assert_allclose(res.data, ref.data, rtol=1e-12, atol=1e-12, err_msg=expr)

@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define PDEHIP_MAX_DIM 3
-#define PDEHIP_ABI_VERSION 6
+#define PDEHIP_ABI_VERSION 7
 
 enum { PDEHIP_F64 = 0, PDEHIP_F32 = 1 };
 /* derivative flavour, pde/backends/numba/operators/cartesian.py:386-587 `method` */
@@ -420,6 +420,16 @@ int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *r
 int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
                          void *c_ext, void *out_ext, double dt, int euler, void *stream);
 int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
+                           int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
+                           void *stream);
+/* Communication-avoiding variant (ABI version 7): FOUR halo layers per side, ONE exchange per FOUR steps (two two-step sweeps; the first
+ * computes the own layers and two more per exchanged side, the second the own layers).  The part of the first sweep that reads own cells only
+ * runs while the exchange of the group before is in flight; the boundary part waits for it - all sweeps on ONE stream, the halo stream
+ * carries ncclSend / ncclRecv only.  Same arithmetic, bit-identical results.  Replaces the blocking per-step exchange of
+ * pde/solvers/explicit_mpi.py:133-226 + pde/backends/numba_mpi/backend.py:163-194.  Same contract and preconditions as
+ * pdehip_slab_euler2_run, with >= 8 local layers on EVERY rank (the caller checks globally) and *ok != 0 from pdehip_slab_euler4_supported. */
+int pdehip_slab_euler4_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok);
+int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
                            int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                            void *stream);
 

@@ -165,6 +165,12 @@ struct HipOps {
         const long v = e ? atol(e) : 0;
         return v < 0 ? 0 : v;
     }
+    // schedule of slab::euler4_run: 1 = the first sweep of a group cut in two (interior / boundary), 2 = both sweeps cut (PDEHIP_SLAB_DEEP_MODE)
+    int deep_mode()
+    {
+        const char *e = getenv("PDEHIP_SLAB_DEEP_MODE");   // (read per run: a test switches it inside one process)
+        return (e && atoi(e) == 2) ? 2 : 1;
+    }
     int record(int ev, void *st) { PDEHIP_HIP(hipEventRecord(c->ev[ev], as_stream(st))); return 0; }
     int wait(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), c->ev[ev], 0)); return 0; }
     int group_start() { PDEHIP_NCCL(g_rccl.GroupStart()); return 0; }
@@ -347,6 +353,27 @@ int context(void *comm, int lower, int upper, Comm **out)
     return 0;
 }
 
+// private arrays of the two-step slab loops: the layout of a slab of nloc + 2 * (depth - 1) layers, i.e. `depth` halo layers per side
+int slab_private_arrays(Comm *c, const pdehip_grid_t *g_local, const slab::Geo &q, long depth, hipStream_t comp)
+{
+    pdehip_grid_t ge = *g_local;
+    ge.shape[0] = q.nloc + 2 * (depth - 1);
+    NGrid ne;
+    PDEHIP_TRY(norm_grid(&ge, &ne));
+    const size_t need = (size_t)(ne.pc + kAllocSlack) * q.esz;
+    if (c->ext_bytes < need) {
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
+        c->ext[0] = c->ext[1] = nullptr; c->ext_bytes = 0;
+        PDEHIP_HIP(hipMalloc(&c->ext[0], need));
+        PDEHIP_HIP(hipMalloc(&c->ext[1], need));
+        c->ext_bytes = need;
+        PDEHIP_HIP(hipMemsetAsync(c->ext[0], 0, need, comp));
+        PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
+    }
+    return 0;
+}
+
 int check_rhs(const pdehip_rhs_t *rhs)
 {
     if (!rhs) PDEHIP_FAIL(E_VALUE, "rhs descriptor is NULL");
@@ -464,26 +491,37 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     NGrid n;
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
-    hipStream_t comp = as_stream(stream);
-    // private arrays with two halo layers per side: the layout of a slab of nloc+2 layers
-    pdehip_grid_t ge = *g_local;
-    ge.shape[0] = q.nloc + 2;
-    NGrid ne;
-    PDEHIP_TRY(norm_grid(&ge, &ne));
-    const size_t need = (size_t)(ne.pc + kAllocSlack) * q.esz;
-    if (c->ext_bytes < need) {
-        PDEHIP_HIP(hipStreamSynchronize(c->halo));
-        (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
-        c->ext[0] = c->ext[1] = nullptr; c->ext_bytes = 0;
-        PDEHIP_HIP(hipMalloc(&c->ext[0], need));
-        PDEHIP_HIP(hipMalloc(&c->ext[1], need));
-        c->ext_bytes = need;
-        PDEHIP_HIP(hipMemsetAsync(c->ext[0], 0, need, comp));
-        PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
-    }
+    PDEHIP_TRY(slab_private_arrays(c, g_local, q, 2, as_stream(stream)));
     HipOps ops{c};
     if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
+}
+
+int pdehip_slab_euler4_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    if (!g_local || !rhs || !ok) PDEHIP_FAIL(E_VALUE, "slab_euler4_supported: NULL pointer");
+    *ok = 0;
+    if (g_local->shape[0] < 8) return 0;
+    return pdehip_slab_euler2_supported(g_local, rhs, ok);   // the same launches, other layer ranges
+}
+
+// four steps per exchange on a slab (loop: slab::euler4_run); the private arrays with four halo layers per side live in the communicator
+int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper,
+                           void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) PDEHIP_FAIL(E_VALUE, "slab_euler4_run: NULL pointer");
+    if (nsteps < 0) PDEHIP_FAIL(E_VALUE, "slab_euler4_run: negative step count");
+    int ok = 0;
+    PDEHIP_TRY(pdehip_slab_euler4_supported(g_local, rhs, &ok));
+    if (!ok) PDEHIP_FAIL(E_NOTIMPL, "slab_euler4_run: grid or faces are not covered by the two-step kernel, or fewer than 8 local layers");
+    if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler4_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
+    Comm *c = static_cast<Comm *>(comm);
+    NGrid n;
+    slab::Geo q;
+    PDEHIP_TRY(make_geo(g_local, &n, &q));
+    PDEHIP_TRY(slab_private_arrays(c, g_local, q, 4, as_stream(stream)));
+    HipOps ops{c};
+    return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
 int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)

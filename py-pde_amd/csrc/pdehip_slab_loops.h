@@ -287,6 +287,106 @@ int euler2_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_
     return 0;
 }
 
+// `depth` layers per side of `ext` (layers 0..depth-1 | own depth..n+depth-1 | n+depth..n+2*depth-1): halos of several sweeps at once
+template <class Ops>
+int exchange_deep(Ops &ops, const Geo &q, void *ext, long depth, int lower, int upper, void *st)
+{
+    if (lower < 0 && upper < 0) return 0;
+    SLAB_TRY(ops.group_start());
+    if (lower >= 0) SLAB_TRY(ops.send(layer(ext, q, depth), (size_t)depth * q.lp, lower, st));                    // own first layers -> lower
+    if (upper >= 0) SLAB_TRY(ops.recv(layer(ext, q, q.nloc + depth), (size_t)depth * q.lp, upper, st));           // upper halo <- upper
+    if (upper >= 0) SLAB_TRY(ops.send(layer(ext, q, q.nloc), (size_t)depth * q.lp, upper, st));                   // own last layers -> upper
+    if (lower >= 0) SLAB_TRY(ops.recv(layer(ext, q, 0), (size_t)depth * q.lp, lower, st));                        // lower halo <- lower
+    return ops.group_end();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Communication-avoiding variant of euler2_run (round 6): FOUR halo layers per side, ONE exchange per FOUR steps (two two-step sweeps).
+//   private arrays (layers 0..3 | own 4..n+3 | n+4..n+7), group of four steps, everything that computes on ONE stream:
+//     A : cur -> nxt, own layers and two more per exchanged side ([2, n+6): valid because cur holds four halo layers)
+//     B : nxt -> cur, own layers ([4, n+4): reads the two extra layers A produced)
+//     X : send / receive the four outermost own layers of cur (halo stream)
+//   A is cut in two launches: A_int = the layers that read own cells only ([6, n+2)) runs while X of the group before is in flight, A_bnd
+//   (4 + 4 layers, two-ended launch) waits for it.  So the exchange has a whole sweep to hide behind, nothing small ever has to find wave
+//   slots NEXT to a sweep except the RCCL kernel itself (the boundary -> send / receive -> boundary cycle of euler2_run - 88 us per pair
+//   against 71 us of interior, profiles/r05_probe_block.md - is gone), and the number of messages, RCCL groups, events and stream
+//   hand-overs per step halves.  Price: A computes 4 extra layers per group (+3 % at 64 own layers).  mode 2 also cuts B (B_bnd first, X
+//   starts behind it and has B_int and the next A_int to hide behind).
+// Same arithmetic as every other path: the redundant layers are computed from the same inputs in the same order on both ranks.
+// Requires >= 8 own layers on EVERY rank (the caller decides globally, pdehip_slab_euler4_supported).
+// Replaces: the per-step blocking exchange of pde/solvers/explicit_mpi.py:133-226 + pde/backends/numba_mpi/backend.py:163-194.
+// ---------------------------------------------------------------------------------------------------------
+template <class Ops>
+int euler4_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, int lower, int upper, void *buf_a, void *ext0,
+               void *ext1, double dt, int64_t nsteps, void **result, void *comp)
+{
+    constexpr long D = 4;   // halo depth
+    void *halo = ops.halo();
+    const int xe = xends(lower, upper);
+    const long n = q.nloc;
+    const int mode = ops.deep_mode();
+    char *cur = static_cast<char *>(ext0), *nxt = static_cast<char *>(ext1);
+    SLAB_TRY(ops.copy(layer(cur, q, D), layer(buf_a, q, 1), (size_t)n * q.lp, comp));
+    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
+    local_faces(rhs->bc_c, lower, upper, faces);
+    // two steps src -> dst on private layers [first, first + count); xplain as in euler2_run (1: real layers beyond both ends);
+    // ends > 0: the first and the last `ends` layers of the range only
+    auto sweep2 = [&](void *st, char *src, char *dst, long first, long count, int xplain, int ends) -> int {
+        if (count <= 0) return 0;
+        pdehip_grid_t gs = *g;
+        gs.shape[0] = count;
+        pdehip_bc_face_t sf[2 * PDEHIP_MAX_DIM];
+        for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) sf[i] = faces[i];
+        // a physical upper face: its cell indices count from the first layer of the range
+        sf[1].index1 += count - n; sf[1].index2 += count - n;
+        bool done = false;
+        SLAB_TRY(ops.euler2(&gs, layer(src, q, first - 1), layer(dst, q, first - 1), rhs->param, dt, sf, st, &done, xplain, false, ends));
+        if (!done) return ops.fail("internal: two-step kernel refused a sub-slab");
+        return 0;
+    };
+    const long lo = lower >= 0 ? D - 2 : D, hi = upper >= 0 ? n + D + 2 : n + D;   // layers A produces
+    SLAB_TRY(ops.record(EV_COMP, comp));
+    SLAB_TRY(ops.wait(halo, EV_COMP));
+    SLAB_TRY(exchange_deep(ops, q, cur, D, lower, upper, halo));
+    SLAB_TRY(ops.record(EV_HALO, halo));
+    int64_t s = 0;
+    for (; s + 4 <= nsteps; s += 4) {
+        SLAB_TRY(sweep2(comp, cur, nxt, lo + D, hi - lo - 2 * D, 1, 0));   // A_int: reads own layers only
+        SLAB_TRY(ops.wait(comp, EV_HALO));                                 // halos of cur have landed
+        SLAB_TRY(sweep2(comp, cur, nxt, lo, hi - lo, xe, (int)D));         // A_bnd
+        if (mode == 2 && n > 2 * D) {
+            SLAB_TRY(sweep2(comp, nxt, cur, D, n, xe, (int)D));            // B_bnd: the layers the exchange sends
+            SLAB_TRY(ops.record(EV_BND, comp));
+            SLAB_TRY(sweep2(comp, nxt, cur, 2 * D, n - 2 * D, 1, 0));      // B_int
+        } else {
+            SLAB_TRY(sweep2(comp, nxt, cur, D, n, xe, 0));                 // B
+            SLAB_TRY(ops.record(EV_BND, comp));
+        }
+        if (s + 4 < nsteps) {   // (nothing reads the halos after the last step)
+            SLAB_TRY(ops.wait(halo, EV_BND));
+            SLAB_TRY(exchange_deep(ops, q, cur, D, lower, upper, halo));
+            SLAB_TRY(ops.record(EV_HALO, halo));
+        }
+    }
+    SLAB_TRY(ops.wait(comp, EV_HALO));
+    const int64_t rest = nsteps - s;
+    if (rest >= 2) {
+        // two steps: the own layers, and one more per exchanged side when a single step follows
+        const long lo2 = (rest == 3 && lower >= 0) ? D - 1 : D, hi2 = (rest == 3 && upper >= 0) ? n + D + 1 : n + D;
+        SLAB_TRY(sweep2(comp, cur, nxt, lo2, hi2 - lo2, xe, 0));
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    if (rest % 2) {
+        // one single step; layers D-1 and n+D act as its ghost layers (exchanged, or computed by the sweep above)
+        SLAB_TRY(ops.lap(g, layer(cur, q, D - 1), layer(cur, q, D - 1), layer(nxt, q, D - 1), K_EULER, rhs->param, dt, 0.0, faces, comp, nullptr));
+        char *t = cur; cur = nxt; nxt = t;
+    }
+    // the halo stream is idle here (its last exchange was awaited above); the next run may reuse the private arrays
+    SLAB_TRY(ops.copy(layer(buf_a, q, 1), layer(cur, q, D), (size_t)n * q.lp, comp));
+    *result = buf_a;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_out = dt * rhs(in) on the slab, followed in the same sweep (flags & F_FUSED_STAGE) by the Runge-Kutta combination
 // `sf`; Euler form (out = in + dt*rhs(in)) with euler = true and sf = NULL.  `in` (and for Cahn-Hilliard `out`) are slab

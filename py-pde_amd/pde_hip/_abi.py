@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 MAX_DIM = 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F64, F32 = 0, 1
 CENTRAL, FORWARD, BACKWARD = 0, 1, 2
@@ -227,6 +227,8 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_euler2_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    "slab_euler4_supported": [_pg, _pr, C.POINTER(_i)],
+    "slab_euler4_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_ch_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_ch_sweep": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i, _vp],
     # slab-parallel Runge-Kutta / adaptive loop / generic right-hand side (one C call per run)

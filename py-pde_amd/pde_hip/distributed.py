@@ -212,15 +212,20 @@ class SlabStepper:
         e2 = C.c_int(0)
         if self.kind == _abi.RHS_DIFFUSION and self.exchanging and min(self.mesh.counts) >= 4:
             self.lib.slab_euler2_supported(C.byref(self.g), C.byref(self.rhs), C.byref(e2))
+        # ... and four steps per exchange (four halo layers per side, csrc/pdehip_slab_loops.h: euler4_run) with >= 8 layers on every rank
+        e4 = C.c_int(0)
+        if e2.value and min(self.mesh.counts) >= 8 and os.environ.get("PDEHIP_SLAB_EULER4", "1") != "0":
+            self.lib.slab_euler4_supported(C.byref(self.g), C.byref(self.rhs), C.byref(e4))
         if os.environ.get("PDEHIP_SLAB_EULER2", "1") == "0" or self.bc_program is not None:
-            e2.value = 0     # (faces that change from step to step: one step per sweep)
+            e2.value = e4.value = 0     # (faces that change from step to step: one step per sweep)
         if self.kind == _abi.RHS_CAHN_HILLIARD and min(self.mesh.counts) < 2:
             local.value &= ~FUSED_CH
-        agreed = self.control.all_and(local.value | (4 if e2.value else 0))
+        agreed = self.control.all_and(local.value | (4 if e2.value else 0) | (8 if e4.value else 0))
         self.flags = agreed & (FUSED_CH | FUSED_STAGE)
         if self.kind == _abi.RHS_CAHN_HILLIARD and not self.flags & FUSED_CH:
             self.flags = 0   # the stage epilogue of Cahn-Hilliard rides on the two-level sweep
         self._euler2 = bool(agreed & 4)
+        self._euler4 = bool(agreed & 8) and self._euler2
 
     @staticmethod
     def _describe(eq, grid):
@@ -297,7 +302,9 @@ class SlabStepper:
         elif self.kind != _abi.RHS_DIFFUSION or self.bc_program is not None:
             self.lib.slab_euler_sweeps(self.comm, g, rhs, self._lo, self._up, self.flags, cur.ptr, nxt.ptr, dt, nsteps, C.byref(res), self.stream)
         else:
-            run = self.lib.slab_euler2_run if self._euler2 and nsteps >= 2 else self.lib.slab_euler_run
+            run = self.lib.slab_euler_run
+            if self._euler2 and nsteps >= 2:
+                run = self.lib.slab_euler4_run if self._euler4 and nsteps >= 4 else self.lib.slab_euler2_run
             run(self.comm, g, rhs, self._lo, self._up, cur.ptr, nxt.ptr, dt, nsteps, C.byref(res), self.stream)
         return cur if res.value == cur.ptr else nxt
 
@@ -365,7 +372,8 @@ class SlabStepper:
         """Slab-parallel twin of ``eq.solve(...)`` with ``tracker=None``; returns (global final state, info)."""
         cur = self.scatter(global_valid)
         nxt = self.buf("state_b")
-        info: dict[str, Any] = {"steps": 0, "world_size": self.size, "flags": self.flags, "two_steps_per_sweep": self._euler2}
+        info: dict[str, Any] = {"steps": 0, "world_size": self.size, "flags": self.flags, "two_steps_per_sweep": self._euler2,
+                                "steps_per_exchange": 4 if self._euler4 else (2 if self._euler2 else 1)}
         if dt is not None:
             steps = max(1, round(t_range / dt))
             if solver == "euler":

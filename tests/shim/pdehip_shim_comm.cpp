@@ -151,6 +151,7 @@ size_t full_bytes(const pdehip_grid_t *g)
 struct HostOps {
     Comm *c;
     long slab_thick() { const char *e = getenv("PDEHIP_SLAB_THICK"); const long v = e ? atol(e) : 0; return v < 0 ? 0 : v; }
+    int deep_mode() { const char *e = getenv("PDEHIP_SLAB_DEEP_MODE"); return (e && atoi(e) == 2) ? 2 : 1; }
     void *halo() { return (void *)1; }
     int record(int, void *) { return 0; }
     int wait(void *, int) { return 0; }
@@ -484,6 +485,37 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     HostOps ops{c};
     if (rhs->bc_program) return failf(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
+}
+
+int pdehip_slab_euler4_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
+{
+    *ok = 0;
+    if (g_local->shape[0] < 8) return 0;
+    return pdehip_slab_euler2_supported(g_local, rhs, ok);
+}
+
+int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower, int upper, void *buf_a, void *buf_b,
+                           double dt, int64_t nsteps, void **result, void *stream)
+{
+    if (!comm || !rhs || !buf_a || !buf_b || !result) return failf(E_VALUE, "slab_euler4_run: NULL pointer");
+    if (nsteps < 0) return failf(E_VALUE, "slab_euler4_run: negative step count");
+    int ok = 0;
+    pdehip_slab_euler4_supported(g_local, rhs, &ok);
+    if (!ok) return failf(E_NOTIMPL, "slab_euler4_run: grid or faces are not covered by the two-step kernel, or fewer than 8 local layers");
+    if (rhs->bc_program) return failf(E_NOTIMPL, "slab_euler4_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
+    Comm *c = static_cast<Comm *>(comm);
+    slab::Geo q;
+    SLAB_TRY(make_geo(g_local, &q));
+    pdehip_grid_t ge = *g_local;
+    ge.shape[0] = q.nloc + 6;
+    const size_t need = full_bytes(&ge);
+    if (c->ext_bytes < need) {
+        free(c->ext[0]); free(c->ext[1]);
+        c->ext[0] = calloc(1, need); c->ext[1] = calloc(1, need);
+        c->ext_bytes = need;
+    }
+    HostOps ops{c};
+    return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
 int pdehip_slab_ch_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)

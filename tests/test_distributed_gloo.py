@@ -156,6 +156,7 @@ def test_two_step_slab_loop_with_thick_boundary_chunks(monkeypatch):
     """PDEHIP_SLAB_THICK=<layers> (round 5; off by default): the schedule that cuts the two-step sweep of a slab into its
     first / last layers and the layers in between on ONE stream, with the exchange next to the second launch - two ranks, bit-exact."""
     monkeypatch.setenv("PDEHIP_SLAB_THICK", "3")
+    monkeypatch.setenv("PDEHIP_SLAB_EULER4", "0")   # (nine layers per rank would take four steps per exchange)
     results = run_distributed("solve_all_cases", 2, True)
     checked = 0
     for name, (mk_eq, mk_grid, t_range, dt, solver) in CASES.items():
@@ -165,11 +166,32 @@ def test_two_step_slab_loop_with_thick_boundary_chunks(monkeypatch):
         data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)
         expect, steps, _ = _serial_reference(eq, grid, data, t_range, dt, solver)
         for rank in range(2):
-            final, nsteps, _, _, two = results[rank][name]
+            final, nsteps, _, _, two, _ = results[rank][name]
             assert two and nsteps == steps
             np.testing.assert_array_equal(final, expect, err_msg=f"{name} rank {rank}")
             checked += 1
     assert checked == 4
+
+
+def test_four_steps_per_exchange_with_both_sweeps_cut(monkeypatch):
+    """PDEHIP_SLAB_DEEP_MODE=2: the schedule of slab::euler4_run that cuts BOTH sweeps of a group (the exchange starts behind the boundary
+    part of the second one) - two and three ranks, every remainder of the step count, physical faces on the outer ranks; bit-exact."""
+    monkeypatch.setenv("PDEHIP_SLAB_DEEP_MODE", "2")
+    for size in (2, 3):
+        results = run_distributed("solve_all_cases", size, True)
+        checked = 0
+        for name, (mk_eq, mk_grid, t_range, dt, solver) in CASES.items():
+            if not name.startswith("diff3d_deep"):
+                continue
+            eq, grid = mk_eq(), mk_grid()
+            data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)
+            expect, steps, _ = _serial_reference(eq, grid, data, t_range, dt, solver)
+            for rank in range(size):
+                final, nsteps, _, _, two, per_exchange = results[rank][name]
+                assert two and per_exchange == 4 and nsteps == steps
+                np.testing.assert_array_equal(final, expect, err_msg=f"{name} rank {rank}")
+                checked += 1
+        assert checked == 4 * size
 
 
 CASES = {
@@ -184,6 +206,14 @@ CASES = {
     "diff3d_thick_periodic": (lambda: pde_hip.DiffusionPDE(0.6), lambda: pde_hip.UnitGrid([18, 4, 6], periodic=True), 0.7, 0.1, "euler"),
     "diff3d_thick_walls": (lambda: pde_hip.DiffusionPDE(0.9, bc={"x-": {"value": 0.3}, "x+": {"derivative": -0.2}, "y": "periodic", "z": {"value": 0.1}}),
                            lambda: pde_hip.CartesianGrid([[0, 9], [0, 2], [0, 3]], [17, 4, 6], periodic=[False, True, False]), 0.35, 0.05, "euler"),
+    # >= 8 layers on every rank: four steps per exchange (slab::euler4_run); 8 / 7 / 9 / 10 steps = every remainder of the group of four
+    "diff3d_deep_periodic_r0": (lambda: pde_hip.DiffusionPDE(0.6), lambda: pde_hip.UnitGrid([34, 4, 6], periodic=True), 0.8, 0.1, "euler"),
+    "diff3d_deep_periodic_r3": (lambda: pde_hip.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 0.2}, "z": "periodic"}),
+                                lambda: pde_hip.UnitGrid([35, 4, 6], periodic=[True, False, True]), 0.7, 0.1, "euler"),
+    "diff3d_deep_walls_r1": (lambda: pde_hip.DiffusionPDE(0.9, bc={"x-": {"value": 0.3}, "x+": {"derivative": -0.2}, "y": "periodic", "z": {"value": 0.1}}),
+                             lambda: pde_hip.CartesianGrid([[0, 9], [0, 2], [0, 3]], [33, 4, 6], periodic=[False, True, False]), 0.45, 0.05, "euler"),
+    "diff3d_deep_walls_r2": (lambda: pde_hip.DiffusionPDE(0.8, bc={"x-": {"derivative": 0.4}, "x+": {"type": "mixed", "value": 0.5, "const": 0.2}, "y": {"derivative": 0.1}, "z": "periodic"}),
+                             lambda: pde_hip.CartesianGrid([[0, 9], [0, 2], [0, 3]], [36, 4, 6], periodic=[False, False, True]), 0.5, 0.05, "euler"),
     "diff3d_rk4": (lambda: pde_hip.DiffusionPDE(0.5), lambda: pde_hip.UnitGrid([9, 4, 6], periodic=[False, True, True]), 0.3, 0.05, "runge-kutta"),
     "diff3d_rkf45": (lambda: pde_hip.DiffusionPDE(1.0, bc={"x": {"value": 0.2}, "y": "periodic", "z": "periodic"}),
                      lambda: pde_hip.UnitGrid([10, 4, 4], periodic=[False, True, True]), 1.0, None, "runge-kutta"),
@@ -204,7 +234,7 @@ def solve_all_cases(rank, size):
         stepper = SlabStepper(eq, grid)
         final, info = stepper.solve(data, t_range, dt, solver)
         stepper.close()
-        out[name] = (final, info["steps"], info["dt"], info["flags"], info["two_steps_per_sweep"])
+        out[name] = (final, info["steps"], info["dt"], info["flags"], info["two_steps_per_sweep"], info["steps_per_exchange"])
     return out
 
 
@@ -221,11 +251,13 @@ def test_distributed_equals_serial(size, fused):
         data = np.random.default_rng(7).uniform(-0.5, 0.5, grid.shape)
         expect, steps, dt_last = _serial_reference(eq, grid, data, t_range, dt, solver)
         for rank in range(size):
-            final, nsteps, dt_r, flags, two = results[rank][name]
+            final, nsteps, dt_r, flags, two, per_exchange = results[rank][name]
             np.testing.assert_array_equal(final, expect, err_msg=f"{name} rank {rank}")
             assert nsteps == steps
             assert dt_r == pytest.approx(dt_last, rel=1e-12)
-            assert (flags, two) == results[0][name][3:], "ranks disagree on the code path"
+            assert (flags, two, per_exchange) == results[0][name][3:], "ranks disagree on the code path"
+            if name.startswith("diff3d_deep"):
+                assert per_exchange == 4, name
             if not fused:
                 assert flags == 0
             else:   # the fused loops really ran where the kernels cover the case

@@ -58,11 +58,12 @@ def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
     """pdehip_slab_euler2_run: two halo layers exchanged (to self) once per two steps, odd step counts end in a single step."""
     from pde_hip.distributed import SlabStepper
 
+    monkeypatch.setenv("PDEHIP_SLAB_EULER4", "0")   # (16 layers would take four steps per exchange: the test below)
     grid = pde_hip.UnitGrid((16, 8, 128), periodic=[True, False, True])
     data = np.random.default_rng(6).uniform(-1, 1, grid.shape)
     eq = pde_hip.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 0.2}, "z": "periodic"})
     st = SlabStepper(eq, grid, force_exchange=True)
-    assert st._euler2
+    assert st._euler2 and not st._euler4
     final, info = st.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
     st.close()
     np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps))
@@ -78,6 +79,69 @@ def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
     np.testing.assert_array_equal(final2, final)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("shape,bc", [((16, 8, 128), {"x": "periodic", "y": {"value": 0.2}, "z": "periodic"}),
+                                      ((9, 12, 256), {"x": "periodic", "y": "periodic", "z": {"derivative": -0.1}}),
+                                      ((8, 6, 130), {"x": "periodic", "y": "periodic", "z": "periodic"})])
+def test_four_steps_per_exchange_slab_loop(monkeypatch, mode, shape, bc):
+    """pdehip_slab_euler4_run (round 6): FOUR halo layers exchanged (to self) once per four steps - the first sweep of a group computes two
+    layers more per side, its boundary part waits for the exchange; every remainder of the step count; PDEHIP_SLAB_DEEP_MODE=2 also cuts
+    the second sweep.  Bit-identical to the serial oracle."""
+    from pde_hip.distributed import SlabStepper
+
+    monkeypatch.setenv("PDEHIP_SLAB_DEEP_MODE", mode)
+    periodic = [v == "periodic" for v in bc.values()]
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    data = np.random.default_rng(6).uniform(-1, 1, grid.shape)
+    eq = pde_hip.DiffusionPDE(0.7, bc=bc)
+    for steps in (4, 5, 6, 7, 13, 16):
+        st = SlabStepper(eq, grid, force_exchange=True)
+        assert st._euler2 and st._euler4
+        final, info = st.solve(data, t_range=steps * 0.05, dt=0.05, solver="euler")
+        st.close()
+        assert info["steps"] == steps and info["steps_per_exchange"] == 4
+        np.testing.assert_array_equal(final, _expect(_abi.RHS_DIFFUSION, 0.7, grid, eq.bc, data, 0.05, steps), err_msg=f"{steps} steps")
+    # fewer than 8 layers, or switched off: two steps per exchange
+    st1 = SlabStepper(eq, pde_hip.UnitGrid((7,) + tuple(shape[1:]), periodic=periodic), force_exchange=True)
+    assert st1._euler2 and not st1._euler4
+    st1.close()
+    monkeypatch.setenv("PDEHIP_SLAB_EULER4", "0")
+    st2 = SlabStepper(eq, grid, force_exchange=True)
+    assert st2._euler2 and not st2._euler4
+    st2.close()
+
+
+def test_four_steps_per_exchange_between_physical_faces():
+    """The same loop on a rank WITHOUT neighbours (direct C call, lower = upper = -1): no halos, the boundary launches meet the physical
+    faces of the slowest axis (index translation of the upper face for ranges that do not start at the first own layer)."""
+    from pde_hip.backend import convert_bcs
+    from pde_hip.device import DeviceArray, GridInfo
+    from pde_hip.distributed import SlabStepper
+
+    shape = (20, 8, 128)
+    grid = pde_hip.UnitGrid(shape, periodic=False)
+    pairs = [({"value": 0.4}, {"derivative": -0.2}), ({"derivative": 0.3}, {"value": -0.1}), ({"type": "mixed", "value": 0.5, "const": 0.2}, {"value": 0.0})]
+    bc = {f"{a}{s}": v for a, (lo, hi) in zip(grid.axes, pairs) for s, v in (("-", lo), ("+", hi))}
+    data = np.random.default_rng(9).uniform(-1, 1, shape)
+    helper = SlabStepper(pde_hip.DiffusionPDE(), pde_hip.UnitGrid(shape, periodic=True), force_exchange=True)
+    lib, comm = helper.lib, helper.comm
+    info = GridInfo(grid.shape, grid.discretization, np.float64)
+    rhs = _abi.RHS()
+    rhs.kind, rhs.param = _abi.RHS_DIFFUSION, 0.6
+    convert_bcs(grid.get_boundary_conditions(bc)).copy_into(rhs.bc_c)
+    ok = C.c_int(0)
+    lib.slab_euler4_supported(info.ref, C.byref(rhs), C.byref(ok))
+    assert ok.value
+    a, b = DeviceArray(info), DeviceArray(info)
+    res = C.c_void_p()
+    for steps in (4, 7, 10):
+        a.set_valid(data)
+        lib.slab_euler4_run(comm, info.ref, C.byref(rhs), -1, -1, a.ptr, b.ptr, 0.05, steps, C.byref(res), None)
+        lib.stream_synchronize(None)
+        np.testing.assert_array_equal((b if res.value == b.ptr else a).get_valid(), _expect(_abi.RHS_DIFFUSION, 0.6, grid, bc, data, 0.05, steps))
+    helper.close()
+
+
 @pytest.mark.parametrize("thick", [2, 5, 8])
 def test_two_steps_per_sweep_slab_loop_with_thick_boundary_chunks(monkeypatch, thick):
     """PDEHIP_SLAB_THICK (round 5; off by default - measured slower to self, profiles/r05_probe_block.md): the first and
@@ -85,6 +149,7 @@ def test_two_steps_per_sweep_slab_loop_with_thick_boundary_chunks(monkeypatch, t
     from pde_hip.distributed import SlabStepper
 
     monkeypatch.setenv("PDEHIP_SLAB_THICK", str(thick))
+    monkeypatch.setenv("PDEHIP_SLAB_EULER4", "0")
     grid = pde_hip.UnitGrid((24, 8, 128), periodic=[True, False, True])
     data = np.random.default_rng(6).uniform(-1, 1, grid.shape)
     eq = pde_hip.DiffusionPDE(0.7, bc={"x": "periodic", "y": {"value": 0.2}, "z": "periodic"})

@@ -422,6 +422,10 @@ int pdehip_slab_ch_sweep(void *comm, const pdehip_grid_t *g_local, const pdehip_
 int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int lower,
                            int upper, void *buf_a, void *buf_b, double dt, int64_t nsteps, void **result,
                            void *stream);
+/* Scratch buffers of the process-wide context that serves the slab / block loops WITHOUT a communicator (comm == NULL: one process, no
+ * neighbours): freed here (after the runs that use them), allocated again on demand.  A communicator frees its own in pdehip_comm_destroy.
+ * (ABI version 7; the reference has no counterpart: numpy arrays are garbage-collected.) */
+int pdehip_release_scratch(void);
 /* Communication-avoiding variant (ABI version 7): FOUR halo layers per side, ONE exchange per FOUR steps (two two-step sweeps; the first
  * computes the own layers and two more per exchanged side, the second the own layers).  The part of the first sweep that reads own cells only
  * runs while the exchange of the group before is in flight; the boundary part waits for it - all sweeps on ONE stream, the halo stream

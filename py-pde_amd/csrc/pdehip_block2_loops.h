@@ -164,7 +164,8 @@ inline int make_plan(const long *n, const int *dims, const int *coords, const in
     p->send_total = off;
     // receive regions: the message of peer q holds ITS directions d (in order) with neighbour(q, d) == me; its own cells next to its
     // face d are my halo in direction -d.  (Every block has the extents of mine along the axes a message spans only if the grid
-    // divides evenly; the caller checks that all ranks agree on the region sizes through the message lengths.)
+    // divides evenly or the cut is the tensor-product one of pde_hip/mesh.py, which is what BlockStepper builds; the ranks agree on the schedule
+    // switches PDEHIP_BLOCK2_* before the first run - pde_hip/distributed.py: agree_on_environment.)
     off = 0;
     for (int q = 0; q < p->npeers; q++) {
         p->peers[q].recv_off = off;

@@ -15,7 +15,6 @@
 // synchronises with the host.
 #include <dlfcn.h>
 
-#include <map>
 #include <rccl/rccl.h>
 
 #include "pdehip_common.h"
@@ -68,18 +67,57 @@ int load_rccl(const char *path)
         if (_r != ncclSuccess) PDEHIP_FAIL(E_RUNTIME, "%s failed: %s", #expr, g_rccl.GetErrorString(_r)); \
     } while (0)
 
+struct Block2Ctx;   // scratch of the fast block loop (defined next to it, below); owned by the communicator
+void block2_release(Block2Ctx *x);
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, size = 1;
     hipStream_t halo = nullptr;  // stream of the exchange + boundary-layer kernels
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // slab::EV_COMP, EV_HALO, EV_BND, EV_BND2
     double *scratch2 = nullptr;  // device: {value, nan flag} for the MAX all-reduce
-    void *ext[2] = {nullptr, nullptr};   // slab copies with TWO halo layers per side (two-steps-per-sweep loop)
+    void *ext[4] = {nullptr, nullptr, nullptr, nullptr};   // private slab arrays with two / four halo layers per side (two-steps-per-sweep loops)
     size_t ext_bytes = 0;
+    int ext_count = 0;
     // block decomposition: contiguous staging buffers of the packed faces, [axis][side][0 send / 1 receive]
     void *stg[3][2][2] = {{{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}, {{nullptr, nullptr}, {nullptr, nullptr}}};
     size_t stg_bytes[3] = {0, 0, 0};
+    Block2Ctx *b2 = nullptr;     // (was a process-wide table keyed by the Comm pointer and never released)
+    // The scratch above (ext, stg, b2) is shared by every run on this context - all steppers without a communicator share the serial
+    // context - and those runs enqueue on their own streams: a run waits for the end of the run before it (ScratchTurn).
+    hipEvent_t ev_done = nullptr;
+    bool ev_done_recorded = false;
 };
+
+// one run's turn on the scratch of a context: waits (on the device) for the run before it, marks its own end
+struct ScratchTurn {
+    Comm *c;
+    hipStream_t st;
+    ScratchTurn(Comm *c_, hipStream_t st_) : c(c_), st(st_)
+    {
+        if (c->ev_done && c->ev_done_recorded) (void)hipStreamWaitEvent(st, c->ev_done, 0);
+    }
+    ~ScratchTurn()
+    {
+        if (c->ev_done && hipEventRecord(c->ev_done, st) == hipSuccess) c->ev_done_recorded = true;
+    }
+};
+
+// frees every scratch buffer of a context (after the work that uses them)
+void release_scratch(Comm *c)
+{
+    if (c->ev_done && c->ev_done_recorded) (void)hipEventSynchronize(c->ev_done);
+    if (c->halo) (void)hipStreamSynchronize(c->halo);
+    for (auto &e : c->ext) { (void)hipFree(e); e = nullptr; }
+    c->ext_bytes = 0; c->ext_count = 0;
+    for (int a = 0; a < 3; a++) {
+        for (int side = 0; side < 2; side++)
+            for (int r = 0; r < 2; r++) { (void)hipFree(c->stg[a][side][r]); c->stg[a][side][r] = nullptr; }
+        c->stg_bytes[a] = 0;
+    }
+    block2_release(c->b2);
+    c->b2 = nullptr;
+}
 
 // serial use of the slab loops (comm == NULL, no neighbours): streams / events of a process-wide context without RCCL
 Comm *serial_context()
@@ -101,6 +139,7 @@ int ensure_streams(Comm *c)
     }
     for (auto &e : c->ev)
         if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!c->ev_done) PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     return 0;
 }
 
@@ -165,11 +204,14 @@ struct HipOps {
         const long v = e ? atol(e) : 0;
         return v < 0 ? 0 : v;
     }
-    // schedule of slab::euler4_run: 1 = the first sweep of a group cut in two (interior / boundary), 2 = both sweeps cut (PDEHIP_SLAB_DEEP_MODE)
+    // schedule of pdehip_slab_euler4_run (PDEHIP_SLAB_DEEP_MODE): 1 = the first sweep of a group cut in two (interior / boundary), 2 = both sweeps cut,
+    // 3 = the boundary layers on the halo stream, a group ahead (slab::euler4p_run)
+    static constexpr int kDeepModeDefault = 3;
     int deep_mode()
     {
         const char *e = getenv("PDEHIP_SLAB_DEEP_MODE");   // (read per run: a test switches it inside one process)
-        return (e && atoi(e) == 2) ? 2 : 1;
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 3) ? v : kDeepModeDefault;
     }
     int record(int ev, void *st) { PDEHIP_HIP(hipEventRecord(c->ev[ev], as_stream(st))); return 0; }
     int wait(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), c->ev[ev], 0)); return 0; }
@@ -320,6 +362,8 @@ int make_block(Comm *c, const pdehip_grid_t *g, const NGrid &n, const int *nb6, 
     for (int a = 0; a < g->ndim; a++) {
         const size_t need = q->face_elems(a) * q->esz;
         if ((q->nb[a][0] >= 0 || q->nb[a][1] >= 0) && c->stg_bytes[a] < need) {
+            if (c->ev_done && c->ev_done_recorded) PDEHIP_HIP(hipEventSynchronize(c->ev_done));
+            PDEHIP_HIP(hipStreamSynchronize(c->halo));
             for (int side = 0; side < 2; side++)
                 for (int r = 0; r < 2; r++) {
                     if (c->stg[a][side][r]) (void)hipFree(c->stg[a][side][r]);
@@ -354,22 +398,24 @@ int context(void *comm, int lower, int upper, Comm **out)
 }
 
 // private arrays of the two-step slab loops: the layout of a slab of nloc + 2 * (depth - 1) layers, i.e. `depth` halo layers per side
-int slab_private_arrays(Comm *c, const pdehip_grid_t *g_local, const slab::Geo &q, long depth, hipStream_t comp)
+int slab_private_arrays(Comm *c, const pdehip_grid_t *g_local, const slab::Geo &q, long depth, hipStream_t comp, int count = 2)
 {
     pdehip_grid_t ge = *g_local;
     ge.shape[0] = q.nloc + 2 * (depth - 1);
     NGrid ne;
     PDEHIP_TRY(norm_grid(&ge, &ne));
     const size_t need = (size_t)(ne.pc + kAllocSlack) * q.esz;
-    if (c->ext_bytes < need) {
+    if (c->ext_bytes < need || c->ext_count < count) {
+        if (c->ev_done && c->ev_done_recorded) PDEHIP_HIP(hipEventSynchronize(c->ev_done));
         PDEHIP_HIP(hipStreamSynchronize(c->halo));
-        (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
-        c->ext[0] = c->ext[1] = nullptr; c->ext_bytes = 0;
-        PDEHIP_HIP(hipMalloc(&c->ext[0], need));
-        PDEHIP_HIP(hipMalloc(&c->ext[1], need));
-        c->ext_bytes = need;
-        PDEHIP_HIP(hipMemsetAsync(c->ext[0], 0, need, comp));
-        PDEHIP_HIP(hipMemsetAsync(c->ext[1], 0, need, comp));
+        const size_t bytes = need > c->ext_bytes ? need : c->ext_bytes;
+        for (auto &e : c->ext) { (void)hipFree(e); e = nullptr; }
+        c->ext_bytes = 0; c->ext_count = 0;
+        for (int k = 0; k < count; k++) {
+            PDEHIP_HIP(hipMalloc(&c->ext[k], bytes));
+            PDEHIP_HIP(hipMemsetAsync(c->ext[k], 0, bytes, comp));
+        }
+        c->ext_bytes = bytes; c->ext_count = count;
     }
     return 0;
 }
@@ -415,13 +461,21 @@ int pdehip_comm_destroy(void *comm)
 {
     if (!comm) return 0;
     Comm *c = static_cast<Comm *>(comm);
-    (void)hipStreamSynchronize(c->halo);
+    release_scratch(c);
     g_rccl.CommDestroy(c->comm);
     (void)hipStreamDestroy(c->halo);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->ev_done);
     (void)hipFree(c->scratch2);
-    (void)hipFree(c->ext[0]); (void)hipFree(c->ext[1]);
     delete c;
+    return 0;
+}
+
+// the scratch buffers of the process-wide context that serves runs WITHOUT a communicator (steppers of one process, no neighbours): a
+// stepper that closes hands them back (they are allocated again on demand)
+int pdehip_release_scratch(void)
+{
+    release_scratch(serial_context());
     return 0;
 }
 
@@ -492,6 +546,7 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     PDEHIP_TRY(slab_private_arrays(c, g_local, q, 2, as_stream(stream)));
+    ScratchTurn turn(c, as_stream(stream));
     HipOps ops{c};
     if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
@@ -519,8 +574,11 @@ int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     NGrid n;
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
-    PDEHIP_TRY(slab_private_arrays(c, g_local, q, 4, as_stream(stream)));
     HipOps ops{c};
+    const bool piped = ops.deep_mode() == 3;
+    PDEHIP_TRY(slab_private_arrays(c, g_local, q, 4, as_stream(stream), piped ? 4 : 2));
+    ScratchTurn turn(c, as_stream(stream));
+    if (piped) return slab::euler4p_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext, dt, nsteps, result, stream);
     return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 
@@ -701,6 +759,7 @@ int pdehip_block_exchange(void *comm, const pdehip_grid_t *g_local, const int *n
     NGrid n;
     block::Geo q;
     PDEHIP_TRY(block_context(comm, g_local, nb6, &c, &n, &q));
+    ScratchTurn turn(c, as_stream(stream));
     HipOps ops{c};
     ops.bn = &n;
     return block::exchange(ops, q, buf_full, stream);
@@ -721,6 +780,7 @@ int pdehip_block_run(void *comm, const pdehip_grid_t *g_local, const pdehip_rhs_
     NGrid n;
     block::Geo q;
     PDEHIP_TRY(block_context(comm, g_local, nb6, &c, &n, &q));
+    ScratchTurn turn(c, as_stream(stream));
     HipOps ops{c};
     ops.bn = &n;
     return block::run(ops, g_local, q, rhs, fuse_stage != 0, scheme, y_full, ynew_full, work_host, err_dev, dt, nsteps, ctl, result, stream);
@@ -1023,11 +1083,11 @@ struct Block2Ctx {
     hipStream_t comp_masked = nullptr, halo_masked = nullptr;
     int reserved = -1;
 };
-// (one context per communicator; the serial context of a process without neighbours has its own)
+// (one context per communicator, owned by it and released with it; the serial context of a process without neighbours has its own)
 Block2Ctx *block2_ctx(Comm *c)
 {
-    static std::map<Comm *, Block2Ctx> table;
-    return &table[c];
+    if (!c->b2) c->b2 = new Block2Ctx();
+    return c->b2;
 }
 
 struct HipOps2 {
@@ -1227,6 +1287,20 @@ int block2_check(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const in
 
 }  // namespace
 
+namespace {
+void block2_release(Block2Ctx *x)
+{
+    if (!x) return;
+    (void)hipFree(x->ext[0]); (void)hipFree(x->ext[1]);
+    (void)hipFree(x->msg[0]); (void)hipFree(x->msg[1]);
+    for (auto &e : x->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (x->comp_masked) (void)hipStreamDestroy(x->comp_masked);
+    if (x->halo_masked) (void)hipStreamDestroy(x->halo_masked);
+    delete x;
+}
+}  // namespace
+
 extern "C" {
 
 int pdehip_block2_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const int *cut3, int *ok)
@@ -1262,6 +1336,7 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
     const long n[3] = {g_local->shape[0], g_local->shape[1], g_local->shape[2]};
     if (block2::make_plan(n, dims3, coords3, cut3, &plan) != 0) PDEHIP_FAIL(E_VALUE, "block2_euler_run: the box is too small for two halo layers");
     Block2Ctx *x = block2_ctx(c);
+    ScratchTurn turn(c, as_stream(stream));
     for (auto &e : x->ev)
         if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HipOps2 ops;
@@ -1301,6 +1376,7 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
     ops.direct = mode >= 1 && !cut3[2] && any && !direct_off && g_local->shape[2] % (16 / elem_size(g_local->dtype)) == 0;
     const size_t need = (size_t)(ops.ne.pc + kAllocSlack) * ops.es;
     if (x->ext_bytes < need) {
+        if (c->ev_done && c->ev_done_recorded) PDEHIP_HIP(hipEventSynchronize(c->ev_done));
         PDEHIP_HIP(hipStreamSynchronize(c->halo));
         PDEHIP_HIP(hipStreamSynchronize(comp));
         (void)hipFree(x->ext[0]); (void)hipFree(x->ext[1]);
@@ -1313,6 +1389,7 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
     }
     const size_t mneed = (plan.send_total > plan.recv_total ? plan.send_total : plan.recv_total) * ops.es + 256;
     if (x->msg_bytes < mneed) {
+        if (c->ev_done && c->ev_done_recorded) PDEHIP_HIP(hipEventSynchronize(c->ev_done));
         PDEHIP_HIP(hipStreamSynchronize(c->halo));
         (void)hipFree(x->msg[0]); (void)hipFree(x->msg[1]);
         x->msg[0] = x->msg[1] = nullptr; x->msg_bytes = 0;

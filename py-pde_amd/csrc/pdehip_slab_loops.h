@@ -388,6 +388,91 @@ int euler4_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Four steps per exchange with the BOUNDARY WORK OFF THE CRITICAL PATH (schedule 3 of pdehip_slab_euler4_run).
+// In schedules 1 / 2 above the boundary parts of the sweeps are small launches IN the chain of sweeps (17 us each for 8 us of traffic: a
+// short march is latency-bound) and the stream hand-over behind the RCCL kernel is exposed (profiles/r06_probe_slab.md).  Here a group of
+// four steps is two INDEPENDENT chains that meet once per group:
+//   comp stream : A_int (cur -> mid, the layers that read own cells only), B_int (mid -> nxt, the layers that read only what A_int wrote)
+//   halo stream : P = the boundary layers of nxt (own layers < 4 from an exchanged side, four steps ahead) straight from cur and its four
+//                 halo layers - two short two-step passes through a scratch array (12 -> 8 -> 4 layers per side); X = send / receive of
+//                 those layers and of the halos of nxt.
+//   A_int(g+1) waits for P(g) (recorded a whole group earlier: no hand-over latency); P(g+1) for B_int(g) and, in stream order, X(g).
+// P recomputes what A_int / B_int also touch at the seam (12 + 8 layers per side and group instead of 4 + 4: +6 % of a 64-layer slab) - from
+// the same inputs in the same order, so every cell still gets the bits of the serial run.  Three state arrays in rotation (cur -> mid -> nxt):
+// X(g) writes halos nobody reads any more, P(g) writes layers of nxt that B_int(g-1) has finished reading.
+// ---------------------------------------------------------------------------------------------------------
+template <class Ops>
+int euler4p_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs_t *rhs, int lower, int upper, void *buf_a, void *const *ext4,
+                double dt, int64_t nsteps, void **result, void *comp)
+{
+    constexpr long D = 4;
+    void *halo = ops.halo();
+    const int xe = xends(lower, upper);
+    const long n = q.nloc;
+    char *cur = static_cast<char *>(ext4[0]), *mid = static_cast<char *>(ext4[1]), *nxt = static_cast<char *>(ext4[2]);
+    char *tmp = static_cast<char *>(ext4[3]);
+    SLAB_TRY(ops.copy(layer(cur, q, D), layer(buf_a, q, 1), (size_t)n * q.lp, comp));
+    pdehip_bc_face_t faces[2 * PDEHIP_MAX_DIM];
+    local_faces(rhs->bc_c, lower, upper, faces);
+    auto sweep2 = [&](void *st, char *src, char *dst, long first, long count, int xplain, int ends) -> int {
+        if (count <= 0) return 0;
+        pdehip_grid_t gs = *g;
+        gs.shape[0] = count;
+        pdehip_bc_face_t sf[2 * PDEHIP_MAX_DIM];
+        for (int i = 0; i < 2 * PDEHIP_MAX_DIM; i++) sf[i] = faces[i];
+        sf[1].index1 += count - n; sf[1].index2 += count - n;   // a physical upper face: indices count from the first layer of the range
+        bool done = false;
+        SLAB_TRY(ops.euler2(&gs, layer(src, q, first - 1), layer(dst, q, first - 1), rhs->param, dt, sf, st, &done, xplain, false, ends));
+        if (!done) return ops.fail("internal: two-step kernel refused a sub-slab");
+        return 0;
+    };
+    // `depth` layers next to every EXCHANGED side of the range [first, first + count), real layers beyond both ends of each piece
+    auto seams = [&](void *st, char *src, char *dst, long first, long count, long depth) -> int {
+        if (lower >= 0 && upper >= 0) return sweep2(st, src, dst, first, count, 1, (int)depth);   // both in ONE launch
+        if (lower >= 0) return sweep2(st, src, dst, first, depth, 1, 0);
+        if (upper >= 0) return sweep2(st, src, dst, first + count - depth, depth, 1, 0);
+        return 0;
+    };
+    // layers the interior sweeps produce: a physical side is part of them (its face is applied by the kernel)
+    const long a0 = lower >= 0 ? D + 2 : D, a1 = upper >= 0 ? n + D - 2 : n + D;       // A_int
+    const long b0 = lower >= 0 ? 2 * D : D, b1 = upper >= 0 ? n : n + D;               // B_int
+    const long lo = lower >= 0 ? D - 2 : D, hi = upper >= 0 ? n + D + 2 : n + D;       // pass 1 of P spans [lo, hi)
+    SLAB_TRY(ops.record(EV_COMP, comp));
+    SLAB_TRY(ops.wait(halo, EV_COMP));
+    SLAB_TRY(exchange_deep(ops, q, cur, D, lower, upper, halo));
+    const int64_t groups = nsteps / 4, rest = nsteps - 4 * groups;
+    for (int64_t k = 0; k < groups; k++) {
+        if (k > 0) {
+            SLAB_TRY(ops.wait(comp, EV_BND2));   // P(k-1): the seam layers of cur
+            SLAB_TRY(ops.wait(halo, EV_BND));    // B_int(k-1): cur next to the seams, and it has let go of what P(k) overwrites
+        }
+        // boundary chain first: its few workgroups should be dispatched before the sweeps fill the chip
+        SLAB_TRY(seams(halo, cur, tmp, lo, hi - lo, 2 * D));      // two steps: 8 layers per exchanged side
+        SLAB_TRY(seams(halo, tmp, nxt, D, n, D));                 // two more: the 4 own layers per exchanged side
+        SLAB_TRY(ops.record(EV_BND2, halo));
+        if (k + 1 < groups || rest > 0) SLAB_TRY(exchange_deep(ops, q, nxt, D, lower, upper, halo));
+        SLAB_TRY(sweep2(comp, cur, mid, a0, a1 - a0, xe, 0));     // A_int
+        SLAB_TRY(sweep2(comp, mid, nxt, b0, b1 - b0, xe, 0));     // B_int
+        SLAB_TRY(ops.record(EV_BND, comp));
+        char *t = cur; cur = nxt; nxt = mid; mid = t;
+    }
+    SLAB_TRY(ops.record(EV_HALO, halo));
+    SLAB_TRY(ops.wait(comp, EV_HALO));
+    if (rest >= 2) {
+        const long lo2 = (rest == 3 && lower >= 0) ? D - 1 : D, hi2 = (rest == 3 && upper >= 0) ? n + D + 1 : n + D;
+        SLAB_TRY(sweep2(comp, cur, mid, lo2, hi2 - lo2, xe, 0));
+        char *t = cur; cur = mid; mid = t;
+    }
+    if (rest % 2) {
+        SLAB_TRY(ops.lap(g, layer(cur, q, D - 1), layer(cur, q, D - 1), layer(mid, q, D - 1), K_EULER, rhs->param, dt, 0.0, faces, comp, nullptr));
+        char *t = cur; cur = mid; mid = t;
+    }
+    SLAB_TRY(ops.copy(layer(buf_a, q, 1), layer(cur, q, D), (size_t)n * q.lp, comp));
+    *result = buf_a;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_out = dt * rhs(in) on the slab, followed in the same sweep (flags & F_FUSED_STAGE) by the Runge-Kutta combination
 // `sf`; Euler form (out = in + dt*rhs(in)) with euler = true and sf = NULL.  `in` (and for Cahn-Hilliard `out`) are slab
 // arrays with ONE SPARE LAYER of allocated memory beyond each ghost layer, so that the same memory is the two-halo-layer

@@ -227,6 +227,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_euler2_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    "release_scratch": [],
     "slab_euler4_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_euler4_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "slab_ch_supported": [_pg, _pr, C.POINTER(_i)],

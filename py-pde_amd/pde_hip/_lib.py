@@ -14,8 +14,16 @@ from pathlib import Path
 
 from . import _abi
 
-# PDEHIP_LIB: another build of the same library (A/B timing of kernel variants); default = the in-tree build
-LIB_PATH = Path(os.environ.get("PDEHIP_LIB") or (Path(__file__).resolve().parent.parent / "lib" / "libpdehip.so"))
+# The library is the in-tree build.  PDEHIP_LIB=<path> (another build of the same library: A/B timing of kernel variants, the test
+# harness's multi-process workers) is honoured ONLY together with PDEHIP_ALLOW_LIB_OVERRIDE=1 - a lone environment variable must not be
+# able to redirect the product to some other ABI-compatible object; set without the permission it is an error.
+_IN_TREE = Path(__file__).resolve().parent.parent / "lib" / "libpdehip.so"
+_OVERRIDE = os.environ.get("PDEHIP_LIB")
+if _OVERRIDE and os.environ.get("PDEHIP_ALLOW_LIB_OVERRIDE") != "1":
+    msg = ("PDEHIP_LIB is set but PDEHIP_ALLOW_LIB_OVERRIDE=1 is not: refusing to load another library in place of "
+           f"{_IN_TREE} (development / test harness only)")
+    raise ImportError(msg)
+LIB_PATH = Path(_OVERRIDE) if _OVERRIDE else _IN_TREE
 
 _E_VALUE, _E_NOTIMPL = 1, 2
 

@@ -101,6 +101,17 @@ def default_control():
     return SerialControl()
 
 
+def agree_on_environment(control, names) -> None:
+    """The schedule switches the C loops read from the environment (``PDEHIP_SLAB_*``, ``PDEHIP_BLOCK2_*``) change WHICH messages a rank
+    sends and in WHICH order; RCCL pairs sends and receives by order only, so ranks with different settings would exchange the wrong
+    layers without any error.  Every rank publishes its settings; any difference is an error on every rank."""
+    mine = tuple(os.environ.get(n, "") for n in names)
+    everyone = control.allgather(mine)
+    if any(e != everyone[0] for e in everyone):
+        msg = "the ranks disagree on " + ", ".join(names) + ": " + "; ".join(f"rank {r}: {e}" for r, e in enumerate(everyone))
+        raise RuntimeError(msg)
+
+
 def rccl_library_path() -> str:
     """The librccl.so libpdehip resolves with dlsym: the copy torch ships (one RCCL per process when torch's own
     RCCL backend is also in use), else the system one; ``PDEHIP_RCCL`` overrides."""
@@ -207,6 +218,7 @@ class SlabStepper:
             self.lib.comm_create(path, uid, self.rank, self.size, C.byref(self.comm))
         # code paths: every rank asks its library, the answers are ANDed over all ranks, so that nobody exchanges two
         # layers while its neighbour exchanges one
+        agree_on_environment(self.control, ("PDEHIP_SLAB_EULER2", "PDEHIP_SLAB_EULER4", "PDEHIP_SLAB_DEEP_MODE", "PDEHIP_SLAB_THICK", "PDEHIP_SLAB_RIM"))
         local = C.c_int(0)
         self.lib.slab_flags_supported(C.byref(self.g), C.byref(self.rhs), self._lo, self._up, C.byref(local))
         e2 = C.c_int(0)
@@ -396,11 +408,17 @@ class SlabStepper:
         return self.gather(cur), info
 
     def close(self) -> None:
-        """Release the communicator and the stream (the stepper cannot be used afterwards; its arrays are freed with the object)."""
+        """Release the communicator (with its scratch arrays) and the stream (the stepper cannot be used afterwards; its arrays are freed
+        with the object).  Without a communicator the loops used the process-wide scratch: handed back too (allocated again on demand)."""
         if self.comm is not None:
             self.synchronize()
             self.lib.comm_destroy(self.comm)
             self.comm = None
+        elif getattr(self, "stream", None) is not None:
+            try:
+                self.lib.release_scratch()
+            except Exception:  # noqa: BLE001 - see below
+                pass
         if getattr(self, "stream", None) is not None:
             stream, self.stream = self.stream, None
             try:
@@ -483,6 +501,7 @@ class BlockStepper:
         # periodic on every axis and not cut along the fastest one.  Decided for ALL ranks alike (PDEHIP_BLOCK2=0: the exact one-step loop).
         nd = len(grid.shape)
         self.cut = [int(self.dims[a] > 1 or (force_exchange and bool(grid.periodic[a]))) for a in range(nd)]
+        agree_on_environment(self.control, ("PDEHIP_BLOCK2", "PDEHIP_BLOCK2_MODE", "PDEHIP_BLOCK2_DIRECT", "PDEHIP_BLOCK2_CUS"))
         fast = 0
         if (nd == 3 and all(grid.periodic) and self.kind == _abi.RHS_DIFFUSION and self.bc_program is None
                 and os.environ.get("PDEHIP_BLOCK2", "1") != "0"):
@@ -593,11 +612,17 @@ class BlockStepper:
         return self.gather(cur), info
 
     def close(self) -> None:
-        """Release the communicator and the stream (the stepper cannot be used afterwards; its arrays are freed with the object)."""
+        """Release the communicator (with its scratch arrays) and the stream (the stepper cannot be used afterwards; its arrays are freed
+        with the object).  Without a communicator the loops used the process-wide scratch: handed back too (allocated again on demand)."""
         if self.comm is not None:
             self.synchronize()
             self.lib.comm_destroy(self.comm)
             self.comm = None
+        elif getattr(self, "stream", None) is not None:
+            try:
+                self.lib.release_scratch()
+            except Exception:  # noqa: BLE001 - see below
+                pass
         if getattr(self, "stream", None) is not None:
             stream, self.stream = self.stream, None
             try:

@@ -102,14 +102,28 @@ def _install_evolution_rate_dispatch() -> None:
         return
     original = PDE.make_evolution_rate
 
-    def make_evolution_rate(self, state, backend):
-        resolved = get_backend(backend)
-        if getattr(resolved, "implementation", None) == "hip":
-            return resolved.make_pde_rhs(self, state)
-        return original(self, state, backend)
+    import functools
+    import inspect
+
+    signature = inspect.signature(original)
+
+    @functools.wraps(original)
+    def make_evolution_rate(self, *args, **kwargs):
+        #  the call is passed on exactly as it came - whatever parameters, keywords and defaults the installed py-pde has;
+        # only a backend argument that IS this backend (an object or the registered name "hip") is intercepted
+        try:
+            bound = signature.bind(self, *args, **kwargs)
+            bound.apply_defaults()
+            backend = bound.arguments.get("backend")
+            state = bound.arguments.get("state")
+        except TypeError:
+            return original(self, *args, **kwargs)    # let py-pde raise its own error for a malformed call
+        is_hip = getattr(backend, "implementation", None) == "hip" or backend == "hip"
+        if not is_hip or state is None:
+            return original(self, *args, **kwargs)
+        return get_backend(backend).make_pde_rhs(self, state)
 
     make_evolution_rate._hip_dispatch = True  # type: ignore[attr-defined]
-    make_evolution_rate.__doc__ = original.__doc__
     PDE.make_evolution_rate = make_evolution_rate  # type: ignore[method-assign]
 
 

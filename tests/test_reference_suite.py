@@ -75,6 +75,10 @@ SUITES: dict[str, dict[str, str]] = {
 }
 
 
+# the reference's statistical tests that draw from an unseeded generator (see test_reference_generic_tests_with_hip)
+STATISTICAL = ("test_stochastic_solvers_two_interfaces", "test_stochastic_solver_equilibrium", "test_stochastic_solvers_geometric_brownian_motion", "test_stochastic_solvers[")
+
+
 def _run(rel: str, fused: bool) -> dict[str, str]:
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([str(HERE), str(REF), env.get("PYTHONPATH", "")])
@@ -104,12 +108,13 @@ def test_reference_generic_tests_with_hip(rel, fused):
     results = _run(rel, fused)
     assert all("hip" in name for name in results), results
     unexpected = {n: r for n, r in results.items() if r != "PASSED" and not any(k in n for k in expected_fail)}
-    if unexpected:
-        # some of the reference's tests are statistical with an UNSEEDED generator (`np.random.randn` inside a user function of
-        # test_stochastic_solvers_two_interfaces, Kolmogorov-Smirnov tests): one in a few hundred runs fails for every backend.  A failure must
-        # repeat to count; a deterministic one does
+    flaky = {n: r for n, r in unexpected.items() if any(k in n for k in STATISTICAL)}
+    if flaky:
+        # a few of the reference's tests are statistical with an UNSEEDED generator (`np.random.randn` inside a user function, Kolmogorov-
+        # Smirnov tests): one in a few hundred runs fails for every backend.  For THOSE (an explicit list, ADVICE r5 - a retry of everything
+        # would also hide stream races or uninitialised halos of this backend) a failure must repeat to count
         again = _run(rel, fused)
-        unexpected = {n: r for n, r in unexpected.items() if again.get(n) != "PASSED"}
+        unexpected = {n: r for n, r in unexpected.items() if n not in flaky or again.get(n) != "PASSED"}
     assert not unexpected, f"{rel}: {unexpected}"
     stale = [k for k in expected_fail if any(k in n and r == "PASSED" for n, r in results.items())]
     assert not stale, f"{rel}: listed as 'next' but passing now: {stale}"

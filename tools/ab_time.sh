@@ -4,9 +4,9 @@
 B=${1:?path to the other libpdehip.so}
 for r in 1 2 3; do
   timeout 100 python tools/time_euler2.py 512 200 2>&1 | tail -1 | sed 's/^/A /'
-  PDEHIP_LIB=$B timeout 100 python tools/time_euler2.py 512 200 2>&1 | tail -1 | sed 's/^/B /'
+  PDEHIP_ALLOW_LIB_OVERRIDE=1 PDEHIP_LIB=$B timeout 100 python tools/time_euler2.py 512 200 2>&1 | tail -1 | sed 's/^/B /'
 done
 for n in 256 128,512,512; do
   timeout 100 python tools/time_euler2.py $n 300 2>&1 | tail -1 | sed 's/^/A /'
-  PDEHIP_LIB=$B timeout 100 python tools/time_euler2.py $n 300 2>&1 | tail -1 | sed 's/^/B /'
+  PDEHIP_ALLOW_LIB_OVERRIDE=1 PDEHIP_LIB=$B timeout 100 python tools/time_euler2.py $n 300 2>&1 | tail -1 | sed 's/^/B /'
 done

@@ -128,6 +128,23 @@ struct InputBCs {
     long idx[3][2];
     double c[3][2], f[3][2];
 };
+// periodic (1) / local (0) / not covered (-1) classification of the two faces of one axis
+inline int classify_axis(const InputBCs &fg, int ax, long n)
+{
+    const bool on = fg.on[ax][0] && fg.on[ax][1];
+    const bool per = on && fg.idx[ax][0] == n - 1 && fg.idx[ax][1] == 0 && fg.c[ax][0] == 0 && fg.c[ax][1] == 0 &&
+                     fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
+    const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n - 1;
+    return per ? 1 : (loc ? 0 : -1);
+}
+// every array of a Runge-Kutta stage epilogue on a 16-byte boundary (the vector accesses of the stage sweeps)
+inline bool stage_aligned(const LapArgs &a)
+{
+    uintptr_t bits = (uintptr_t)a.st_y | (uintptr_t)a.st_out;
+    for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
+    return bits % 16 == 0;
+}
+bool force_generic_kernels();   // PDEHIP_FORCE_GENERIC=1 (pdehip_kernels.hip)
 // StageFuse (what follows a slope k = dt*rhs in a Runge-Kutta scheme, fused into the sweep that computes k): pdehip_slab_loops.h
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,
                    double s2, double gamma, const void *y, hipStream_t st, const InputBCs *fg = nullptr,
@@ -137,6 +154,8 @@ int launch_div_march(const NGrid &n, int method, const void *in, void *out, cons
 bool laplace_can_fuse_bcs(const NGrid &n, const void *in, const void *out, const void *y);
 int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void *data, hipStream_t st);
 int preload_shell_kernels();     // pdehip_shell.hip: the same for its code object
+int preload_e2_kernels();        // pdehip_kernels_e2.hip
+int preload_t2_kernels();        // pdehip_kernels_t2.hip
 int preload_stencil_kernels();   // pdehip_kernels.hip: load the code object of the stencil kernels now (see pdehip_set_device)
 // launch configuration of the two-level kernel handed to a caller that launches a run-time compiled instance itself
 struct Euler2Plan {

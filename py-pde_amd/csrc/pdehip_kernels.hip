@@ -22,8 +22,6 @@ namespace pdehip {
 
 
 #include "pdehip_march.inc"
-#include "pdehip_march2.inc"
-#include "pdehip_tile2d.inc"
 #include "pdehip_div.inc"
 
 // ---------------------------------------------------------------------------------------------
@@ -147,12 +145,6 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     return 0;
 }
 
-static bool stage_aligned(const LapArgs &a)
-{
-    uintptr_t bits = (uintptr_t)a.st_y | (uintptr_t)a.st_out;
-    for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
-    return bits % 16 == 0;
-}
 
 template <typename T, int MODE>
 static int launch_laplace_t(const NGrid &n, const LapArgs &a, const OutStr &o, hipStream_t st)
@@ -435,478 +427,9 @@ int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, i
 #undef PDEHIP_MODE_SWITCH
 }
 
-// ---------------------------------------------------------------------------------------------
-// two Euler steps per sweep (pdehip_march2.inc).  *done = false when the grid / BCs are outside
-// what the kernel covers; the caller then takes two single steps.
-// ---------------------------------------------------------------------------------------------
-struct Tune2 { int ry; long blocks; int off; bool set; int order; };
-static const Tune2 &tune2()
-{
-    static Tune2 t = {0, 0, 0, false, -1};
-    if (!t.set) {
-        t.set = true;
-        // PDEHIP_EULER2="ry,blocks,waves" tile rows / wave tiles per sweep / waves per workgroup (tuning aid),
-        // PDEHIP_EULER2=off disables the kernel
-        const char *e = getenv("PDEHIP_EULER2");
-        if (e && !strcmp(e, "off")) t.off = 1;
-        else if (e) sscanf(e, "%d,%ld,%d", &t.ry, &t.blocks, &t.order);
-    }
-    return t;
-}
-
-// fp32 tiles (fp32 storage, fp64 registers).  The wide tile - 4 cells per lane (16-byte accesses), 2 rows - is at 252 VGPRs
-// without room for the stage epilogue (256 + 64 B of scratch with it).  The NARROW tile - 2 cells per lane (8-byte accesses),
-// 4 rows, the shape of the fp64 tile - needs 194 VGPRs (204 with the stage epilogue) and recomputes 1.5 x instead of 2 x of
-// the intermediate level.  PDEHIP_F32_TILE="vec,ry[,stage_vec,stage_ry]" overrides the choice (tuning aid).
-struct TuneF32 { int vec, ry, svec, sry; };
-static const TuneF32 &tune_f32()
-{
-    static TuneF32 t = {0, 0, 0, 0};
-    static bool set = false;
-    if (!set) {
-        set = true;
-        const char *e = getenv("PDEHIP_F32_TILE");
-        if (e) sscanf(e, "%d,%d,%d,%d", &t.vec, &t.ry, &t.svec, &t.sry);
-    }
-    return t;
-}
-
-template <typename T, int VEC>
-static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
-                            Euler2Plan *plan, int ry_f32)
-{
-    constexpr int CW = 64 * VEC;
-    const Tune2 &t2 = tune2();
-    // fp64: 4-row tiles (226 VGPRs, 2 waves per SIMD); fp32: see tune_f32()
-    const bool has_y = n.ndim == 3;   // 2-D: march along the first grid axis, a "plane" is one row (a.n1 == 1)
-    int ry = (t2.ry && t2.ry != 8) ? t2.ry : 4;   // (8: the tall tile where it applies, see `tall`)
-    if (sizeof(T) == 4) ry = ry_f32;
-    // the tall tile (8 rows, one wave per SIMD, four plane buffers: pdehip_march2.inc): the plain two-step diffusion sweep of fp64
-    // grids whose rows end at chunk boundaries.  PDEHIP_EULER2=8 selects it (measurement: profiles/r03_e2_tile_shapes.log)
-    // Round 5 (rows on 128-byte lines): the tall tile wins for fields well beyond the Infinity Cache - 512^3 0.2157 -> 0.2108 ms per step (mean of
-    // four alternations), 512 x 512 x 256 +3.7 %, 384^3 +2.6 % - and loses below (256^3 -3 %, 128 x 512 x 512 -0.7 %): profiles/r05_ab_tall_tile.log.
-    // PDEHIP_EULER2=8 forces it, PDEHIP_EULER2=4 the 4-row tile.  (The tall tile WITH the ragged-row code, for extents that are not multiples of the tile,
-    // was built and measured slower than the 4-row tile everywhere - 513^3 440 against 479, 511^3 538 against 599 Gcell-steps/s: profiles/r05_ab_tall_ragged.log.)
-    const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0;
-    const bool tall = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
-                      (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
-    // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
-    // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
-    // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
-    // of non-periodic rows has no exactly fitting tile at all.
-    // "Open" rows: a row one to eight cells longer than a whole number of chunks (513 = 4 x 128 + 1) gave the moved last chunk a wave of
-    // its own that marched every plane for one vector - 25 % more waves (fp64 513^3 0.281 against 0.228 ms per step at 512^3, fp32 0.268
-    // against 0.167).  Instead the tiles cover the whole chunks - the halo columns right of the last one are real cells, or the virtual
-    // column through the `zhi2` code of the ragged instances - and the remaining columns are recomputed from the input by the LDS-tiled
-    // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
-    static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
-    long open_tail = 0;
-    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
-    const long n2t = a.n2 - open_tail;   // the columns the tiles cover
-    const int ry_want = ry;
-    while (ry > 1 && a.n1 % ry) ry /= 2;
-    if (has_y && ry < ry_want) {
-        int big = ry_want;
-        while (big > ry && a.n1 < 8L * big) big /= 2;
-        if (big > ry) ry = big;
-        else if (ry == 1) ry = 2;   // (1-row tiles exist for periodic rows of fp32 grids only and recompute 3 x)
-    }
-    // the stage epilogue (six more streams) does not fit the ragged 4-row fp64 tile without spilling: 2-row tiles there
-    const long n2v = (n2t + VEC - 1) / VEC * VEC;   // a row that ends inside a vector: the last chunk is moved back by n2v - n2 cells
-    if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
-    if (!has_y) ry = 1;
-    if (tall) ry = 8;
-    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
-    const bool overlap = n2v != n2t || a.n1 % ry != 0;
-    // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
-    // with local faces): the narrow tile takes those grids (launch_euler2_t)
-    if (sizeof(T) == 4 && VEC == 4 && ((has_y && a.n1 % ry != 0 && !a.per[1]) || (a.n2 % CW == 1 && !a.per[2]))) return 0;
-    if (overlap && m2 == E2_CH_STAGE) {
-        // cells of overlapping tiles are computed and stored twice: nothing a sweep writes may be one of its pointwise inputs
-        // (the new state of RK4 written over the old one: those sweeps combine with the pointwise kernels)
-        bool alias = a.st_out == a.st_y || a.out == a.st_y;
-        for (int m = 0; m < 5; m++) alias = alias || (a.st_k[m] && (a.st_k[m] == a.st_out || a.st_k[m] == a.out));
-        if (alias) return 0;
-    }
-    a.ntz = (n2t + CW - 1) / CW;   // the row may end inside the last chunk
-    a.z_open = open_tail > 0;
-    a.nty = (a.n1 + ry - 1) / ry;
-    const long tiles = a.ntz * a.nty;
-    // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
-    if (ends > 0) {
-        // boundary sweep of a slab: the first and the last `ends` planes in ONE launch
-        a.lx = ends; a.nxc = 2; a.xstride = a.n0 - ends;
-    } else if (!has_y) {
-        // 2-D: a wave's march is a chain of dependent row loads (~1 us each out of the Infinity Cache for grids of a few
-        // MB), so short chunks win until the chip is full: up to ~4096 waves, chunks of at least `minlx` rows (the
-        // 4 overlap rows per chunk cost no HBM traffic for cache-resident grids)
-        const long minlx = t2.order > 0 ? t2.order : 2;
-        long nxc = (t2.blocks ? t2.blocks : 4096) / tiles;
-        if (nxc > a.n0 / minlx) nxc = a.n0 / minlx;
-        if (nxc < 1) nxc = 1;
-        const long lx = (a.n0 + nxc - 1) / nxc;
-        a.lx = (int)lx;
-        a.nxc = (a.n0 + lx - 1) / lx;
-        a.xstride = lx;
-    } else {
-        // ONE full round of 2048 wave tiles (256 CUs x 8 wave slots at 2 waves per SIMD): measured best or equal from 64 to
-        // 512 planes (0.126 vs 0.131 ms/step at 256 planes, 0.066 vs 0.071 at 128 with 4096 tiles; in the slab loop the
-        // boundary sweep and the RCCL kernel otherwise queue up behind the second round:
-        // profiles/r01_time_tiles_vs_planes.log).  Interior sweep of a THIN slab (exchange-bound): at most 1536, so that
-        // the RCCL kernel of the halo stream finds free wave slots at once — workgroups march for the whole sweep, a kernel
-        // launched behind a full round waits for it to end (measured: 90 us for 13 us of work).
-        const bool thin = xplain && a.n0 < 96;
-        // a box of the fast block loop (plain rows / columns): 7/8 of a round - the rim, pack, RCCL and unpack kernels of the halo stream
-        // otherwise wait for the END of the sweep (0.0536 -> 0.0501 ms per step at 256 x 128 x 512, profiles/r05_probe_block.md)
-        const bool boxed = a.per[1] == 2 || a.per[2] == 2;
-        const bool wide1 = sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y;   // (euler2_stage1w_kernel: one wave per SIMD)
-        const long cap = t2.blocks ? t2.blocks : ((tall || wide1) ? 1024 : (thin ? 1536 : (boxed ? 1792 : 2048)));   // (the tall tile runs one wave per SIMD)
-        static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
-        long nxc;
-        if (thin) {
-            nxc = cap / tiles;
-            long minlx = 16;
-            while (minlx > 2 && tiles * (a.n0 / minlx) < cap) minlx /= 2;
-            if (floor_env > 0) minlx = floor_env;
-            if (nxc > a.n0 / minlx) nxc = a.n0 / minlx;
-            if (nxc < 1) nxc = 1;
-        } else {
-            // The number of x-chunks by a cost model.  A wave marches lx + 2 planes; the chip holds `cap` of them.  While they
-            // fit (W <= cap) the sweep is bound by the bytes (W * L) down to the latency floor of a lone march; beyond, the
-            // waves left over for the last round march ALONE at that floor: tile counts just above a divisor of `cap` (512 x 513
-            // x 512: 516 tiles, 4 chunks = 2064 waves took 0.307 ms per step against 0.225 for 512^3; 300^3: 225 tiles, 10
-            // chunks = 2250 waves) take one chunk less instead.  Chunks shorter than 16 planes (two recomputed planes per
-            // chunk: > 12.5 % extra work) only while the first round is not full (100^3: 19.7 -> 8.1 us per step).
-            double best = 0;
-            nxc = 1;
-            for (long c = 1; c <= a.n0 / 2 || c == 1; c++) {
-                const long lx = (a.n0 + c - 1) / c, real = (a.n0 + lx - 1) / lx;
-                if (real != c) continue;   // the same chunking as a smaller count
-                if (floor_env > 0 ? lx < floor_env : (lx < 16 && (c - 1) * tiles >= cap)) break;
-                const long W = real * tiles;
-                const double full = (double)(W / cap), part = (double)(W % cap) / (double)cap;
-                // a wave needs 1.6 - 1.9 us per plane whether the chip is full or not (200^3: 1200 waves of 19 planes took as long
-                // per plane as 2000 waves of 12): one round costs its march length, nearly whatever its size; the waves of an
-                // incomplete LAST round start while the round before drains (measured: 0.36 of a round for a handful)
-                double rounds = W <= cap ? 0.85 + 0.15 * (double)W / (double)cap : full + (part > 0 ? (part > 0.36 ? part : 0.36) : 0.0);
-                const double cost = (double)(lx + 2) * rounds;
-                if (best == 0 || cost < best) { best = cost; nxc = c; }
-            }
-        }
-        const long lx = (a.n0 + nxc - 1) / nxc;
-        a.lx = (int)lx;
-        a.nxc = (a.n0 + lx - 1) / lx;
-        a.xstride = lx;
-    }
-    // waves per workgroup = neighbouring chunks of the same rows (1, 2 or 4; PDEHIP_EULER2 third field overrides)
-    int nwz = (a.ntz % 4 == 0) ? 4 : (a.ntz % 2 == 0 ? 2 : 1), nwy = 1;
-    if (has_y && t2.order > 0) {   // tuning aid: third field = 10 * (waves along the rows) + (waves along the fastest axis)
-        const int wz_ = t2.order % 10, wy_ = t2.order / 10 > 0 ? t2.order / 10 : 1;
-        if (wz_ > 0 && a.ntz % wz_ == 0 && a.nty % wy_ == 0 && wz_ * wy_ <= 4) { nwz = wz_; nwy = wy_; }
-    }
-    a.nwy = nwy;
-    a.nblocks = a.nxc * tiles / (nwz * nwy);
-    a.no_swizzle = 0;
-    const dim3 grid((unsigned)a.nblocks), block(64 * nwz * nwy);
-    // real halo planes instead of BCs on the slowest axis: both sides (1), upper side only (2), lower side only (3)
-    if (xplain) a.per[0] = xplain == 1 ? 2 : (xplain == 2 ? 3 : 4);
-    if (plan) {   // the caller launches a run-time compiled instance itself (pdehip_jit.hip)
-        if (has_y ? (ry != 2 && ry != 4) : ry != 1) return 0;
-        plan->a = a; plan->grid = (unsigned)a.nblocks; plan->block = 64u * nwz * nwy; plan->ry = ry; plan->has_y = has_y;
-        *done = true;
-        return 0;
-    }
-    // the stage epilogue exists for real halo layers on BOTH sides (a run-time argument of the plain instances) but not as
-    // one-sided (XS) instances: the first / last slab of a non-periodic axis combines with the pointwise kernels
-    if (m2 == E2_CH_STAGE && xplain > 1) return 0;
-    if constexpr (sizeof(T) == 8 && VEC == 2) {
-        if (tall) {
-            if (dry_run) { *done = true; return 0; }
-            const bool nt_ = ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
-            const bool unit_ = a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
-            if (unit_ && nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
-            else if (unit_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
-            else if (nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, false>), grid, block, 0, st, a);
-            PDEHIP_HIP(hipGetLastError());
-            *done = true;
-            return 0;
-        }
-    }
-    {   // is there an offline instance of this tile?  (the list below, PDEHIP_E2; asked before a dry run answers "covered")
-        const bool xs_ = xplain > 1;
-        bool have;
-        if (!has_y) have = ry == 1 && !xs_ && (sizeof(T) == 8 || VEC == 4);
-        else if (sizeof(T) == 8) have = ry == 4 || ry == 2;
-        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_);
-        else have = ry == 4 || ry == 2 || (ry == 1 && !xs_);
-        if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = ry == 2 && !xs_;   // (two waves per SIMD: 256 VGPRs + scratch; ry 2: euler2_stage1w_kernel)
-        // a 1-row tile of a 3-D grid is its own neighbour's halo: the tile of row 1 reads the virtual row -1, which only the
-        // tile of row 0 transforms (`ylo`) - correct for periodic rows only
-        if (has_y && ry == 1 && !a.per[1]) have = false;
-        if (!have) return 0;
-    }
-    if (dry_run) { *done = true; return 0; }
-    if (m2 == E2_CUSTOM || m2 == E2_CUSTOM2) PDEHIP_FAIL(E_RUNTIME, "internal: the custom two-level kernel exists only as a run-time build");
-    // the variant without the ragged-row code (rows end at chunk boundaries) exists for the 4-row fp64 tile only: there
-    // the 5 VGPRs decide whether the loads can be issued early (8-19 % at 256^3 and slab-sized grids)
-    // XS: the one-sided halo modes of the first / last slab of a non-periodic axis are separate instances (with the
-    // ragged-row code): compiled into the hot instances they cost 5-9 % through register allocation alone
-    const bool xs = xplain > 1;
-    // (the virtual rows next to a moved last tile - pdehip_march2.inc: ylo2 / yhi2 - are part of the ragged-row code)
-    // (... and so is the virtual FAR column right of the last chunk of an open row with one more cell: zhi2)
-    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && a.n1 % ry != 0 && !a.per[1]) || (open_tail == 1 && !a.per[2]);
-    // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
-#if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
-    const bool nt = false;   // A/B variant: non-temporal loads, plain stores
-#else
-    const bool nt = !ragged && m2 != E2_CH_STAGE && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
-#endif
-    // unit spacing and D = 1 (UnitGrid benchmarks): the 3-D instances exist without the multiplications by 1.0 (fp32 and the
-    // cache-resident sizes are VALU-bound: up to 10 %)
-    static const bool unit_off = getenv("PDEHIP_NO_UNIT") != nullptr;   // A/B aid
-    const bool unit = !unit_off && a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
-#define PDEHIP_E2(RY_, HY_, RG_, XS_, NT_)                                                                                               \
-    if (!launched && ry == RY_ && has_y == HY_ && ragged == RG_ && xs == XS_ && nt == NT_) {                                             \
-        launched = true;                                                                                                                 \
-        if (m2 == E2_DIFFUSION) {                                                                                                       \
-            if constexpr (!XS_) {   /* every instance except the one-sided slab ends */                                                       \
-                if (unit) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION_UNIT, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);  \
-                else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);            \
-            } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_DIFFUSION, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);             \
-        }                                                                                                                                \
-        else if (m2 == E2_CH_EULER) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_EULER, HY_, RG_, XS_, NT_>), grid, block, 0, st, a); \
-        else if (m2 == E2_CH_STAGE) {                                                                                                    \
-            if constexpr (!XS_ && !NT_ && !(sizeof(T) == 8 && RY_ == 4 && RG_) && !(sizeof(T) == 4 && VEC == 4 && HY_ && RY_ > 1)) hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_STAGE, HY_, RG_, false, false>), grid, block, 0, st, a); \
-            else return 0;                                                                                                               \
-        } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
-    }
-    bool launched = false;
-    if constexpr (sizeof(T) == 4 && VEC == 4) {
-        if (m2 == E2_CH_STAGE && ry == 2 && has_y && !xs) {   // the wide fp32 stage tile at one wave per SIMD (pdehip_march2.inc)
-            hipLaunchKernelGGL((euler2_stage1w_kernel<T, VEC, 2, true>), grid, block, 0, st, a);
-            launched = true;
-        }
-    }
-    if constexpr (sizeof(T) == 8 || VEC == 4) {
-        PDEHIP_E2(1, false, true, false, false)
-        PDEHIP_E2(2, true, true, false, false)
-        PDEHIP_E2(2, true, true, true, false)
-    }
-    if constexpr (sizeof(T) == 8) {
-        PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(4, true, false, false, false) PDEHIP_E2(4, true, false, false, true)
-        PDEHIP_E2(4, true, true, true, false)
-    }
-    if constexpr (sizeof(T) == 4 && VEC == 4) { PDEHIP_E2(1, true, true, false, false) }   // 1-row wide tile (with the stage epilogue: 220 VGPRs)
-    if constexpr (sizeof(T) == 4 && VEC == 2) {   // narrow fp32 tiles, 3-D only
-        PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(2, true, true, false, false) PDEHIP_E2(1, true, true, false, false)
-        PDEHIP_E2(4, true, true, true, false) PDEHIP_E2(2, true, true, true, false)
-    }
-#undef PDEHIP_E2
-    if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
-    PDEHIP_HIP(hipGetLastError());
-    if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, st));   // the last one to four columns of every row
-    *done = true;
-    return 0;
-}
-
-template <typename T>
-static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
-                           Euler2Plan *plan)
-{
-    if constexpr (sizeof(T) == 8) {
-        return launch_euler2_tv<double, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 0);
-    } else {
-        const TuneF32 &tf = tune_f32();
-        const bool stage = m2 == E2_CH_STAGE;
-        // Measured at 256^3 / 512^3 (profiles/r03_f32_tiles.md): the sweeps without the stage epilogue are fastest on the wide
-        // 2-row tile (diffusion 0.0233 vs 0.0249 ms per step, Cahn-Hilliard 0.0575 vs 0.0585); the Runge-Kutta stage sweeps
-        // need the narrow 4-row tile to carry their epilogue at all (RKF45 attempt 0.786 -> 0.755 ms).  The run-time built
-        // kernels of pdehip_jit.hip keep the wide tile (`plan`).
-        int vec = 4, ry = 2;
-        if (n.ndim == 3 && !plan) {
-            if (stage) { vec = tf.svec ? tf.svec : 2; ry = tf.svec ? tf.sry : 4; }
-            else if (tf.vec) { vec = tf.vec; ry = tf.ry; }
-            else {
-                // rows that fill the 128-cell chunks of the narrow tile much better than the 256-cell chunks of the wide one
-                // (300 cells: 78 % against 59 % of the lanes own cells; 513: 80 % against 67 %)
-                // (rows one or two cells beyond whole chunks leave those cells to another kernel: launch_euler2_tv, "open" rows)
-                auto fill = [&](long cw) {
-                    const long t = a.n2 % cw;
-                    return (a.n2 > cw && t >= 1 && t <= 8) ? 1.0 : (double)a.n2 / (double)((a.n2 + cw - 1) / cw * cw);
-                };
-                const double wide = fill(256), narrow = fill(128);
-                if (narrow > 1.15 * wide) { vec = 2; ry = 4; }
-            }
-        }
-        // PDEHIP_F32_STAGE_WIDE=1: the stage sweeps on the wide 2-row tile at ONE wave per SIMD (16-byte accesses; euler2_stage1w_kernel)
-        static const int stage_wide = getenv("PDEHIP_F32_STAGE_WIDE") ? atoi(getenv("PDEHIP_F32_STAGE_WIDE")) : 0;
-        if (stage && stage_wide && n.ndim == 3 && !plan && !tf.svec) { vec = 4; ry = 2; }
-        else if (stage && vec == 4 && ry > 1 && n.ndim == 3) ry = 1;   // the wide tile carries the stage epilogue with one row only
-        if (vec == 2) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry);
-        PDEHIP_TRY((launch_euler2_tv<float, 4>(n, a, xplain, st, done, dry_run, ends, m2, plan, ry)));
-        // what the wide tile declines (rows shorter than its chunk that end inside a 4-cell vector, moved last tiles next to
-        // local faces) the narrow tile (2-cell vectors, 4 rows) may still take
-        if (!*done && n.ndim == 3 && !plan) return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 4);
-        return 0;
-    }
-}
-
-// periodic (1) / local (0) / not covered (-1) classification of the two faces of one axis
-static int classify_axis(const InputBCs &fg, int ax, long n)
-{
-    const bool on = fg.on[ax][0] && fg.on[ax][1];
-    const bool per = on && fg.idx[ax][0] == n - 1 && fg.idx[ax][1] == 0 && fg.c[ax][0] == 0 && fg.c[ax][1] == 0 &&
-                     fg.f[ax][0] == 1 && fg.f[ax][1] == 1;
-    const bool loc = on && fg.idx[ax][0] == 0 && fg.idx[ax][1] == n - 1;
-    return per ? 1 : (loc ? 0 : -1);
-}
-
-// K Euler steps of a 2-D grid per launch with the time levels in LDS (pdehip_tile2d.inc).  mode 0: diffusion (s1 = D), 1:
-// Cahn-Hilliard (gamma; fm = faces of mu).  *done = false when grid / faces / step count are not covered.
-constexpr int kTile2Halo = 8;
-int tile2d_max_steps(int mode) { return (mode == 1 || mode == 4) ? kTile2Halo / 2 : kTile2Halo; }
-
-// arguments and launch geometry of tile2d_kernel; mode 2 = the run-time built instance (pdehip_jit.hip fills par / scales)
-int plan_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
-                const InputBCs *fm, int nsteps, Tile2Args *pa, unsigned *nblocks, int *ptcw, bool *done)
-{
-    *done = false;
-    if (n.ndim != 2 || in == out || nsteps < 1 || nsteps > tile2d_max_steps(mode) || tune().force_generic) return 0;
-    if (n.n[1] >= (1L << 30) || n.n[2] >= (1L << 30)) return 0;   // 32-bit window arithmetic
-    const bool two = mode == 1 || mode == 3 || mode == 4;   // a second table of conditions: mu (Cahn-Hilliard) / the second field (mode 3) / the temporary (mode 4)
-    if (two && !fm) PDEHIP_FAIL(E_RUNTIME, "internal: tile sweep of two fields without the second table of conditions");
-    Tile2Args &a = *pa;
-    memset(&a, 0, sizeof(a));
-    for (int k = 0; k < 2; k++) {
-        const int ax = 1 + k;
-        const int cls = classify_axis(fc, ax, n.n[ax]);
-        if (cls < 0 || (two && classify_axis(*fm, ax, n.n[ax]) != cls)) return 0;
-        a.per[k] = cls;
-        for (int side = 0; side < 2; side++) {
-            a.c[0][k][side] = fc.c[ax][side]; a.f[0][k][side] = fc.f[ax][side];
-            if (two) { a.c[1][k][side] = fm->c[ax][side]; a.f[1][k][side] = fm->f[ax][side]; }
-        }
-    }
-    a.in = in; a.out = out;
-    a.n0 = n.n[1]; a.n1 = n.n[2]; a.p1 = n.p[1]; a.off = n.off; a.pc = n.pc;
-    a.sx = n.lap_scale[1]; a.sy = n.lap_scale[2];
-    a.s1 = s1; a.s2 = s2; a.gamma = gamma; a.nsteps = nsteps;
-    for (int k = 0; k < 2; k++) {   // scales of the generated epilogue's inputs (as in jit_apply_impl)
-        const double dx = n.dx[1 + k];
-        a.gs[k] = 0.25 / (dx * dx); a.dd1[k] = 2 * dx; a.dd2[k] = 1 / (dx * dx); a.dg[k] = 0.5 / dx;
-    }
-    // tile 32 x 64 (halo redundancy 1.9 x at H = 8); grids that would give fewer than one workgroup per CU take 32 x 32 tiles
-    // (2.25 x): a workgroup's K levels run one after the other on ONE CU, so spreading wins over redundancy there
-    const long tiles64 = ((n.n[2] + 63) / 64) * ((n.n[1] + 31) / 32);
-    const int tcw = tiles64 >= 256 ? 64 : 32;
-    a.tiles1 = (int)((n.n[2] + tcw - 1) / tcw);
-    *nblocks = (unsigned)(a.tiles1 * ((n.n[1] + 31) / 32));
-    *ptcw = tcw;
-    *done = true;
-    return 0;
-}
-
-int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1, double s2, double gamma, const InputBCs &fc,
-                  const InputBCs *fm, int nsteps, hipStream_t st, bool *done)
-{
-    Tile2Args a;
-    unsigned nblocks = 0;
-    int tcw = 0;
-    PDEHIP_TRY(plan_tile2d(n, in, out, mode, s1, s2, gamma, fc, fm, nsteps, &a, &nblocks, &tcw, done));
-    if (!*done) return 0;
-    *done = false;
-    const dim3 grid(nblocks), block(1024);
-#define PDEHIP_T2(T, M)                                                                                            \
-    do {                                                                                                           \
-        if (tcw == 64) hipLaunchKernelGGL((tile2d_kernel<T, M, 32, 64, kTile2Halo>), grid, block, 0, st, a);       \
-        else hipLaunchKernelGGL((tile2d_kernel<T, M, 32, 32, kTile2Halo>), grid, block, 0, st, a);                 \
-    } while (0)
-    if (n.dtype == PDEHIP_F64) {
-        if (mode == 0) PDEHIP_T2(double, 0); else PDEHIP_T2(double, 1);
-    } else {
-        if (mode == 0) PDEHIP_T2(float, 0); else PDEHIP_T2(float, 1);
-    }
-#undef PDEHIP_T2
-    PDEHIP_HIP(hipGetLastError());
-    *done = true;
-    return 0;
-}
-
-int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s2, const InputBCs &fg,
-                  int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2, const InputBCs *fg1, double gamma,
-                  Euler2Plan *plan, const StageFuse *stage, int yzplain)
-{
-    *done = false;
-    if ((m2 == E2_CH_STAGE) != (stage != nullptr)) PDEHIP_FAIL(E_RUNTIME, "internal: stage sweep without / with a stage descriptor");
-    const long vec = 16 / elem_size(n.dtype);
-    if ((m2 == E2_CH_EULER || m2 == E2_CH_SCALED || m2 == E2_CH_STAGE) && !fg1) PDEHIP_FAIL(E_RUNTIME, "internal: fused Cahn-Hilliard sweep without the faces of mu");
-    if (tune2().off || tune().force_generic || (n.ndim != 3 && n.ndim != 2) || in == out) return 0;
-    // kernel axes (march, rows, lanes) <- normalised grid axes: 3-D (0, 1, 2); 2-D (1, -, 2): the march axis is the first
-    // grid axis and there are no rows
-    const int am = n.ndim == 3 ? 0 : 1;
-    if (n.ndim == 2 && xplain) return 0;
-    if (n.n[am] < (xplain ? 1 : 4) || (n.ndim == 3 && n.n[1] < 4) || n.n[2] < 4 || n.p[am] >= (1L << 31)) return 0;
-    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[am] % vec || n.p[1] % vec) return 0;
-    LapArgs a;
-    memset(&a, 0, sizeof(a));
-    for (int k = 0; k < 3; k++) {   // k = kernel axis
-        if (k == 0 && xplain == 1) continue;
-        if (k == 0 && xplain > 1) {
-            // first / last slab of a non-periodic axis: ONE local face (the other side has real halo planes)
-            const int side = xplain == 2 ? 0 : 1;
-            const InputBCs &f1 = fg1 ? *fg1 : fg;
-            const long want = side ? n.n[am] - 1 : 0;
-            if (!fg.on[am][side] || fg.idx[am][side] != want || !f1.on[am][side] || f1.idx[am][side] != want) return 0;
-            a.ibc[0][side].on = 1; a.ibc[0][side].idx = want; a.ibc[0][side].c = fg.c[am][side]; a.ibc[0][side].f = fg.f[am][side];
-            a.ibc1[0][side].on = 1; a.ibc1[0][side].idx = want; a.ibc1[0][side].c = f1.c[am][side]; a.ibc1[0][side].f = f1.f[am][side];
-            continue;
-        }
-        if (k == 1 && n.ndim == 2) { a.per[1] = 1; continue; }
-        // block decomposition (pdehip_block2_loops.h): `n` describes a BOX of a larger array - two real halo rows (bit 0) / columns
-        // (bit 1) on either side in memory; no faces on those axes
-        if (k >= 1 && n.ndim == 3 && (yzplain & (1 << (k - 1)))) { a.per[k] = 2; continue; }
-        const int ax = (k == 0) ? am : k;
-        // both faces periodic, or both local (virtual point from the adjacent cell); the same for both levels
-        const int cls = classify_axis(fg, ax, n.n[ax]);
-        if (cls < 0 || (fg1 && classify_axis(*fg1, ax, n.n[ax]) != cls)) return 0;
-        a.per[k] = cls;
-        for (int side = 0; side < 2; side++) {
-            a.ibc[k][side].on = 1;
-            a.ibc[k][side].idx = fg.idx[ax][side];
-            a.ibc[k][side].c = fg.c[ax][side];
-            a.ibc[k][side].f = fg.f[ax][side];
-            const InputBCs &f1 = fg1 ? *fg1 : fg;
-            a.ibc1[k][side].on = 1;
-            a.ibc1[k][side].idx = f1.idx[ax][side];
-            a.ibc1[k][side].c = f1.c[ax][side];
-            a.ibc1[k][side].f = f1.f[ax][side];
-        }
-    }
-    a.gamma = gamma;
-    if (stage) {
-        if (!stage->y || !stage->out2 || stage->out2 == in || ((stage->kind == 0 || stage->kind == 3) && !out)) PDEHIP_FAIL(E_VALUE, "stage sweep: NULL or aliased array pointer");
-        a.st_kind = stage->kind; a.st_y = stage->y; a.st_out = stage->out2; a.st_err = stage->err;
-        int nk = 0;
-        for (int m = 0; m < 5 && stage->k[m]; m++, nk++) { a.st_k[m] = stage->k[m]; a.st_c[m] = stage->c[m]; }
-        if ((stage->kind == 1 && nk != 3) || (stage->kind == 2 && (nk != 4 || !stage->err)) || (stage->kind == 3 && nk != 1) ||
-            (stage->kind == 4 && (nk != 2 || !stage->err || stage->k[1] != in)))
-            PDEHIP_FAIL(E_RUNTIME, "internal: malformed stage descriptor");
-        a.st_c[5] = stage->c_new;
-        if (!stage_aligned(a)) return 0;
-    }
-    a.in = in; a.out = out; a.y = in;
-    a.n0 = n.n[am]; a.n1 = n.ndim == 3 ? n.n[1] : 1; a.n2 = n.n[2];
-    a.p0 = n.p[am]; a.p1 = n.ndim == 3 ? n.p[1] : 0; a.off = n.off;
-    a.o_off = n.off; a.o_s0 = a.p0; a.o_s1 = a.p1;
-    a.sx = n.lap_scale[am]; a.sy = n.lap_scale[1]; a.sz = n.lap_scale[2];
-    a.s1 = s1; a.s2 = s2;
-    a.ndim = n.ndim; a.any_ibc = 1;
-    // squared central gradient of the custom epilogue, kernel-axis order (cartesian.py:661: 0.25 / dx**2)
-    a.gs[0] = 0.25 / (n.dx[am] * n.dx[am]); a.gs[1] = 0.25 / (n.dx[1] * n.dx[1]); a.gs[2] = 0.25 / (n.dx[2] * n.dx[2]);
-    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2, plan);
-    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2, plan);
-}
+// (the two-step sweeps: pdehip_kernels_e2.hip; the LDS-tiled 2-D sweeps: pdehip_kernels_t2.hip - separate translation units, so that an
+// edit of one family rebuilds in two minutes instead of six)
+bool force_generic_kernels() { return tune().force_generic; }
 
 // ---------------------------------------------------------------------------------------------
 // ghost cells: one launch for all faces.  Faces only read interior cells and write disjoint

@@ -183,6 +183,8 @@ int pdehip_set_device(int device)
     std::lock_guard<std::mutex> guard(m);
     if (!loaded) {
         PDEHIP_TRY(preload_stencil_kernels());
+        PDEHIP_TRY(preload_e2_kernels());
+        PDEHIP_TRY(preload_t2_kernels());
         PDEHIP_TRY(preload_shell_kernels());
         loaded = true;
     }

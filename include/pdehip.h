@@ -141,6 +141,9 @@ int pdehip_bcprog_destroy(void *handle);
 
 /* ---- runtime ------------------------------------------------------------------ */
 const char *pdehip_last_error(void);
+/* name of the stencil-kernel instance the calling thread launched last (template name with its tile shape and switches), "" before the first
+ * launch; ABI version 7.  Measurement aid: bench.py labels its roofline with the instance that ran.  (No counterpart in the reference.) */
+const char *pdehip_last_kernel_name(void);
 int pdehip_abi_version(void);
 int pdehip_device_count(int *count);
 int pdehip_set_device(int device);

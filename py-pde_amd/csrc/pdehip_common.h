@@ -144,6 +144,7 @@ inline bool stage_aligned(const LapArgs &a)
     for (int m = 0; m < 5; m++) bits |= (uintptr_t)a.st_k[m];
     return bits % 16 == 0;
 }
+void note_kernel(const char *fmt, ...);   // pdehip_runtime.hip: name of the kernel instance launched last (pdehip_last_kernel_name)
 bool force_generic_kernels();   // PDEHIP_FORCE_GENERIC=1 (pdehip_kernels.hip)
 // StageFuse (what follows a slope k = dt*rhs in a Runge-Kutta scheme, fused into the sweep that computes k): pdehip_slab_loops.h
 int launch_laplace(const NGrid &n, const void *in, void *out, const OutStr &o, int mode, double s1,

@@ -127,6 +127,8 @@ static int launch_march(const LapArgs &a0, bool y_is_in, long want_blocks, hipSt
     const int ncomp_out = (MODE == LAP_GRAD_C || MODE == LAP_GRAD_F || MODE == LAP_GRAD_B) ? 3 : (MODE == LAP_STAGE ? 2 : 1);
     static const bool nt_off = getenv("PDEHIP_NO_NT") != nullptr;   // A/B aid
     const bool nt = HAS_X && !tails && !nt_off && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) * ncomp_out > 192.0 * 1048576.0);
+    note_kernel("lap_march_kernel<%s,%d,RY=%d,CZ=%d,WY=%d,PF=%d,mode=%d,%s,%s,%s>", sizeof(T) == 8 ? "double" : "float", VEC, RY, CZ, WY, PF, MODE, HAS_X ? "3-D" : "2-D",
+                tails ? "tails" : "aligned rows", (!tails && HAS_X && nt) ? "NT" : "plain stores");
 #define PDEHIP_MARCH(YIN_, IBC_)                                                                                                       \
     do {                                                                                                                               \
         if (tails) hipLaunchKernelGGL((lap_march_kernel<T, VEC, RY, CZ, WY, PF, MODE, HAS_X, YIN_, IBC_, true>), grid, block, 0, st, a);  \

@@ -59,7 +59,10 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // four alternations), 512 x 512 x 256 +3.7 %, 384^3 +2.6 % - and loses below (256^3 -3 %, 128 x 512 x 512 -0.7 %): profiles/r05_ab_tall_tile.log.
     // PDEHIP_EULER2=8 forces it, PDEHIP_EULER2=4 the 4-row tile.  (The tall tile WITH the ragged-row code, for extents that are not multiples of the tile,
     // was built and measured slower than the 4-row tile everywhere - 513^3 440 against 479, 511^3 538 against 599 Gcell-steps/s: profiles/r05_ab_tall_ragged.log.)
-    const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0;
+    // Round 6: by default only for all-periodic grids (the 3-buffer instance without the face code, euler2_tall_per_kernel); with faces the 4-row tile
+    // with late loads and branches is ahead of the tall one now (512^3: 0.443 against 0.488 ms per launch, profiles/r06_e2_bench6.md)
+    const bool all_periodic = xplain == 0 && a.per[0] == 1 && a.per[1] == 1 && a.per[2] == 1;
+    const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0 && all_periodic && !(getenv("PDEHIP_E2_PER3") && getenv("PDEHIP_E2_PER3")[0] == '0');
     const bool tall = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
                       (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
     // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
@@ -200,6 +203,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
             const bool nt_ = ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
             const bool unit_ = a.sx == 1.0 && a.sy == 1.0 && a.sz == 1.0 && a.s1 == 1.0;
             if (per3) {
+                note_kernel("euler2_tall_per_kernel<double,2,%s,%s> (8 rows, 3 plane buffers, 1 wave per SIMD, all-periodic)", unit_ ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt_ ? "NT" : "plain stores");
                 if (unit_ && nt_) hipLaunchKernelGGL((euler2_tall_per_kernel<T, VEC, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
                 else if (unit_) hipLaunchKernelGGL((euler2_tall_per_kernel<T, VEC, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
                 else if (nt_) hipLaunchKernelGGL((euler2_tall_per_kernel<T, VEC, E2_DIFFUSION, true>), grid, block, 0, st, a);
@@ -208,6 +212,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
                 *done = true;
                 return 0;
             }
+            note_kernel("euler2_tall_kernel<double,2,8,%s,%s> (8 rows, 4 plane buffers, 1 wave per SIMD)", unit_ ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt_ ? "NT" : "plain stores");
             if (unit_ && nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
             else if (unit_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
             else if (nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, true>), grid, block, 0, st, a);
@@ -268,6 +273,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     bool launched = false;
     if constexpr (sizeof(T) == 8 && VEC == 2) {
         if (per3 && ry == 4 && !ragged && !open_tail) {   // (fp64, 4 rows, rows that end at chunk boundaries)
+            note_kernel("euler2_per_kernel<double,2,%s,%s> (4 rows, 2 waves per SIMD, all-periodic)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt ? "NT" : "plain stores");
             if (unit && nt) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
             else if (unit) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
             else if (nt) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION, true>), grid, block, 0, st, a);
@@ -297,6 +303,9 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
 #undef PDEHIP_E2
     if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
+    if (!(per3 && ry == 4 && !ragged && !open_tail) && !(sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y && !xs))
+        note_kernel("euler2_kernel<%s,%d,%d,m2=%d%s,%s,%s,%s,%s>", sizeof(T) == 8 ? "double" : "float", VEC, ry, m2, (unit && m2 == E2_DIFFUSION && !xs) ? " unit" : "", has_y ? "3-D" : "2-D",
+                    ragged ? "ragged" : "aligned rows", xs ? "one-sided" : "two-sided", nt ? "NT" : "plain stores");
     PDEHIP_HIP(hipGetLastError());
     if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, st));   // the last one to four columns of every row
     *done = true;

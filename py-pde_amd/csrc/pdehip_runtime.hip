@@ -1,4 +1,5 @@
 // pdehip_runtime.hip — device/stream/memory plumbing of the C ABI (include/pdehip.h).
+#include <cstdarg>
 #include "pdehip_common.h"
 #include <cstring>
 #include <mutex>
@@ -7,6 +8,15 @@
 namespace pdehip {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
+// the stencil kernel instance the calling thread launched last (pdehip_last_kernel_name: bench.py labels its roofline with what actually ran)
+static thread_local char g_last_kernel[192] = "";
+void note_kernel(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
 }  // namespace pdehip
 
 using namespace pdehip;
@@ -165,6 +175,7 @@ int transfer_valid(const pdehip_grid_t *g, int ncomp, void *host, const int64_t 
 extern "C" {
 
 const char *pdehip_last_error(void) { return g_last_error.c_str(); }
+const char *pdehip_last_kernel_name(void) { return g_last_kernel; }
 int pdehip_abi_version(void) { return PDEHIP_ABI_VERSION; }
 
 int pdehip_device_count(int *count)

@@ -191,6 +191,7 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
 
 RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
     "last_error": ([], C.c_char_p),
+    "last_kernel_name": ([], C.c_char_p),
     "abi_version": ([], _i),
     "device_count": ([C.POINTER(_i)], _i),
     "set_device": ([_i], _i),

@@ -72,6 +72,7 @@ static int fused_enabled(void)
 /* ---- runtime -------------------------------------------------------------------------- */
 const char *pdehip_last_error(void) { return g_err; }
 int pdehip_abi_version(void) { return PDEHIP_ABI_VERSION; }
+const char *pdehip_last_kernel_name(void) { return "host shim (tests only): the CPU oracle stands in for every kernel"; }
 int pdehip_device_count(int *count)
 {
     const char *e = getenv("PDEHIP_SHIM_DEVICES");

@@ -20,6 +20,7 @@ using namespace pdehip;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 struct Geo { long n, p1, p0, off, total; };
+static double *g_pong = nullptr;   // argv[4] = 1: launches alternate in -> out, out -> pong (the time loop's access pattern: the output of a sweep is the next input)
 
 template <int RY, bool NT, int WAVES, int NB, bool PER3, int M2 = E2_DIFFUSION_UNIT, int TWEAK = 0>
 static double run(const char *name, const Geo &g, const double *in, double *out, long cap, int reps, int nwz_want)
@@ -42,8 +43,9 @@ static double run(const char *name, const Geo &g, const double *in, double *out,
     int nwz = nwz_want; while (a.ntz % nwz) nwz /= 2;
     a.nwy = 1; a.nblocks = a.nxc * tiles / nwz; a.no_swizzle = 0;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&]() { hipLaunchKernelGGL((e2v_kernel<double, 2, RY, M2, NT, WAVES, NB, PER3, TWEAK>), dim3((unsigned)a.nblocks), dim3(64 * nwz), 0, 0, a); };
-    launch(); CK(hipDeviceSynchronize());
+    int flip = 0;
+    auto launch = [&]() { if (g_pong) { a.in = flip ? out : in; a.y = a.in; a.out = flip ? g_pong : out; flip ^= 1; } hipLaunchKernelGGL((e2v_kernel<double, 2, RY, M2, NT, WAVES, NB, PER3, TWEAK>), dim3((unsigned)a.nblocks), dim3(64 * nwz), 0, 0, a); };
+    launch(); CK(hipDeviceSynchronize()); flip = 0;
     CK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; r++) launch();
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -70,6 +72,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&in, g.total * 8)); CK(hipMalloc(&ref, g.total * 8)); CK(hipMalloc(&out, g.total * 8));
     CK(hipMemcpy(in, h.data(), g.total * 8, hipMemcpyHostToDevice));
     CK(hipMemset(ref, 0, g.total * 8));
+    if (argc > 4 && atoi(argv[4]) == 1) { CK(hipMalloc(&g_pong, g.total * 8)); CK(hipMemset(g_pong, 0, g.total * 8)); }
     std::vector<double> href((size_t)g.total), hout((size_t)g.total);
     auto check = [&](const char *name) {
         CK(hipMemcpy(hout.data(), out, g.total * 8, hipMemcpyDeviceToHost));
@@ -78,26 +81,23 @@ int main(int argc, char **argv)
             const long o = g.off + i * g.p0 + j * g.p1;
             bad += memcmp(&hout[o], &href[o], n * 8) != 0;
         }
-        if (bad) printf("  !! %s: %ld rows differ from the library's tile\n", name, bad);
+        if (bad && !g_pong) printf("  !! %s: %ld rows differ from the library's tile\n", name, bad);
         CK(hipMemset(out, 0, g.total * 8));
     };
     for (int round = 0; round < rounds; round++) {
         run<8, true, 1, 4, false>("tall 2x8 1w 4buf (library)", g, in, ref, 1024, reps, 4);
         if (round == 0) CK(hipMemcpy(href.data(), ref, g.total * 8, hipMemcpyDeviceToHost));
         run<8, true, 1, 3, true>("2x8 1w 3buf, all-periodic", g, in, out, 1024, reps, 4); check("2x8 3buf per3");
-        run<8, true, 1, 3, false>("2x8 1w 3buf, faces", g, in, out, 1024, reps, 4); check("2x8 3buf");
-        run<8, true, 1, 3, false, E2_DIFFUSION_UNIT, 2>("2x8 1w 3buf, faces, branches", g, in, out, 1024, reps, 4); check("2x8 3buf br");
-        run<8, true, 1, 4, false, E2_DIFFUSION_UNIT, 2>("tall 4buf, faces, branches", g, in, out, 1024, reps, 4); check("tall br");
-        run<4, true, 2, 3, false, E2_DIFFUSION_UNIT, 2>("2x4 2w 3buf, faces, branches", g, in, out, 2048, reps, 4); check("4-row br");
-        run<4, true, 2, 3, false, E2_DIFFUSION_UNIT, 3>("2x4 2w 3buf, faces, br, late", g, in, out, 2048, reps, 4); check("4-row br late");
-        run<8, false, 1, 3, true>("2x8 1w 3buf, per, plain stores", g, in, out, 1024, reps, 4); check("2x8 3buf per3 plain");
-        run<8, true, 1, 3, true>("2x8 1w 3buf, per, 2048 waves", g, in, out, 2048, reps, 4); check("2x8 3buf per3 x");
-        run<8, true, 1, 3, true, E2_DIFFUSION>("2x8 1w 3buf, per, scaled", g, in, out, 1024, reps, 4); check("2x8 3buf per3 scaled");
-        run<8, true, 1, 3, true, E2_DIFFUSION_UNIT, 1>("2x8 1w 3buf, per, late loads", g, in, out, 1024, reps, 4); check("2x8 3buf per3 late");
-        run<4, true, 2, 3, false>("2x4 2w 3buf (library 4-row)", g, in, out, 2048, reps, 4); check("4-row");
-        run<4, true, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w 3buf, per, late loads", g, in, out, 2048, reps, 4); check("4-row per3 late");
-        run<4, false, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w 3buf, per, late, plain st", g, in, out, 2048, reps, 4); check("4-row per3 late plain");
-        run<4, true, 1, 3, true>("2x4 1w 3buf, all-periodic", g, in, out, 1024, reps, 4); check("4-row 1w 3buf per3");
+        run<4, true, 2, 3, false>("2x4 2w NT (library 4-row)", g, in, out, 2048, reps, 4); check("4-row");
+        run<4, true, 2, 3, false, E2_DIFFUSION_UNIT, 3>("2x4 2w NT faces, br, late", g, in, out, 2048, reps, 4); check("4-row br late");
+        run<4, true, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w NT per, late", g, in, out, 2048, reps, 4); check("4-row per3 late");
+        run<4, false, 2, 3, false>("2x4 2w plain (library 4-row)", g, in, out, 2048, reps, 4); check("4-row plain");
+        run<4, false, 2, 3, false, E2_DIFFUSION_UNIT, 1>("2x4 2w plain faces, late", g, in, out, 2048, reps, 4); check("4-row plain late");
+        run<4, false, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w plain per, late", g, in, out, 2048, reps, 4); check("4-row plain per late");
+        run<4, false, 2, 3, true, E2_DIFFUSION_UNIT, 0>("2x4 2w plain per, early", g, in, out, 2048, reps, 4); check("4-row plain per early");
+        run<8, false, 1, 3, true>("2x8 1w 3buf per, plain", g, in, out, 1024, reps, 4); check("2x8 plain per");
+        run<4, false, 2, 3, false, E2_DIFFUSION, 0>("2x4 2w plain scaled (library)", g, in, out, 2048, reps, 4); check("4-row plain scaled");
+        run<4, false, 2, 3, false, E2_DIFFUSION, 1>("2x4 2w plain scaled, late", g, in, out, 2048, reps, 4); check("4-row plain scaled late");
     }
     return 0;
 }

@@ -638,20 +638,8 @@ def bench_distributed(args) -> dict:
     dt = 0.1
 
     def gather_to_rank0(buf):
-        local = stepper.gather_local(buf)
-        if world == 1:
-            return local
-        import torch.distributed as dist
-
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(local, parts, dst=0)
-        if rank != 0:
-            return None
-        if blocks:
-            from pde_hip.mesh import combine_blocks
-
-            return combine_blocks(parts, stepper.dims, 3)
-        return np.concatenate(parts, axis=0)
+        # raw buffers, every part crosses the control plane once (pde_hip.distributed.gather_parts)
+        return stepper.gather(buf, root=0)
 
     # parity: 6 steps (three two-step sweeps with their exchanges) from the seeded state, whole field hashed on rank 0
     stepper.set_local(a, local0)
@@ -712,6 +700,16 @@ def bench_distributed(args) -> dict:
     per_rank = control.allgather({"rank": rank, "layers": local_shape[0], "ms_per_step": own_stats["median"],
                                   "compute_only_ms_per_step": alone_stats["median"],
                                   "exchange_exposed_ms_per_step": round(own_stats["median"] - alone_stats["median"], 5)})
+    # what RCCL itself reports (VERDICT r5 "next" #8b): ranks in the communicator, its version, the device and PCI bus id behind every rank
+    rccl = None
+    if getattr(stepper, "comm", None) is not None:
+        five, bus = (C.c_int * 5)(), C.create_string_buffer(64)
+        stepper.lib.comm_info(stepper.comm, five, bus, 64)
+        mine = {"rank": rank, "nccl_comm_count": int(five[0]), "nccl_user_rank": int(five[1]), "nccl_device": int(five[2]), "hip_device": int(five[4]),
+                "pci_bus_id": bus.value.decode(errors="replace")}
+        ranks = control.allgather(mine)
+        rccl = {"nranks": int(five[0]), "version": int(five[3]), "ranks": ranks,
+                "distinct_devices": len({(r["pci_bus_id"], r["hip_device"]) for r in ranks})}
     stepper.close()
     if world > 1:
         import torch.distributed as dist
@@ -727,7 +725,7 @@ def bench_distributed(args) -> dict:
                 "note": "per GPU, rank 0; wall-clock of K steps of the serial two-step loop on a grid of the slab's shape (no HIP events: the "
                         "loop runs on the library's own streams); the exchange and its choreography are what `per_rank` shows on top"}
     return {"wall": wall_stats["median"] * 1e-3 * args.steps, "wall_stats": wall_stats, "rank": rank, "finite": ok, "info": info, "parity": parity,
-            "state_sha256": digest, "per_rank": per_rank, "roofline": roofline}
+            "state_sha256": digest, "per_rank": per_rank, "roofline": roofline, "rccl": rccl}
 
 
 def _free_port() -> int:
@@ -791,7 +789,7 @@ def main():
         ngpu = world
         wall = r["wall"]
         line = {"roofline": r["roofline"], "cpu_baseline": None, "slab": r["info"], "finite": r["finite"], "parity": r["parity"],
-                "state_sha256_after_6_steps": r["state_sha256"], "per_rank": r["per_rank"]}
+                "state_sha256_after_6_steps": r["state_sha256"], "per_rank": r["per_rank"], "rccl": r["rccl"]}
         if "decomposition" in r["info"]:
             parallelism = (f"blocks{'x'.join(str(d) for d in r['info']['decomposition'])} (boxes with two-layer halos incl. edges, one RCCL message per "
                            "neighbouring rank, rim kernel + interior sweep)")

@@ -144,6 +144,14 @@ const char *pdehip_last_error(void);
 /* name of the stencil-kernel instance the calling thread launched last (template name with its tile shape and switches), "" before the first
  * launch; ABI version 7.  Measurement aid: bench.py labels its roofline with the instance that ran.  (No counterpart in the reference.) */
 const char *pdehip_last_kernel_name(void);
+/* Arithmetic mode of the stencil kernels (Laplacian / gradient / divergence, the fused right-hand sides and time steps, ghost cells, run-time
+ * compiled expression kernels), process-wide; ABI version 7.  0 (default): compiled with -ffp-contract=off - every rounding of the reference's
+ * expression order, results bit-identical to its numpy / torch-CPU evaluation.  1: the same kernels compiled with FMA contraction - what
+ * numba's default `fastmath` (pde/backends/numba/utils.py:330-336; config `backend.numba.fastmath`, pde/backends/numba/config.py:20-26) allows
+ * the reference's own numba backend; results agree with the exact build within 1e-10 relative (tests/test_hip_fastmath.py), ~10-20 % fewer
+ * fp64 operations per cell.  Set it before building steppers: kernels of expression PDEs are compiled for the mode current at their first use. */
+int pdehip_set_fastmath(int on);
+int pdehip_get_fastmath(int *on);
 int pdehip_abi_version(void);
 int pdehip_device_count(int *count);
 int pdehip_set_device(int device);
@@ -395,6 +403,10 @@ int pdehip_rkf45_attempt(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, void *
 int pdehip_comm_unique_id(const char *librccl_path, void *id128);
 int pdehip_comm_create(const char *librccl_path, const void *id128, int rank, int size, void **comm);
 int pdehip_comm_destroy(void *comm);
+/* What RCCL reports about the communicator (ABI version 7; measurement aid: the N > 1 bench line records that RCCL really spans N ranks on N
+ * devices): out5 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion, HIP device of the caller}, -1 where unavailable;
+ * pci_bus_id (>= 16 bytes) = hipDeviceGetPCIBusId of that device.  Reference counterpart: MPI.COMM_WORLD.size / rank of pde/tools/mpi.py:40-61. */
+int pdehip_comm_info(void *comm, int *out5, char *pci_bus_id, size_t n);
 /* send valid layers 1 / n of the local slab to the neighbours, receive their layers into the ghost
  * layers n+1 / 0 (ncclSend/ncclRecv in one group, enqueued on `stream`) */
 int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper,

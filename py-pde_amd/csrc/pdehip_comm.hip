@@ -17,6 +17,9 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <vector>
+
 #include "pdehip_common.h"
 #include "pdehip_slab_loops.h"
 #include "pdehip_block_loops.h"
@@ -36,6 +39,11 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    // (optional: what the communicator reports about itself, pdehip_comm_info)
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 Rccl g_rccl;
 
@@ -57,6 +65,10 @@ int load_rccl(const char *path)
     PDEHIP_SYM(Recv, "ncclRecv");
     PDEHIP_SYM(AllReduce, "ncclAllReduce");
 #undef PDEHIP_SYM
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+    g_rccl.CommCuDevice = reinterpret_cast<decltype(g_rccl.CommCuDevice)>(dlsym(h, "ncclCommCuDevice"));
+    g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(h, "ncclGetVersion"));
     g_rccl.handle = h;
     return 0;
 }
@@ -87,6 +99,10 @@ struct Comm {
     // context - and those runs enqueue on their own streams: a run waits for the end of the run before it (ScratchTurn).
     hipEvent_t ev_done = nullptr;
     bool ev_done_recorded = false;
+    // streams found to share a hardware queue with a compute stream (separate_queues): kept alive so that their queue stays taken
+    std::vector<hipStream_t> parked;
+    hipStream_t probed_for = nullptr;   // the compute stream the halo stream was last checked against
+    bool probed = false;
 };
 
 // one run's turn on the scratch of a context: waits (on the device) for the run before it, marks its own end
@@ -108,6 +124,9 @@ void release_scratch(Comm *c)
 {
     if (c->ev_done && c->ev_done_recorded) (void)hipEventSynchronize(c->ev_done);
     if (c->halo) (void)hipStreamSynchronize(c->halo);
+    for (auto st : c->parked) (void)hipStreamDestroy(st);
+    c->parked.clear();
+    c->probed = false;
     for (auto &e : c->ext) { (void)hipFree(e); e = nullptr; }
     c->ext_bytes = 0; c->ext_count = 0;
     for (int a = 0; a < 3; a++) {
@@ -126,21 +145,67 @@ Comm *serial_context()
     return &ctx;
 }
 
+constexpr int kHaloPriorityDefault = 0;
+
 int ensure_streams(Comm *c)
 {
     if (!c->halo) {
         // The halo stream carries the boundary sweeps and the RCCL kernels.  A HIGH-PRIORITY stream was measured SLOWER (64 x 512 x
         // 512 slab, halo to self: 0.060 vs 0.043 ms per step, profiles/r03_probe_slab.md), so it is a plain stream unless
         // PDEHIP_HALO_PRIORITY=1 asks for the experiment.
+        // PDEHIP_HALO_PRIORITY: 0 plain stream (default), 1 highest, -1 lowest priority.  Streams of different priority never share a hardware queue:
+        // round 6 found the compute stream and a plain halo stream of the same process on ONE hardware queue whenever the process had created an odd
+        // number of other streams before (0.054 instead of 0.040 ms per step on a 64-layer slab: the two chains of the loop serialise,
+        // profiles/r06_probe_slab.md).
         int lo = 0, hi = 0;
-        static const bool plain = !(getenv("PDEHIP_HALO_PRIORITY") && atoi(getenv("PDEHIP_HALO_PRIORITY")) == 1);
-        if (plain || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hi == lo) PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
-        else PDEHIP_HIP(hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, hi));
+        const int want = getenv("PDEHIP_HALO_PRIORITY") ? atoi(getenv("PDEHIP_HALO_PRIORITY")) : kHaloPriorityDefault;
+        if (want == 0 || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hi == lo) PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+        else PDEHIP_HIP(hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, want > 0 ? hi : lo));   // (hi = the numerically lowest value = highest priority)
     }
     for (auto &e : c->ev)
         if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!c->ev_done) PDEHIP_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     return 0;
+}
+
+// ~`ticks` of the 100 MHz wall clock on one lane (separate_queues)
+__global__ void spin_kernel(long ticks)
+{
+    const long t0 = (long)wall_clock64();
+    while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// The overlapped loops need the compute stream and the halo stream on DIFFERENT hardware queues.  The HIP runtime maps streams onto a handful
+// of queues by creation order; round 6 found the two on ONE queue whenever the process had created an odd number of other streams before
+// (bench.py after its side measurements: 0.054 instead of 0.040 ms per step on a 64-layer slab - the two chains of the loop serialise;
+// priorities move the collision elsewhere: profiles/r06_probe_slab.md).  So: measured, once per pair of streams.  Two 200 us spin kernels,
+// one per stream; if they take the time of both, the halo stream is parked (kept alive: its queue stays taken) and a new one is created,
+// up to 6 times.  ~1 ms per communicator.  PDEHIP_QUEUE_PROBE=0: off.
+int separate_queues(Comm *c, hipStream_t comp)
+{
+    static const bool off = getenv("PDEHIP_QUEUE_PROBE") && getenv("PDEHIP_QUEUE_PROBE")[0] == '0';
+    if (off || (c->probed && c->probed_for == comp)) return 0;
+    c->probed = true; c->probed_for = comp;
+    const long ticks = 20000;   // 200 us
+    for (int attempt = 0; attempt < 6; attempt++) {
+        PDEHIP_HIP(hipStreamSynchronize(comp));
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, comp, 100L);      // (code object loaded, both queues awake)
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, c->halo, 100L);
+        PDEHIP_HIP(hipStreamSynchronize(comp));
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, comp, ticks);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, c->halo, ticks);
+        PDEHIP_HIP(hipStreamSynchronize(comp));
+        PDEHIP_HIP(hipStreamSynchronize(c->halo));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < 330.0) return 0;   // overlapped (two in a row would take >= 400)
+        c->parked.push_back(c->halo);
+        c->halo = nullptr;
+        PDEHIP_HIP(hipStreamCreateWithFlags(&c->halo, hipStreamNonBlocking));
+    }
+    return 0;   // (no separate queue found: the loops are still correct, only slower)
 }
 
 __global__ void pack_nan_kernel(const double *in, double *out2)
@@ -479,6 +544,26 @@ int pdehip_release_scratch(void)
     return 0;
 }
 
+// what RCCL itself says about the communicator: out5 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion, HIP device of the
+// calling thread} (-1 where the library lacks the entry point), pci_bus_id of that device ("" if unknown)
+int pdehip_comm_info(void *comm, int *out5, char *pci_bus_id, size_t n)
+{
+    if (!comm || !out5) PDEHIP_FAIL(E_VALUE, "comm_info: NULL pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    for (int k = 0; k < 5; k++) out5[k] = -1;
+    if (g_rccl.CommCount) PDEHIP_NCCL(g_rccl.CommCount(c->comm, &out5[0]));
+    if (g_rccl.CommUserRank) PDEHIP_NCCL(g_rccl.CommUserRank(c->comm, &out5[1]));
+    if (g_rccl.CommCuDevice) PDEHIP_NCCL(g_rccl.CommCuDevice(c->comm, &out5[2]));
+    if (g_rccl.GetVersion) PDEHIP_NCCL(g_rccl.GetVersion(&out5[3]));
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) out5[4] = dev;
+    if (pci_bus_id && n > 0) {
+        pci_bus_id[0] = 0;
+        if (dev >= 0 && hipDeviceGetPCIBusId(pci_bus_id, (int)n, dev) != hipSuccess) pci_bus_id[0] = 0;
+    }
+    return 0;
+}
+
 int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper, void *stream)
 {
     if (!comm || !buf_full) PDEHIP_FAIL(E_VALUE, "halo_exchange: NULL pointer");
@@ -507,6 +592,7 @@ int pdehip_slab_euler_run(void *comm, const pdehip_grid_t *g_local, const pdehip
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{static_cast<Comm *>(comm)};
+    if (lower >= 0 || upper >= 0) PDEHIP_TRY(separate_queues(ops.c, as_stream(stream)));
     // (two streams per step: faces that change with time take the single-stream sweeps, pdehip_slab_euler_sweeps)
     if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
     return slab::euler_run(ops, g_local, q, rhs, lower, upper, buf_a, buf_b, dt, nsteps, result, stream);
@@ -546,6 +632,7 @@ int pdehip_slab_euler2_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     PDEHIP_TRY(slab_private_arrays(c, g_local, q, 2, as_stream(stream)));
+    if (lower >= 0 || upper >= 0) PDEHIP_TRY(separate_queues(c, as_stream(stream)));
     ScratchTurn turn(c, as_stream(stream));
     HipOps ops{c};
     if (rhs->bc_program) PDEHIP_FAIL(E_NOTIMPL, "slab_euler2_run: time-dependent boundary conditions run through pdehip_slab_euler_sweeps");
@@ -577,6 +664,7 @@ int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     HipOps ops{c};
     const bool piped = ops.deep_mode() == 3;
     PDEHIP_TRY(slab_private_arrays(c, g_local, q, 4, as_stream(stream), piped ? 4 : 2));
+    if (lower >= 0 || upper >= 0) PDEHIP_TRY(separate_queues(c, as_stream(stream)));
     ScratchTurn turn(c, as_stream(stream));
     if (piped) return slab::euler4p_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext, dt, nsteps, result, stream);
     return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
@@ -1336,6 +1424,7 @@ int pdehip_block2_euler_run(void *comm, const pdehip_grid_t *g_local, const pdeh
     const long n[3] = {g_local->shape[0], g_local->shape[1], g_local->shape[2]};
     if (block2::make_plan(n, dims3, coords3, cut3, &plan) != 0) PDEHIP_FAIL(E_VALUE, "block2_euler_run: the box is too small for two halo layers");
     Block2Ctx *x = block2_ctx(c);
+    if (any) PDEHIP_TRY(separate_queues(c, as_stream(stream)));
     ScratchTurn turn(c, as_stream(stream));
     for (auto &e : x->ev)
         if (!e) PDEHIP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -158,13 +158,17 @@ extern "C" __global__ void __launch_bounds__(1024) pde_kernel(pdehip::Tile2Args 
 }
 )SRC";
 
-int compile_variant(Jit *j, const std::string &key, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
+// cache key of a variant in the current arithmetic mode (pdehip_set_fastmath)
+std::string mode_key(const std::string &key) { return (fastmath_on() && !key.empty()) ? key + "#fast" : key; }
+
+int compile_variant(Jit *j, const std::string &key_in, bool generic, const char *tname, int vec, int ry, int cz, bool hasx, bool ibc, Variant *out,
                     int two_level = 0,    // 0: one-level kernel, E2_CUSTOM / E2_CUSTOM2: two-level kernel
                     bool stage = false,   // one-level kernel followed by the Runge-Kutta stage epilogue (LapArgs::st_*)
                     int wy = 1,           // waves per workgroup (stacked along the rows), one-level kernel
                     bool tails = true)    // rows that end inside a vector / leave idle chunks in a tile (pdehip_march.inc)
 {
     PDEHIP_TRY(load_rtc());
+    const std::string key = mode_key(key_in);   // (the exact and the contracted build of a variant are different kernels)
     // kernels already built in this process for the same epilogue(s) and variant: every eq.solve creates new handles for the
     // same expressions, and a hiprtc build costs 50-150 ms (a 4000-step run of a 256^2 grid spent 9/10 of its wall time there)
     const std::string shared_key = j->body + '\x01' + j->body2 + '\x01' + key;
@@ -196,7 +200,7 @@ int compile_variant(Jit *j, const std::string &key, bool generic, const char *tn
     hiprtcProgram prog = nullptr;
     if (g_rtc.CreateProgram(&prog, src.c_str(), "pde_kernel.hip", 4, hdr_src, hdr_name) != 0)
         PDEHIP_FAIL(E_RUNTIME, "hiprtcCreateProgram failed");
-    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+    std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", fastmath_on() ? "-ffp-contract=fast" : "-ffp-contract=off",
                                      std::string("-DPDE_T=") + tname, "-DPDE_VEC=" + std::to_string(vec), "-DPDE_RY=" + std::to_string(ry),
                                      "-DPDE_CZ=" + std::to_string(cz), std::string("-DPDE_HASX=") + (hasx ? "true" : "false"),
                                      std::string("-DPDE_IBC=") + (ibc ? "true" : "false"), "-DPDE_M2=" + std::to_string(two_level == kTileVariant ? 0 : two_level),
@@ -394,7 +398,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         const bool tails = (n.n[2] % vec != 0) || (chunks % cz != 0);
         const std::string key = std::string(tname) + "," + std::to_string(ry) + "," + std::to_string(cz) + "," + (hasx ? "x" : "-") + (ibc ? "b" : "-") +
                                 (stage ? "s" : "-") + std::to_string(wy) + (tails ? "t" : "-");
-        auto it = j->cache.find(key);
+        auto it = j->cache.find(mode_key(key));
         if (it != j->cache.end()) v = it->second;
         else PDEHIP_TRY(compile_variant(j, key, false, tname, vec, ry, cz, hasx, ibc, &v, 0, stage != nullptr, wy, tails));
         a.ntz = (a.n2 + 64L * vec * cz - 1) / (64L * vec * cz);
@@ -418,7 +422,7 @@ int jit_apply_impl(void *handle, const pdehip_grid_t *g, void *in_full, const vo
         threads = 64 * wy;
     } else {
         const std::string key = std::string("generic,") + tname;
-        auto it = j->cache.find(key);
+        auto it = j->cache.find(mode_key(key));
         if (it != j->cache.end()) v = it->second;
         else PDEHIP_TRY(compile_variant(j, key, true, tname, 1, 1, 1, false, false, &v));
         long b = (n.n[0] * n.n[1] * n.n[2] + 255) / 256;
@@ -506,7 +510,7 @@ int pdehip_jit_euler2(void *handle, const pdehip_grid_t *g, const void *in_full,
     const char *tname = f64 ? "double" : "float";
     const std::string key = std::string("two,") + tname + "," + std::to_string(plan.ry) + (plan.has_y ? ",y" : ",-");
     Variant v;
-    auto it = j->cache.find(key);
+    auto it = j->cache.find(mode_key(key));
     if (it != j->cache.end()) v = it->second;
     else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, E2_CUSTOM));
     void *kargs[] = {&plan.a};
@@ -551,7 +555,7 @@ int pdehip_jit_fused2(void *handle, const pdehip_grid_t *g, const void *in_full,
     const char *tname = f64 ? "double" : "float";
     const std::string key = std::string("fused2,") + tname + "," + std::to_string(plan.ry) + (plan.has_y ? ",y" : ",-");
     Variant v;
-    auto it = j->cache.find(key);
+    auto it = j->cache.find(mode_key(key));
     if (it != j->cache.end()) v = it->second;
     else PDEHIP_TRY(compile_variant(j, key, false, tname, f64 ? 2 : 4, plan.ry, 1, plan.has_y, true, &v, E2_CUSTOM2));
     void *kargs[] = {&plan.a};
@@ -969,7 +973,7 @@ int pdehip_jit_euler_run(const pdehip_grid_t *g, const pdehip_jit_pass_t *passes
                 const char *tname = n.dtype == PDEHIP_F64 ? "double" : "float";
                 const std::string key = std::string(two ? "tile2," : (chain ? "tile4," : "tile,")) + tname + "," + std::to_string(tcw);
                 Variant v;
-                auto it = j->cache.find(key);
+                auto it = j->cache.find(mode_key(key));
                 if (it != j->cache.end()) v = it->second;
                 else PDEHIP_TRY(compile_variant(j, key, false, tname, n.dtype == PDEHIP_F64 ? 2 : 4, mode, tcw, false, true, &v, kTileVariant));
                 void *kargs[] = {&ta};

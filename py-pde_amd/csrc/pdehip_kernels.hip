@@ -18,7 +18,16 @@
 // the CPU oracle.
 #include "pdehip_common.h"
 
+// Compiled TWICE (py-pde_amd/Makefile): as pdehip::exactv with -ffp-contract=off (bit-identical to the CPU oracle; the default) and, with
+// -DPDEHIP_FAST_VARIANT -ffp-contract=fast, as pdehip::fastv (FMA contraction like numba's default fastmath, pde/backends/numba/utils.py:330-336;
+// opt-in through pdehip_set_fastmath, results within 1e-10 of the exact build).  pdehip_dispatch.hip picks one per call.
+#ifdef PDEHIP_FAST_VARIANT
+#define PDEHIP_VARIANT_NS fastv
+#else
+#define PDEHIP_VARIANT_NS exactv
+#endif
 namespace pdehip {
+namespace PDEHIP_VARIANT_NS {
 
 
 #include "pdehip_march.inc"
@@ -555,4 +564,5 @@ int launch_ghosts(const NGrid &n, int ncomp, const pdehip_bc_face_t *faces, void
     return 0;
 }
 
+}  // namespace PDEHIP_VARIANT_NS
 }  // namespace pdehip

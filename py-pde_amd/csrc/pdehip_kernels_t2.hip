@@ -2,7 +2,16 @@
 // (round 6): its own translation unit.  Same compile flags (-ffp-contract=off).
 #include "pdehip_common.h"
 
+// Compiled TWICE (py-pde_amd/Makefile): as pdehip::exactv with -ffp-contract=off (bit-identical to the CPU oracle; the default) and, with
+// -DPDEHIP_FAST_VARIANT -ffp-contract=fast, as pdehip::fastv (FMA contraction like numba's default fastmath, pde/backends/numba/utils.py:330-336;
+// opt-in through pdehip_set_fastmath, results within 1e-10 of the exact build).  pdehip_dispatch.hip picks one per call.
+#ifdef PDEHIP_FAST_VARIANT
+#define PDEHIP_VARIANT_NS fastv
+#else
+#define PDEHIP_VARIANT_NS exactv
+#endif
 namespace pdehip {
+namespace PDEHIP_VARIANT_NS {
 
 #include "pdehip_tile2d.inc"
 
@@ -57,10 +66,11 @@ int launch_tile2d(const NGrid &n, const void *in, void *out, int mode, double s1
     Tile2Args a;
     unsigned nblocks = 0;
     int tcw = 0;
-    PDEHIP_TRY(plan_tile2d(n, in, out, mode, s1, s2, gamma, fc, fm, nsteps, &a, &nblocks, &tcw, done));
+    PDEHIP_TRY(PDEHIP_VARIANT_NS::plan_tile2d(n, in, out, mode, s1, s2, gamma, fc, fm, nsteps, &a, &nblocks, &tcw, done));
     if (!*done) return 0;
     *done = false;
     const dim3 grid(nblocks), block(1024);
+    note_kernel("tile2d_kernel<%s,mode=%d,32x%d tile> (%d steps per launch, time levels in LDS)", n.dtype == PDEHIP_F64 ? "double" : "float", mode, tcw, nsteps);
 #define PDEHIP_T2(T, M)                                                                                            \
     do {                                                                                                           \
         if (tcw == 64) hipLaunchKernelGGL((tile2d_kernel<T, M, 32, 64, kTile2Halo>), grid, block, 0, st, a);       \
@@ -85,4 +95,5 @@ int preload_t2_kernels()
     return 0;
 }
 
+}  // namespace PDEHIP_VARIANT_NS
 }  // namespace pdehip

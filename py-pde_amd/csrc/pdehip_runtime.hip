@@ -14,8 +14,9 @@ void note_kernel(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    const int len = vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
     va_end(ap);
+    if (fastmath_on() && len > 0 && len < (int)sizeof(g_last_kernel) - 40) snprintf(g_last_kernel + len, sizeof(g_last_kernel) - len, " [fastmath: FMA contraction]");
 }
 }  // namespace pdehip
 

@@ -192,6 +192,8 @@ COMPUTE_PROTOTYPES: dict[str, tuple[list, bool]] = {
 RUNTIME_PROTOTYPES: dict[str, tuple[list, object]] = {
     "last_error": ([], C.c_char_p),
     "last_kernel_name": ([], C.c_char_p),
+    "set_fastmath": ([_i], _i),
+    "get_fastmath": ([C.POINTER(_i)], _i),
     "abi_version": ([], _i),
     "device_count": ([C.POINTER(_i)], _i),
     "set_device": ([_i], _i),
@@ -226,6 +228,7 @@ COMM_PROTOTYPES: dict[str, list] = {
     "halo_exchange": [_vp, _pg, _vp, _i, _i, _vp],
     "allreduce_max": [_vp, _vp, _vp],
     "slab_euler_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
+    "comm_info": [_vp, C.POINTER(_i), C.c_char_p, C.c_size_t],
     "slab_euler2_supported": [_pg, _pr, C.POINTER(_i)],
     "slab_euler2_run": [_vp, _pg, _pr, _i, _i, _vp, _vp, _d, _i64, _pvp, _vp],
     "release_scratch": [],

@@ -172,6 +172,8 @@ def require_device(device: int | None = None) -> _Lib:
         lib.set_device(dev)
         _DEVICE = dev
         _threads_ready.add(threading.get_ident())
+        if os.environ.get("PDEHIP_FASTMATH", "0") == "1":
+            lib.set_fastmath(1)   # opt-in FMA contraction for code that drives the library without a backend object (pde_hip/backend.py: `fastmath`)
     else:
         if device is not None and int(device) != _DEVICE:
             msg = (

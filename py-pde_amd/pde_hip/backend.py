@@ -47,6 +47,9 @@ class OperatorInfo(NamedTuple):
     name: str = ""
 
 
+_FASTMATH_APPLIED: bool | None = None   # the arithmetic mode last handed to the library (HipBackendMixin._lib)
+
+
 # ---------------------------------------------------------------------------------------------
 # boundary conditions -> pdehip_bc_face_t[6]
 # ---------------------------------------------------------------------------------------------
@@ -473,13 +476,39 @@ class HipBackendMixin:
         ``ImportError`` there (``pde/backends/registry.py:241-245``), so construction must succeed on a box
         without a GPU.  The first compute call selects the device and raises ``RuntimeError`` without one."""
         self._device_request = None if device is None else int(device)
+        self._fastmath: bool | None = None   # None: from the configuration / PDEHIP_FASTMATH (see `fastmath`)
         self.stream = None  # HIP default stream; multi-GPU paths create their own
         self._info_cache: dict[tuple, GridInfo] = {}
 
     @property
+    def fastmath(self) -> bool:
+        """Arithmetic mode of the stencil kernels: False (default) = every rounding of the reference's expression order, bit-identical to its
+        numpy / torch-CPU evaluation; True = the same kernels compiled with FMA contraction, like the reference's numba backend under its default
+        ``fastmath`` (``pde/backends/numba/utils.py:330-336``, config ``backend.numba.fastmath``) - within 1e-10 of the exact build.
+        ``config["backend.hip.fastmath"]`` with py-pde, ``backend.fastmath = True`` or ``PDEHIP_FASTMATH=1`` otherwise."""
+        if self._fastmath is not None:
+            return self._fastmath
+        try:
+            if "fastmath" in self.config:
+                return bool(self.config["fastmath"])
+        except TypeError:
+            pass
+        return os.environ.get("PDEHIP_FASTMATH", "0") == "1"
+
+    @fastmath.setter
+    def fastmath(self, value) -> None:
+        self._fastmath = None if value is None else bool(value)
+
+    @property
     def _lib(self):
-        """libpdehip with the device of this backend selected (loud failure without library / GPU)."""
-        return require_device(self._device_request)
+        """libpdehip with the device of this backend selected (loud failure without library / GPU) and its arithmetic mode applied."""
+        global _FASTMATH_APPLIED
+        lib = require_device(self._device_request)
+        want = self.fastmath
+        if want is not _FASTMATH_APPLIED:
+            lib.set_fastmath(1 if want else 0)     # (process-wide in the library: one mode at a time)
+            _FASTMATH_APPLIED = want
+        return lib
 
     @property
     def device(self) -> int:

@@ -60,7 +60,7 @@ class SlabMesh:
             self._subgrid._discretization = np.array(grid.discretization, dtype=float)
         return self._subgrid
 
-    def slab_faces(self, bcs, *, force_exchange: bool = False, upload=None, comp_shape: tuple[int, ...] = (), component=None):
+    def slab_faces(self, bcs, *, force_exchange: bool = False, upload=None, comp_shape: tuple[int, ...] = (), component=None, part=None):
         """Face table of THIS slab from the boundary conditions of the WHOLE grid (any ``BoundariesList``: the mirror's or
         py-pde's own).  Replaces ``GridMesh.extract_boundary_conditions`` + ``_MPIBC`` (pde/grids/_mesh.py:535-569,
         pde/grids/boundaries/local.py:561-662): faces towards a neighbour are marked SKIP (their ghost layer is filled by the
@@ -89,7 +89,11 @@ class SlabMesh:
         # conditions given as expressions (incl. time-dependent ones and ones that read the field): evaluated for THIS slab - the
         # face cut to the slab's layers, wall coordinates of the whole grid - and refreshed by a device program (bc_expr.py)
         expr_faces = expression_faces(bcs)
-        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component)
+        if part is not None and expr_faces:
+            # (single device: pde_hip/bc_expr.py splits `A + B * value`; the per-slab device programs have no complex form yet)
+            msg = "hip backend: conditions given as expressions for complex fields on decomposed grids are not supported"
+            raise NotImplementedError(msg)
+        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component, part=part)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         exchanged = {(0, False): self.lower is not None, (0, True): self.upper is not None}
         if force_exchange and self.size == 1 and bool(self.grid.periodic[0]):
@@ -320,7 +324,7 @@ class BlockMesh:
         """Local block of global valid data (``GridMesh.extract_field_data``, _mesh.py:446-479)."""
         return data[(...,) + tuple(slice(lo, hi) for lo, hi in zip(self.lo, self.hi))]
 
-    def block_faces(self, bcs, *, upload=None, comp_shape: tuple[int, ...] = (), component=None):
+    def block_faces(self, bcs, *, upload=None, comp_shape: tuple[int, ...] = (), component=None, part=None):
         """Face table of THIS block from the conditions of the WHOLE grid: faces towards a neighbour are SKIP (filled by the
         exchange; the wrap-around of a decomposed periodic axis must be plainly periodic), physical faces keep their condition
         with the index translated into the block, per-face arrays are cut to the block's extent along the other axes."""
@@ -342,7 +346,11 @@ class BlockMesh:
                     msg = "block-parallel stepping supports conditions of scalar fields only"
                     raise NotImplementedError(msg)
         expr_faces = expression_faces(bcs)       # as in SlabMesh.slab_faces: cut to the block, coordinates of the whole grid
-        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component)
+        if part is not None and expr_faces:
+            # (single device: pde_hip/bc_expr.py splits `A + B * value`; the per-slab device programs have no complex form yet)
+            msg = "hip backend: conditions given as expressions for complex fields on decomposed grids are not supported"
+            raise NotImplementedError(msg)
+        glob = convert_bcs(bcs, comp_shape if component is not None else (), skip=set(expr_faces), upload=_Host, component=component, part=part)
         by_ptr = {h.ptr: h.arr for h in glob.keepalive}
         out = FaceTable()
         dynamic = []

@@ -44,6 +44,13 @@ from .device import DeviceArray
 DEFAULT_CONFIG = {
     "device": Parameter(value=-1, cls=int, description="Index of the HIP device (MI355X) the backend runs on; `hip:<n>` overrides it. "
                         "-1: the process default (LOCAL_RANK under a one-process-per-GPU launcher, else 0)."),
+    "fastmath": Parameter(
+        value=False,
+        cls=bool,
+        description="Compile-time arithmetic of the stencil kernels.  False (default): every rounding of the reference's expression order - "
+        "results bit-identical to the numpy / torch-CPU backends.  True: the same kernels with FMA contraction, like the numba backend under "
+        "its default `backend.numba.fastmath` - fewer fp64 operations per cell, results within 1e-10 (relative) of the exact build.",
+    ),
     "resident_state": Parameter(
         value=True,
         cls=bool,
@@ -153,17 +160,46 @@ class HipSlabSolver(AdaptiveSolverBase):
 
     name = "hip_slab"
 
-    def __init__(self, pde, scheme: str = "euler", *, backend="hip", adaptive: bool = False, tolerance: float = 1e-4, decomposition="slab"):
+    def __init__(self, pde, scheme: str = "euler", *, backend="hip", adaptive: bool = False, tolerance: float = 1e-4, decomposition="slab",
+                 gather: str = "all"):
         """``decomposition``: ``"slab"`` (axis-0 slabs: contiguous faces, two steps per sweep), ``"auto"`` (blocks by the reference's
-        rule, pde/grids/_mesh.py:59-93: 2 x 2 x 2 for a cubic grid on 8 ranks) or a list of blocks per axis (``GridMesh.from_grid``)."""
+        rule, pde/grids/_mesh.py:59-93: 2 x 2 x 2 for a cubic grid on 8 ranks) or a list of blocks per axis (``GridMesh.from_grid``).
+
+        ``gather``: who receives the field when a stepper call ends (tracker interrupts, end of the run).  ``"all"`` (default): every rank -
+        trackers run on every rank and see the same field, so they take the same decisions; raw buffers, one broadcast per part.  ``"root"``:
+        rank 0 only, like the main node of the reference's ``ExplicitMPISolver`` (``GridMesh.combine_field_data_mpi``, pde/grids/_mesh.py:593-615)
+        - every part crosses the control plane once (total traffic: one field per interrupt instead of N); the state of the other ranks carries
+        their OWN part only, ``eq.solve`` returns that there, and trackers that look at the data (plots, storage, steady-state) belong on rank 0
+        - trackers that can END a run must not be data-dependent on the other ranks."""
         super().__init__(pde, backend=backend, adaptive=adaptive, tolerance=tolerance)
         self.decomposition = decomposition
+        if gather not in {"all", "root"}:
+            msg = f"Unknown gather mode `{gather}` (all, root)"
+            raise ValueError(msg)
+        self.gather = gather
         if scheme in {"rk", "rk45", "runge-kutta"}:
             scheme = "runge-kutta"
         if scheme not in {"euler", "runge-kutta"}:
             msg = f"Unknown scheme `{scheme}` (euler, runge-kutta)"
             raise ValueError(msg)
         self.scheme = scheme
+
+    def _collect(self, stepper, arr, state_field) -> None:
+        """The result of a stepper call into ``state_field.data`` (see ``gather``): straight into its memory where the dtype and layout allow."""
+        data = state_field.data
+        root = 0 if self.gather == "root" else None
+        direct = isinstance(data, np.ndarray) and data.flags.c_contiguous and data.flags.writeable and data.dtype == np.dtype(stepper.dtype)
+        full = stepper.gather(arr, root=root, out=data if direct else None)
+        if not direct:
+            if full is not None:
+                state_field.data[...] = full
+            else:   # (a rank that receives nothing keeps its own part current)
+                mesh = stepper.mesh
+                lead = data.ndim - len(state_field.grid.shape)
+                lo = list(mesh.lo) if isinstance(mesh.lo, (list, tuple)) else [mesh.lo]
+                hi = list(mesh.hi) if isinstance(mesh.hi, (list, tuple)) else [mesh.hi]
+                box = (slice(None),) * lead + tuple(slice(a, b) for a, b in zip(lo, hi))
+                state_field.data[box] = arr.get_valid(stream=stepper.stream) if hasattr(arr, "get_valid") else stepper.gather_local(arr)
 
     def make_stepper(self, state, dt: float | None = None):
         from . import _abi
@@ -244,7 +280,7 @@ class HipSlabSolver(AdaptiveSolverBase):
                     res = a
                 self.info["steps"] += steps
                 t_last = t_start + (steps - 1) * dt_fixed + dt_fixed
-            state_field.data[...] = stepper.gather(res)
+            self._collect(stepper, res, state_field)
             return t_last
 
         slab_stepper.slab = stepper  # type: ignore[attr-defined]
@@ -314,7 +350,7 @@ def _decomposed_expression_stepper(self, state, dt: float, device, has_hook: boo
         finally:
             # (also when a hook ended the run with StopIteration: every rank holds the whole field the hooks left behind)
             self.info["steps"] += int(sinfo["steps"]) - before
-            state_field.data[...] = stepper.gather(arr)
+            self._collect(stepper, arr, state_field)
             if has_hook:
                 self.info["post_step_data_list"] = stepper.control.allgather(self.info["post_step_data"])
         self.info["dt"], self.info["stochastic"] = float(sinfo["dt"]), bool(sinfo.get("stochastic", False))

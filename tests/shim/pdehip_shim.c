@@ -72,6 +72,9 @@ static int fused_enabled(void)
 /* ---- runtime -------------------------------------------------------------------------- */
 const char *pdehip_last_error(void) { return g_err; }
 int pdehip_abi_version(void) { return PDEHIP_ABI_VERSION; }
+static int g_shim_fastmath = 0;   /* recorded only: the oracle has one arithmetic */
+int pdehip_set_fastmath(int on) { g_shim_fastmath = on ? 1 : 0; return 0; }
+int pdehip_get_fastmath(int *on) { *on = g_shim_fastmath; return 0; }
 const char *pdehip_last_kernel_name(void) { return "host shim (tests only): the CPU oracle stands in for every kernel"; }
 int pdehip_device_count(int *count)
 {

@@ -427,6 +427,15 @@ int pdehip_comm_destroy(void *comm)
     return 0;
 }
 
+int pdehip_comm_info(void *comm, int *out5, char *pci_bus_id, size_t n)
+{
+    if (!comm || !out5) return failf(E_VALUE, "comm_info: NULL pointer");
+    Comm *c = static_cast<Comm *>(comm);
+    out5[0] = c->size; out5[1] = c->rank; out5[2] = c->rank; out5[3] = 0; out5[4] = c->rank;   // (mailbox transport: one "device" per rank)
+    if (pci_bus_id && n > 0) snprintf(pci_bus_id, n, "shim:%02d", c->rank);
+    return 0;
+}
+
 int pdehip_halo_exchange(void *comm, const pdehip_grid_t *g_local, void *buf_full, int lower, int upper, void *stream)
 {
     if (!comm || !buf_full) return failf(E_VALUE, "halo_exchange: NULL pointer");

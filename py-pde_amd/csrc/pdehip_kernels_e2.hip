@@ -258,7 +258,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
 #if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
     const bool nt = false;   // A/B variant: non-temporal loads, plain stores
 #else
-    const bool nt = !ragged && m2 != E2_CH_STAGE && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
+    // (round 6: also the ragged 4-row fp64 diffusion tile of two-sided grids - 500 x 500 x 300, rows that end inside a chunk - has a streaming-store form)
+    const bool nt = (!ragged || (sizeof(T) == 8 && ry == 4 && has_y && !xs && m2 == E2_DIFFUSION)) && m2 != E2_CH_STAGE && ((double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0);
 #endif
     // unit spacing and D = 1 (UnitGrid benchmarks): the 3-D instances exist without the multiplications by 1.0 (fp32 and the
     // cache-resident sizes are VALU-bound: up to 10 %)
@@ -281,7 +282,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
     bool launched = false;
     if constexpr (sizeof(T) == 8 && VEC == 2) {
-        if (per3 && ry == 4 && !ragged && !open_tail) {   // (fp64, 4 rows, rows that end at chunk boundaries)
+        if (per3 && ry == 4 && !ragged) {   // (fp64, 4 rows, rows that end at chunk boundaries - or open rows: their last columns follow below)
             note_kernel("euler2_per_kernel<double,2,%s,%s> (4 rows, 2 waves per SIMD, all-periodic)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt ? "NT" : "plain stores");
             if (unit && nt) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
             else if (unit) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
@@ -303,6 +304,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
     if constexpr (sizeof(T) == 8) {
         PDEHIP_E2(4, true, true, false, false) PDEHIP_E2(4, true, false, false, false) PDEHIP_E2(4, true, false, false, true)
+        PDEHIP_E2(4, true, true, false, true)
         PDEHIP_E2(4, true, true, true, false)
     }
     if constexpr (sizeof(T) == 4 && VEC == 4) { PDEHIP_E2(1, true, true, false, false) }   // 1-row wide tile (with the stage epilogue: 220 VGPRs)
@@ -312,7 +314,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
 #undef PDEHIP_E2
     if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
-    if (!(per3 && ry == 4 && !ragged && !open_tail) && !(sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y && !xs))
+    if (!(per3 && ry == 4 && !ragged) && !(sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y && !xs))
         note_kernel("euler2_kernel<%s,%d,%d,m2=%d%s,%s,%s,%s,%s>", sizeof(T) == 8 ? "double" : "float", VEC, ry, m2, (unit && m2 == E2_DIFFUSION && !xs) ? " unit" : "", has_y ? "3-D" : "2-D",
                     ragged ? "ragged" : "aligned rows", xs ? "one-sided" : "two-sided", nt ? "NT" : "plain stores");
     PDEHIP_HIP(hipGetLastError());

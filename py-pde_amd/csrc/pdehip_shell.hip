@@ -322,6 +322,9 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t 
             F.f[0] = F.f[1] = la.ibc[k][side].f;
         }
     }
+    // (Round 6 tried a transposed kernel here - a lane = a row, strips of six cells of six planes in registers, row neighbours by DPP, like
+    // rimz_kernel of the fast block loop: bit-exact and SLOWER than the LDS boxes below, 0.2333 against 0.2229 ms per step at 512 x 512 x 513,
+    // 0.2507 against 0.2300 at 512 x 512 x 520 - eighteen loads per lane, each a cache line of its own: profiles/r06_call12_time_sizes.md.  Removed.)
     long total = 0;
     for (int c = 0; c < columns; c += 2) {   // two layers per job, from the end of the row inwards
         ShellJob &J = a.job[a.njobs++];

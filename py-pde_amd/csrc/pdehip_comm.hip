@@ -270,13 +270,14 @@ struct HipOps {
         return v < 0 ? 0 : v;
     }
     // schedule of pdehip_slab_euler4_run (PDEHIP_SLAB_DEEP_MODE): 1 = the first sweep of a group cut in two (interior / boundary), 2 = both sweeps cut,
-    // 3 = the boundary layers on the halo stream, a group ahead (slab::euler4p_run)
+    // 3 = the boundary layers on the halo stream, a group ahead (slab::euler4p_run), 4 = the same with the second boundary pass behind the first
+    // interior sweep of its group (less redundant work)
     static constexpr int kDeepModeDefault = 3;
     int deep_mode()
     {
         const char *e = getenv("PDEHIP_SLAB_DEEP_MODE");   // (read per run: a test switches it inside one process)
         const int v = e ? atoi(e) : 0;
-        return (v >= 1 && v <= 3) ? v : kDeepModeDefault;
+        return (v >= 1 && v <= 4) ? v : kDeepModeDefault;
     }
     int record(int ev, void *st) { PDEHIP_HIP(hipEventRecord(c->ev[ev], as_stream(st))); return 0; }
     int wait(void *st, int ev) { PDEHIP_HIP(hipStreamWaitEvent(as_stream(st), c->ev[ev], 0)); return 0; }
@@ -662,7 +663,7 @@ int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehi
     slab::Geo q;
     PDEHIP_TRY(make_geo(g_local, &n, &q));
     HipOps ops{c};
-    const bool piped = ops.deep_mode() == 3;
+    const bool piped = ops.deep_mode() >= 3;
     PDEHIP_TRY(slab_private_arrays(c, g_local, q, 4, as_stream(stream), piped ? 4 : 2));
     if (lower >= 0 || upper >= 0) PDEHIP_TRY(separate_queues(c, as_stream(stream)));
     ScratchTurn turn(c, as_stream(stream));

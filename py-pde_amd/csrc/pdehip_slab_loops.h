@@ -441,17 +441,29 @@ int euler4p_run(Ops &ops, const pdehip_grid_t *g, const Geo &q, const pdehip_rhs
     SLAB_TRY(ops.wait(halo, EV_COMP));
     SLAB_TRY(exchange_deep(ops, q, cur, D, lower, upper, halo));
     const int64_t groups = nsteps / 4, rest = nsteps - 4 * groups;
+    // Schedule 4 ("lean", PDEHIP_SLAB_DEEP_MODE=4): the second boundary pass reads the layers A_int produces anyway instead of recomputing them -
+    // pass 1 only the 4 layers per side that need the halos (straight into `mid`, next to A_int's range), pass 2 behind A_int of the SAME group.
+    // 4 + 4 layers of boundary work per side and group instead of 8 + 4; the exchange then has B_int and the next A_int to hide behind.
+    const bool lean = ops.deep_mode() == 4;
     for (int64_t k = 0; k < groups; k++) {
         if (k > 0) {
             SLAB_TRY(ops.wait(comp, EV_BND2));   // P(k-1): the seam layers of cur
             SLAB_TRY(ops.wait(halo, EV_BND));    // B_int(k-1): cur next to the seams, and it has let go of what P(k) overwrites
         }
         // boundary chain first: its few workgroups should be dispatched before the sweeps fill the chip
-        SLAB_TRY(seams(halo, cur, tmp, lo, hi - lo, 2 * D));      // two steps: 8 layers per exchanged side
-        SLAB_TRY(seams(halo, tmp, nxt, D, n, D));                 // two more: the 4 own layers per exchanged side
+        if (lean) {
+            SLAB_TRY(seams(halo, cur, mid, lo, hi - lo, D));          // two steps: the 4 layers per exchanged side that read the halos
+            SLAB_TRY(sweep2(comp, cur, mid, a0, a1 - a0, xe, 0));     // A_int
+            SLAB_TRY(ops.record(EV_COMP, comp));
+            SLAB_TRY(ops.wait(halo, EV_COMP));
+            SLAB_TRY(seams(halo, mid, nxt, D, n, D));                 // two more: the 4 own layers per exchanged side
+        } else {
+            SLAB_TRY(seams(halo, cur, tmp, lo, hi - lo, 2 * D));      // two steps: 8 layers per exchanged side
+            SLAB_TRY(seams(halo, tmp, nxt, D, n, D));                 // two more: the 4 own layers per exchanged side
+        }
         SLAB_TRY(ops.record(EV_BND2, halo));
         if (k + 1 < groups || rest > 0) SLAB_TRY(exchange_deep(ops, q, nxt, D, lower, upper, halo));
-        SLAB_TRY(sweep2(comp, cur, mid, a0, a1 - a0, xe, 0));     // A_int
+        if (!lean) SLAB_TRY(sweep2(comp, cur, mid, a0, a1 - a0, xe, 0));     // A_int
         SLAB_TRY(sweep2(comp, mid, nxt, b0, b1 - b0, xe, 0));     // B_int
         SLAB_TRY(ops.record(EV_BND, comp));
         char *t = cur; cur = nxt; nxt = mid; mid = t;

@@ -151,7 +151,7 @@ size_t full_bytes(const pdehip_grid_t *g)
 struct HostOps {
     Comm *c;
     long slab_thick() { const char *e = getenv("PDEHIP_SLAB_THICK"); const long v = e ? atol(e) : 0; return v < 0 ? 0 : v; }
-    int deep_mode() { const char *e = getenv("PDEHIP_SLAB_DEEP_MODE"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 3) ? v : 3; }
+    int deep_mode() { const char *e = getenv("PDEHIP_SLAB_DEEP_MODE"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 4) ? v : 3; }
     void *halo() { return (void *)1; }
     int record(int, void *) { return 0; }
     int wait(void *, int) { return 0; }
@@ -534,7 +534,7 @@ int pdehip_slab_euler4_run(void *comm, const pdehip_grid_t *g_local, const pdehi
         if (need > c->ext_bytes) c->ext_bytes = need;
     }
     HostOps ops{c};
-    if (ops.deep_mode() == 3) return slab::euler4p_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext, dt, nsteps, result, stream);
+    if (ops.deep_mode() >= 3) return slab::euler4p_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext, dt, nsteps, result, stream);
     return slab::euler4_run(ops, g_local, q, rhs, lower, upper, buf_a, c->ext[0], c->ext[1], dt, nsteps, result, stream);
 }
 

@@ -173,7 +173,7 @@ def test_two_step_slab_loop_with_thick_boundary_chunks(monkeypatch):
     assert checked == 4
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "4"])
 def test_four_steps_per_exchange_other_schedules(monkeypatch, mode):
     """PDEHIP_SLAB_DEEP_MODE=1 / 2: the schedules of slab::euler4_run with the boundary parts of the sweeps as launches of their own in the
     chain of sweeps (the default, 3, computes them a group ahead on the halo stream: test_distributed_equals_serial) - two and three ranks,

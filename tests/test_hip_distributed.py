@@ -79,7 +79,7 @@ def test_two_steps_per_sweep_slab_loop(monkeypatch, steps):
     np.testing.assert_array_equal(final2, final)
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("shape,bc", [((16, 8, 128), {"x": "periodic", "y": {"value": 0.2}, "z": "periodic"}),
                                       ((9, 12, 256), {"x": "periodic", "y": "periodic", "z": {"derivative": -0.1}}),
                                       ((8, 6, 130), {"x": "periodic", "y": "periodic", "z": "periodic"})])

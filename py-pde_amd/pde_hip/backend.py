@@ -94,6 +94,10 @@ class HipBackendMixin(OperatorGlueMixin, RhsPlanningMixin, StepperMixin):
     @fastmath.setter
     def fastmath(self, value) -> None:
         self._fastmath = None if value is None else bool(value)
+        from ._lib import current_device
+
+        if current_device() is not None:
+            _ = self._lib      # a device is selected already: the mode reaches the library now (operators made earlier hold the library, not this property)
 
     @property
     def _lib(self):

@@ -132,8 +132,10 @@ def main() -> int:
         seen = []
         tracker = pde.CallbackTracker(lambda s, t: seen.append((t, float(s.data.sum()))), interrupts=kw["t_range"] / 2)
         decomposition = os.environ.get("PDEHIP_WORKER_DECOMPOSITION", "slab")    # "auto": blocks by the reference's rule
+        # PDEHIP_WORKER_GATHER=root: the field goes to rank 0 only when a stepper call ends (the other ranks keep their own part)
+        gather = os.environ.get("PDEHIP_WORKER_GATHER", "all")
         res, info = eq.solve(state, solver="hip_slab", backend="hip", tracker=tracker, ret_info=True,
-                             decomposition=opts.get("decomposition", decomposition), **kw)
+                             decomposition=opts.get("decomposition", decomposition), gather=gather, **kw)
         if opts.get("decomposition") and world > 1 and info["solver"]["decomposition"] != [1, world]:
             failures.append(f"{name}: decomposition {info['solver']['decomposition']}")
         report[name] = {"steps": info["solver"]["steps"], "world": info["solver"]["world_size"], "interrupts": len(seen),

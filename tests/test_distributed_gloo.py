@@ -1096,12 +1096,13 @@ def test_bench_with_a_block_decomposition():
 FUZZ_CASES = 7    # random grids / conditions / solvers per world (tests/pypde_slab_worker.py)
 
 
-@pytest.mark.parametrize("world,decomposition", [(3, "slab"), (4, "auto")])
-def test_real_pypde_drives_the_slab_path(world, decomposition):
+@pytest.mark.parametrize("world,decomposition,gather", [(3, "slab", "all"), (4, "auto", "all"), (2, "slab", "root"), (4, "auto", "root")])
+def test_real_pypde_drives_the_slab_path(world, decomposition, gather):
     """`eq.solve(state, solver="hip_slab", backend="hip")` of the REAL py-pde (pde_hip.pypde_plugin.HipSlabSolver, the
     counterpart of the reference's ExplicitMPISolver) on N ranks under torch.distributed.run: Euler, RK4 and adaptive RKF45
     with tracker interrupts - and conditions that depend on time, position and (non-linearly) on the field - equal the
-    reference's own serial numpy + scipy run (<= 1e-10, equal step counts)."""
+    reference's own serial numpy + scipy run (<= 1e-10, equal step counts).  `gather`: the field on every rank when a stepper call ends
+    (raw broadcasts), or on rank 0 only (`HipSlabSolver(gather="root")`, the reference's main-node model: every part crosses the control plane once)."""
     import json
     import subprocess
     from pathlib import Path
@@ -1114,7 +1115,7 @@ def test_real_pypde_drives_the_slab_path(world, decomposition):
         pytest.skip("py-pde (reference) not available")
     so = shimlib.build()
     env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120",
-           "PDEHIP_WORKER_DECOMPOSITION": decomposition, "PDEHIP_WORKER_FUZZ": str(FUZZ_CASES)}
+           "PDEHIP_WORKER_DECOMPOSITION": decomposition, "PDEHIP_WORKER_FUZZ": str(FUZZ_CASES), "PDEHIP_WORKER_GATHER": gather}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "pypde_slab_worker.py")]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))

@@ -1157,3 +1157,27 @@ def test_evaluate_of_expressions_with_operators(hip1, monkeypatch, shape, period
         res = evaluate(expr, fields, backend="hip")
         assert isinstance(res, cls) and res.data.shape == ref.data.shape
         np.testing.assert_allclose(res.data, ref.data, rtol=1e-12, atol=1e-12, err_msg=expr)
+
+
+def test_fastmath_is_an_opt_in_of_the_configuration(hip1):
+    """`config["backend.hip.fastmath"]` (default False: the bit-exact build) reaches the library as `pdehip_set_fastmath` before the next compute call -
+    the counterpart of `backend.numba.fastmath` (pde/backends/numba/config.py:20-26, default True there).  The shim only records the mode."""
+    import ctypes as C
+
+    assert pde.config["backend"]["hip"]["fastmath"] is False
+    grid = pde.UnitGrid([8, 8], periodic=True)
+    field = pde.ScalarField.random_uniform(grid, rng=np.random.default_rng(1))
+    on = C.c_int(-1)
+    field.laplace("periodic", backend=hip1)
+    _lib.get_lib().get_fastmath(C.byref(on))
+    assert on.value == 0
+    try:
+        hip1.fastmath = True        # (what `pde.config["backend.hip.fastmath"] = True` does for backends created afterwards)
+        field.laplace("periodic", backend=hip1)
+        _lib.get_lib().get_fastmath(C.byref(on))
+        assert on.value == 1
+    finally:
+        hip1.fastmath = None
+    field.laplace("periodic", backend=hip1)
+    _lib.get_lib().get_fastmath(C.byref(on))
+    assert on.value == 0

@@ -88,16 +88,11 @@ int main(int argc, char **argv)
         run<8, true, 1, 4, false>("tall 2x8 1w 4buf (library)", g, in, ref, 1024, reps, 4);
         if (round == 0) CK(hipMemcpy(href.data(), ref, g.total * 8, hipMemcpyDeviceToHost));
         run<8, true, 1, 3, true>("2x8 1w 3buf, all-periodic", g, in, out, 1024, reps, 4); check("2x8 3buf per3");
-        run<4, true, 2, 3, false>("2x4 2w NT (library 4-row)", g, in, out, 2048, reps, 4); check("4-row");
-        run<4, true, 2, 3, false, E2_DIFFUSION_UNIT, 3>("2x4 2w NT faces, br, late", g, in, out, 2048, reps, 4); check("4-row br late");
+        run<6, true, 1, 3, true>("2x6 1w 3buf, all-periodic", g, in, out, 1024, reps, 4); check("2x6 3buf per3");
+        run<6, true, 1, 3, true, E2_DIFFUSION_UNIT, 1>("2x6 1w 3buf, per, late", g, in, out, 1024, reps, 4); check("2x6 3buf per3 late");
+        run<6, true, 1, 4, true>("2x6 1w 4buf, all-periodic", g, in, out, 1024, reps, 4); check("2x6 4buf per3");
+        run<6, true, 1, 3, true>("2x6 1w 3buf, per, 1376 waves", g, in, out, 1376, reps, 4); check("2x6 3buf per3 x");
         run<4, true, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w NT per, late", g, in, out, 2048, reps, 4); check("4-row per3 late");
-        run<4, false, 2, 3, false>("2x4 2w plain (library 4-row)", g, in, out, 2048, reps, 4); check("4-row plain");
-        run<4, false, 2, 3, false, E2_DIFFUSION_UNIT, 1>("2x4 2w plain faces, late", g, in, out, 2048, reps, 4); check("4-row plain late");
-        run<4, false, 2, 3, true, E2_DIFFUSION_UNIT, 1>("2x4 2w plain per, late", g, in, out, 2048, reps, 4); check("4-row plain per late");
-        run<4, false, 2, 3, true, E2_DIFFUSION_UNIT, 0>("2x4 2w plain per, early", g, in, out, 2048, reps, 4); check("4-row plain per early");
-        run<8, false, 1, 3, true>("2x8 1w 3buf per, plain", g, in, out, 1024, reps, 4); check("2x8 plain per");
-        run<4, false, 2, 3, false, E2_DIFFUSION, 0>("2x4 2w plain scaled (library)", g, in, out, 2048, reps, 4); check("4-row plain scaled");
-        run<4, false, 2, 3, false, E2_DIFFUSION, 1>("2x4 2w plain scaled, late", g, in, out, 2048, reps, 4); check("4-row plain scaled late");
     }
     return 0;
 }

@@ -9,9 +9,12 @@ N > 1 slab-decomposes the SAME grid along axis 0 (strong scaling) with RCCL halo
 overlapped with the interior kernel (pde_hip/distributed.py).
 
 Rank 0 prints ONE JSON line with the whole-job throughput in Mcells/s (cell-steps per second),
-plus `roofline` for the dominant kernel (HIP-event timing on the launch stream) and, at N = 1,
+plus `roofline` for the dominant kernel (HIP-event timing on the launch stream; `kernel` = the instance name the
+library reports for what it dispatched, `traffic` = PMC bytes per launch of exactly that instance from profiles/traffic.json) and, at N = 1,
 `cpu_baseline` = the CPU oracle (plain-C restatement of the reference formulas, OpenMP) timed on
-this box's host cores on a bounded sample of the same workload.
+this box's host cores on a bounded sample of the same workload (two builds: the exact one and numba's fastmath flag set),
+`extra.slab_share_to_self` = the N-GPU slab step of this grid measured on this one GPU with the halo exchange sent to self.
+The N > 1 line carries `rccl`: what RCCL reports about its communicator (ranks, devices, PCI bus ids).
 """
 
 from __future__ import annotations

@@ -277,6 +277,18 @@ TWO_STEP_CASES = {
     # (a periodic axis shorter than the tile of the recomputing kernel: its boxes reach beyond the images they may read)
     "3d-short-periodic-rows": ([[0, 1], [0, 1], [0, 8]], (8, 6, 128), [False, True, False], {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z"},
                                                                                           "y": "periodic", "z-": {"value_expression": "0.1 * t"}, "z+": {"derivative_expression": "0.05 * x * sin(t)"}}),
+    # rows that end at chunk boundaries (the streaming sweep without the ragged-row code), several chunks per row and tiles per column
+    "3d-aligned-all-faces": ([[0, 1]] * 3, (12, 8, 256), False, {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative_expression": "0.1 * cos(t) * z"},
+                                                              "y-": {"value_expression": "x * z * (1 + t)"}, "y+": {"derivative_expression": "0.05 * x * sin(t)"},
+                                                              "z-": {"value_expression": "tanh(x - y) * t"}, "z+": {"derivative_expression": "0.1 * y * cos(2 * t)"}}),
+    "3d-aligned-interior-tiles": ([[0, 1], [0, 2], [0, 3]], (6, 16, 384), False, {"x-": {"derivative_expression": "0.1 * cos(t) * z"}, "x+": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"},
+                                                                                 "y-": {"derivative_expression": "0.05 * x * sin(t) + 0.1 * z"}, "y+": {"value_expression": "x * z * (1 + t)"},
+                                                                                 "z-": {"derivative_expression": "0.1 * y * cos(2 * t)"}, "z+": {"value_expression": "tanh(x - y) * t"}}),
+    "3d-aligned-two-chunks": ([[0, 1], [0, 2], [0, 4]], (10, 12, 256), False, {"x": {"value": 0.1}, "y-": {"type": "mixed_expression", "value": "0.5 + 0.1 * x + 0.2 * t", "const": "0.3 * sin(t + z)"},
+                                                                            "y+": {"derivative": -0.2}, "z-": {"value": 0.3}, "z+": {"value_expression": "0.1 * x * cos(2 * t) + y"}}),
+    "3d-aligned-periodic-march": ([[0, 1], [0, 1], [0, 4]], (16, 8, 256), [True, False, False], {"x": "periodic", "y-": {"derivative_expression": "0.3 * sin(x + 2 * t) * z"},
+                                                                                             "y+": {"value_expression": "0.2 * z * t"}, "z-": {"derivative_expression": "0.1 * x * y"},
+                                                                                             "z+": {"value_expression": "cos(3 * t + y)"}}),
     "3d-position-only": ([[0, 1]] * 3, (8, 12, 64), False, {"x": {"value": 0.1}, "y-": {"value_expression": "sin(3 * x) * z"}, "y+": {"derivative": 0.0}, "z": {"derivative_expression": "0.2 * x - y"}}),
 }
 

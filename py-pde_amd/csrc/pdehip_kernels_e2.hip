@@ -143,7 +143,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         // a box of the fast block loop (plain rows / columns): 7/8 of a round - the rim, pack, RCCL and unpack kernels of the halo stream
         // otherwise wait for the END of the sweep (0.0536 -> 0.0501 ms per step at 256 x 128 x 512, profiles/r05_probe_block.md)
         const bool boxed = a.per[1] == 2 || a.per[2] == 2;
-        const bool wide1 = sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y;   // (euler2_stage1w_kernel: one wave per SIMD)
+        const bool wide1 = sizeof(T) == 4 && VEC == 4 && (m2 == E2_CH_STAGE ? ry == 2 : ry == 4) && has_y;   // (euler2_stage1w_kernel, euler2_wide4_kernel: one wave per SIMD)
         const long cap = t2.blocks ? t2.blocks : ((tall || wide1) ? 1024 : (thin ? 1536 : (boxed ? 1792 : 2048)));   // (the tall tile runs one wave per SIMD)
         static const long floor_env = getenv("PDEHIP_E2_MINLX") ? atol(getenv("PDEHIP_E2_MINLX")) : 0;   // tuning aid
         long nxc;
@@ -236,7 +236,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         bool have;
         if (!has_y) have = ry == 1 && !xs_ && (sizeof(T) == 8 || VEC == 4);
         else if (sizeof(T) == 8) have = ry == 4 || ry == 2;
-        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_);
+        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_) || (ry == 4 && !xs_ && xplain == 0 && m2 == E2_DIFFUSION && !plan && ends == 0 && a.per[1] != 2 && a.per[2] != 2);   // (4: euler2_wide4_kernel)
         else have = ry == 4 || ry == 2 || (ry == 1 && !xs_);
         if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = ry == 2 && !xs_;   // (two waves per SIMD: 256 VGPRs + scratch; ry 2: euler2_stage1w_kernel)
         // a 1-row tile of a 3-D grid is its own neighbour's halo: the tile of row 1 reads the virtual row -1, which only the
@@ -280,7 +280,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
             else return 0;                                                                                                               \
         } else hipLaunchKernelGGL((euler2_kernel<T, VEC, RY_, E2_CH_SCALED, HY_, RG_, XS_, NT_>), grid, block, 0, st, a);                  \
     }
-    bool launched = false;
+    bool launched = false, noted = false;
     if constexpr (sizeof(T) == 8 && VEC == 2) {
         if (per3 && ry == 4 && !ragged) {   // (fp64, 4 rows, rows that end at chunk boundaries - or open rows: their last columns follow below)
             note_kernel("euler2_per_kernel<double,2,%s,%s> (4 rows, 2 waves per SIMD, all-periodic)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt ? "NT" : "plain stores");
@@ -292,6 +292,22 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         }
     }
     if constexpr (sizeof(T) == 4 && VEC == 4) {
+        if (ry == 4 && m2 == E2_DIFFUSION) {   // fp32 diffusion: the wide 4-row tile at one wave per SIMD (pdehip_march2.inc; `have` above)
+            // streaming stores for all-periodic fields beyond the Infinity Cache only (512^3: 874 against 848 Gcell-steps/s); with faces they LOSE
+            // (616 against 659: profiles/r06_f32_wide4.md)
+            const bool nt4 = all_periodic && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0;
+            note_kernel("euler2_wide4_kernel<float,4,%s,%s,%s> (4 rows, 1 wave per SIMD)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt4 ? "NT" : "plain stores", all_periodic ? "all-periodic" : "faces");
+#define PDEHIP_W4(M2_, NT_, P3_) hipLaunchKernelGGL((euler2_wide4_kernel<T, VEC, M2_, NT_, P3_>), grid, block, 0, st, a)
+            if (all_periodic) {
+                if (unit && nt4) PDEHIP_W4(E2_DIFFUSION_UNIT, true, true); else if (unit) PDEHIP_W4(E2_DIFFUSION_UNIT, false, true);
+                else if (nt4) PDEHIP_W4(E2_DIFFUSION, true, true); else PDEHIP_W4(E2_DIFFUSION, false, true);
+            } else {
+                if (unit) PDEHIP_W4(E2_DIFFUSION_UNIT, false, false); else PDEHIP_W4(E2_DIFFUSION, false, false);
+            }
+#undef PDEHIP_W4
+            launched = true;
+            noted = true;
+        }
         if (m2 == E2_CH_STAGE && ry == 2 && has_y && !xs) {   // the wide fp32 stage tile at one wave per SIMD (pdehip_march2.inc)
             hipLaunchKernelGGL((euler2_stage1w_kernel<T, VEC, 2, true>), grid, block, 0, st, a);
             launched = true;
@@ -314,7 +330,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
 #undef PDEHIP_E2
     if (!launched) return 0;   // no instance of this shape (the caller takes the pass-by-pass path)
-    if (!(per3 && ry == 4 && !ragged) && !(sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y && !xs))
+    if (!noted && !(per3 && ry == 4 && !ragged) && !(sizeof(T) == 4 && VEC == 4 && m2 == E2_CH_STAGE && ry == 2 && has_y && !xs))
         note_kernel("euler2_kernel<%s,%d,%d,m2=%d%s,%s,%s,%s,%s>", sizeof(T) == 8 ? "double" : "float", VEC, ry, m2, (unit && m2 == E2_DIFFUSION && !xs) ? " unit" : "", has_y ? "3-D" : "2-D",
                     ragged ? "ragged" : "aligned rows", xs ? "one-sided" : "two-sided", nt ? "NT" : "plain stores");
     PDEHIP_HIP(hipGetLastError());
@@ -337,6 +353,21 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         // need the narrow 4-row tile to carry their epilogue at all (RKF45 attempt 0.786 -> 0.755 ms).  The run-time built
         // kernels of pdehip_jit.hip keep the wide tile (`plan`).
         int vec = 4, ry = 2;
+        // two-sided diffusion: the wide tile with four rows at one wave per SIMD (round 6; PDEHIP_F32_WIDE4=0: off, A/B)
+        static const bool wide4_off = getenv("PDEHIP_F32_WIDE4") && getenv("PDEHIP_F32_WIDE4")[0] == '0';
+        // (grids of a few MB are bound by the latency of a march, not by instructions: 64 x 64 x 256 lost 4 %)
+        const bool wide4 = !wide4_off && n.ndim == 3 && !plan && !stage && m2 == E2_DIFFUSION && xplain == 0 && ends == 0 && a.per[1] != 2 && a.per[2] != 2 &&
+                           a.n1 % 4 == 0 && !tf.vec && (double)a.n0 * a.n1 * a.n2 >= 2097152.0;
+        // (rows that fill the 256-cell chunks of the wide tile badly go to the narrow tile below: 384 cells = 1.5 chunks lost 24 % here)
+        auto fill4 = [&](long cw) {
+            const long t = a.n2 % cw;
+            return (a.n2 > cw && t >= 1 && t <= 8) ? 1.0 : (double)a.n2 / (double)((a.n2 + cw - 1) / cw * cw);
+        };
+        if (wide4 && !(fill4(128) > 1.15 * fill4(256))) {
+            bool ok4 = false;
+            PDEHIP_TRY((launch_euler2_tv<float, 4>(n, a, xplain, st, &ok4, dry_run, ends, m2, plan, 4)));
+            if (ok4) { *done = true; return 0; }
+        }
         if (n.ndim == 3 && !plan) {
             if (stage) { vec = tf.svec ? tf.svec : 2; ry = tf.svec ? tf.sry : 4; }
             else if (tf.vec) { vec = tf.vec; ry = tf.ry; }

@@ -174,6 +174,28 @@ def test_cfg4_512cube_full_field():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("periodic", [False, [True, False, False]], ids=["walls", "periodic-march-axis"])
+def test_fields_beyond_400MB_with_faces(periodic):
+    """fp64 fields beyond 400 MB with local faces (the streaming-store form of the 4-row tile, its face code in branches): 4 Euler steps (two
+    sweeps, the x-chunk seams included) of 224 x 512 x 512 with value / derivative / mixed conditions, every cell against the oracle."""
+    grid = pde_hip.CartesianGrid([[0, 2], [0, 3], [0, 1]], (224, 512, 512), periodic=periodic)
+    bc = {"x": "periodic"} if periodic else {"x-": {"value": 0.2}, "x+": {"derivative": 0.1}}
+    bc.update({"y-": {"value": -0.1}, "y+": {"derivative": 0.3}, "z-": {"type": "mixed", "value": 0.7, "const": 0.2}, "z+": {"value": 0.4}})
+    rng = np.random.default_rng(5)
+    u = rng.uniform(-1, 1, grid.shape)
+    D, dt = 0.8, 0.1 * float(min(grid.discretization)) ** 2
+    res = pde_hip.DiffusionPDE(D, bc=bc).solve(pde_hip.ScalarField(grid, u), t_range=4 * dt, dt=dt, solver="euler", backend="hip", tracker=None)
+    name = pde_hip.get_backend("hip")._lib.last_kernel_name().decode()
+    g = oracle_grid(grid)
+    faces = host_faces(grid.get_boundary_conditions(bc))
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, D, faces.c)
+    expect = interior(grid, O.euler_run(g, rhs, to_full(grid, u), dt, 4))
+    np.testing.assert_array_equal(res.data, expect)
+    assert np.abs(res.data - u).max() > 1e-3
+    assert "euler2_kernel<double,2,4" in name and "NT" in name, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cid", ["cfg5_expression_256cube_f32_rkf45", "cfg5_expression_256cube_f32_rkf45_long"])
 def test_cfg5_256cube_f32_expression_rkf45(cid):
     """cfg5: PDE({'c': 'laplace(c**3 - c - laplace(c))'}) on 256^3 fp32, adaptive RKF45 (tolerance 1e-4, dt0 = 1e-3):

@@ -236,7 +236,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         bool have;
         if (!has_y) have = ry == 1 && !xs_ && (sizeof(T) == 8 || VEC == 4);
         else if (sizeof(T) == 8) have = ry == 4 || ry == 2;
-        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_) || (ry == 4 && !xs_ && xplain == 0 && m2 == E2_DIFFUSION && !plan && ends == 0 && a.per[1] != 2 && a.per[2] != 2);   // (4: euler2_wide4_kernel)
+        else if (VEC == 4) have = ry == 2 || (ry == 1 && !xs_) || (ry == 4 && all_periodic && m2 == E2_DIFFUSION && !plan && ends == 0);   // (4: euler2_wide4_kernel)
         else have = ry == 4 || ry == 2 || (ry == 1 && !xs_);
         if (m2 == E2_CH_STAGE && sizeof(T) == 4 && VEC == 4 && has_y && ry > 1) have = ry == 2 && !xs_;   // (two waves per SIMD: 256 VGPRs + scratch; ry 2: euler2_stage1w_kernel)
         // a 1-row tile of a 3-D grid is its own neighbour's halo: the tile of row 1 reads the virtual row -1, which only the
@@ -293,17 +293,12 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
     if constexpr (sizeof(T) == 4 && VEC == 4) {
         if (ry == 4 && m2 == E2_DIFFUSION) {   // fp32 diffusion: the wide 4-row tile at one wave per SIMD (pdehip_march2.inc; `have` above)
-            // streaming stores for all-periodic fields beyond the Infinity Cache only (512^3: 874 against 848 Gcell-steps/s); with faces they LOSE
-            // (616 against 659: profiles/r06_f32_wide4.md)
-            const bool nt4 = all_periodic && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0;
-            note_kernel("euler2_wide4_kernel<float,4,%s,%s,%s> (4 rows, 1 wave per SIMD)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt4 ? "NT" : "plain stores", all_periodic ? "all-periodic" : "faces");
-#define PDEHIP_W4(M2_, NT_, P3_) hipLaunchKernelGGL((euler2_wide4_kernel<T, VEC, M2_, NT_, P3_>), grid, block, 0, st, a)
-            if (all_periodic) {
-                if (unit && nt4) PDEHIP_W4(E2_DIFFUSION_UNIT, true, true); else if (unit) PDEHIP_W4(E2_DIFFUSION_UNIT, false, true);
-                else if (nt4) PDEHIP_W4(E2_DIFFUSION, true, true); else PDEHIP_W4(E2_DIFFUSION, false, true);
-            } else {
-                if (unit) PDEHIP_W4(E2_DIFFUSION_UNIT, false, false); else PDEHIP_W4(E2_DIFFUSION, false, false);
-            }
+            // streaming stores for fields beyond the Infinity Cache (512^3: 874 against 848 Gcell-steps/s)
+            const bool nt4 = (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 192.0 * 1048576.0;
+            note_kernel("euler2_wide4_kernel<float,4,%s,%s> (4 rows, 1 wave per SIMD, all-periodic)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt4 ? "NT" : "plain stores");
+#define PDEHIP_W4(M2_, NT_) hipLaunchKernelGGL((euler2_wide4_kernel<T, VEC, M2_, NT_>), grid, block, 0, st, a)
+            if (unit && nt4) PDEHIP_W4(E2_DIFFUSION_UNIT, true); else if (unit) PDEHIP_W4(E2_DIFFUSION_UNIT, false);
+            else if (nt4) PDEHIP_W4(E2_DIFFUSION, true); else PDEHIP_W4(E2_DIFFUSION, false);
 #undef PDEHIP_W4
             launched = true;
             noted = true;
@@ -353,10 +348,11 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         // need the narrow 4-row tile to carry their epilogue at all (RKF45 attempt 0.786 -> 0.755 ms).  The run-time built
         // kernels of pdehip_jit.hip keep the wide tile (`plan`).
         int vec = 4, ry = 2;
-        // two-sided diffusion: the wide tile with four rows at one wave per SIMD (round 6; PDEHIP_F32_WIDE4=0: off, A/B)
+        // all-periodic diffusion: the wide tile with four rows at one wave per SIMD (round 6; PDEHIP_F32_WIDE4=0: off, A/B).  With faces it was measured
+        // too: 441.6-443.1 against 420.5-424.7 us per launch at 512^3, 61.7 against 61.6 at 256^3 in the kernel trace (profiles/r06_f32_wide4.md) - not used there
         static const bool wide4_off = getenv("PDEHIP_F32_WIDE4") && getenv("PDEHIP_F32_WIDE4")[0] == '0';
         // (grids of a few MB are bound by the latency of a march, not by instructions: 64 x 64 x 256 lost 4 %)
-        const bool wide4 = !wide4_off && n.ndim == 3 && !plan && !stage && m2 == E2_DIFFUSION && xplain == 0 && ends == 0 && a.per[1] != 2 && a.per[2] != 2 &&
+        const bool wide4 = !wide4_off && n.ndim == 3 && !plan && !stage && m2 == E2_DIFFUSION && xplain == 0 && ends == 0 && a.per[0] == 1 && a.per[1] == 1 && a.per[2] == 1 &&
                            a.n1 % 4 == 0 && !tf.vec && (double)a.n0 * a.n1 * a.n2 >= 2097152.0;
         // (rows that fill the 256-cell chunks of the wide tile badly go to the narrow tile below: 384 cells = 1.5 chunks lost 24 % here)
         auto fill4 = [&](long cw) {

@@ -436,6 +436,9 @@ def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=
     if upload is None:
         upload = _upload_f64
     expr_faces = expression_faces(bcs, skip)
+    if expr_faces and part in ("cpl-", "cpl+", "zero"):
+        msg = "hip backend: expression conditions next to conditions with complex factors (on the same operator) are not supported"
+        raise NotImplementedError(msg)
     table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload, part=part)
     dynamic = []
     for bc in expr_faces.values():

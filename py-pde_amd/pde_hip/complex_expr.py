@@ -25,6 +25,12 @@ from __future__ import annotations
 from typing import Any
 
 IM_OPERAND = "_imop"     # suffix of an operator name whose operand is the IMAGINARY part of the operator's complex argument
+# Conditions with a COMPLEX factor (mixed conditions with a complex coefficient) couple the parts: Re ghost = Re c + Re f * a - Im f * b,
+# Im ghost = Im c + Re f * b + Im f * a for the operand a + i b.  The stencils are linear in their ghost cells, so the coupling terms are
+# differences of two applications of the same stencil to the OTHER part: one with the conditions (0, -/+ Im f), one with (0, 0) - the
+# interiors cancel exactly, what remains is the contribution of -/+ Im f * (adjacent cell) at the cells next to those faces.  Suffixes of
+# the operator names -> ``convert_bcs(part=...)``:
+COUPLING_SUFFIXES = {"_cplre": "cpl-", "_cplim": "cpl+", "_cplz": "zero"}
 
 
 def part_names(var: str) -> tuple[str, str]:
@@ -90,12 +96,13 @@ def lower_vector_operators(e, nd: int):
 
 
 def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any], axes: tuple[str, ...], aliases: dict[str, str] | None = None,
-                     user_funcs: dict[str, Any] | None = None) -> tuple[str, str, dict[str, float], dict[str, str]]:
+                     user_funcs: dict[str, Any] | None = None, coupled=None) -> tuple[str, str, dict[str, float], dict[str, str]]:
     """Real and imaginary part of the right-hand side ``expr_str`` as expression strings over the parts ``part_names(v)`` of the
     (complex) fields ``variables``; complex scalar constants are folded in, real ones stay symbols.  Returns ``(re, im, consts, aliases)``:
     the constants the new expressions still need and the operator aliases they use - ``laplace(w)`` of a complex argument ``w`` becomes
     ``laplace(Re w) + I * laplace_imop(Im w)``: the same stencil, but the conditions of the second operand are the IMAGINARY parts of the
-    operator's boundary values (``convert_bcs(part="im")``), whatever equation the term ends up in."""
+    operator's boundary values (``convert_bcs(part="im")``), whatever equation the term ends up in.  ``coupled(base) -> bool``: the
+    conditions of operator ``base`` have complex factors - its applications get the coupling terms (COUPLING_SUFFIXES)."""
     import sympy as sp
 
     if user_funcs:
@@ -182,6 +189,19 @@ def split_expression(expr_str: str, variables: list[str], consts: dict[str, Any]
                 if ai != 0:
                     new_aliases[name + IM_OPERAND] = base
                     im_part = hold(sp.Function(name + IM_OPERAND)(ai))
+                if coupled is not None and coupled(base):
+                    if base in vector_atoms:
+                        msg = f"hip backend: conditions with complex factors on the vector operator behind `{name}` are not supported"
+                        raise NotImplementedError(msg)
+                    for sfx in COUPLING_SUFFIXES:
+                        new_aliases[name + sfx] = base
+                    if ai != 0:
+                        re_part = re_part + hold(sp.Function(name + "_cplre")(ai)) - hold(sp.Function(name + "_cplz")(ai))
+                    if ar != 0:
+                        im_part = im_part + hold(sp.Function(name + "_cplim")(ar)) - hold(sp.Function(name + "_cplz")(ar))
+            elif base == "gradient_squared" and coupled is not None and coupled(base):
+                msg = "hip backend: `gradient_squared` of a complex field with complex-factor conditions is not supported"
+                raise NotImplementedError(msg)
             elif base == "gradient_squared" and ai == 0:
                 re_part, im_part = hold(fn(ar)), sp.Integer(0)
             elif base == "gradient_squared" and name == base:

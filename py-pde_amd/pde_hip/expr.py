@@ -362,6 +362,12 @@ class ExpressionPlan:
                     self.reductions.append(name)
                     self.passes.append(_Pass(name, [], f"integral{len(self.reductions) - 1}", None, P_FIRST_REDUCTION + len(self.reductions) - 1))
                 return sp.Symbol(f"p[{P_FIRST_REDUCTION + self.reductions.index(name)}]", real=True)
+            from .complex_expr import COUPLING_SUFFIXES
+
+            if expr.func.__name__.endswith(tuple(COUPLING_SUFFIXES)):
+                # the coupling terms of complex-factor conditions (complex_expr.py): the same stencil with OTHER face tables than the operator's
+                # own application to this array - a pass takes one table, so each of them is a pass (and a temporary) of its own
+                return self._arrays[self._materialise(expr.func(arg))]
             return expr.func(arg)
         if expr.args:
             return expr.func(*[self._lower_ops(a) for a in expr.args])

@@ -42,6 +42,23 @@ class FaceTable:
             dst[i] = self.c[i]
 
 
+def has_complex_factors(bcs) -> bool:
+    """A condition of ``bcs`` multiplies the field value by a number with an imaginary part (a mixed condition with a complex coefficient):
+    real and imaginary part of the ghost cells depend on BOTH parts of the field (see :func:`convert_bcs`)."""
+    if not hasattr(bcs, "__iter__"):
+        return False
+    for bc_axis in bcs:
+        for bc in (bc_axis.low, bc_axis.high):
+            get = getattr(bc, "get_virtual_point_data", None)
+            if get is None or type(bc).__name__ in {"ExpressionBC", "ExpressionValueBC", "ExpressionDerivativeBC", "ExpressionMixedBC", "UserBC", "_MPIBC"}:
+                continue
+            data = get()
+            factors = (data[1],) if len(data) == 3 else (data[1], data[3])
+            if any(np.iscomplexobj(f) and np.any(np.imag(f) != 0) for f in factors):
+                return True
+    return False
+
+
 def _upload_f64(arr: np.ndarray) -> DeviceBuffer:
     arr = np.ascontiguousarray(arr, dtype=np.float64)
     buf = DeviceBuffer(arr.nbytes)
@@ -66,8 +83,12 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
     ``component``: the table of ONE component of a vector field's conditions (``comp_shape == (dim,)``) as a table for a
     scalar array - the terms of ``divergence`` inside expression PDEs are evaluated component by component.
     ``part``: "re" / "im" - the table for the real / imaginary part of a COMPLEX field: the virtual point ``const + factor * value``
-    splits into the parts as long as the factors are real (value, derivative and curvature conditions with complex values; a mixed
-    condition with a complex coefficient would couple the parts and is refused).
+    splits into ``Re const + Re factor * Re value`` and ``Im const + Re factor * Im value`` (value, derivative and curvature conditions
+    with complex values).  A COMPLEX factor (mixed / Robin conditions with a complex coefficient, ``pde/grids/boundaries/local.py:1927-1938``)
+    couples the parts: ``Re ghost = ... - Im factor * Im value``, ``Im ghost = ... + Im factor * Re value``.  Every stencil is linear in its
+    ghost cells, so the coupling is the DIFFERENCE of two applications of the operator to the OTHER part (round 6, :func:`has_complex_factors`,
+    pde_hip/complex_expr.py): ``part`` "cpl-" / "cpl+" - constant 0, factor ``-/+ Im factor`` on the local faces - and "zero" - constant 0,
+    factor 0 on the local faces; periodic axes stay periodic in all of them.
     """
     if upload is None:
         upload = _upload_f64
@@ -77,7 +98,11 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
         raise NotImplementedError(msg)
     grid = bcs.grid
     table = FaceTable()
+    if part not in (None, "re", "im", "cpl-", "cpl+", "zero"):
+        msg = f"unknown part `{part}`"
+        raise ValueError(msg)
     for ax, bc_axis in enumerate(bcs):
+        axis_periodic = bool(getattr(bc_axis, "periodic", False))
         for upper, bc in ((False, bc_axis.low), (True, bc_axis.high)):
             face = table.c[2 * ax + int(upper)]
             if skip and (ax, upper) in skip:
@@ -107,11 +132,16 @@ def convert_bcs(bcs, comp_shape: tuple[int, ...] = (), *, skip: set[tuple[int, b
                 if part is None:
                     msg = "hip backend: complex-valued boundary conditions need a complex field"
                     raise NotImplementedError(msg)
-                if np.any(np.imag(f1) != 0) or np.any(np.imag(f2) != 0):
-                    msg = "hip backend: boundary conditions with complex coefficients of the field value couple real and imaginary part"
-                    raise NotImplementedError(msg)
-                const = np.real(const) if part == "re" else np.imag(const)
-                f1, f2 = np.real(f1), np.real(f2)
+                if part in ("re", "im"):
+                    # (complex factors: the caller adds the coupling terms - has_complex_factors)
+                    const = np.real(const) if part == "re" else np.imag(const)
+                    f1, f2 = np.real(f1), np.real(f2)
+                elif axis_periodic:
+                    const, f1, f2 = np.real(const), np.real(f1), np.real(f2)   # (0, +-1: the link to the other side of the axis)
+                else:
+                    sign = {"cpl-": -1.0, "cpl+": 1.0, "zero": 0.0}[part]
+                    const = np.zeros_like(np.real(const))
+                    f1, f2 = sign * np.imag(f1) + 0.0, sign * np.imag(f2) + 0.0
             const, f1, f2 = np.asarray(const, dtype=np.float64), np.asarray(f1, dtype=np.float64), np.asarray(f2, dtype=np.float64)
             if const.ndim == 0 and f1.ndim == 0 and f2.ndim == 0:
                 face.const_v, face.factor1, face.factor2 = float(const), float(f1), float(f2)

@@ -221,6 +221,16 @@ class OperatorGlueMixin:
         ginfo = self.grid_info(grid, real)
         # (expression conditions: evaluated per part for `args["t"]` before they are applied, like for real fields)
         tables = {part: convert_bcs_with_expressions(bcs, part=part) if expression_faces(bcs) else convert_bcs(bcs, part=part) for part in ("re", "im")}
+        # conditions with complex factors couple the parts (pde_hip/faces.py: convert_bcs): the operator is linear in its ghost cells, the
+        # coupling terms are differences of two more applications to the OTHER part
+        from .faces import has_complex_factors
+
+        coupling = None
+        if has_complex_factors(bcs):
+            if expression_faces(bcs):
+                msg = "hip backend: expression conditions next to conditions with complex factors are not supported"
+                raise NotImplementedError(msg)
+            coupling = {part: convert_bcs(bcs, part=part) for part in ("cpl-", "cpl+", "zero")}
         lib, nd = self._lib, len(grid.shape)
 
         def apply_op(arr, out=None, args=None):
@@ -235,14 +245,22 @@ class OperatorGlueMixin:
                 msg = f"Incompatible shapes {tuple(out.shape)} != {shape_out}"
                 raise ValueError(msg)
             parts = []
-            for part, take in (("re", np.real), ("im", np.imag)):
-                native = DeviceArray(ginfo).set_valid(np.ascontiguousarray(take(arr), dtype=real), self.stream)
-                if getattr(tables[part], "time_dependent", False):
-                    tables[part].update(args, state=native, stream=self.stream)
-                lib.set_ghost_cells(ginfo.ref, 1, tables[part].c, native.ptr, self.stream)
+
+            def applied(native, table):
+                lib.set_ghost_cells(ginfo.ref, 1, table.c, native.ptr, self.stream)
                 res = DeviceArray(ginfo, shape_out[: len(shape_out) - nd])
                 op_no_bc(native, res)
-                parts.append(res.get_valid(stream=self.stream))
+                return res.get_valid(stream=self.stream)
+
+            natives = {}
+            for part, take in (("re", np.real), ("im", np.imag)):
+                native = natives[part] = DeviceArray(ginfo).set_valid(np.ascontiguousarray(take(arr), dtype=real), self.stream)
+                if getattr(tables[part], "time_dependent", False):
+                    tables[part].update(args, state=native, stream=self.stream)
+                parts.append(applied(native, tables[part]))
+            if coupling is not None:
+                parts[0] = parts[0] + (applied(natives["im"], coupling["cpl-"]) - applied(natives["im"], coupling["zero"]))
+                parts[1] = parts[1] + (applied(natives["re"], coupling["cpl+"]) - applied(natives["re"], coupling["zero"]))
             result = parts[0] + 1j * parts[1]
             if out is not None:
                 out[...] = result

@@ -431,7 +431,17 @@ class RhsPlanningMixin:
             real_consts: dict[str, Any] = {}
             for var in variables:
                 expr_src = rhs[var] if builtin else pde_expression(eq, var)
-                re_s, im_s, keep, more = split_expression(str(expr_src), variables, consts, tuple(grid.axes), aliases)
+                def coupled(base, var=var):
+                    # (conditions with complex factors couple the parts: complex_expr.COUPLING_SUFFIXES)
+                    from .faces import has_complex_factors
+
+                    try:
+                        bc = builtin[2][(var, base)] if builtin else pde_bc_for(eq, var, base)
+                        return has_complex_factors(grid.get_boundary_conditions(bc, rank=0))
+                    except (KeyError, NotImplementedError):
+                        return False
+
+                re_s, im_s, keep, more = split_expression(str(expr_src), variables, consts, tuple(grid.axes), aliases, coupled=coupled)
                 real_consts.update(keep)
                 aliases = {**aliases, **more}
                 part_exprs[part_names(var)[0]], part_exprs[part_names(var)[1]] = re_s, im_s
@@ -464,8 +474,13 @@ class RhsPlanningMixin:
                     # complex fields: the operand of `<op>_imop` is the imaginary part of the operator's complex argument (complex_expr.py)
                     from .complex_expr import IM_OPERAND
 
+                    from .complex_expr import COUPLING_SUFFIXES
+
                     op_part = "im" if op.endswith(IM_OPERAND) else "re"
                     base = base[: -len(IM_OPERAND)] if base.endswith(IM_OPERAND) else base
+                    for sfx, sfx_part in COUPLING_SUFFIXES.items():
+                        if op.endswith(sfx):
+                            op_part, base = sfx_part, op[: -len(sfx)]
                     if base.startswith("gradient_squared_d"):   # the central differences inside gradient_squared of a complex argument
                         base = "gradient_squared"
                 if op in getattr(plan, "vector_ops", {}):

@@ -39,6 +39,13 @@ CASES = [
     dict(id="divgrad_dot_2d", shape=[8, 6], periodic=[True, False], var="c",
          rhs="I * divergence((1 + 0.5*I) * gradient(c)) + 0.1 * dot(gradient(c), gradient(c)) - 0.1 * c",
          bc={"x": "periodic", "y": {"value": [0.3, -0.2]}}, t_range=0.02, dt=1e-3),
+    # round 6: mixed (Robin) conditions with a COMPLEX coefficient of the field value (pde/grids/boundaries/local.py:1927-1938): the factor of the
+    # virtual point is complex, real and imaginary part of the ghost cells depend on both parts of the field
+    dict(id="schroedinger_robin_2d", shape=[10, 8], periodic=[False, True], rhs="(0.2 + I) * laplace(p)", var="p",
+         bc={"x-": {"type": "mixed", "value": [0.5, 1.5], "const": [0.2, -0.3]}, "x+": {"value": [1.0, 2.0]}, "y": "periodic"}, t_range=0.05, dt=1e-3),
+    dict(id="schroedinger_robin_3d", shape=[6, 8, 64], periodic=[False, False, True], rhs="(0.2 + I) * laplace(p)", var="p",
+         bc={"x": {"type": "mixed", "value": [-0.4, 0.8], "const": [0.1, 0.2]}, "y-": {"derivative": [0.05, 0.1]},
+             "y+": {"type": "mixed", "value": [0.3, -0.6], "const": 0.0}, "z": "periodic"}, t_range=0.04, dt=2e-3),
 ]
 SOLVERS = [("euler", False), ("runge-kutta", False), ("runge-kutta", True), ("euler", True)]
 

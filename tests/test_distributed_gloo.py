@@ -432,6 +432,11 @@ COMPLEX_CASES = {
                                 lambda: pde_hip.CartesianGrid([[0, 8], [0, 4], [0, 6]], [8, 4, 6], periodic=[False, True, False]), 0.02, None, "runge-kutta", "complex"),
     "two_complex_fields2d": (lambda: pde_hip.PDE({"a": "I * laplace(a) - b", "b": "laplace(b) + I * a"}, bc={"x": "periodic", "y": {"value": 0.5j}}),
                              lambda: pde_hip.CartesianGrid([[0, 6], [0, 4]], [12, 8], periodic=[True, False]), 0.05, 1e-3, "euler", "complex2"),
+    # a mixed condition with a COMPLEX coefficient (complex factor of the virtual point: the parts couple through two more stencil passes per part,
+    # pde_hip/complex_expr.py) on the face of a cut axis and on an uncut one
+    "schroedinger_robin3d": (lambda: pde_hip.PDE({"p": "(0.2 + I) * laplace(p)"}, bc={"x": {"type": "mixed", "value": -0.4 + 0.8j, "const": 0.1 + 0.2j}, "y": "periodic",
+                                                                                    "z-": {"derivative": 0.05 + 0.1j}, "z+": {"type": "mixed", "value": 0.3 - 0.6j, "const": 0.0}}),
+                             lambda: pde_hip.CartesianGrid([[0, 8], [0, 4], [0, 6]], [8, 4, 6], periodic=[False, True, False]), 0.02, 1e-3, "runge-kutta", "complex"),
 }
 
 

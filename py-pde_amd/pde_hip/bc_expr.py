@@ -105,10 +105,17 @@ class _AffineFace:
             value = by_name.get("value", sp.Symbol("value", real=True))
             a_re, a_im = sp.expand(offset.xreplace(real)).as_real_imag()
             b_re, b_im = sp.expand(slope.xreplace(real)).as_real_imag()
-            if sp.simplify(b_im) != 0:
-                msg = f"hip backend: the boundary expression `{expr}` multiplies the field value by a complex number (it couples real and imaginary part)"
-                raise NotImplementedError(msg)
-            offset, slope = (a_re if part == "re" else a_im), b_re
+            # (a complex slope couples the parts: the callers add the coupling terms - pde_hip/faces.py: has_complex_factors, convert_bcs -
+            # from the tables "cpl-" / "cpl+" (constant 0, slope -/+ Im B) and "zero")
+            if part in ("re", "im"):
+                offset, slope = (a_re if part == "re" else a_im), b_re
+            elif part in ("cpl-", "cpl+"):
+                offset, slope = sp.Integer(0), (-b_im if part == "cpl-" else b_im)
+            elif part == "zero":
+                offset, slope = sp.Integer(0), sp.Integer(0)
+            else:
+                msg = f"unknown part `{part}`"
+                raise ValueError(msg)
             if (offset.atoms(sp.re, sp.im, sp.arg) | slope.atoms(sp.re, sp.im, sp.arg)):
                 msg = f"hip backend: cannot split the boundary expression `{expr}` into real and imaginary part"
                 raise NotImplementedError(msg)
@@ -436,8 +443,8 @@ def convert_bcs_with_expressions(bcs, comp_shape: tuple[int, ...] = (), *, skip=
     if upload is None:
         upload = _upload_f64
     expr_faces = expression_faces(bcs, skip)
-    if expr_faces and part in ("cpl-", "cpl+", "zero"):
-        msg = "hip backend: expression conditions next to conditions with complex factors (on the same operator) are not supported"
+    if part in ("cpl-", "cpl+", "zero") and any(getattr(bc, "_is_func", False) for bc in expr_faces.values()):
+        msg = "hip backend: conditions given as Python functions next to conditions with complex factors (on the same operator) are not supported"
         raise NotImplementedError(msg)
     table = convert_bcs(bcs, comp_shape, skip=set(skip or ()) | set(expr_faces), upload=upload, part=part)
     dynamic = []

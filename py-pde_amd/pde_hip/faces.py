@@ -50,7 +50,27 @@ def has_complex_factors(bcs) -> bool:
     for bc_axis in bcs:
         for bc in (bc_axis.low, bc_axis.high):
             get = getattr(bc, "get_virtual_point_data", None)
-            if get is None or type(bc).__name__ in {"ExpressionBC", "ExpressionValueBC", "ExpressionDerivativeBC", "ExpressionMixedBC", "UserBC", "_MPIBC"}:
+            if type(bc).__name__ in {"ExpressionBC", "ExpressionValueBC", "ExpressionDerivativeBC", "ExpressionMixedBC"}:
+                # a condition given as an expression: the slope of its virtual point with respect to `value`
+                if getattr(bc, "_is_func", False):
+                    continue
+                import sympy as sp
+
+                try:
+                    expr = sp.sympify(bc.virtual_point_sympy if hasattr(bc, "virtual_point_sympy") else bc._func_expression._sympy_expr)
+                except (AttributeError, sp.SympifyError):
+                    continue
+                value = {sym.name: sym for sym in expr.free_symbols}.get("value")
+                if value is None:
+                    continue
+                slope = sp.diff(expr, value)
+                if slope.has(value):
+                    continue   # (not affine in `value`: refused where the table is built)
+                real = {sym: sp.Symbol(sym.name, real=True) for sym in slope.free_symbols}
+                if sp.simplify(sp.expand(slope.xreplace(real)).as_real_imag()[1]) != 0:
+                    return True
+                continue
+            if get is None or type(bc).__name__ in {"UserBC", "_MPIBC"}:
                 continue
             data = get()
             factors = (data[1],) if len(data) == 3 else (data[1], data[3])

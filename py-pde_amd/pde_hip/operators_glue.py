@@ -227,10 +227,7 @@ class OperatorGlueMixin:
 
         coupling = None
         if has_complex_factors(bcs):
-            if expression_faces(bcs):
-                msg = "hip backend: expression conditions next to conditions with complex factors are not supported"
-                raise NotImplementedError(msg)
-            coupling = {part: convert_bcs(bcs, part=part) for part in ("cpl-", "cpl+", "zero")}
+            coupling = {part: convert_bcs_with_expressions(bcs, part=part) if expression_faces(bcs) else convert_bcs(bcs, part=part) for part in ("cpl-", "cpl+", "zero")}
         lib, nd = self._lib, len(grid.shape)
 
         def apply_op(arr, out=None, args=None):
@@ -259,6 +256,9 @@ class OperatorGlueMixin:
                     tables[part].update(args, state=native, stream=self.stream)
                 parts.append(applied(native, tables[part]))
             if coupling is not None:
+                for part, operand in (("cpl-", "im"), ("cpl+", "re"), ("zero", "re")):
+                    if getattr(coupling[part], "time_dependent", False):
+                        coupling[part].update(args, state=natives[operand], stream=self.stream)
                 parts[0] = parts[0] + (applied(natives["im"], coupling["cpl-"]) - applied(natives["im"], coupling["zero"]))
                 parts[1] = parts[1] + (applied(natives["re"], coupling["cpl+"]) - applied(natives["re"], coupling["zero"]))
             result = parts[0] + 1j * parts[1]

@@ -43,6 +43,9 @@ CASES = [
     # virtual point is complex, real and imaginary part of the ghost cells depend on both parts of the field
     dict(id="schroedinger_robin_2d", shape=[10, 8], periodic=[False, True], rhs="(0.2 + I) * laplace(p)", var="p",
          bc={"x-": {"type": "mixed", "value": [0.5, 1.5], "const": [0.2, -0.3]}, "x+": {"value": [1.0, 2.0]}, "y": "periodic"}, t_range=0.05, dt=1e-3),
+    dict(id="expression_complex_slope_2d", shape=[8, 6], periodic=[False, True], rhs="I * laplace(p) - 0.1 * p * Abs(p)**2", var="p",
+         bc={"x-": {"value_expression": "I*t + 0.1*y"}, "x+": {"derivative_expression": "(1 + 2*I)*cos(t) - (0.5 + 0.3*I)*value"}, "y": "periodic"},
+         t_range=0.05, dt=1e-3),
     dict(id="schroedinger_robin_3d", shape=[6, 8, 64], periodic=[False, False, True], rhs="(0.2 + I) * laplace(p)", var="p",
          bc={"x": {"type": "mixed", "value": [-0.4, 0.8], "const": [0.1, 0.2]}, "y-": {"derivative": [0.05, 0.1]},
              "y+": {"type": "mixed", "value": [0.3, -0.6], "const": 0.0}, "z": "periodic"}, t_range=0.04, dt=2e-3),
@@ -70,7 +73,7 @@ def main():
             complex_valued = True
 
             def evolution_rate(self, state, t=0, cid=cid, bc=bc):
-                if cid == "gross_pitaevskii_expression_bcs_2d":
+                if cid in ("gross_pitaevskii_expression_bcs_2d", "expression_complex_slope_2d"):
                     c = state.data
                     return pde.ScalarField(state.grid, 1j * state.laplace(bc, args={"t": t}).data - 0.1 * c * np.abs(c) ** 2)
                 if cid == "divgrad_dot_2d":

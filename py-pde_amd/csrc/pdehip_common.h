@@ -170,7 +170,7 @@ int euler_multi_2d(const pdehip_grid_t *g, const pdehip_rhs_t *rhs, const void *
 // expression conditions (pdehip_jit.hip)
 int euler2_timed_faces(const pdehip_grid_t *g, const void *in, void *out, double s1, double s2, const pdehip_bc_face_t *faces,
                        void *bc_program, void *stream, bool *done);
-int shell_open_rows(const NGrid &n, const LapArgs &a, int columns, hipStream_t st);   // the columns behind the tiles of a two-step sweep over open rows
+int shell_open_rows(const NGrid &n, const LapArgs &a, int columns, int rows, hipStream_t st);   // the columns / rows behind the tiles of a two-step sweep over open rows
 bool bcprog_reads(void *handle);
 bool bcprog_second_set(void *handle, const double *const_arr, const double **c2, const double **f2);
 int bcprog_run_pair(void *handle, double t0, double t1, void *stream);

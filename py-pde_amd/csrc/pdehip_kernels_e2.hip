@@ -72,8 +72,8 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // with late loads and branches is ahead of the tall one now (512^3: 0.443 against 0.488 ms per launch, profiles/r06_e2_bench6.md)
     const bool all_periodic = xplain == 0 && a.per[0] == 1 && a.per[1] == 1 && a.per[2] == 1;
     const bool tall_auto = t2.ry == 0 && (double)a.n0 * a.n1 * a.n2 * sizeof(T) > 400.0 * 1048576.0 && all_periodic && !(getenv("PDEHIP_E2_PER3") && getenv("PDEHIP_E2_PER3")[0] == '0');
-    const bool tall = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 && a.n2 % CW == 0 && a.n1 % 8 == 0 &&
-                      (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
+    const bool tall_want = sizeof(T) == 8 && VEC == 2 && (t2.ry == 8 || tall_auto) && has_y && !plan && xplain == 0 && ends == 0 &&
+                           (m2 == E2_DIFFUSION) && a.per[1] != 2 && a.per[2] != 2;
     // Row counts that are not a multiple of the tile: the last tile is moved back until it ends with the last row (it
     // recomputes rows of its neighbour, pdehip_march2.inc).  With at least 8 tiles per column the big tile with <= 1/8 of
     // redundant rows beats the exactly fitting smaller one (1.5 x instead of 2 x of the intermediate level); an odd number
@@ -85,13 +85,35 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     // kernel of pdehip_shell.hip (two layers next to the upper face of the fastest axis).  PDEHIP_OPEN_ROWS=0: off (A/B).
     static const bool open_off = getenv("PDEHIP_OPEN_ROWS") && getenv("PDEHIP_OPEN_ROWS")[0] == '0';
     long open_tail = 0;
-    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && !tall && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
+    if (!open_off && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && a.n2 > CW && a.n2 % CW >= 1 && a.n2 % CW <= 8 && a.per[1] != 2 && a.per[2] != 2) open_tail = a.n2 % CW;
     const long n2t = a.n2 - open_tail;   // the columns the tiles cover
+    // "Open" COLUMNS of tiles (round 6): one to four rows beyond a whole number of tiles (513 = 64 x 8 + 1) are left to the same recomputing kernel
+    // instead of a moved last tile - the tiles then divide the wave slots like those of the multiple of the tile below (513^3: 516 tiles of 4 rows
+    // gave 3 x-chunks = 1548 of 2048 wave slots; 512 rows x 512 columns: the tall tile, 256 x 4 = 1024 of 1024).  The halo rows of the last tiles are
+    // real rows (or the wrapped ones: `a.n1` stays the row count of the grid); next to a local upper face the last tile's output row under the
+    // virtual row is wrong and recomputed with the rows behind it (the two layers of a job overlap it for an odd remainder).
+    // fp64 fields of 8 M cells and more (below, the extra launch costs more than the moved tile).  PDEHIP_OPEN_ROWS=0 / PDEHIP_OPEN_Y=0: off (A/B).
+    static const bool open_y_off = getenv("PDEHIP_OPEN_Y") && getenv("PDEHIP_OPEN_Y")[0] == '0';
+    long open_y = 0;
+    // (fp32: for the wide 4-row tile of all-periodic grids - launch_euler2_t asks for it with ry_f32 = 4)
+    const bool open_y_type = (sizeof(T) == 8 && VEC == 2) || (sizeof(T) == 4 && VEC == 4 && ry_f32 == 4);
+    if (!open_off && !open_y_off && open_y_type && has_y && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && a.per[1] != 2 && a.per[2] != 2 &&
+        (double)a.n0 * a.n1 * a.n2 >= 8388608.0 && a.n1 >= 64) {
+        const long unit_rows = (tall_want && n2t % CW == 0 && (t2.ry == 8 || (n2t / CW) % 4 == 0) && (a.n1 % 8) >= 1 && (a.n1 % 8) <= 4) ? 8 : 4;
+        const long r = a.n1 % unit_rows;
+        if (r >= 1 && r <= (unit_rows == 8 ? 4 : 3)) open_y = r;
+    }
+    const long n1t = a.n1 - open_y;      // the rows the tiles cover
+    // (the tall tile has no code for the virtual FAR column of an open row with one more cell: the ragged 4-row instance takes those)
+    // (chosen automatically only where the chunks of a row come in fours - workgroups of four waves that stream whole rows: 300 x 512 x 640, five
+    // chunks = one-wave workgroups, 561.6 on the tall tile against 585.4 Gcell-steps/s on the 4-row tile, 384 columns 518 against 572:
+    // profiles/r06_call32_sizes.log)
+    const bool tall = tall_want && n2t % CW == 0 && n1t % 8 == 0 && !(open_tail == 1 && !a.per[2]) && (t2.ry == 8 || (n2t / CW) % 4 == 0);
     const int ry_want = ry;
-    while (ry > 1 && a.n1 % ry) ry /= 2;
+    while (ry > 1 && n1t % ry) ry /= 2;
     if (has_y && ry < ry_want) {
         int big = ry_want;
-        while (big > ry && a.n1 < 8L * big) big /= 2;
+        while (big > ry && n1t < 8L * big) big /= 2;
         if (big > ry) ry = big;
         else if (ry == 1) ry = 2;   // (1-row tiles exist for periodic rows of fp32 grids only and recompute 3 x)
     }
@@ -100,11 +122,11 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     if (m2 == E2_CH_STAGE && sizeof(T) == 8 && ry == 4 && n2v % CW != 0) ry = 2;
     if (!has_y) ry = 1;
     if (tall) ry = 8;
-    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || a.n1 < ry || (n2v != n2t && n2t < CW)) return 0;
-    const bool overlap = n2v != n2t || a.n1 % ry != 0;
+    if ((ry != 1 && ry != 2 && ry != 4 && !tall) || n1t < ry || (n2v != n2t && n2t < CW)) return 0;
+    const bool overlap = n2v != n2t || n1t % ry != 0;
     // the wide fp32 tile has no registers for the virtual row / column in a tile's OUTER halo position (next to a moved tile
     // with local faces): the narrow tile takes those grids (launch_euler2_t)
-    if (sizeof(T) == 4 && VEC == 4 && ((has_y && a.n1 % ry != 0 && !a.per[1]) || (a.n2 % CW == 1 && !a.per[2]))) return 0;
+    if (sizeof(T) == 4 && VEC == 4 && ((has_y && n1t % ry != 0 && !a.per[1]) || (a.n2 % CW == 1 && !a.per[2]))) return 0;
     if (overlap && m2 == E2_CH_STAGE) {
         // cells of overlapping tiles are computed and stored twice: nothing a sweep writes may be one of its pointwise inputs
         // (the new state of RK4 written over the old one: those sweeps combine with the pointwise kernels)
@@ -114,7 +136,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
     a.ntz = (n2t + CW - 1) / CW;   // the row may end inside the last chunk
     a.z_open = open_tail > 0;
-    a.nty = (a.n1 + ry - 1) / ry;
+    a.nty = (n1t + ry - 1) / ry;
     const long tiles = a.ntz * a.nty;
     // every x-chunk recomputes two planes of the intermediate level and re-reads four input planes
     if (ends > 0) {
@@ -218,6 +240,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
                 else if (nt_) hipLaunchKernelGGL((euler2_tall_per_kernel<T, VEC, E2_DIFFUSION, true>), grid, block, 0, st, a);
                 else hipLaunchKernelGGL((euler2_tall_per_kernel<T, VEC, E2_DIFFUSION, false>), grid, block, 0, st, a);
                 PDEHIP_HIP(hipGetLastError());
+                if (open_tail || open_y) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, (int)open_y, st));
                 *done = true;
                 return 0;
             }
@@ -227,6 +250,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
             else if (nt_) hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((euler2_tall_kernel<T, VEC, 8, E2_DIFFUSION, false>), grid, block, 0, st, a);
             PDEHIP_HIP(hipGetLastError());
+            if (open_tail || open_y) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, (int)open_y, st));
             *done = true;
             return 0;
         }
@@ -253,7 +277,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const bool xs = xplain > 1;
     // (the virtual rows next to a moved last tile - pdehip_march2.inc: ylo2 / yhi2 - are part of the ragged-row code)
     // (... and so is the virtual FAR column right of the last chunk of an open row with one more cell: zhi2)
-    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && a.n1 % ry != 0 && !a.per[1]) || (open_tail == 1 && !a.per[2]);
+    const bool ragged = xs || !(sizeof(T) == 8 && ry == 4 && n2v % CW == 0) || (has_y && n1t % ry != 0 && !a.per[1]) || (open_tail == 1 && !a.per[2]);
     // NT: streaming stores, for the hot instance and fields that do not fit the 256 MB Infinity Cache
 #if defined(PDEHIP_NT_LOADS) && PDEHIP_NT_LOADS == 2
     const bool nt = false;   // A/B variant: non-temporal loads, plain stores
@@ -329,7 +353,7 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
         note_kernel("euler2_kernel<%s,%d,%d,m2=%d%s,%s,%s,%s,%s>", sizeof(T) == 8 ? "double" : "float", VEC, ry, m2, (unit && m2 == E2_DIFFUSION && !xs) ? " unit" : "", has_y ? "3-D" : "2-D",
                     ragged ? "ragged" : "aligned rows", xs ? "one-sided" : "two-sided", nt ? "NT" : "plain stores");
     PDEHIP_HIP(hipGetLastError());
-    if (open_tail) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, st));   // the last one to four columns of every row
+    if (open_tail || open_y) PDEHIP_TRY(shell_open_rows(n, a, (int)open_tail, (int)open_y, st));   // the last columns of every row, the last rows of every plane
     *done = true;
     return 0;
 }
@@ -353,7 +377,8 @@ static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st
         static const bool wide4_off = getenv("PDEHIP_F32_WIDE4") && getenv("PDEHIP_F32_WIDE4")[0] == '0';
         // (grids of a few MB are bound by the latency of a march, not by instructions: 64 x 64 x 256 lost 4 %)
         const bool wide4 = !wide4_off && n.ndim == 3 && !plan && !stage && m2 == E2_DIFFUSION && xplain == 0 && ends == 0 && a.per[0] == 1 && a.per[1] == 1 && a.per[2] == 1 &&
-                           a.n1 % 4 == 0 && !tf.vec && (double)a.n0 * a.n1 * a.n2 >= 2097152.0;
+                           (a.n1 % 4 == 0 || ((double)a.n0 * a.n1 * a.n2 >= 8388608.0 && a.n1 >= 64)) &&   // (or one to three rows more, left open: launch_euler2_tv)
+                           !tf.vec && (double)a.n0 * a.n1 * a.n2 >= 2097152.0;
         // (rows that fill the 256-cell chunks of the wide tile badly go to the narrow tile below: 384 cells = 1.5 chunks lost 24 % here)
         auto fill4 = [&](long cw) {
             const long t = a.n2 % cw;

@@ -307,7 +307,8 @@ int preload_shell_kernels()
 
 // The last one to eight columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
 // the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
-int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t st)
+// `rows` (round 6, "open" columns of tiles): the same for the last one to four ROWS of every plane - the two layers next to the upper face of the rows.
+int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, int rows, hipStream_t st)
 {
     ShellArgs a;
     memset(&a, 0, sizeof(a));
@@ -332,7 +333,14 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, hipStream_t 
         J.nb0 = (n.n[0] + 7) / 8; J.nb1 = (n.n[1] + 15) / 16; J.nb2 = 1;   // TileDims<2>
         total += J.nb0 * J.nb1;
     }
-    if (columns < 1 || columns > 8 || n.n[2] < 16) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns", columns);
+    for (int c = 0; c < rows; c += 2) {
+        ShellJob &J = a.job[a.njobs++];
+        J.ax = 1; J.side = 1; J.first = total; J.origin = (int)n.n[1] - 2 - c;
+        J.nb0 = (n.n[0] + 3) / 4; J.nb1 = 1; J.nb2 = (n.n[2] + 31) / 32;   // TileDims<1>
+        total += J.nb0 * J.nb2;
+    }
+    if (columns < 0 || columns > 8 || rows < 0 || rows > 4 || columns + rows < 1 || n.n[2] < 16 || (rows && (n.ndim != 3 || n.n[1] < 16)))
+        PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns, %d rows", columns, rows);
     a.in = la.in; a.out = la.out; a.off = n.off;
     for (int k = 0; k < 3; k++) { a.n[k] = n.n[k]; a.p[k] = n.p[k]; a.sc[k] = n.lap_scale[k]; a.ni[k] = (int)n.n[k]; }
     a.pi[0] = (int)n.p[0]; a.pi[1] = (int)n.p[1];

@@ -100,3 +100,40 @@ def test_odd_cubes_full_field(n):
     g = oracle_grid(grid)
     rhs = O.make_rhs(_abi.RHS_DIFFUSION, 1.0, host_faces(grid.get_boundary_conditions("auto_periodic_neumann")).c)
     np.testing.assert_array_equal(res.data, interior(grid, O.euler_run(g, rhs, to_full(grid, u), 0.1, 3)))
+
+
+OPEN_CASES = {
+    # shape, periodic, bc: fields of 8 M cells and more whose row COUNT is one to four beyond a whole number of tiles ("open" columns of tiles,
+    # round 6: launch_euler2_tv) - alone, together with open rows (columns beyond whole chunks), with local faces on either axis
+    "walls-1-row-8-columns": ((40, 513, 520), False, {"x": {"value": 0.2}, "y-": {"derivative": 0.1}, "y+": {"value": -0.3}, "z-": {"type": "mixed", "value": 0.5, "const": 0.1}, "z+": {"derivative": -0.2}}),
+    "periodic-rows-3": ((72, 323, 384), [False, True, False], {"x": {"derivative": 0.1}, "y": "periodic", "z": {"value": 0.4}}),
+    "walls-2-rows-1-column": ((64, 518, 257), False, {"x": {"value": 0.0}, "y": {"value": 0.5}, "z-": {"derivative": 0.2}, "z+": {"value": -0.1}}),
+    "all-periodic-tall-4-rows": ((224, 516, 512), True, {}),
+    "walls-tall-forced-sizes": ((224, 515, 512), False, {"x": {"value": 0.1}, "y-": {"value": 0.3}, "y+": {"derivative": -0.4}, "z": {"derivative": 0.0}}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(OPEN_CASES))
+def test_open_rows_and_open_tile_columns_full_field(case):
+    """4 Euler steps (two sweeps + the recomputed rows / columns behind them), every cell against the oracle."""
+    shape, periodic, bc = OPEN_CASES[case]
+    grid = pde_hip.UnitGrid(shape, periodic=periodic)
+    bcs = bc if bc else "auto_periodic_neumann"
+    u = np.random.default_rng(3).uniform(-1, 1, shape)
+    res = pde_hip.DiffusionPDE(0.7, bc=bcs).solve(pde_hip.ScalarField(grid, u), t_range=0.4, dt=0.1, solver="euler", backend="hip", tracker=None)
+    g = oracle_grid(grid)
+    rhs = O.make_rhs(_abi.RHS_DIFFUSION, 0.7, host_faces(grid.get_boundary_conditions(bcs)).c)
+    np.testing.assert_array_equal(res.data, interior(grid, O.euler_run(g, rhs, to_full(grid, u), 0.1, 4)))
+
+
+@pytest.mark.parametrize("shape", [(96, 513, 513), (80, 515, 520)])
+def test_open_rows_and_open_tile_columns_fp32(shape):
+    """fp32 all-periodic: the wide 4-row tile over a whole number of tiles and chunks, the rows / columns behind them recomputed (round 6) - every
+    cell bit-identical to the oracle's fp32 loop (fp32 storage, fp64 registers)."""
+    grid = pde_hip.UnitGrid(shape, periodic=True)
+    data = np.random.default_rng(4).uniform(-1, 1, shape).astype(np.float32)
+    res, info = pde_hip.DiffusionPDE(0.8).solve(pde_hip.ScalarField(grid, data, dtype=np.float32), t_range=0.4, dt=0.1, solver="euler", backend="hip", ret_info=True, tracker=None)
+    case = {"pde": "diffusion", "D": 0.8, "gamma": 0.0, "bc": "auto_periodic_neumann", "t_range": 0.4, "dt": 0.1, "solver": "euler"}
+    expect, steps, _ = oracle_solve(case, grid, np.float32, data)
+    assert info["solver"]["steps"] == steps
+    np.testing.assert_array_equal(res.data, expect)

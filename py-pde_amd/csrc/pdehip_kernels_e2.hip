@@ -99,9 +99,20 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     const bool open_y_type = (sizeof(T) == 8 && VEC == 2) || (sizeof(T) == 4 && VEC == 4 && ry_f32 == 4);
     if (!open_off && !open_y_off && open_y_type && has_y && !plan && xplain == 0 && ends == 0 && m2 == E2_DIFFUSION && a.per[1] != 2 && a.per[2] != 2 &&
         (double)a.n0 * a.n1 * a.n2 >= 8388608.0 && a.n1 >= 64) {
-        const long unit_rows = (tall_want && n2t % CW == 0 && (t2.ry == 8 || (n2t / CW) % 4 == 0) && (a.n1 % 8) >= 1 && (a.n1 % 8) <= 4) ? 8 : 4;
+        // (the recomputing kernel takes six jobs of two layers: the open columns of the fastest axis first)
+        const long jobs_left = 6 - (open_tail + 1) / 2;
+        const bool tall_rows = tall_want && n2t % CW == 0 && (t2.ry == 8 || (n2t / CW) % 4 == 0) && (a.n1 % 8) >= 1 && ((a.n1 % 8) + 1) / 2 <= jobs_left;
+        const long unit_rows = tall_rows ? 8 : 4;
         const long r = a.n1 % unit_rows;
-        if (r >= 1 && r <= (unit_rows == 8 ? 4 : 3)) open_y = r;
+        if (r >= 1 && r <= (unit_rows == 8 ? 7 : 3) && (r + 1) / 2 <= jobs_left) {
+            // ... where it fills the wave slots better than the moved last tile does (519 rows = 129 tiles of 4 + 3: as badly quantised as 130 tiles -
+            // the extra launch then only costs: 517^3 fp32 664 -> 642 Gcell-steps/s, profiles/r06_call35_sizes.log)
+            auto fill = [](long tiles, long slots) { return tiles >= slots ? 1.0 : (double)((slots / tiles) * tiles) / (double)slots; };
+            const long ntz_ = (n2t + CW - 1) / CW;
+            const long slots_open = (unit_rows == 8 || sizeof(T) == 4) ? 1024 : 2048, slots_moved = sizeof(T) == 4 ? 1024 : 2048;
+            const double with_open = fill((a.n1 - r) / unit_rows * ntz_, slots_open), with_moved = fill((a.n1 + 3) / 4 * ntz_, slots_moved);
+            if (with_open > with_moved + 0.08) open_y = r;
+        }
     }
     const long n1t = a.n1 - open_y;      // the rows the tiles cover
     // (the tall tile has no code for the virtual FAR column of an open row with one more cell: the ragged 4-row instance takes those)

@@ -307,7 +307,7 @@ int preload_shell_kernels()
 
 // The last one to eight columns of every row behind a two-step sweep whose tiles cover whole chunks only (launch_euler2_tv, "open" rows):
 // the two layers of cells next to the upper face of the fastest axis, with the scalar conditions of the sweep (`a`: kernel axes).
-// `rows` (round 6, "open" columns of tiles): the same for the last one to four ROWS of every plane - the two layers next to the upper face of the rows.
+// `rows` (round 6, "open" columns of tiles): the same for the last one to seven ROWS of every plane - the two layers next to the upper face of the rows.
 int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, int rows, hipStream_t st)
 {
     ShellArgs a;
@@ -327,6 +327,7 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, int rows, hi
     // rimz_kernel of the fast block loop: bit-exact and SLOWER than the LDS boxes below, 0.2333 against 0.2229 ms per step at 512 x 512 x 513,
     // 0.2507 against 0.2300 at 512 x 512 x 520 - eighteen loads per lane, each a cache line of its own: profiles/r06_call12_time_sizes.md.  Removed.)
     long total = 0;
+    if ((columns + 1) / 2 + (rows + 1) / 2 > 6) PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns, %d rows: more than six jobs", columns, rows);
     for (int c = 0; c < columns; c += 2) {   // two layers per job, from the end of the row inwards
         ShellJob &J = a.job[a.njobs++];
         J.ax = 2; J.side = 1; J.first = total; J.origin = (int)n.n[2] - 2 - c;
@@ -339,7 +340,7 @@ int shell_open_rows(const NGrid &n, const LapArgs &la, int columns, int rows, hi
         J.nb0 = (n.n[0] + 3) / 4; J.nb1 = 1; J.nb2 = (n.n[2] + 31) / 32;   // TileDims<1>
         total += J.nb0 * J.nb2;
     }
-    if (columns < 0 || columns > 8 || rows < 0 || rows > 4 || columns + rows < 1 || n.n[2] < 16 || (rows && (n.ndim != 3 || n.n[1] < 16)))
+    if (columns < 0 || columns > 8 || rows < 0 || rows > 7 || a.njobs > 6 || columns + rows < 1 || n.n[2] < 16 || (rows && (n.ndim != 3 || n.n[1] < 16)))
         PDEHIP_FAIL(E_RUNTIME, "internal: open rows of %d columns, %d rows", columns, rows);
     a.in = la.in; a.out = la.out; a.off = n.off;
     for (int k = 0; k < 3; k++) { a.n[k] = n.n[k]; a.p[k] = n.p[k]; a.sc[k] = n.lap_scale[k]; a.ni[k] = (int)n.n[k]; }

@@ -109,6 +109,8 @@ OPEN_CASES = {
     "periodic-rows-3": ((72, 323, 384), [False, True, False], {"x": {"derivative": 0.1}, "y": "periodic", "z": {"value": 0.4}}),
     "walls-2-rows-1-column": ((64, 518, 257), False, {"x": {"value": 0.0}, "y": {"value": 0.5}, "z-": {"derivative": 0.2}, "z+": {"value": -0.1}}),
     "all-periodic-tall-4-rows": ((224, 516, 512), True, {}),
+    "all-periodic-tall-7-rows-2-columns": ((200, 519, 514), True, {}),
+    "all-periodic-tall-5-rows": ((224, 517, 512), True, {}),
     "walls-tall-forced-sizes": ((224, 515, 512), False, {"x": {"value": 0.1}, "y-": {"value": 0.3}, "y+": {"derivative": -0.4}, "z": {"derivative": 0.0}}),
 }
 

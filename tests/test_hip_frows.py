@@ -289,6 +289,11 @@ TWO_STEP_CASES = {
     "3d-aligned-periodic-march": ([[0, 1], [0, 1], [0, 4]], (16, 8, 256), [True, False, False], {"x": "periodic", "y-": {"derivative_expression": "0.3 * sin(x + 2 * t) * z"},
                                                                                              "y+": {"value_expression": "0.2 * z * t"}, "z-": {"derivative_expression": "0.1 * x * y"},
                                                                                              "z+": {"value_expression": "cos(3 * t + y)"}}),
+    # 8 M cells and more, one row / eight columns beyond whole tiles / chunks: the sweep over a whole number of tiles, the rows and columns behind
+    # them recomputed with the stand-in faces (shell_open_rows), THEN the two layers next to every face given as arrays with the true coefficients
+    "3d-open-rows-and-columns": ([[0, 1], [0, 2], [0, 2]], (40, 513, 520), False, {"x-": {"value_expression": "0.2 * sin(3 * t) + 0.05 * y"}, "x+": {"derivative": 0.1},
+                                                                              "y-": {"derivative_expression": "0.05 * x * sin(t)"}, "y+": {"value_expression": "x * z * (1 + t)"},
+                                                                              "z-": {"value": 0.3}, "z+": {"derivative_expression": "0.1 * y * cos(2 * t)"}}),
     "3d-position-only": ([[0, 1]] * 3, (8, 12, 64), False, {"x": {"value": 0.1}, "y-": {"value_expression": "sin(3 * x) * z"}, "y+": {"derivative": 0.0}, "z": {"derivative_expression": "0.2 * x - y"}}),
 }
 

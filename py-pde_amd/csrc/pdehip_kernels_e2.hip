@@ -317,6 +317,18 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
     }
     bool launched = false, noted = false;
     if constexpr (sizeof(T) == 8 && VEC == 2) {
+        // a slab of a grid that is periodic along its rows and its fastest axis, real halo planes on both sides (interior and boundary sweeps of the
+        // slab loops): the all-periodic 4-row body with the march axis as the arguments say (PER3 = 2).  PDEHIP_E2_PERYZ=0: off (A/B)
+        static const bool peryz_off = getenv("PDEHIP_E2_PERYZ") && getenv("PDEHIP_E2_PERYZ")[0] == '0';
+        if (!launched && !peryz_off && xplain == 1 && a.per[1] == 1 && a.per[2] == 1 && m2 == E2_DIFFUSION && has_y && !plan && ry == 4 && !ragged && !open_tail && !open_y) {
+            note_kernel("euler2_peryz_kernel<double,2,%s,%s> (4 rows, 2 waves per SIMD, rows and fastest axis periodic, halo planes along the march axis)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt ? "NT" : "plain stores");
+            if (unit && nt) hipLaunchKernelGGL((euler2_peryz_kernel<T, VEC, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);
+            else if (unit) hipLaunchKernelGGL((euler2_peryz_kernel<T, VEC, E2_DIFFUSION_UNIT, false>), grid, block, 0, st, a);
+            else if (nt) hipLaunchKernelGGL((euler2_peryz_kernel<T, VEC, E2_DIFFUSION, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((euler2_peryz_kernel<T, VEC, E2_DIFFUSION, false>), grid, block, 0, st, a);
+            launched = true;
+            noted = true;
+        }
         if (per3 && ry == 4 && !ragged) {   // (fp64, 4 rows, rows that end at chunk boundaries - or open rows: their last columns follow below)
             note_kernel("euler2_per_kernel<double,2,%s,%s> (4 rows, 2 waves per SIMD, all-periodic)", unit ? "E2_DIFFUSION_UNIT" : "E2_DIFFUSION", nt ? "NT" : "plain stores");
             if (unit && nt) hipLaunchKernelGGL((euler2_per_kernel<T, VEC, E2_DIFFUSION_UNIT, true>), grid, block, 0, st, a);

@@ -958,7 +958,7 @@ def test_multirank_worker_and_bench_under_torchrun(world):
     from test_hip_multirank import launch_worker
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "2"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "300", "OMP_NUM_THREADS": "2"}
     cases = ["diffusion_euler_thin", "cahn_hilliard_rk4", "diffusion_rkf45", "slab_expression_bcs_rk4", "block_expression_bcs_rkf45", "generic_divgrad_rkf45",
              "block_diffusion_euler_fast", "block_diffusion_euler_walls"]
     report = launch_worker(world, env, timeout=900, args=cases)
@@ -1039,7 +1039,7 @@ def test_bench_line_of_eight_ranks_carries_the_parity_digest():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "300", "OMP_NUM_THREADS": "1"}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**os.environ, **env}, cwd=str(ROOT))
@@ -1062,7 +1062,7 @@ def test_bare_bench_spawns_its_own_ranks_and_refuses_a_mismatch():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "300", "OMP_NUM_THREADS": "1"}
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**clean, **env}, cwd=str(ROOT))
@@ -1086,7 +1086,7 @@ def test_bench_with_a_block_decomposition():
     import shimlib
 
     so = shimlib.build()
-    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120", "OMP_NUM_THREADS": "1"}
+    env = {"PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "300", "OMP_NUM_THREADS": "1"}
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     for dec, fast, dims in (("2,4,1", True, [2, 4, 1]), ("auto", True, [2, 2, 2])):
         cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--size", "32", "--decomposition", dec]
@@ -1119,7 +1119,8 @@ def test_real_pypde_drives_the_slab_path(world, decomposition, gather):
     if not refpath.available():
         pytest.skip("py-pde (reference) not available")
     so = shimlib.build()
-    env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "120",
+    env = {**os.environ, "PDEHIP_LIB": str(so), "PDEHIP_ALLOW_LIB_OVERRIDE": "1", "PDEHIP_SHIM_DEVICES": "8", "PDEHIP_SHIM_FUSED": "1", "PDEHIP_SHIM_COMM_TIMEOUT": "300",
+           "OMP_NUM_THREADS": "2",   # (the host shim's kernels are OpenMP loops: N ranks x all cores starve each other - and the mailbox transport - on a busy machine)
            "PDEHIP_WORKER_DECOMPOSITION": decomposition, "PDEHIP_WORKER_FUZZ": str(FUZZ_CASES), "PDEHIP_WORKER_GATHER": gather}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(ROOT / "tests" / "pypde_slab_worker.py")]

@@ -1359,8 +1359,8 @@ int block2_check(const pdehip_grid_t *g_local, const pdehip_rhs_t *rhs, const in
     if (g_local->ndim != 3 || rhs->kind != PDEHIP_RHS_DIFFUSION || rhs->bc_program) return 0;
     const long vec = 16 / elem_size(g_local->dtype);
     if (g_local->shape[2] % vec || g_local->shape[0] < 4 || g_local->shape[1] < 4 || (cut3[2] && g_local->shape[2] < 8)) return 0;
-    // (fp32 with a cut fastest axis: the interior box would start two cells into a four-cell vector - the exact one-step loop takes it)
-    if (cut3[2] && g_local->dtype != PDEHIP_F64) return 0;
+    // (fp32 with a cut fastest axis: the interior box starts two cells into a four-cell vector - the narrow tile's 8-byte vectors take it since
+    // the end of round 6, launch_euler2: narrow_only)
     bool done = false;
     PDEHIP_TRY(euler2_box(g_local, rhs->bc_c, cut3, (const void *)16, (void *)32, rhs->param, 0.0, nullptr, &done, true));
     if (done) {   // ... and the interior box of the boundary-first schedules

@@ -383,13 +383,19 @@ static int launch_euler2_tv(const NGrid &n, LapArgs a, int xplain, hipStream_t s
 
 template <typename T>
 static int launch_euler2_t(const NGrid &n, LapArgs a, int xplain, hipStream_t st, bool *done, bool dry_run, int ends, int m2,
-                           Euler2Plan *plan)
+                           Euler2Plan *plan, bool narrow_only)
 {
     if constexpr (sizeof(T) == 8) {
         return launch_euler2_tv<double, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 0);
     } else {
         const TuneF32 &tf = tune_f32();
         const bool stage = m2 == E2_CH_STAGE;
+        // an fp32 box that starts two cells into a four-cell vector (the interior of a block whose fastest axis is cut: pdehip_block2_loops.h):
+        // the narrow tile's 8-byte vectors take it
+        if (narrow_only) {
+            if (n.ndim != 3 || plan || stage) return 0;
+            return launch_euler2_tv<float, 2>(n, a, xplain, st, done, dry_run, ends, m2, plan, 4);
+        }
         // Measured at 256^3 / 512^3 (profiles/r03_f32_tiles.md): the sweeps without the stage epilogue are fastest on the wide
         // 2-row tile (diffusion 0.0233 vs 0.0249 ms per step, Cahn-Hilliard 0.0575 vs 0.0585); the Runge-Kutta stage sweeps
         // need the narrow 4-row tile to carry their epilogue at all (RKF45 attempt 0.786 -> 0.755 ms).  The run-time built
@@ -454,7 +460,8 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     const int am = n.ndim == 3 ? 0 : 1;
     if (n.ndim == 2 && xplain) return 0;
     if (n.n[am] < (xplain ? 1 : 4) || (n.ndim == 3 && n.n[1] < 4) || n.n[2] < 4 || n.p[am] >= (1L << 31)) return 0;
-    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || n.off % vec || n.p[am] % vec || n.p[1] % vec) return 0;
+    const bool narrow_only = n.dtype == PDEHIP_F32 && n.off % vec != 0 && n.off % 2 == 0;   // (see launch_euler2_t)
+    if ((uintptr_t)in % 16 || (uintptr_t)out % 16 || (n.off % vec && !narrow_only) || n.p[am] % vec || n.p[1] % vec) return 0;
     LapArgs a;
     memset(&a, 0, sizeof(a));
     for (int k = 0; k < 3; k++) {   // k = kernel axis
@@ -511,8 +518,8 @@ int launch_euler2(const NGrid &n, const void *in, void *out, double s1, double s
     a.ndim = n.ndim; a.any_ibc = 1;
     // squared central gradient of the custom epilogue, kernel-axis order (cartesian.py:661: 0.25 / dx**2)
     a.gs[0] = 0.25 / (n.dx[am] * n.dx[am]); a.gs[1] = 0.25 / (n.dx[1] * n.dx[1]); a.gs[2] = 0.25 / (n.dx[2] * n.dx[2]);
-    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2, plan);
-    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2, plan);
+    if (n.dtype == PDEHIP_F64) return launch_euler2_t<double>(n, a, xplain, st, done, dry_run, ends, m2, plan, false);
+    return launch_euler2_t<float>(n, a, xplain, st, done, dry_run, ends, m2, plan, narrow_only);
 }
 
 // (see preload_stencil_kernels, pdehip_kernels.hip: the code object of this translation unit is loaded when the device is selected, not in the middle of a run)

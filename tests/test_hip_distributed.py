@@ -315,11 +315,7 @@ def test_fast_block_loop_to_self(shape, cut, dtype):
     st._cut3 = (C.c_int * 3)(*st.cut)
     ok = C.c_int(0)
     st.lib.block2_supported(st.info.ref, C.byref(st._rhs2), st._cut3, C.byref(ok))
-    if cut[2] and dtype == np.float32:
-        assert ok.value == 0      # (the interior box would start inside a four-cell vector: such runs take the exact one-step loop)
-        st.close()
-        return
-    assert ok.value == 1
+    assert ok.value == 1       # (fp32 with a cut fastest axis too since the end of round 6: the interior box on the narrow tile)
     g = oracle_grid(grid, dtype)
     hf = host_faces(grid.get_boundary_conditions("periodic"))
     rhs = O.make_rhs(_abi.RHS_DIFFUSION, 0.6, hf.c, hf.c, None)
